@@ -1,0 +1,107 @@
+"""Independent cross-check of the oracle's java.util.regex restatement against
+CPython's `re` (another leftmost-greedy backtracking engine) on the regex subset
+Gorp can generate.  Python's re is a stand-in, not the
+oracle: inputs are kept to printable ASCII + space/tab, where '.' and \\s agree
+between the two engines."""
+import random
+import re
+
+import pytest
+
+from oracle import oracle as O
+
+ATOMS = ["a", "b", "c", "x", "\\d", "\\w", "\\S", "\\s", "[ \\t]", "[a-c]", "[^ab]", ".", "\\.", "=", ":", "\\[", "\\]",
+         "\\D", "\\W", "[\\d.]", "[^\\s\"]", "\""]
+QUANT = ["", "", "", "+", "*", "?", "{2}", "{1,3}", "{2,}", "+?", "*?", "??"]
+ALPHA = "abcx019 =:.[]\"\t_-Z"
+
+
+def gen_regex(rng, depth=0):
+    n = rng.randint(1, 4)
+    parts = []
+    for _ in range(n):
+        r = rng.random()
+        if depth < 2 and r < 0.25:
+            inner = gen_regex(rng, depth + 1)
+            parts.append("(" + inner + ")" + rng.choice(QUANT))
+        elif depth < 2 and r < 0.35:
+            inner = gen_regex(rng, depth + 1)
+            parts.append("(?:" + inner + ")" + rng.choice(QUANT))
+        elif depth < 2 and r < 0.45:
+            parts.append("(?:" + gen_regex(rng, depth + 1) + "|" + gen_regex(rng, depth + 1) + ")")
+        else:
+            parts.append(rng.choice(ATOMS) + rng.choice(QUANT))
+    return "".join(parts)
+
+
+def py_groups(rx, s):
+    m = re.fullmatch(rx, s, re.ASCII)
+    if m is None:
+        return None
+    return [None if m.start(i) < 0 else (m.start(i), m.end(i)) for i in range(1, m.re.groups + 1)]
+
+
+def test_fixed_examples():
+    cases = [
+        ("\\<\\d+\\>(\\S+)[ \\t]+(\\S+)[ \\t]+RealSource:[ \\t]+\\\"(\\S+)\\\"",
+         '<86>2015-05-12T20:57:53.302858+00:00 10.1.11.141 RealSource: "10.10.5.3"'),
+        ("\\\"(\\S+)\\\"", '"ab"c"'),
+        ("(a|ab)(c|bcd)(d*)", "abcd"),
+        ("(a*)(a*)", "aaa"),
+        ("(a*?)(a*)", "aaa"),
+        ("(?:(a)|b)*", "ab"),
+        ("(a)|(b)", "b"),
+        ("x(\\d+)?y", "xy"),
+        ("([a-zA-Z\\.]+):((?:[0-9]+))/(?:[a-zA-Z]+)", "foo.bar.com:8080/user"),
+        ("(.*)=(.*)", "a=b=c"),
+        ("(.*?)=(.*)", "a=b=c"),
+    ]
+    for rx, s in cases:
+        assert O.jdk_matches(rx, s) == py_groups(rx, s), (rx, s)
+
+
+def test_random_regexes_against_python_re():
+    rng = random.Random(20260101)
+    checked = matched = 0
+    for _ in range(1500):
+        rx = gen_regex(rng)
+        try:
+            re.compile(rx, re.ASCII)
+        except re.error:
+            continue
+        for _ in range(12):
+            s = "".join(rng.choice(ALPHA) for _ in range(rng.randint(0, 10)))
+            exp = py_groups(rx, s)
+            got = O.jdk_matches(rx, s)
+            assert (got is None) == (exp is None), (rx, s, got, exp)
+            checked += 1
+            if exp is not None:
+                matched += 1
+                # Engines legitimately differ on what a group inside a loop keeps after an
+                # empty/skipped later iteration; compare full spans when no group is quantified.
+                if not re.search(r"\)[+*?{]", rx):
+                    assert got == exp, (rx, s, got, exp)
+    assert checked > 5000 and matched > 200
+
+
+def test_unsupported_constructs_are_rejected_loudly():
+    for rx in ["a\\b", "(?=a)a", "(?<n>a)", "a++", "\\1", "[a&&b]", "[a[b]]", "\\p{L}", "\\Qa\\E"]:
+        with pytest.raises(O.OracleError):
+            O.jdk_matches(rx, "a")
+    for rx in ["*a", "a{", "(a", "a)", "[a", "a{2,1}", "[b-a]"]:
+        with pytest.raises(O.OracleError):
+            O.jdk_matches(rx, "a")
+
+
+def test_anchors_and_line_terminators():
+    # '^'/'$' are anchors for java.util.regex but literals for the automaton
+    assert O.jdk_matches("^a$", "a") == []
+    assert O.jdk_matches("a$", "a\n") is None       # matches() must consume the whole input
+    assert O.jdk_matches("a$\\n", "a\n") == []
+    assert O.jdk_matches("a.", "a\r") is None
+    assert O.jdk_matches("a.", "a\n") is None
+    assert O.jdk_matches("a.", "a") is None
+    assert O.jdk_matches("a.", "a ") is None
+    assert O.jdk_matches("a.", "a\t") == []
+    assert O.jdk_matches("a\\s", "a\x0b") == []
+    assert O.jdk_matches("a\\s", "a\x08") is None
