@@ -1,0 +1,93 @@
+"""ctypes binding of libgorp_hip.so (the C ABI in include/gorp_hip.h).
+
+The library is the product: if it is missing this module raises -- there is no
+Python or CPU fallback for the hot path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgorp_hip.so")
+
+GX_OK = 0
+GX_E_REGEX_SYNTAX = 1
+GX_E_UNSUPPORTED_CONSTRUCT = 2
+GX_E_DEVICE = 3
+GX_E_ARG = 4
+GX_E_NOMEM = 5
+GX_E_LIMIT = 6
+GX_CREATE_HOST_ONLY = 1
+
+# every symbol include/gorp_hip.h declares
+SYMBOLS = [
+    "gx_create_from_patterns", "gx_blob_size", "gx_blob_copy", "gx_create_from_blob", "gx_destroy",
+    "gx_num_extractions", "gx_num_groups", "gx_max_groups", "gx_stat", "gx_extract_batch",
+    "gx_extract_one_utf16", "gx_match_one_utf16", "gx_last_error", "gx_device_count",
+    "gx_quote_literal_as_regexp", "gx_massage_regexp_for_automaton", "gx_massage_regexp_for_jdk",
+]
+
+
+class gx_batch_opts(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("device_pointers", C.c_uint32),
+        ("offsets64", C.c_uint32),
+        ("match_only", C.c_uint32),
+        ("stream", C.c_void_p),
+        ("no_sync", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "gorp_amd: %s not found. Build it with `python -m gorp_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback for the extract path." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.gx_create_from_patterns.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int32, C.c_uint32,
+                                          C.POINTER(C.c_void_p)]
+    L.gx_create_from_patterns.restype = C.c_int
+    L.gx_blob_size.argtypes = [C.c_void_p]
+    L.gx_blob_size.restype = C.c_size_t
+    L.gx_blob_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.gx_blob_copy.restype = C.c_int
+    L.gx_create_from_blob.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.gx_create_from_blob.restype = C.c_int
+    L.gx_destroy.argtypes = [C.c_void_p]
+    L.gx_destroy.restype = None
+    L.gx_num_extractions.argtypes = [C.c_void_p]
+    L.gx_num_extractions.restype = C.c_int32
+    L.gx_num_groups.argtypes = [C.c_void_p, C.c_int32]
+    L.gx_num_groups.restype = C.c_int32
+    L.gx_max_groups.argtypes = [C.c_void_p]
+    L.gx_max_groups.restype = C.c_int32
+    L.gx_stat.argtypes = [C.c_void_p, C.c_int32]
+    L.gx_stat.restype = C.c_int64
+    L.gx_extract_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                   C.POINTER(gx_batch_opts)]
+    L.gx_extract_batch.restype = C.c_int
+    L.gx_extract_one_utf16.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p]
+    L.gx_extract_one_utf16.restype = C.c_int
+    L.gx_match_one_utf16.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+    L.gx_match_one_utf16.restype = C.c_int
+    L.gx_last_error.argtypes = []
+    L.gx_last_error.restype = C.c_char_p
+    L.gx_device_count.argtypes = []
+    L.gx_device_count.restype = C.c_int
+    for f in ("gx_quote_literal_as_regexp", "gx_massage_regexp_for_automaton", "gx_massage_regexp_for_jdk"):
+        getattr(L, f).argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        getattr(L, f).restype = C.c_int
+    _lib = L
+    return L
+
+
+def last_error():
+    m = lib().gx_last_error()
+    return m.decode("utf-8", "replace") if m else ""

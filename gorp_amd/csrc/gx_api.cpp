@@ -1,0 +1,338 @@
+// gx_api.cpp -- C ABI of libgorp_hip.so (declared in include/gorp_hip.h).
+// Host logic only: compile tables, upload them once, launch kernels, move
+// results.  There is no CPU execution path for the hot loops in this library:
+// every extract/match entry point runs the HIP kernels or fails with GX_E_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <new>
+#include <string>
+
+#include "gx_compile.hpp"
+#include "gx_device.hpp"
+
+using namespace gx;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define GX_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) throw GxError(GX_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+struct Image {
+    std::vector<uint8_t> bytes;
+    template <typename V> size_t put(const V* p, size_t count) {
+        while (bytes.size() % 16) bytes.push_back(0);
+        size_t at = bytes.size();
+        const uint8_t* b = reinterpret_cast<const uint8_t*>(p);
+        bytes.insert(bytes.end(), b, b + count * sizeof(V));
+        return at;
+    }
+    template <typename V> size_t put(const std::vector<V>& v) { return put(v.data(), v.size()); }
+};
+
+}  // namespace
+
+struct gx_handle {
+    Tables T;
+    std::vector<uint8_t> blob;
+    bool on_device = false;
+    int device = 0;
+    void* dimage = nullptr;
+    size_t image_bytes = 0;
+    GxDev dev{};
+    int max_regs = 0;
+    std::mutex mu;  // serialises host-pointer batches that share nothing else
+};
+
+namespace {
+
+void upload(gx_handle* h) {
+    const Tables& T = h->T;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        throw GxError(GX_E_DEVICE, "no HIP device available (libgorp_hip needs a gfx950 GPU; there is no CPU fallback)");
+    GX_HIP(hipGetDevice(&h->device));
+
+    Image img;
+    const size_t o_cls = img.put(T.cls256, 256);
+    const size_t o_hilo = img.put(T.hi_lo);
+    const size_t o_hicls = img.put(T.hi_cls);
+    size_t o_next16 = 0, o_next32 = 0;
+    const bool small = T.m_states <= 65536;
+    if (small) {
+        std::vector<uint16_t> n16(T.m_next.begin(), T.m_next.end());
+        o_next16 = img.put(n16);
+    } else o_next32 = img.put(T.m_next);
+    const size_t o_acc = img.put(T.m_accept_first);
+    std::vector<uint32_t> trans_all, trans_off, fin_off;
+    std::vector<int32_t> fin_all, ngroups;
+    int max_regs = 0;
+    for (auto& r : T.rules) {
+        trans_off.push_back(static_cast<uint32_t>(trans_all.size()));
+        trans_all.insert(trans_all.end(), r.trans.begin(), r.trans.end());
+        fin_off.push_back(static_cast<uint32_t>(fin_all.size()));
+        fin_all.insert(fin_all.end(), r.fin.begin(), r.fin.end());
+        ngroups.push_back(r.n_groups);
+        max_regs = std::max(max_regs, r.n_regs);
+    }
+    if (trans_all.empty()) { trans_all.push_back(0); trans_off.push_back(0); fin_all.push_back(-1); fin_off.push_back(0); ngroups.push_back(0); }
+    h->max_regs = max_regs;
+    if (max_regs > 96) throw GxError(GX_E_LIMIT, "capture automaton needs more than 96 registers");
+    const size_t o_trans = img.put(trans_all);
+    const size_t o_troff = img.put(trans_off);
+    const size_t o_fin = img.put(fin_all);
+    const size_t o_finoff = img.put(fin_off);
+    const size_t o_ng = img.put(ngroups);
+    const size_t o_opsoff = img.put(T.ops_off);
+    std::vector<uint16_t> ops = T.ops;
+    if (ops.empty()) ops.push_back(0);
+    const size_t o_ops = img.put(ops);
+    std::vector<uint16_t> fin_tags = T.fin_tags;
+    if (fin_tags.empty()) fin_tags.push_back(0);
+    const size_t o_fintags = img.put(fin_tags);
+
+    GX_HIP(hipMalloc(&h->dimage, img.bytes.size()));
+    h->image_bytes = img.bytes.size();
+    GX_HIP(hipMemcpy(h->dimage, img.bytes.data(), img.bytes.size(), hipMemcpyHostToDevice));
+    const uint8_t* base = static_cast<const uint8_t*>(h->dimage);
+    GxDev& d = h->dev;
+    d.cls256 = base + o_cls;
+    d.hi_lo = reinterpret_cast<const uint16_t*>(base + o_hilo);
+    d.hi_cls = reinterpret_cast<const uint16_t*>(base + o_hicls);
+    d.n_hi = static_cast<int32_t>(T.hi_lo.size());
+    d.ncls = T.ncls;
+    d.m_next16 = small ? reinterpret_cast<const uint16_t*>(base + o_next16) : nullptr;
+    d.m_next32 = small ? nullptr : reinterpret_cast<const uint32_t*>(base + o_next32);
+    d.m_accept_first = reinterpret_cast<const int32_t*>(base + o_acc);
+    d.m_states = T.m_states;
+    d.m_dead = T.m_dead;
+    d.c_trans = reinterpret_cast<const uint32_t*>(base + o_trans);
+    d.c_trans_off = reinterpret_cast<const uint32_t*>(base + o_troff);
+    d.c_fin = reinterpret_cast<const int32_t*>(base + o_fin);
+    d.c_fin_off = reinterpret_cast<const uint32_t*>(base + o_finoff);
+    d.c_ngroups = reinterpret_cast<const int32_t*>(base + o_ng);
+    d.ops_off = reinterpret_cast<const uint32_t*>(base + o_opsoff);
+    d.ops = reinterpret_cast<const uint16_t*>(base + o_ops);
+    d.fin_tags = reinterpret_cast<const uint16_t*>(base + o_fintags);
+    d.n_rules = T.n_rules;
+    d.max_groups = T.max_groups;
+    d.max_regs = max_regs;
+    d.has_capture = T.has_capture ? 1 : 0;
+    h->on_device = true;
+}
+
+int finish_create(std::unique_ptr<gx_handle>& h, uint32_t flags, gx_handle** out) {
+    h->blob = pack_blob(h->T);
+    if (!(flags & GX_CREATE_HOST_ONLY)) upload(h.get());
+    *out = h.release();
+    return GX_OK;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    void alloc(size_t bytes) { GX_HIP(hipMalloc(&p, bytes ? bytes : 16)); }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* gx_last_error(void) { return g_last_error.c_str(); }
+
+int gx_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+int gx_create_from_patterns(const char* const* automaton_rx, const char* const* jdk_rx, int32_t n, uint32_t flags,
+                            gx_handle** out) {
+    if (!automaton_rx || !out || n <= 0) return fail(GX_E_ARG, "gx_create_from_patterns: bad argument");
+    try {
+        std::vector<ustr> a, j;
+        for (int32_t i = 0; i < n; ++i) {
+            if (!automaton_rx[i] || (jdk_rx && !jdk_rx[i])) return fail(GX_E_ARG, "gx_create_from_patterns: null pattern");
+            a.push_back(utf8_to_u16(automaton_rx[i]));
+            if (jdk_rx) j.push_back(utf8_to_u16(jdk_rx[i]));
+        }
+        std::unique_ptr<gx_handle> h(new gx_handle());
+        h->T = compile_tables(a, jdk_rx ? &j : nullptr);
+        return finish_create(h, flags, out);
+    } catch (GxError& e) { return fail(e.code, e.what()); }
+    catch (std::bad_alloc&) { return fail(GX_E_NOMEM, "out of memory"); }
+    catch (std::exception& e) { return fail(GX_E_ARG, e.what()); }
+}
+
+int gx_create_from_blob(const void* blob, size_t size, uint32_t flags, gx_handle** out) {
+    if (!blob || !out) return fail(GX_E_ARG, "gx_create_from_blob: bad argument");
+    try {
+        std::unique_ptr<gx_handle> h(new gx_handle());
+        h->T = unpack_blob(blob, size);
+        return finish_create(h, flags, out);
+    } catch (GxError& e) { return fail(e.code, e.what()); }
+    catch (std::bad_alloc&) { return fail(GX_E_NOMEM, "out of memory"); }
+    catch (std::exception& e) { return fail(GX_E_ARG, e.what()); }
+}
+
+size_t gx_blob_size(const gx_handle* h) { return h ? h->blob.size() : 0; }
+
+int gx_blob_copy(const gx_handle* h, void* dst, size_t cap) {
+    if (!h || !dst || cap < h->blob.size()) return fail(GX_E_ARG, "gx_blob_copy: bad argument");
+    memcpy(dst, h->blob.data(), h->blob.size());
+    return GX_OK;
+}
+
+void gx_destroy(gx_handle* h) {
+    if (!h) return;
+    if (h->dimage) (void)hipFree(h->dimage);
+    delete h;
+}
+
+int32_t gx_num_extractions(const gx_handle* h) { return h ? h->T.n_rules : 0; }
+int32_t gx_num_groups(const gx_handle* h, int32_t k) {
+    if (!h || k < 0 || k >= static_cast<int32_t>(h->T.rules.size())) return 0;
+    return h->T.rules[k].n_groups;
+}
+int32_t gx_max_groups(const gx_handle* h) { return h ? h->T.max_groups : 0; }
+
+int64_t gx_stat(const gx_handle* h, int32_t which) {
+    if (!h) return -1;
+    switch (which) {
+    case 0: return h->T.m_states;
+    case 1: return h->T.ncls;
+    case 2: { int64_t s = 0; for (auto& r : h->T.rules) s += r.n_states; return s; }
+    case 3: { int64_t m = 0; for (auto& r : h->T.rules) m = std::max<int64_t>(m, r.n_regs); return m; }
+    case 4: return static_cast<int64_t>(h->blob.size());
+    case 5: return 0;
+    default: return -1;
+    }
+}
+
+int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, uint64_t n, int32_t* match_id, int32_t* caps,
+                     const gx_batch_opts* opts) {
+    if (!h || !offsets || !match_id || (n && !bytes && false)) return fail(GX_E_ARG, "gx_extract_batch: bad argument");
+    if (!h->on_device) return fail(GX_E_DEVICE, "handle was created host-only; no device tables (there is no CPU fallback)");
+    gx_batch_opts o{};
+    if (opts) {
+        if (opts->struct_size != sizeof(gx_batch_opts)) return fail(GX_E_ARG, "gx_batch_opts.struct_size mismatch");
+        o = *opts;
+    }
+    const bool match_only = o.match_only || !h->T.has_capture;
+    if (!match_only && !caps) return fail(GX_E_ARG, "gx_extract_batch: caps is NULL");
+    try {
+        GX_HIP(hipSetDevice(h->device));
+        hipStream_t stream = static_cast<hipStream_t>(o.stream);
+        GxBatch b{};
+        b.n = n;
+        b.wide = 0;
+        b.offsets64 = o.offsets64 ? 1 : 0;
+        b.match_only = match_only ? 1 : 0;
+        const size_t off_w = o.offsets64 ? 8 : 4;
+        const size_t slots = 2 * static_cast<size_t>(h->T.max_groups);
+        if (o.device_pointers) {
+            b.data = bytes; b.offsets = offsets; b.match_id = match_id; b.caps = match_only ? nullptr : caps;
+            GX_HIP(launch_extract_generic(h->dev, b, stream));
+            if (!o.no_sync) GX_HIP(hipStreamSynchronize(stream));
+            return GX_OK;
+        }
+        // host pointers: stage through device buffers
+        std::lock_guard<std::mutex> lock(h->mu);
+        uint64_t total = 0;
+        if (n) total = o.offsets64 ? static_cast<const uint64_t*>(offsets)[n] : static_cast<const uint32_t*>(offsets)[n];
+        DevBuf d_bytes, d_off, d_mid, d_caps;
+        d_bytes.alloc(total); d_off.alloc((n + 1) * off_w); d_mid.alloc(n * 4);
+        if (!match_only) d_caps.alloc(n * slots * 4);
+        if (total) GX_HIP(hipMemcpyAsync(d_bytes.p, bytes, total, hipMemcpyHostToDevice, stream));
+        GX_HIP(hipMemcpyAsync(d_off.p, offsets, (n + 1) * off_w, hipMemcpyHostToDevice, stream));
+        b.data = d_bytes.p; b.offsets = d_off.p; b.match_id = static_cast<int32_t*>(d_mid.p);
+        b.caps = match_only ? nullptr : static_cast<int32_t*>(d_caps.p);
+        GX_HIP(launch_extract_generic(h->dev, b, stream));
+        if (n) GX_HIP(hipMemcpyAsync(match_id, d_mid.p, n * 4, hipMemcpyDeviceToHost, stream));
+        if (!match_only && n && slots) GX_HIP(hipMemcpyAsync(caps, d_caps.p, n * slots * 4, hipMemcpyDeviceToHost, stream));
+        GX_HIP(hipStreamSynchronize(stream));
+        return GX_OK;
+    } catch (GxError& e) { return fail(e.code, e.what()); }
+    catch (std::bad_alloc&) { return fail(GX_E_NOMEM, "out of memory"); }
+}
+
+static int one_line(gx_handle* h, const uint16_t* s, int32_t len, int32_t* match_id, int32_t* caps, int32_t* state, bool match_only) {
+    if (!h || len < 0 || (len && !s)) return fail(GX_E_ARG, "bad argument");
+    if (!h->on_device) return fail(GX_E_DEVICE, "handle was created host-only; no device tables (there is no CPU fallback)");
+    try {
+        GX_HIP(hipSetDevice(h->device));
+        std::lock_guard<std::mutex> lock(h->mu);
+        const size_t slots = 2 * static_cast<size_t>(h->T.max_groups);
+        DevBuf d_s, d_off, d_out;
+        d_s.alloc(static_cast<size_t>(len) * 2);
+        d_off.alloc(8);
+        d_out.alloc((2 + slots) * 4);
+        uint32_t offs[2] = {0, static_cast<uint32_t>(len)};
+        if (len) GX_HIP(hipMemcpy(d_s.p, s, static_cast<size_t>(len) * 2, hipMemcpyHostToDevice));
+        GX_HIP(hipMemcpy(d_off.p, offs, 8, hipMemcpyHostToDevice));
+        GxBatch b{};
+        b.data = d_s.p; b.offsets = d_off.p; b.n = 1; b.wide = 1; b.offsets64 = 0;
+        b.match_only = (match_only || !h->T.has_capture) ? 1 : 0;
+        int32_t* out = static_cast<int32_t*>(d_out.p);
+        b.match_id = out; b.state_out = out + 1; b.caps = b.match_only ? nullptr : out + 2;
+        GX_HIP(launch_extract_generic(h->dev, b, nullptr));
+        std::vector<int32_t> host(2 + slots, -1);
+        GX_HIP(hipMemcpy(host.data(), d_out.p, (b.match_only ? 2 : 2 + slots) * 4, hipMemcpyDeviceToHost));
+        if (match_id) *match_id = host[0];
+        if (state) *state = host[1];
+        if (caps) for (size_t t = 0; t < slots; ++t) caps[t] = b.match_only ? -1 : host[2 + t];
+        return GX_OK;
+    } catch (GxError& e) { return fail(e.code, e.what()); }
+    catch (std::bad_alloc&) { return fail(GX_E_NOMEM, "out of memory"); }
+}
+
+int gx_extract_one_utf16(gx_handle* h, const uint16_t* s, int32_t len, int32_t* match_id, int32_t* caps) {
+    if (!match_id) return fail(GX_E_ARG, "gx_extract_one_utf16: match_id is NULL");
+    return one_line(h, s, len, match_id, caps, nullptr, false);
+}
+
+int gx_match_one_utf16(gx_handle* h, const uint16_t* s, int32_t len, int32_t* indexes, int32_t cap) {
+    int32_t mid = -1, state = -1;
+    int rc = one_line(h, s, len, &mid, nullptr, &state, true);
+    if (rc != GX_OK) return -rc;
+    if (state < 0) return 0;
+    const uint32_t b = h->T.m_accept_off[state], e = h->T.m_accept_off[state + 1];
+    for (uint32_t i = b; i < e && static_cast<int32_t>(i - b) < cap; ++i) indexes[i - b] = h->T.m_accept_list[i];
+    return static_cast<int>(e - b);
+}
+
+static int string_result(const ustr& r, char* out, size_t cap, size_t* out_len) {
+    std::string u = u16_to_utf8(r);
+    if (out_len) *out_len = u.size();
+    if (!out || cap < u.size() + 1) return fail(GX_E_ARG, "output buffer too small");
+    memcpy(out, u.c_str(), u.size() + 1);
+    return GX_OK;
+}
+
+int gx_quote_literal_as_regexp(const char* text, char* out, size_t cap, size_t* out_len) {
+    if (!text) return fail(GX_E_ARG, "null text");
+    try { return string_result(quote_literal_as_regexp(utf8_to_u16(text)), out, cap, out_len); }
+    catch (GxError& e) { return fail(e.code, e.what()); }
+}
+int gx_massage_regexp_for_automaton(const char* pattern, char* out, size_t cap, size_t* out_len) {
+    if (!pattern) return fail(GX_E_ARG, "null pattern");
+    try { return string_result(massage_regexp_for_automaton(utf8_to_u16(pattern)), out, cap, out_len); }
+    catch (GxError& e) { return fail(e.code, e.what()); }
+}
+int gx_massage_regexp_for_jdk(const char* pattern, char* out, size_t cap, size_t* out_len) {
+    if (!pattern) return fail(GX_E_ARG, "null pattern");
+    try { return string_result(massage_regexp_for_jdk(utf8_to_u16(pattern)), out, cap, out_len); }
+    catch (GxError& e) { return fail(e.code, e.what()); }
+}
+
+}  // extern "C"

@@ -1,0 +1,855 @@
+// gx_compile.cpp -- regex strings -> (match DFA, per-extraction tagged DFAs).
+//
+// Pipeline (all over one shared partition of the UTF-16 alphabet into classes):
+//   AST -> prioritised Thompson program -> per-extraction DFA -> Hopcroft
+//   -> product over extractions (what Automata.construct does,
+//      core/autom/Automata.java:57-124) -> Hopcroft again on the product
+//   AST(JDK dialect) -> prioritised program with tags -> tagged DFA per extraction
+//      (replaces the backtracking Matcher of
+//       core/jdkre/JDKRegexpCookedExtraction.java:36-59 with a single forward pass)
+#include "gx_compile.hpp"
+
+#include <map>
+#include <unordered_map>
+
+namespace gx {
+namespace {
+
+// ---------------------------------------------------------------------------
+// Prioritised Thompson program
+// ---------------------------------------------------------------------------
+struct Inst {
+    enum Op : uint8_t { CHAR, SPLIT, JMP, TAG, MATCH, FAIL } op;
+    int x = 0, y = 0;  // CHAR: x = set id; SPLIT: x preferred over y; JMP: x; TAG: x = tag number
+};
+
+struct Prog {
+    std::vector<Inst> code;
+    int ngroups = 0;
+};
+
+const size_t PROG_LIMIT = 400000;
+
+struct SetPool {
+    std::map<std::vector<std::pair<int, int>>, int> index;
+    std::vector<CharSet> sets;
+    int intern(const CharSet& s) {
+        auto it = index.find(s.iv);
+        if (it != index.end()) return it->second;
+        int id = static_cast<int>(sets.size());
+        index.emplace(s.iv, id);
+        sets.push_back(s);
+        return id;
+    }
+};
+
+class ProgBuilder {
+public:
+    ProgBuilder(Prog& p, SetPool& pool, bool tags) : p_(p), pool_(pool), tags_(tags) {}
+
+    void build(const Ast* root) {
+        gen(root);
+        emit(Inst::MATCH);
+    }
+
+private:
+    Prog& p_;
+    SetPool& pool_;
+    bool tags_;
+
+    int emit(Inst::Op op, int x = 0, int y = 0) {
+        if (p_.code.size() >= PROG_LIMIT) throw GxError(GX_E_LIMIT, "regex expands to too many instructions");
+        Inst in;
+        in.op = op; in.x = x; in.y = y;
+        p_.code.push_back(in);
+        return static_cast<int>(p_.code.size()) - 1;
+    }
+    int here() const { return static_cast<int>(p_.code.size()); }
+
+    void split_to(int at, int body, int exit, bool greedy) {
+        p_.code[at].x = greedy ? body : exit;
+        p_.code[at].y = greedy ? exit : body;
+    }
+
+    void gen(const Ast* n) {
+        switch (n->kind) {
+        case Ast::EMPTY: return;
+        case Ast::FAIL: emit(Inst::FAIL); return;
+        case Ast::SET: emit(Inst::CHAR, pool_.intern(n->set)); return;
+        case Ast::CAT: for (auto& k : n->kids) gen(k.get()); return;
+        case Ast::GROUP:
+            if (tags_ && n->cap > 0) emit(Inst::TAG, 2 * (n->cap - 1));
+            gen(n->kids[0].get());
+            if (tags_ && n->cap > 0) emit(Inst::TAG, 2 * (n->cap - 1) + 1);
+            return;
+        case Ast::ALT: {
+            std::vector<int> exits;
+            for (size_t i = 0; i < n->kids.size(); ++i) {
+                if (i + 1 == n->kids.size()) { gen(n->kids[i].get()); break; }
+                int sp = emit(Inst::SPLIT);
+                p_.code[sp].x = here();
+                gen(n->kids[i].get());
+                exits.push_back(emit(Inst::JMP));
+                p_.code[sp].y = here();
+            }
+            for (int j : exits) p_.code[j].x = here();
+            return;
+        }
+        case Ast::REP: {
+            const Ast* body = n->kids[0].get();
+            for (int i = 0; i < n->min; ++i) gen(body);
+            if (n->max < 0) {
+                int sp = emit(Inst::SPLIT);
+                gen(body);
+                emit(Inst::JMP, sp);
+                split_to(sp, sp + 1, here(), n->greedy);
+            } else {
+                std::vector<int> sps;
+                for (int i = n->min; i < n->max; ++i) { sps.push_back(emit(Inst::SPLIT)); gen(body); }
+                for (int sp : sps) split_to(sp, sp + 1, here(), n->greedy);
+            }
+            return;
+        }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// Character classes: coarsest partition of [0,0xFFFF] that every set respects
+// ---------------------------------------------------------------------------
+struct Classes {
+    int ncls = 0;
+    std::vector<int> bounds;        // ascending interval starts
+    std::vector<int> bound_cls;     // class of [bounds[i], bounds[i+1])
+    std::vector<std::vector<uint64_t>> set_mask;  // per set id: bitmask over classes
+    int words = 0;
+
+    bool set_has(int set_id, int cls) const { return (set_mask[set_id][cls >> 6] >> (cls & 63)) & 1; }
+};
+
+Classes build_classes(const SetPool& pool) {
+    Classes C;
+    std::vector<int> b{0};
+    for (auto& s : pool.sets)
+        for (auto& r : s.iv) { b.push_back(r.first); if (r.second < 0xFFFF) b.push_back(r.second + 1); }
+    std::sort(b.begin(), b.end());
+    b.erase(std::unique(b.begin(), b.end()), b.end());
+    C.bounds = b;
+    const size_t nset = pool.sets.size();
+    // membership signature of each atomic interval
+    std::map<std::vector<uint64_t>, int> sig_index;
+    const size_t sw = (nset + 63) / 64;
+    std::vector<std::vector<uint64_t>> sigs(b.size(), std::vector<uint64_t>(sw, 0));
+    for (size_t si = 0; si < nset; ++si) {
+        for (auto& r : pool.sets[si].iv) {
+            size_t i = std::lower_bound(b.begin(), b.end(), r.first) - b.begin();
+            for (; i < b.size() && b[i] <= r.second; ++i) sigs[i][si >> 6] |= 1ull << (si & 63);
+        }
+    }
+    C.bound_cls.resize(b.size());
+    for (size_t i = 0; i < b.size(); ++i) {
+        auto it = sig_index.find(sigs[i]);
+        if (it == sig_index.end()) it = sig_index.emplace(sigs[i], static_cast<int>(sig_index.size())).first;
+        C.bound_cls[i] = it->second;
+    }
+    C.ncls = static_cast<int>(sig_index.size());
+    C.words = (C.ncls + 63) / 64;
+    C.set_mask.assign(nset, std::vector<uint64_t>(C.words, 0));
+    for (size_t i = 0; i < b.size(); ++i) {
+        int c = C.bound_cls[i];
+        for (size_t si = 0; si < nset; ++si)
+            if ((sigs[i][si >> 6] >> (si & 63)) & 1) C.set_mask[si][c >> 6] |= 1ull << (c & 63);
+    }
+    return C;
+}
+
+// ---------------------------------------------------------------------------
+// Plain DFA over classes (-1 = no transition), with an integer label per state
+// ---------------------------------------------------------------------------
+struct Dfa {
+    int n = 0, ncls = 0;
+    std::vector<int32_t> next;   // [n * ncls]
+    std::vector<int32_t> label;  // -1 = not accepting
+};
+
+const size_t DFA_LIMIT = 2000000;
+
+// epsilon-closure "core": the CHAR / MATCH pcs reachable without consuming input
+void closure_core(const Prog& p, int pc, std::vector<char>& seen, std::vector<int>& out, std::vector<int>& stack) {
+    stack.push_back(pc);
+    while (!stack.empty()) {
+        int q = stack.back(); stack.pop_back();
+        if (seen[q]) continue;
+        seen[q] = 1;
+        const Inst& in = p.code[q];
+        switch (in.op) {
+        case Inst::CHAR: case Inst::MATCH: out.push_back(q); break;
+        case Inst::SPLIT: stack.push_back(in.y); stack.push_back(in.x); break;
+        case Inst::JMP: stack.push_back(in.x); break;
+        case Inst::TAG: stack.push_back(q + 1); break;
+        case Inst::FAIL: break;
+        }
+    }
+}
+
+Dfa subset_construct(const Prog& p, const Classes& C) {
+    Dfa d;
+    d.ncls = C.ncls;
+    std::map<std::vector<int>, int> index;
+    std::vector<std::vector<int>> states;
+    std::vector<char> seen(p.code.size(), 0);
+    std::vector<int> stack, core;
+    auto close_from = [&](const std::vector<int>& seeds) {
+        std::vector<int> out;
+        std::fill(seen.begin(), seen.end(), 0);
+        for (int s : seeds) closure_core(p, s, seen, out, stack);
+        std::sort(out.begin(), out.end());
+        return out;
+    };
+    states.push_back(close_from({0}));
+    index[states[0]] = 0;
+    for (size_t i = 0; i < states.size(); ++i) {
+        if (states.size() > DFA_LIMIT) throw GxError(GX_E_LIMIT, "extraction automaton too large");
+        const std::vector<int> cur = states[i];
+        bool acc = false;
+        for (int q : cur) if (p.code[q].op == Inst::MATCH) acc = true;
+        d.label.push_back(acc ? 0 : -1);
+        for (int c = 0; c < C.ncls; ++c) {
+            std::vector<int> seeds;
+            for (int q : cur) if (p.code[q].op == Inst::CHAR && C.set_has(p.code[q].x, c)) seeds.push_back(q + 1);
+            if (seeds.empty()) { d.next.push_back(-1); continue; }
+            std::vector<int> tgt = close_from(seeds);
+            if (tgt.empty()) { d.next.push_back(-1); continue; }
+            auto it = index.find(tgt);
+            if (it == index.end()) { it = index.emplace(tgt, static_cast<int>(states.size())).first; states.push_back(tgt); }
+            d.next.push_back(it->second);
+        }
+    }
+    d.n = static_cast<int>(states.size());
+    return d;
+}
+
+// Hopcroft partition refinement.  Input DFA may be partial; output is the
+// minimal partial DFA with unreachable and dead states removed (state 0 stays
+// the start state even when its language is empty).
+Dfa minimize(const Dfa& in) {
+    const int K = in.ncls;
+    const int N = in.n + 1;  // + explicit sink
+    const int SINK = in.n;
+    auto nx = [&](int s, int c) -> int {
+        if (s == SINK) return SINK;
+        int t = in.next[static_cast<size_t>(s) * K + c];
+        return t < 0 ? SINK : t;
+    };
+    // inverse transitions, CSR per class
+    std::vector<std::vector<int>> inv_off(K, std::vector<int>(N + 1, 0));
+    std::vector<std::vector<int>> inv(K);
+    for (int c = 0; c < K; ++c) {
+        auto& off = inv_off[c];
+        for (int s = 0; s < N; ++s) off[nx(s, c) + 1]++;
+        for (int t = 0; t < N; ++t) off[t + 1] += off[t];
+        inv[c].assign(N, 0);
+        std::vector<int> fill(off.begin(), off.end() - 1);
+        for (int s = 0; s < N; ++s) inv[c][fill[nx(s, c)]++] = s;
+    }
+    // initial partition by label
+    std::vector<int> perm(N), pos(N), blk(N);
+    std::vector<int> bbeg, bend, bmark;
+    {
+        std::map<int, std::vector<int>> by_label;
+        for (int s = 0; s < N; ++s) by_label[s == SINK ? -1 : in.label[s]].push_back(s);
+        int at = 0;
+        for (auto& kv : by_label) {
+            int b = static_cast<int>(bbeg.size());
+            bbeg.push_back(at);
+            for (int s : kv.second) { perm[at] = s; pos[s] = at; blk[s] = b; ++at; }
+            bend.push_back(at);
+            bmark.push_back(0);
+        }
+    }
+    std::vector<char> in_work(bbeg.size(), 1);
+    std::vector<int> work;
+    for (size_t b = 0; b < bbeg.size(); ++b) work.push_back(static_cast<int>(b));
+    std::vector<int> touched, snapshot;
+    while (!work.empty()) {
+        int A = work.back(); work.pop_back();
+        in_work[A] = 0;
+        snapshot.assign(perm.begin() + bbeg[A], perm.begin() + bend[A]);
+        for (int c = 0; c < K; ++c) {
+            touched.clear();
+            for (int t : snapshot) {
+                for (int k = inv_off[c][t]; k < inv_off[c][t + 1]; ++k) {
+                    int s = inv[c][k];
+                    int b = blk[s];
+                    int i = pos[s], j = bbeg[b] + bmark[b];
+                    if (i < j) continue;  // already marked
+                    if (bmark[b] == 0) touched.push_back(b);
+                    int other = perm[j];
+                    perm[i] = other; pos[other] = i;
+                    perm[j] = s; pos[s] = j;
+                    bmark[b]++;
+                }
+            }
+            for (int b : touched) {
+                int m = bmark[b], size = bend[b] - bbeg[b];
+                bmark[b] = 0;
+                if (m == size) continue;
+                int nb = static_cast<int>(bbeg.size());
+                if (m <= size - m) {  // marked front part becomes the new block
+                    bbeg.push_back(bbeg[b]); bend.push_back(bbeg[b] + m);
+                    bbeg[b] += m;
+                } else {              // unmarked back part becomes the new block
+                    bbeg.push_back(bbeg[b] + m); bend.push_back(bend[b]);
+                    bend[b] = bbeg[b] + m;
+                }
+                bmark.push_back(0);
+                for (int i = bbeg[nb]; i < bend[nb]; ++i) blk[perm[i]] = nb;
+                in_work.push_back(1);
+                work.push_back(nb);  // nb is the smaller half; if b is queued both halves are now queued
+                (void)in_work;
+            }
+        }
+    }
+    // liveness on the quotient: blocks that can reach an accepting block
+    const int B = static_cast<int>(bbeg.size());
+    std::vector<std::vector<int>> rev(B);
+    std::vector<int> rep(B);
+    for (int b = 0; b < B; ++b) rep[b] = perm[bbeg[b]];
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < K; ++c) rev[blk[nx(rep[b], c)]].push_back(b);
+    std::vector<char> live(B, 0);
+    std::vector<int> st;
+    for (int b = 0; b < B; ++b) if (rep[b] != SINK && blk[rep[b]] == b && in.label[rep[b]] >= 0) { live[b] = 1; st.push_back(b); }
+    while (!st.empty()) {
+        int b = st.back(); st.pop_back();
+        for (int pb : rev[b]) if (!live[pb]) { live[pb] = 1; st.push_back(pb); }
+    }
+    // renumber reachable live blocks breadth-first from the start block
+    Dfa out;
+    out.ncls = K;
+    std::vector<int> id(B, -1), order;
+    id[blk[0]] = 0; order.push_back(blk[0]);
+    for (size_t i = 0; i < order.size(); ++i) {
+        int b = order[i];
+        for (int c = 0; c < K; ++c) {
+            int tb = blk[nx(rep[b], c)];
+            if (!live[tb]) { out.next.push_back(-1); continue; }
+            if (id[tb] < 0) { id[tb] = static_cast<int>(order.size()); order.push_back(tb); }
+            out.next.push_back(id[tb]);
+        }
+        out.label.push_back(rep[b] == SINK ? -1 : in.label[rep[b]]);
+    }
+    out.n = static_cast<int>(order.size());
+    return out;
+}
+
+// ---------------------------------------------------------------------------
+// Product of the per-extraction DFAs; label = id of the accept set
+// ---------------------------------------------------------------------------
+struct PairVecHash {
+    size_t operator()(const std::vector<std::pair<int, int>>& v) const {
+        size_t h = 0xcbf29ce484222325ull;
+        for (auto& e : v) { h = (h ^ (static_cast<size_t>(e.first) * 0x9E3779B97F4A7C15ull + e.second)) * 0x100000001b3ull; }
+        return h;
+    }
+};
+
+Dfa product(const std::vector<Dfa>& parts, int ncls, std::vector<std::vector<int32_t>>& accept_sets) {
+    typedef std::vector<std::pair<int, int>> Tuple;
+    Dfa d;
+    d.ncls = ncls;
+    std::unordered_map<Tuple, int, PairVecHash> index;
+    std::vector<Tuple> queue;
+    std::map<std::vector<int32_t>, int> set_index;
+    Tuple init;
+    for (size_t k = 0; k < parts.size(); ++k) init.push_back({static_cast<int>(k), 0});
+    index.emplace(init, 0);
+    queue.push_back(init);
+    for (size_t head = 0; head < queue.size(); ++head) {
+        if (queue.size() > DFA_LIMIT) throw GxError(GX_E_LIMIT, "product automaton too large");
+        const Tuple cur = queue[head];
+        std::vector<int32_t> acc;
+        for (auto& e : cur) if (parts[e.first].label[e.second] >= 0) acc.push_back(e.first);
+        if (acc.empty()) d.label.push_back(-1);
+        else {
+            auto it = set_index.find(acc);
+            if (it == set_index.end()) { it = set_index.emplace(acc, static_cast<int>(accept_sets.size())).first; accept_sets.push_back(acc); }
+            d.label.push_back(it->second);
+        }
+        for (int c = 0; c < ncls; ++c) {
+            Tuple nxt;
+            for (auto& e : cur) {
+                int t = parts[e.first].next[static_cast<size_t>(e.second) * ncls + c];
+                if (t >= 0) nxt.push_back({e.first, t});
+            }
+            if (nxt.empty()) { d.next.push_back(-1); continue; }
+            auto it = index.find(nxt);
+            if (it == index.end()) { it = index.emplace(nxt, static_cast<int>(queue.size())).first; queue.push_back(nxt); }
+            d.next.push_back(it->second);
+        }
+    }
+    d.n = static_cast<int>(queue.size());
+    return d;
+}
+
+// ---------------------------------------------------------------------------
+// Tagged DFA (one lookahead symbol, leftmost-greedy thread priority)
+// ---------------------------------------------------------------------------
+// A state is an ordered list of threads.  Thread order is backtracking
+// priority: the first thread standing on MATCH when the input ends is the
+// path java.util.regex's backtracker would have returned.  Each thread knows,
+// per tag, which register holds the tag's value (or NIL), plus the set of tags
+// it crossed since the last consumed symbol ("pending"); pending tags are
+// written with the current position by the NEXT transition (or by the final
+// step at end of input).
+const int MAX_TAGS = 64;
+const int TDFA_STATE_LIMIT = 60000;
+const int16_t R_NIL = -1, R_NEW = -2;
+
+struct Thread {
+    int pc;
+    uint64_t pending;
+    std::vector<int16_t> reg;  // per tag: register id, R_NIL, or (while building) R_NEW
+    bool operator==(const Thread& o) const { return pc == o.pc && pending == o.pending && reg == o.reg; }
+    bool operator<(const Thread& o) const {
+        if (pc != o.pc) return pc < o.pc;
+        if (pending != o.pending) return pending < o.pending;
+        return reg < o.reg;
+    }
+};
+typedef std::vector<Thread> TState;
+
+struct OpListPool {
+    std::map<std::vector<uint16_t>, int> index;
+    std::vector<std::vector<uint16_t>> lists;
+    OpListPool() { lists.emplace_back(); index.emplace(lists[0], 0); }
+    int intern(const std::vector<uint16_t>& l) {
+        auto it = index.find(l);
+        if (it != index.end()) return it->second;
+        if (lists.size() >= 65535) throw GxError(GX_E_LIMIT, "too many distinct capture programs");
+        int id = static_cast<int>(lists.size());
+        index.emplace(l, id);
+        lists.push_back(l);
+        return id;
+    }
+};
+
+class TdfaBuilder {
+public:
+    TdfaBuilder(const Prog& p, const Classes& C, OpListPool& ops, std::vector<uint16_t>& fin_tags)
+        : p_(p), C_(C), ops_(ops), fin_tags_(fin_tags), ntags_(2 * p.ngroups) {
+        if (ntags_ > MAX_TAGS) throw GxError(GX_E_LIMIT, "more than 32 capture groups in one extraction");
+        pool_.resize(ntags_);
+    }
+
+    RuleTables build() {
+        RuleTables R;
+        R.n_groups = p_.ngroups;
+        seen_.assign(p_.code.size(), 0);
+        TState init;
+        {
+            Thread seed;
+            seed.pc = 0; seed.pending = 0; seed.reg.assign(ntags_, R_NIL);
+            std::vector<Thread> seeds{seed};
+            init = close(seeds);
+        }
+        add_state(init);
+        for (size_t i = 0; i < states_.size(); ++i) {
+            for (int c = 0; c < C_.ncls; ++c) {
+                const TState cur = states_[i];  // copy: states_ may grow
+                uint32_t w = step(cur, c);
+                trans_.push_back(w);
+            }
+        }
+        // append the absorbing dead state
+        const int dead = static_cast<int>(states_.size());
+        R.n_states = dead + 1;
+        R.dead = dead;
+        R.trans.resize(static_cast<size_t>(R.n_states) * C_.ncls);
+        for (size_t i = 0; i < trans_.size(); ++i) {
+            uint32_t w = trans_[i];
+            R.trans[i] = (w == DEAD_MARK) ? static_cast<uint32_t>(dead) : w;
+        }
+        for (int c = 0; c < C_.ncls; ++c) R.trans[static_cast<size_t>(dead) * C_.ncls + c] = static_cast<uint32_t>(dead);
+        R.fin.assign(R.n_states, -1);
+        for (int s = 0; s < dead; ++s) R.fin[s] = final_of(states_[s]);
+        R.n_regs = nregs_;
+        return R;
+    }
+
+private:
+    static const uint32_t DEAD_MARK = 0xFFFFFFFFu;
+    const Prog& p_;
+    const Classes& C_;
+    OpListPool& ops_;
+    std::vector<uint16_t>& fin_tags_;
+    int ntags_;
+    int nregs_ = 0;
+    std::vector<std::vector<int>> pool_;  // per tag: global register ids in allocation order
+    std::vector<TState> states_;
+    std::map<TState, int> exact_;
+    std::map<std::vector<std::pair<int, uint64_t>>, std::vector<int>> by_shape_;
+    std::vector<uint32_t> trans_;
+    std::vector<char> seen_;
+
+    int pool_reg(int tag, size_t idx) {
+        while (pool_[tag].size() <= idx) {
+            if (nregs_ >= 0x7FF0) throw GxError(GX_E_LIMIT, "capture automaton needs too many registers");
+            pool_[tag].push_back(nregs_++);
+        }
+        return pool_[tag][idx];
+    }
+
+    // Ordered epsilon-closure of a list of seed threads (highest priority first).
+    TState close(const std::vector<Thread>& seeds) {
+        TState out;
+        std::fill(seen_.begin(), seen_.end(), 0);
+        std::vector<std::pair<int, uint64_t>> stack;
+        for (const Thread& seed : seeds) {
+            stack.clear();
+            stack.push_back({seed.pc, seed.pending});
+            while (!stack.empty()) {
+                auto top = stack.back(); stack.pop_back();
+                int q = top.first;
+                if (seen_[q]) continue;
+                seen_[q] = 1;
+                const Inst& in = p_.code[q];
+                switch (in.op) {
+                case Inst::CHAR: case Inst::MATCH: {
+                    Thread t;
+                    t.pc = q; t.pending = top.second; t.reg = seed.reg;
+                    // a pending tag's old value is dead: the next step overwrites it
+                    for (int g = 0; g < ntags_; ++g) if ((t.pending >> g) & 1) t.reg[g] = R_NIL;
+                    out.push_back(std::move(t));
+                    break;
+                }
+                case Inst::SPLIT: stack.push_back({in.y, top.second}); stack.push_back({in.x, top.second}); break;
+                case Inst::JMP: stack.push_back({in.x, top.second}); break;
+                case Inst::TAG: stack.push_back({q + 1, top.second | (1ull << in.x)}); break;
+                case Inst::FAIL: break;
+                }
+            }
+        }
+        return out;
+    }
+
+    std::vector<std::pair<int, uint64_t>> shape_of(const TState& s) const {
+        std::vector<std::pair<int, uint64_t>> k;
+        for (auto& t : s) {
+            uint64_t nil = 0;
+            for (int g = 0; g < ntags_; ++g) if (t.reg[g] == R_NIL) nil |= 1ull << g;
+            k.push_back({t.pc, t.pending});
+            k.push_back({-1, nil});
+        }
+        return k;
+    }
+
+    int add_state(const TState& s) {
+        if (static_cast<int>(states_.size()) >= TDFA_STATE_LIMIT) throw GxError(GX_E_LIMIT, "capture automaton too large");
+        int id = static_cast<int>(states_.size());
+        states_.push_back(s);
+        exact_.emplace(s, id);
+        by_shape_[shape_of(s)].push_back(id);
+        return id;
+    }
+
+    // Sequentialise a set of parallel moves dst <- src (src may be GX_SRC_POS).
+    std::vector<uint16_t> order_moves(std::vector<std::pair<int, int>> moves) {
+        std::vector<uint16_t> out;
+        // drop no-ops
+        moves.erase(std::remove_if(moves.begin(), moves.end(), [](const std::pair<int, int>& m) { return m.first == m.second; }), moves.end());
+        while (!moves.empty()) {
+            bool progress = false;
+            for (size_t i = 0; i < moves.size(); ++i) {
+                int dst = moves[i].first;
+                bool blocked = false;
+                for (size_t j = 0; j < moves.size(); ++j)
+                    if (j != i && moves[j].second == dst) { blocked = true; break; }
+                if (blocked) continue;
+                out.push_back(static_cast<uint16_t>(dst));
+                out.push_back(moves[i].second < 0 ? static_cast<uint16_t>(GX_SRC_POS) : static_cast<uint16_t>(moves[i].second));
+                moves.erase(moves.begin() + i);
+                progress = true;
+                break;
+            }
+            if (progress) continue;
+            // only cycles remain: break one with a scratch register
+            if (scratch_ < 0) scratch_ = nregs_++;
+            int src = moves[0].second;
+            out.push_back(static_cast<uint16_t>(scratch_));
+            out.push_back(static_cast<uint16_t>(src));
+            for (auto& m : moves) if (m.second == src) m.second = scratch_;
+        }
+        return out;
+    }
+    int scratch_ = -1;
+
+    uint32_t step(const TState& cur, int cls) {
+        std::vector<Thread> seeds;
+        uint64_t new_tags = 0;
+        for (const Thread& t : cur) {
+            const Inst& in = p_.code[t.pc];
+            if (in.op != Inst::CHAR || !C_.set_has(in.x, cls)) continue;
+            Thread s;
+            s.pc = t.pc + 1; s.pending = 0; s.reg = t.reg;
+            for (int g = 0; g < ntags_; ++g) if ((t.pending >> g) & 1) s.reg[g] = R_NEW;
+            seeds.push_back(std::move(s));
+        }
+        if (seeds.empty()) return DEAD_MARK;
+        TState nxt = close(seeds);
+        if (nxt.empty()) return DEAD_MARK;
+        // choose a concrete register for every tag written by this transition:
+        // the lowest register of the tag's pool that no surviving thread still reads
+        std::vector<int> new_reg(ntags_, -1);
+        for (int g = 0; g < ntags_; ++g) {
+            bool used = false;
+            for (auto& t : nxt) if (t.reg[g] == R_NEW) { used = true; break; }
+            if (!used) continue;
+            new_tags |= 1ull << g;
+            for (size_t idx = 0;; ++idx) {
+                int r = pool_reg(g, idx);
+                bool busy = false;
+                for (auto& t : nxt) if (t.reg[g] == r) { busy = true; break; }
+                if (!busy) { new_reg[g] = r; break; }
+            }
+        }
+        TState resolved = nxt;
+        for (auto& t : resolved) for (int g = 0; g < ntags_; ++g) if (t.reg[g] == R_NEW) t.reg[g] = static_cast<int16_t>(new_reg[g]);
+        std::vector<std::pair<int, int>> moves;
+        auto it = exact_.find(resolved);
+        int target = -1;
+        if (it != exact_.end()) {
+            target = it->second;
+            for (int g = 0; g < ntags_; ++g) if (new_reg[g] >= 0) moves.push_back({new_reg[g], -1});
+        } else {
+            // an existing state of the same shape whose registers can be produced from ours by moves?
+            auto sh = by_shape_.find(shape_of(resolved));
+            if (sh != by_shape_.end()) {
+                for (int cand : sh->second) {
+                    const TState& z = states_[cand];
+                    std::map<int, int> src_of;  // z register -> our register
+                    bool ok = true;
+                    for (size_t j = 0; j < z.size() && ok; ++j)
+                        for (int g = 0; g < ntags_ && ok; ++g) {
+                            int rz = z[j].reg[g], ry = resolved[j].reg[g];
+                            if (rz == R_NIL) continue;
+                            auto f = src_of.find(rz);
+                            if (f == src_of.end()) src_of[rz] = ry;
+                            else if (f->second != ry) ok = false;
+                        }
+                    if (!ok) continue;
+                    target = cand;
+                    for (auto& kv : src_of) {
+                        bool is_new = false;
+                        for (int g = 0; g < ntags_; ++g) if (new_reg[g] == kv.second) is_new = true;
+                        moves.push_back({kv.first, is_new ? -1 : kv.second});
+                    }
+                    break;
+                }
+            }
+            if (target < 0) {
+                target = add_state(resolved);
+                for (int g = 0; g < ntags_; ++g) if (new_reg[g] >= 0) moves.push_back({new_reg[g], -1});
+            }
+        }
+        (void)new_tags;
+        if (target > 0xFFFE) throw GxError(GX_E_LIMIT, "capture automaton too large");
+        int op_id = ops_.intern(order_moves(moves));
+        return static_cast<uint32_t>(target) | (static_cast<uint32_t>(op_id) << 16);
+    }
+
+    int32_t final_of(const TState& s) {
+        for (const Thread& t : s) {
+            if (p_.code[t.pc].op != Inst::MATCH) continue;
+            int32_t off = static_cast<int32_t>(fin_tags_.size());
+            for (int g = 0; g < ntags_; ++g) {
+                if ((t.pending >> g) & 1) fin_tags_.push_back(GX_SRC_POS);
+                else if (t.reg[g] == R_NIL) fin_tags_.push_back(GX_SRC_NIL);
+                else fin_tags_.push_back(static_cast<uint16_t>(t.reg[g]));
+            }
+            if (ntags_ == 0) { fin_tags_.push_back(GX_SRC_NIL); }  // keep offsets distinct from -1
+            return off;
+        }
+        return -1;
+    }
+};
+
+}  // namespace
+
+// ===========================================================================
+Tables compile_tables(const std::vector<ustr>& automaton_rx, const std::vector<ustr>* jdk_rx) {
+    const size_t n = automaton_rx.size();
+    if (n == 0) throw GxError(GX_E_ARG, "no extractions");
+    if (jdk_rx && jdk_rx->size() != n) throw GxError(GX_E_ARG, "pattern list sizes differ");
+    SetPool pool;
+    std::vector<Prog> aprog(n), jprog(jdk_rx ? n : 0);
+    for (size_t k = 0; k < n; ++k) {
+        try {
+            Parsed pa = parse_automaton_dialect(automaton_rx[k]);
+            ProgBuilder(aprog[k], pool, false).build(pa.root.get());
+        } catch (GxError& e) {
+            // message shape of core/autom/PolyMatcher.java:79-81
+            throw GxError(e.code, std::string("Invalid regexp, ") + e.what() + ", source: " + u16_to_utf8(automaton_rx[k]));
+        }
+        if (jdk_rx) {
+            try {
+                Parsed pj = parse_jdk_dialect((*jdk_rx)[k]);
+                jprog[k].ngroups = pj.ngroups;
+                ProgBuilder(jprog[k], pool, true).build(pj.root.get());
+            } catch (GxError& e) {
+                throw GxError(e.code, std::string("Invalid capture regexp for extraction #") + std::to_string(k) + ": " + e.what() +
+                                          ", source: " + u16_to_utf8((*jdk_rx)[k]));
+            }
+        }
+    }
+    Classes C = build_classes(pool);
+
+    Tables T;
+    T.n_rules = static_cast<int>(n);
+    T.ncls = C.ncls;
+    T.has_capture = jdk_rx != nullptr;
+    // class maps
+    {
+        size_t bi = 0;
+        for (int c = 0; c < 256; ++c) {
+            while (bi + 1 < C.bounds.size() && C.bounds[bi + 1] <= c) ++bi;
+            T.cls256[c] = static_cast<uint8_t>(C.bound_cls[bi]);
+        }
+        // classes are numbered by first occurrence in ascending code-unit order, so byte classes fit 8 bits
+        T.hi_lo.push_back(256);
+        {
+            size_t i = std::upper_bound(C.bounds.begin(), C.bounds.end(), 256) - C.bounds.begin() - 1;
+            T.hi_cls.push_back(static_cast<uint16_t>(C.bound_cls[i]));
+            for (++i; i < C.bounds.size(); ++i) {
+                if (static_cast<uint16_t>(C.bound_cls[i]) == T.hi_cls.back()) continue;
+                T.hi_lo.push_back(static_cast<uint16_t>(C.bounds[i]));
+                T.hi_cls.push_back(static_cast<uint16_t>(C.bound_cls[i]));
+            }
+        }
+    }
+    // match automaton
+    {
+        std::vector<Dfa> parts;
+        parts.reserve(n);
+        for (size_t k = 0; k < n; ++k) parts.push_back(minimize(subset_construct(aprog[k], C)));
+        std::vector<std::vector<int32_t>> accept_sets;
+        Dfa prod = minimize(product(parts, C.ncls, accept_sets));
+        const int dead = prod.n;
+        T.m_states = prod.n + 1;
+        T.m_dead = dead;
+        T.m_next.resize(static_cast<size_t>(T.m_states) * C.ncls);
+        for (size_t i = 0; i < prod.next.size(); ++i) T.m_next[i] = prod.next[i] < 0 ? dead : prod.next[i];
+        for (int c = 0; c < C.ncls; ++c) T.m_next[static_cast<size_t>(dead) * C.ncls + c] = dead;
+        T.m_accept_off.push_back(0);
+        for (int s = 0; s < T.m_states; ++s) {
+            int lab = s == dead ? -1 : prod.label[s];
+            if (lab < 0) T.m_accept_first.push_back(-1);
+            else {
+                T.m_accept_first.push_back(accept_sets[lab][0]);
+                for (int32_t k : accept_sets[lab]) T.m_accept_list.push_back(k);
+            }
+            T.m_accept_off.push_back(static_cast<uint32_t>(T.m_accept_list.size()));
+        }
+    }
+    // capture automata
+    if (jdk_rx) {
+        OpListPool ops;
+        for (size_t k = 0; k < n; ++k) {
+            TdfaBuilder b(jprog[k], C, ops, T.fin_tags);
+            T.rules.push_back(b.build());
+            T.max_groups = std::max(T.max_groups, T.rules.back().n_groups);
+        }
+        T.ops_off.push_back(0);
+        for (auto& l : ops.lists) {
+            T.ops.insert(T.ops.end(), l.begin(), l.end());
+            T.ops_off.push_back(static_cast<uint32_t>(T.ops.size() / 2));
+        }
+    } else {
+        T.ops_off = {0, 0};
+    }
+    return T;
+}
+
+// ===========================================================================
+// Blob: one relocatable little-endian image (the RCCL broadcast payload)
+// ===========================================================================
+namespace {
+const uint32_t BLOB_MAGIC = 0x31425847u;  // "GXB1"
+const uint32_t BLOB_VERSION = 1;
+
+struct Writer {
+    std::vector<uint8_t> buf;
+    template <typename V> void pod(const V& v) { const uint8_t* p = reinterpret_cast<const uint8_t*>(&v); buf.insert(buf.end(), p, p + sizeof(V)); }
+    template <typename V> void vec(const std::vector<V>& v) {
+        pod<uint64_t>(v.size());
+        const uint8_t* p = reinterpret_cast<const uint8_t*>(v.data());
+        buf.insert(buf.end(), p, p + v.size() * sizeof(V));
+        while (buf.size() % 8) buf.push_back(0);
+    }
+};
+struct Reader {
+    const uint8_t* p; size_t left;
+    template <typename V> V pod() {
+        if (left < sizeof(V)) throw GxError(GX_E_ARG, "truncated table blob");
+        V v; memcpy(&v, p, sizeof(V)); p += sizeof(V); left -= sizeof(V); return v;
+    }
+    template <typename V> std::vector<V> vec() {
+        uint64_t n = pod<uint64_t>();
+        if (n > left / sizeof(V)) throw GxError(GX_E_ARG, "truncated table blob");
+        std::vector<V> v(n);
+        memcpy(v.data(), p, n * sizeof(V));
+        size_t adv = n * sizeof(V);
+        adv = (adv + 7) & ~size_t(7);
+        if (adv > left) adv = left;
+        p += adv; left -= adv;
+        return v;
+    }
+};
+}  // namespace
+
+std::vector<uint8_t> pack_blob(const Tables& t) {
+    Writer w;
+    w.pod(BLOB_MAGIC); w.pod(BLOB_VERSION);
+    w.pod<int32_t>(t.n_rules); w.pod<int32_t>(t.ncls); w.pod<int32_t>(t.max_groups); w.pod<int32_t>(t.has_capture ? 1 : 0);
+    w.pod<int32_t>(t.m_states); w.pod<int32_t>(t.m_dead);
+    std::vector<uint8_t> c256(t.cls256, t.cls256 + 256);
+    w.vec(c256); w.vec(t.hi_lo); w.vec(t.hi_cls);
+    w.vec(t.m_next); w.vec(t.m_accept_first); w.vec(t.m_accept_off); w.vec(t.m_accept_list);
+    w.pod<uint64_t>(t.rules.size());
+    for (auto& r : t.rules) {
+        w.pod<int32_t>(r.n_groups); w.pod<int32_t>(r.n_states); w.pod<int32_t>(r.n_regs); w.pod<int32_t>(r.dead);
+        w.vec(r.trans); w.vec(r.fin);
+    }
+    w.vec(t.ops_off); w.vec(t.ops); w.vec(t.fin_tags);
+    return w.buf;
+}
+
+Tables unpack_blob(const void* data, size_t size) {
+    Reader r{static_cast<const uint8_t*>(data), size};
+    if (r.pod<uint32_t>() != BLOB_MAGIC) throw GxError(GX_E_ARG, "not a gorp_amd table blob");
+    if (r.pod<uint32_t>() != BLOB_VERSION) throw GxError(GX_E_ARG, "table blob version mismatch");
+    Tables t;
+    t.n_rules = r.pod<int32_t>(); t.ncls = r.pod<int32_t>(); t.max_groups = r.pod<int32_t>(); t.has_capture = r.pod<int32_t>() != 0;
+    t.m_states = r.pod<int32_t>(); t.m_dead = r.pod<int32_t>();
+    std::vector<uint8_t> c256 = r.vec<uint8_t>();
+    if (c256.size() != 256) throw GxError(GX_E_ARG, "corrupt table blob");
+    memcpy(t.cls256, c256.data(), 256);
+    t.hi_lo = r.vec<uint16_t>(); t.hi_cls = r.vec<uint16_t>();
+    t.m_next = r.vec<uint32_t>(); t.m_accept_first = r.vec<int32_t>(); t.m_accept_off = r.vec<uint32_t>(); t.m_accept_list = r.vec<int32_t>();
+    uint64_t nr = r.pod<uint64_t>();
+    if (nr > 1000000) throw GxError(GX_E_ARG, "corrupt table blob");
+    for (uint64_t i = 0; i < nr; ++i) {
+        RuleTables rt;
+        rt.n_groups = r.pod<int32_t>(); rt.n_states = r.pod<int32_t>(); rt.n_regs = r.pod<int32_t>(); rt.dead = r.pod<int32_t>();
+        rt.trans = r.vec<uint32_t>(); rt.fin = r.vec<int32_t>();
+        if (rt.trans.size() != static_cast<size_t>(rt.n_states) * t.ncls || rt.fin.size() != static_cast<size_t>(rt.n_states))
+            throw GxError(GX_E_ARG, "corrupt table blob");
+        t.rules.push_back(std::move(rt));
+    }
+    t.ops_off = r.vec<uint32_t>(); t.ops = r.vec<uint16_t>(); t.fin_tags = r.vec<uint16_t>();
+    if (t.m_next.size() != static_cast<size_t>(t.m_states) * t.ncls || t.hi_lo.size() != t.hi_cls.size() || t.hi_lo.empty())
+        throw GxError(GX_E_ARG, "corrupt table blob");
+    return t;
+}
+
+}  // namespace gx

@@ -1,0 +1,52 @@
+// gx_device.hpp -- device-side view of the compiled tables + kernel launch entry points.
+#pragma once
+#include <cstdint>
+#include <hip/hip_runtime.h>
+
+namespace gx {
+
+// All pointers are device pointers into ONE allocation (the uploaded table image).
+struct GxDev {
+    // class maps
+    const uint8_t* cls256;       // [256]
+    const uint16_t* hi_lo;       // [n_hi] ascending lower bounds, hi_lo[0] == 256
+    const uint16_t* hi_cls;      // [n_hi]
+    int32_t n_hi;
+    int32_t ncls;
+    // match automaton (total; m_dead absorbing)
+    const uint16_t* m_next16;    // [m_states * ncls] when m_states <= 65536, else null
+    const uint32_t* m_next32;    // [m_states * ncls] otherwise
+    const int32_t* m_accept_first;  // [m_states]
+    int32_t m_states;
+    int32_t m_dead;
+    // capture automata, all extractions concatenated
+    const uint32_t* c_trans;     // rule k at c_trans + c_trans_off[k], [n_states_k * ncls]
+    const uint32_t* c_trans_off; // [n_rules]
+    const int32_t* c_fin;        // rule k at c_fin + c_fin_off[k], [n_states_k]
+    const uint32_t* c_fin_off;   // [n_rules]
+    const int32_t* c_ngroups;    // [n_rules]
+    const uint32_t* ops_off;     // [n_oplists + 1] in (dst,src) pairs
+    const uint16_t* ops;         // pairs
+    const uint16_t* fin_tags;
+    int32_t n_rules;
+    int32_t max_groups;
+    int32_t max_regs;
+    int32_t has_capture;
+};
+
+struct GxBatch {
+    const void* data;      // uint8_t (Latin-1) or uint16_t (UTF-16) code units
+    const void* offsets;   // uint32_t or uint64_t [n + 1], in code units
+    uint64_t n;
+    int32_t* match_id;     // [n]
+    int32_t* caps;         // [n * 2 * max_groups] or null when match_only
+    int32_t* state_out;    // optional [n]: final match-automaton state (for PolyMatcher.match)
+    int32_t wide;          // 1: data is uint16_t
+    int32_t offsets64;
+    int32_t match_only;
+};
+
+// Generic kernel: any table size, any line length, bytes or UTF-16.
+hipError_t launch_extract_generic(const GxDev& dev, const GxBatch& b, hipStream_t stream);
+
+}  // namespace gx

@@ -1,0 +1,374 @@
+"""Host-side mirror of the reference's API for the match-and-extract path,
+bound to libgorp_hip.so through its C ABI (include/gorp_hip.h).
+
+Names and behaviour follow salesforce/gorp (core/ = gorp-core/src/main/java/com/salesforce/gorp/):
+    Gorp.construct / extract / extractSafe     core/Gorp.java:50-92,145-186
+    PolyMatcher.create / match                 core/autom/PolyMatcher.java:64-70,123-133
+    ExtractionResult.getId / asMap             core/ExtractionResult.java:39-88
+    ExtractionException                        core/ExtractionException.java:15-34
+    RegexHelper.*                              core/util/RegexHelper.java
+plus what the reference lacks and the GPU needs: extract_batch over a CSR
+byte buffer.  All matching runs in the HIP kernels; nothing here computes a
+match on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+class GorpError(Exception):
+    """A C-ABI call failed (code = GX_E_*)."""
+
+    def __init__(self, code, message):
+        super().__init__("%s (gx error %d)" % (message, code))
+        self.code = code
+        self.message = message
+
+
+class DefinitionParseException(GorpError):
+    """core/DefinitionParseException.java -- definition could not be turned into tables."""
+
+
+class ExtractionException(Exception):
+    """core/ExtractionException.java:15-34 -- the multi-matcher chose an extraction whose
+    generated regexp then failed to match (core/Gorp.java:173-177)."""
+
+    def __init__(self, input_line, message):
+        super().__init__(message)
+        self.input = input_line
+
+    def getInput(self):
+        return self.input
+
+
+def _check(rc):
+    if rc != N.GX_OK:
+        raise GorpError(rc, N.last_error())
+
+
+# ---------------------------------------------------------------------------
+# RegexHelper (core/util/RegexHelper.java) -- implemented in gx_host.cpp
+# ---------------------------------------------------------------------------
+def _string_call(fn, text):
+    raw = text.encode("utf-8")
+    cap = 8 * len(raw) + 64
+    buf = C.create_string_buffer(cap)
+    n = C.c_size_t(0)
+    rc = fn(raw, buf, cap, C.byref(n))
+    if rc == N.GX_E_ARG and n.value + 1 > cap:
+        cap = n.value + 1
+        buf = C.create_string_buffer(cap)
+        rc = fn(raw, buf, cap, C.byref(n))
+    if rc == N.GX_E_REGEX_SYNTAX:
+        raise ValueError(N.last_error())  # IllegalArgumentException in the reference
+    _check(rc)
+    return buf.raw[:n.value].decode("utf-8")
+
+
+class RegexHelper:
+    @staticmethod
+    def quoteLiteralAsRegexp(text):
+        return _string_call(N.lib().gx_quote_literal_as_regexp, text)
+
+    @staticmethod
+    def massageRegexpForAutomaton(pattern):
+        return _string_call(N.lib().gx_massage_regexp_for_automaton, pattern)
+
+    @staticmethod
+    def massageRegexpForJDK(pattern):
+        return _string_call(N.lib().gx_massage_regexp_for_jdk, pattern)
+
+
+# ---------------------------------------------------------------------------
+# Flattened extraction -> the two regex strings (Gorp._buildExtractor, core/Gorp.java:94-129)
+# ---------------------------------------------------------------------------
+class FlattenedExtraction:
+    """core/model/FlattenedExtraction.java:18-36: a named, ordered piece list.
+
+    pieces: ["text", s] (LiteralText) | ["pattern", s] (LiteralPattern)
+            | ["extractor", name, [pieces]] (ExtractorExpression)
+    """
+
+    def __init__(self, name, pieces, append=None):
+        self.name = name
+        self.pieces = pieces
+        self.append = append
+
+    def build(self):
+        autom, jdk, names = [], [], []
+
+        def walk(p):
+            kind = p[0]
+            if kind == "pattern":
+                autom.append(RegexHelper.massageRegexpForAutomaton(p[1]))
+                jdk.append(RegexHelper.massageRegexpForJDK(p[1]))
+            elif kind == "text":
+                q = RegexHelper.quoteLiteralAsRegexp(p[1])
+                autom.append(q)
+                jdk.append(q)
+            elif kind == "extractor":
+                names.append(p[1])
+                autom.append("(")
+                jdk.append("(")
+                for c in p[2]:
+                    walk(c)
+                autom.append(")")
+                jdk.append(")")
+            else:
+                raise DefinitionParseException(N.GX_E_ARG, "Unrecognized DefPiece in FlattenedExtraction: %r" % (kind,))
+
+        for p in self.pieces:
+            walk(p)
+        return "".join(autom), "".join(jdk), names
+
+
+class CookedExtraction:
+    """core/model/CookedExtraction.java:18-66 (data only; matching happens on the GPU)."""
+
+    def __init__(self, index, name, regexp_source, extractor_names, append=None):
+        self._index = index
+        self._name = name
+        self._regexpSource = regexp_source
+        self._extractorNames = list(extractor_names)
+        self._append = append
+
+    def getName(self):
+        return self._name
+
+    def getExtra(self):
+        return self._append
+
+    def getRegexpSource(self):
+        return self._regexpSource
+
+    def getRegexpDesc(self):
+        return self._regexpSource
+
+
+class ExtractionResult:
+    """core/ExtractionResult.java:18-89."""
+
+    def __init__(self, id_, input_line, extraction, names, values):
+        self._id = id_
+        self._input = input_line
+        self._matchedExtraction = extraction
+        self._extractorNames = names
+        self._extractedValues = values
+
+    def getId(self):
+        return self._id
+
+    def getInput(self):
+        return self._input
+
+    def getMatchedExtraction(self):
+        return self._matchedExtraction
+
+    def getExtra(self):
+        return self._matchedExtraction.getExtra()
+
+    def asMap(self, idAs=None):
+        result = {}
+        if idAs is not None:
+            result[idAs] = self._id
+        for n, v in zip(self._extractorNames, self._extractedValues):
+            result[n] = v
+        extra = self.getExtra()
+        if extra:
+            result.update(extra)
+        return result
+
+
+def _utf16(s):
+    raw = s.encode("utf-16-le", "surrogatepass")
+    return np.frombuffer(raw, dtype=np.uint16).copy() if raw else np.zeros(0, np.uint16)
+
+
+class _Handle:
+    """Owns a gx_handle*."""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                N.lib().gx_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def _create(autom, jdk, flags):
+    L = N.lib()
+    n = len(autom)
+    A = (C.c_char_p * n)(*[s.encode("utf-8") for s in autom])
+    J = None
+    if jdk is not None:
+        J = (C.c_char_p * n)(*[s.encode("utf-8") for s in jdk])
+    h = C.c_void_p()
+    rc = L.gx_create_from_patterns(A, J, n, flags, C.byref(h))
+    if rc in (N.GX_E_REGEX_SYNTAX, N.GX_E_UNSUPPORTED_CONSTRUCT, N.GX_E_LIMIT):
+        # core/Gorp.java:84-90
+        raise DefinitionParseException(rc, "Internal error: problem with PolyMatcher construction: " + N.last_error())
+    _check(rc)
+    return _Handle(h)
+
+
+class PolyMatcher:
+    """core/autom/PolyMatcher.java: multi-pattern matcher over one product DFA."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @staticmethod
+    def create(*patterns, host_only=False):
+        if len(patterns) == 1 and isinstance(patterns[0], (list, tuple)):
+            patterns = list(patterns[0])
+        return PolyMatcher(_create(list(patterns), None, N.GX_CREATE_HOST_ONLY if host_only else 0))
+
+    def match(self, s):
+        """Indexes of all patterns that matched (ascending); [] when none."""
+        a = _utf16(s)
+        cap = max(1, N.lib().gx_num_extractions(self._h.ptr))
+        out = np.zeros(cap, np.int32)
+        c = N.lib().gx_match_one_utf16(self._h.ptr, a.ctypes.data if len(a) else None, len(a), out.ctypes.data, cap)
+        if c < 0:
+            raise GorpError(-c, N.last_error())
+        return out[:c].tolist()
+
+    def stat(self, which):
+        return N.lib().gx_stat(self._h.ptr, which)
+
+
+class Gorp:
+    """core/Gorp.java: processor built from a definition; extract() one line or a batch."""
+
+    def __init__(self, handle, extractions):
+        self._h = handle
+        self._matcher = PolyMatcher(handle)
+        self._extractions = extractions
+
+    # -- construction ------------------------------------------------------
+    @staticmethod
+    def construct(extractions, host_only=False):
+        """extractions: list of FlattenedExtraction (what CookedDefinitions.getExtractions() yields)."""
+        autom, jdk, cooked = [], [], []
+        for i, ext in enumerate(extractions):
+            a, j, names = ext.build()
+            autom.append(a)
+            jdk.append(j)
+            cooked.append(CookedExtraction(i, ext.name, j, names, ext.append))
+        h = _create(autom, jdk, N.GX_CREATE_HOST_ONLY if host_only else 0)
+        return Gorp(h, cooked)
+
+    @staticmethod
+    def from_blob(blob, extractions, host_only=False):
+        """Rebuild on another rank from the broadcast table blob (no recompilation)."""
+        b = np.frombuffer(bytes(blob), dtype=np.uint8)
+        h = C.c_void_p()
+        _check(N.lib().gx_create_from_blob(b.ctypes.data, len(b), N.GX_CREATE_HOST_ONLY if host_only else 0, C.byref(h)))
+        return Gorp(_Handle(h), extractions)
+
+    def blob(self):
+        n = N.lib().gx_blob_size(self._h.ptr)
+        out = np.zeros(n, np.uint8)
+        _check(N.lib().gx_blob_copy(self._h.ptr, out.ctypes.data, n))
+        return out
+
+    def getExtractions(self):
+        return list(self._extractions)
+
+    def getMatcher(self):
+        return self._matcher
+
+    @property
+    def max_groups(self):
+        return N.lib().gx_max_groups(self._h.ptr)
+
+    def num_groups(self, k):
+        return N.lib().gx_num_groups(self._h.ptr, k)
+
+    def stat(self, which):
+        return N.lib().gx_stat(self._h.ptr, which)
+
+    # -- per-line API (core/Gorp.java:145-186) -------------------------------
+    def extract(self, input_line, allowFallbacks=False):
+        a = _utf16(input_line)
+        mid = C.c_int32(0)
+        caps = np.full(max(2 * self.max_groups, 1), -1, np.int32)
+        _check(N.lib().gx_extract_one_utf16(self._h.ptr, a.ctypes.data if len(a) else None, len(a), C.byref(mid),
+                                            caps.ctypes.data))
+        return self._materialise(input_line, mid.value, caps, allowFallbacks)
+
+    def extractSafe(self, input_line):
+        return self.extract(input_line, True)
+
+    def _materialise(self, line, match_id, caps, allowFallbacks=False):
+        if match_id == -1:
+            return None
+        if match_id <= -2:
+            k = -2 - match_id
+            extr = self._extractions[k]
+            if allowFallbacks:
+                return None  # core/Gorp.java:178-185 retries the same extraction, then gives up
+            raise ExtractionException(line, "Internal error: high-level match for extraction #%d (%s) failed to match "
+                                            "generated regexp: %s" % (k, extr.getName(), extr.getRegexpDesc()))
+        extr = self._extractions[match_id]
+        values = []
+        for g in range(self.num_groups(match_id)):
+            b, e = int(caps[2 * g]), int(caps[2 * g + 1])
+            values.append(None if b < 0 else line[b:e])
+        return ExtractionResult(extr.getName(), line, extr, extr._extractorNames, values)
+
+    # -- batch API -----------------------------------------------------------
+    def extract_batch(self, data, offsets, match_only=False):
+        """Host buffers: data uint8[total], offsets uint32|uint64[n+1].
+        Returns (match_id int32[n], caps int32[n, 2*max_groups])."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets)
+        if offsets.dtype not in (np.uint32, np.uint64):
+            raise TypeError("offsets must be uint32 or uint64")
+        n = len(offsets) - 1
+        mid = np.zeros(n, np.int32)
+        caps = np.full((n, 2 * self.max_groups), -1, np.int32)
+        o = N.gx_batch_opts()
+        o.struct_size = C.sizeof(N.gx_batch_opts)
+        o.offsets64 = 1 if offsets.dtype == np.uint64 else 0
+        o.match_only = 1 if match_only else 0
+        _check(N.lib().gx_extract_batch(self._h.ptr, data.ctypes.data if data.size else None, offsets.ctypes.data, n,
+                                        mid.ctypes.data, caps.ctypes.data if caps.size else None, C.byref(o)))
+        return mid, caps
+
+    def extract_batch_device(self, data_ptr, offsets_ptr, n, match_id_ptr, caps_ptr, offsets64=False, match_only=False,
+                             stream=None, no_sync=False):
+        """Device pointers (ints), e.g. torch tensors' data_ptr(); results stay in HBM."""
+        o = N.gx_batch_opts()
+        o.struct_size = C.sizeof(N.gx_batch_opts)
+        o.device_pointers = 1
+        o.offsets64 = 1 if offsets64 else 0
+        o.match_only = 1 if match_only else 0
+        o.stream = stream
+        o.no_sync = 1 if no_sync else 0
+        _check(N.lib().gx_extract_batch(self._h.ptr, data_ptr, offsets_ptr, n, match_id_ptr, caps_ptr, C.byref(o)))
+
+    def results(self, data, offsets, match_id, caps, safe=False):
+        """Materialise ExtractionResult objects (or None) for a finished batch."""
+        out = []
+        raw = bytes(np.ascontiguousarray(data, dtype=np.uint8))
+        for i in range(len(match_id)):
+            line = raw[int(offsets[i]):int(offsets[i + 1])].decode("latin-1")
+            out.append(self._materialise(line, int(match_id[i]), caps[i], safe))
+        return out
+
+
+def lines_to_csr(lines, offsets_dtype=np.uint32):
+    """Pack str/bytes lines into the CSR byte buffer gx_extract_batch consumes (Latin-1)."""
+    bs = [ln if isinstance(ln, (bytes, bytearray)) else ln.encode("latin-1") for ln in lines]
+    offsets = np.zeros(len(bs) + 1, dtype=offsets_dtype)
+    if bs:
+        offsets[1:] = np.cumsum([len(b) for b in bs])
+    data = np.frombuffer(b"".join(bs), dtype=np.uint8) if bs else np.zeros(0, np.uint8)
+    return data, offsets

@@ -1,0 +1,130 @@
+/*
+ * gorp_hip.h -- C ABI of libgorp_hip.so: the MI355X (gfx950) implementation of
+ * Gorp's combined-DFA match-and-extract hot path.
+ *
+ * Every entry point cites the reference interface it replaces
+ * (core/ = gorp-core/src/main/java/com/salesforce/gorp/ in salesforce/gorp).
+ * Plain pointers and sizes only; no exceptions cross this boundary; no torch
+ * types.  INTEGRATION.md shows the JNI stub that binds these from Java.
+ *
+ * Per-line results are DATA, never call failures:
+ *   match_id >= 0      index of the first-declared matching extraction
+ *                      (matchIndexes[0], core/Gorp.java:166)
+ *   match_id == -1     no extraction matches -> Gorp.extract returns null
+ *                      (core/Gorp.java:162-164)
+ *   match_id == -2-k   the DFA chose extraction k but its capture regex
+ *                      rejected the line -> ExtractionException
+ *                      (core/Gorp.java:173-177); extractSafe returns null
+ *                      for exactly these lines (core/Gorp.java:178-185)
+ * Captures: for g < gx_num_groups(h, match_id): caps[2g], caps[2g+1] are the
+ * begin/end offsets of Matcher.group(g+1) in code units from the start of the
+ * line (core/jdkre/JDKRegexpCookedExtraction.java:51-59); -1,-1 when group()
+ * would return null.  Slots beyond the matched extraction's group count are -1.
+ */
+#ifndef GORP_HIP_H
+#define GORP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gx_handle gx_handle;
+
+/* Error classes (return values; 0 = OK).  Reference conventions they stand for:
+ * invalid regex -> IllegalArgumentException "Invalid regexp, ..." wrapped in
+ * DefinitionParseException (core/autom/PolyMatcher.java:79-81, core/Gorp.java:84-90). */
+enum {
+    GX_OK = 0,
+    GX_E_REGEX_SYNTAX = 1,         /* a pattern does not parse in its dialect */
+    GX_E_UNSUPPORTED_CONSTRUCT = 2,/* valid java.util.regex, outside Gorp's documented subset (README.md:209-224) */
+    GX_E_DEVICE = 3,               /* no gfx950 device / HIP runtime failure */
+    GX_E_ARG = 4,                  /* bad argument */
+    GX_E_NOMEM = 5,
+    GX_E_LIMIT = 6                 /* automaton exceeds a compile-time limit */
+};
+
+/* gx_create flags */
+#define GX_CREATE_HOST_ONLY 1u     /* compile tables only; do not touch the GPU (used to build the
+                                      blob that is broadcast to other ranks, and by CPU-only checks) */
+
+/* Replaces Gorp.construct's per-extraction back half (core/Gorp.java:58-92):
+ * PolyMatcher.create(automatonInputs) (core/autom/PolyMatcher.java:64-84 ->
+ * Automata.construct, core/autom/Automata.java:57-124) and
+ * ExtractionCooker.cook -> Pattern.compile (core/jdkre/JDKRegexpExtractionCooker.java:20-26).
+ * Inputs are exactly the two regex strings per extraction that
+ * Gorp._buildExtractor emits (core/Gorp.java:94-129), UTF-8 encoded.
+ * jdk_rx may be NULL: matcher only (PolyMatcher.create), no captures.
+ * The group count of extraction k is read from jdk_rx[k] itself
+ * (Matcher.groupCount()). */
+int gx_create_from_patterns(const char* const* automaton_rx, const char* const* jdk_rx,
+                            int32_t n, uint32_t flags, gx_handle** out);
+
+/* Packed, relocatable table blob (the RCCL broadcast payload): rank 0 compiles,
+ * every rank calls gx_create_from_blob.  gx_blob_size returns the byte count;
+ * gx_blob_copy writes it to dst. */
+size_t gx_blob_size(const gx_handle* h);
+int gx_blob_copy(const gx_handle* h, void* dst, size_t cap);
+int gx_create_from_blob(const void* blob, size_t size, uint32_t flags, gx_handle** out);
+
+/* Frees host and device tables.  (Java GC in the reference.) */
+void gx_destroy(gx_handle* h);
+
+/* Introspection (Automata.size(), core/autom/Automata.java:129-131; Matcher.groupCount()). */
+int32_t gx_num_extractions(const gx_handle* h);
+int32_t gx_num_groups(const gx_handle* h, int32_t k);
+int32_t gx_max_groups(const gx_handle* h);
+/* table statistics: 0 = match-DFA states, 1 = char classes, 2 = capture-automaton states (sum),
+ * 3 = capture registers (max over extractions), 4 = blob bytes, 5 = LDS bytes the batch kernel stages */
+int64_t gx_stat(const gx_handle* h, int32_t which);
+
+typedef struct gx_batch_opts {
+    uint32_t struct_size;      /* = sizeof(gx_batch_opts) */
+    uint32_t device_pointers;  /* 1: bytes/offsets/match_id/caps are device pointers on the handle's device */
+    uint32_t offsets64;        /* 1: offsets are uint64_t[n+1] instead of uint32_t[n+1] */
+    uint32_t match_only;       /* 1: PolyMatcher.match only; caps may be NULL */
+    void*    stream;           /* hipStream_t to launch on (NULL = the null stream) */
+    uint32_t no_sync;          /* 1 (device pointers only): return after enqueueing */
+    uint32_t reserved;
+} gx_batch_opts;
+
+/* Replaces the per-line loop "for each line: Gorp.extract(line)"
+ * (core/Gorp.java:145-186 -> PolyMatcher.match core/autom/PolyMatcher.java:123-133
+ *  -> JDKRegexpCookedExtraction.match core/jdkre/JDKRegexpCookedExtraction.java:36-59)
+ * over a batch held as one CSR byte buffer: line i = bytes[offsets[i] .. offsets[i+1]),
+ * each byte one Latin-1 code unit.  match_id[n]; caps[n * 2*gx_max_groups(h)] dense. */
+int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, uint64_t n,
+                     int32_t* match_id, int32_t* caps, const gx_batch_opts* opts);
+
+/* Replaces one Gorp.extract(String) call (core/Gorp.java:145-147): s is the
+ * String's UTF-16 code units.  Runs on the GPU like the batch path.
+ * caps has 2*gx_max_groups(h) slots. */
+int gx_extract_one_utf16(gx_handle* h, const uint16_t* s, int32_t len, int32_t* match_id, int32_t* caps);
+
+/* Replaces PolyMatcher.match(CharSequence) -> int[] (core/autom/PolyMatcher.java:123-133):
+ * all matching extraction indexes, ascending.  Returns the count (<= cap written), or <0 on error. */
+int gx_match_one_utf16(gx_handle* h, const uint16_t* s, int32_t len, int32_t* indexes, int32_t cap);
+
+/* Definition-time string rewriting that defines the two regex dialects
+ * (RegexHelper.quoteLiteralAsRegexp core/util/RegexHelper.java:20-70,
+ *  massageRegexpForAutomaton :79-182, massageRegexpForJDK :210-237), used by
+ * Gorp._buildExtractor (core/Gorp.java:94-129) to produce the inputs of
+ * gx_create_from_patterns.  UTF-8 in, NUL-terminated UTF-8 out; *out_len
+ * receives the length without the NUL.  GX_E_ARG with *out_len set when cap
+ * is too small; GX_E_REGEX_SYNTAX for the IllegalArgumentException cases. */
+int gx_quote_literal_as_regexp(const char* text, char* out, size_t cap, size_t* out_len);
+int gx_massage_regexp_for_automaton(const char* pattern, char* out, size_t cap, size_t* out_len);
+int gx_massage_regexp_for_jdk(const char* pattern, char* out, size_t cap, size_t* out_len);
+
+/* Thread-local message for the last failing call on this thread. */
+const char* gx_last_error(void);
+
+/* Device selection for subsequently created handles (default: current HIP device). */
+int gx_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GORP_HIP_H */

@@ -1,0 +1,295 @@
+"""CPU-side parity of the table compiler (gorp_amd/csrc/gx_compile.cpp) with the
+oracle: the tables are decoded from the blob and walked by tests/blob_interp.py
+(the kernel contract), so these tests need no GPU.  The -m gpu tests repeat the
+comparisons through the real kernels."""
+import random
+
+import numpy as np
+import pytest
+
+from blob_interp import Blob, units_of
+from gorp_amd import _native as N
+from gorp_amd.gorp import DefinitionParseException, FlattenedExtraction, Gorp, PolyMatcher, RegexHelper
+from oracle import oracle as O
+
+
+def product_blob(autom, jdk):
+    from gorp_amd.gorp import _create
+    h = _create(autom, jdk, N.GX_CREATE_HOST_ONLY)
+    n = N.lib().gx_blob_size(h.ptr)
+    out = np.zeros(n, np.uint8)
+    assert N.lib().gx_blob_copy(h.ptr, out.ctypes.data, n) == 0
+    return Blob(out)
+
+
+def both(extractions):
+    fl = [FlattenedExtraction(e["name"], e["pieces"], e.get("append")) for e in extractions]
+    built = [f.build() for f in fl]
+    autom, jdk = [b[0] for b in built], [b[1] for b in built]
+    # the product's RegexHelper must agree with the oracle's restatement of it
+    for e, b in zip(extractions, built):
+        assert O.build_regex_strings(e["pieces"]) == b
+    return product_blob(autom, jdk), O.OracleGorp(autom, jdk)
+
+
+def test_regexhelper_golden(golden):
+    g = golden("regexhelper")
+    for src, exp in g["quoteLiteralAsRegexp"]:
+        assert RegexHelper.quoteLiteralAsRegexp(src) == exp
+    for src, exp in g["massageRegexpForAutomaton"]:
+        assert RegexHelper.massageRegexpForAutomaton(src) == exp
+    for src, exp in g["massageRegexpForJDK"]:
+        assert RegexHelper.massageRegexpForJDK(src) == exp
+    with pytest.raises(ValueError, match="Unrecognized backslash escape"):
+        RegexHelper.massageRegexpForAutomaton("\\q")
+    with pytest.raises(ValueError, match="negated character class"):
+        RegexHelper.massageRegexpForAutomaton("[a\\S]")
+    assert RegexHelper.massageRegexpForAutomaton("[\\Sx]") == "[^ \b\f\n\r\tx]"
+
+
+def test_regexhelper_random_vs_oracle():
+    rng = random.Random(7)
+    alpha = list("ab \t.()[]\\{}|*?+$^<>\"&dswDSWntrfbx0-") + ["\\d", "\\s", "\\w", "\\S", "[", "]", "\\n", "\\.", "\\\\"]
+    for _ in range(3000):
+        s = "".join(rng.choice(alpha) for _ in range(rng.randint(0, 12)))
+        assert RegexHelper.quoteLiteralAsRegexp(s) == O.quote_literal_as_regexp(s)
+        assert RegexHelper.massageRegexpForJDK(s) == O.massage_regexp_for_jdk(s)
+        try:
+            exp = O.massage_regexp_for_automaton(s)
+        except O.OracleError:
+            with pytest.raises(ValueError):
+                RegexHelper.massageRegexpForAutomaton(s)
+            continue
+        assert RegexHelper.massageRegexpForAutomaton(s) == exp
+
+
+def test_multipattern_golden(golden):
+    g = golden("multipattern")
+    b = product_blob(g["patterns"], None)
+    for c in g["cases"]:
+        assert b.match(units_of(c["input"])) == c["match"]
+
+
+def test_polymatch_golden(golden):
+    for t in golden("polymatch")["tests"]:
+        b, orc = both(t["extractions"])
+        for c in t["cases"]:
+            assert b.match(units_of(c["input"])) == c["match"]
+
+
+def test_full_extraction_golden(golden):
+    for t in golden("full_extraction")["tests"]:
+        b, orc = both(t["extractions"])
+        for c in t["cases"]:
+            got = b.extract(units_of(c["input"]))
+            assert got == orc.extract(c["input"]), (t["name"], c["input"])
+            assert got[0] >= 0
+            if "id" in c:
+                assert t["extractions"][got[0]]["name"] == c["id"]
+
+
+def test_configs_golden(golden):
+    g = golden("configs")
+    for key in ("simple_grp", "readme_3"):
+        b, orc = both(g[key]["extractions"])
+        for c in g[key]["cases"]:
+            u = units_of(c["input"])
+            assert b.match(u) == c["match"]
+            assert b.extract(u) == orc.extract(c["input"])
+
+
+def test_blob_roundtrip(golden):
+    g = golden("configs")["readme_3"]
+    fl = [FlattenedExtraction(e["name"], e["pieces"]) for e in g["extractions"]]
+    gorp = Gorp.construct(fl, host_only=True)
+    blob = gorp.blob()
+    again = Gorp.from_blob(blob, gorp.getExtractions(), host_only=True)
+    assert bytes(again.blob()) == bytes(blob)
+    assert gorp.max_groups == 4 and again.num_groups(2) == 4
+
+
+def test_minimised_match_automaton_is_no_larger_than_reference(golden):
+    # product states + 1 dead state <= reference product states + 1 (SURVEY Appendix B sizes)
+    g = golden("configs")["readme_3"]
+    b, orc = both(g["extractions"])
+    assert b.m_states <= orc.num_states + 1
+    assert b.ncls <= orc.num_points
+
+
+def test_errors_are_loud():
+    with pytest.raises(DefinitionParseException, match="Invalid regexp"):
+        PolyMatcher.create("a)", host_only=True)
+    with pytest.raises(DefinitionParseException, match="Invalid regexp"):
+        PolyMatcher.create("(a", host_only=True)
+    with pytest.raises(DefinitionParseException, match="Invalid regexp"):
+        PolyMatcher.create('"abc', host_only=True)
+    from gorp_amd.gorp import _create
+    for rx in ["a\\b", "(?=a)a", "a++", "\\1", "[a&&b]", "\\p{L}", "^a", "a$"]:
+        with pytest.raises(DefinitionParseException) as ei:
+            _create(["a"], [rx], N.GX_CREATE_HOST_ONLY)
+        assert ei.value.code == N.GX_E_UNSUPPORTED_CONSTRUCT, rx
+    for rx in ["*a", "(a", "a)", "[a", "a{2,1}", "[b-a]", "a{"]:
+        with pytest.raises(DefinitionParseException) as ei:
+            _create(["a"], [rx], N.GX_CREATE_HOST_ONLY)
+        assert ei.value.code == N.GX_E_REGEX_SYNTAX, rx
+
+
+def test_no_device_means_error_not_fallback():
+    """Without a GPU the extract entry points must fail; they never compute on the CPU."""
+    if N.lib().gx_device_count() > 0:
+        pytest.skip("a GPU is present")
+    g = Gorp.construct([FlattenedExtraction("r", [["text", "a"]])], host_only=True)
+    from gorp_amd.gorp import GorpError
+    with pytest.raises(GorpError) as ei:
+        g.extract("a")
+    assert ei.value.code == N.GX_E_DEVICE
+    with pytest.raises(GorpError) as ei:
+        g.extract_batch(np.zeros(1, np.uint8), np.array([0, 1], np.uint32))
+    assert ei.value.code == N.GX_E_DEVICE
+    with pytest.raises(GorpError) as ei:
+        Gorp.construct([FlattenedExtraction("r", [["text", "a"]])])
+    assert ei.value.code == N.GX_E_DEVICE
+
+
+# ---------------------------------------------------------------------------
+# Randomised differential tests
+# ---------------------------------------------------------------------------
+ATOMS = ["a", "b", "c", "x", "\\d", "\\w", "\\S", "\\s", "[ \\t]", "[a-c]", "[^ab]", ".", "\\.", "=", ":", "\\[", "\\]",
+         "\\D", "\\W", "[\\d.]", "[^\\s\"]", "\\\""]
+QUANT = ["", "", "", "+", "*", "?", "{2}", "{1,3}", "{2,}"]
+LAZY = ["+?", "*?", "??", "{1,2}?"]
+ALPHA = "abcx019 =:.[]\"\t_-Z\r\x0b\x08\n"
+
+
+def gen_pattern(rng, depth=0, lazy=False):
+    """A Gorp *pattern* (pre-massage): both dialect strings are derived from it."""
+    n = rng.randint(1, 3)
+    parts = []
+    q = QUANT + (LAZY if lazy else [])
+    for _ in range(n):
+        r = rng.random()
+        if depth < 1 and r < 0.2:
+            parts.append("(" + gen_pattern(rng, depth + 1, lazy) + ")" + rng.choice(q))
+        elif depth < 1 and r < 0.3:
+            parts.append("(" + gen_pattern(rng, depth + 1, lazy) + "|" + gen_pattern(rng, depth + 1, lazy) + ")")
+        else:
+            parts.append(rng.choice(ATOMS) + rng.choice(q))
+    return "".join(parts)
+
+
+def gen_pieces(rng, depth=0):
+    out = []
+    for _ in range(rng.randint(1, 3)):
+        r = rng.random()
+        if r < 0.35:
+            out.append(["text", rng.choice(["a", "b ", " c", "x=", ": ", "[", "] ", ".", "  ", "a b", "\"", "GET", "k"])])
+        elif r < 0.7 or depth >= 1:
+            out.append(["pattern", gen_pattern(rng)])
+        else:
+            out.append(["extractor", "g%d" % rng.randint(0, 999), gen_pieces(rng, depth + 1)])
+    return out
+
+
+def gen_line(rng):
+    return "".join(rng.choice(ALPHA) for _ in range(rng.randint(0, 12)))
+
+
+def sample_from_match_automaton(b, rng, max_len=24):
+    """A random line that the product's match automaton accepts (or nearly): a random
+    walk over live transitions, using one representative byte per class."""
+    reps = {}
+    for c in range(256):
+        reps.setdefault(int(b.cls256[c]), []).append(c)
+    st, out = 0, []
+    for _ in range(max_len):
+        if b.m_accept_first[st] >= 0 and rng.random() < 0.3:
+            break
+        live = [c for c in range(b.ncls) if c in reps and b.m_next[st, c] != b.m_dead]
+        if not live:
+            break
+        c = rng.choice(live)
+        printable = [x for x in reps[c] if 32 <= x < 127]
+        out.append(rng.choice(printable if printable and rng.random() < 0.9 else reps[c]))
+        st = int(b.m_next[st, c])
+    return bytes(out).decode("latin-1")
+
+
+def test_random_definitions_match_and_extract():
+    """Whole-path differential: random flattened extractions (1-4 per definition)."""
+    rng = random.Random(1234)
+    n_defs = n_lines = n_hits = n_exc = 0
+    while n_defs < 600:
+        exts = [{"name": "e%d" % i, "pieces": gen_pieces(rng)} for i in range(rng.randint(1, 4))]
+        try:
+            b, orc = both(exts)
+        except (ValueError, O.OracleError, DefinitionParseException):
+            continue
+        n_defs += 1
+        lines = [gen_line(rng) for _ in range(10)] + [sample_from_match_automaton(b, rng) for _ in range(20)]
+        for ln in lines:
+            u = units_of(ln)
+            assert b.match(u) == orc.match(ln), (exts, ln)
+            got, exp = b.extract(u), orc.extract(ln)
+            assert got == exp, (exts, ln, got, exp)
+            n_lines += 1
+            n_hits += got[0] >= 0
+            n_exc += got[0] <= -2
+    assert n_lines == 600 * 30
+    assert n_hits > 3000
+
+
+def _sample_accepted(rng, rx, tries=40):
+    """Random strings accepted by a JDK-dialect regex (found by rejection on the oracle)."""
+    out = []
+    for _ in range(tries):
+        s = "".join(rng.choice("abcx019 =:.\"\t_") for _ in range(rng.randint(0, 9)))
+        if O.jdk_matches(rx, s) is not None:
+            out.append(s)
+    return out
+
+
+def test_random_raw_regex_pairs_capture_parity():
+    """Capture automaton vs the backtracking restatement on raw JDK-dialect regexes,
+    including lazy quantifiers and groups under quantifiers/alternations."""
+    rng = random.Random(99)
+    checked = matched = 0
+    n = 0
+    while n < 1500:
+        pat = gen_pattern(rng, lazy=True)
+        jdk = pat  # capturing groups kept as written
+        autom = ".*"  # let every line through the matcher so the capture automaton decides
+        try:
+            b = product_blob([autom], [jdk])
+            orc = O.OracleGorp([autom], [jdk])
+        except (O.OracleError, DefinitionParseException):
+            continue
+        n += 1
+        lines = [gen_line(rng) for _ in range(15)] + _sample_accepted(rng, jdk)
+        for ln in lines:
+            got, exp = b.extract(units_of(ln)), orc.extract(ln)
+            assert got == exp, (jdk, ln, got, exp)
+            checked += 1
+            matched += got[0] >= 0
+    assert checked > 20000 and matched > 2000
+
+
+def test_utf16_lines_and_high_classes():
+    autom = ["[^a]+", "é+", "中.", "[Ā-࿿]x"]
+    b = product_blob(autom, None)
+    orc = O.OracleGorp(autom)
+    for ln in ["éé", "中x", "Āx", "࿿x", "ကx", "a", "", "￿", "😀"]:
+        assert b.match(units_of(ln)) == orc.match(ln), ln
+
+
+def test_dialect_disagreement_yields_exception_code():
+    for pieces, line, want in [
+        ([["text", "a"], ["extractor", "x", [["pattern", ".*"]]], ["text", "b"]], "a\rb", -2),
+        ([["text", "k"], ["pattern", "\\s"], ["text", "v"]], "k\x08v", -2),
+        ([["text", "k"], ["pattern", "\\s"], ["text", "v"]], "k\x0bv", -1),
+        ([["pattern", "[(]x"]], "(x", 0),
+        ([["pattern", "[(]x"]], "?x", -1),
+    ]:
+        b, orc = both([{"name": "r", "pieces": pieces}])
+        got = b.extract(units_of(line))
+        assert got == orc.extract(line)
+        assert got[0] == want, (pieces, line)
