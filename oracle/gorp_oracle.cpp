@@ -569,8 +569,15 @@ static Dfa regex_to_min_dfa(const ustr& pattern) {
     }
     // Moore partition refinement; class 0 = dead (incl. implicit sink)
     std::vector<int> cls(N);
-    for (int s = 0; s < N; ++s) cls[s] = !live[s] ? 0 : (acc[s] ? 2 : 1);
-    int ncls = 3;
+    bool anyAcc = false, anyNon = false;
+    for (int s = 0; s < N; ++s) {
+        cls[s] = !live[s] ? 0 : (acc[s] ? 2 : 1);
+        if (cls[s] == 2) anyAcc = true;
+        if (cls[s] == 1) anyNon = true;
+    }
+    // number of classes actually in use (dead class always counted); refinement
+    // is monotone, so an unchanged count means an unchanged partition
+    int ncls = 1 + (anyAcc ? 1 : 0) + (anyNon ? 1 : 0);
     for (;;) {
         std::map<std::vector<int>, int> sigidx;
         std::vector<int> ncl(N);

@@ -178,3 +178,14 @@ def test_brics_quirks():
         O.OracleGorp(["a)"])
     with pytest.raises(O.OracleError, match="Invalid regexp"):
         O.OracleGorp(["(a"])
+
+
+def test_minimisation_regression_all_accepting_states():
+    """Found by the compiler-vs-oracle differential test: with no live non-accepting
+    state the refinement loop must not stop after one round."""
+    g = O.OracleGorp(["(\\[[^ ]?)*([^0-9]*)"])
+    assert g.match("__[9\t") == []
+    assert g.match("[9x") == [0]
+    assert g.match("_x") == [0]
+    assert g.match("[9[8__") == [0]
+    assert g.match("[98") == []
