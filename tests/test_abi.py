@@ -1,0 +1,49 @@
+"""The C-ABI library loads and exports every symbol include/gorp_hip.h declares
+(no compute calls: this runs without a GPU)."""
+import os
+import re
+
+from gorp_amd import _native as N
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "gorp_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    names = declared_functions()
+    assert len(names) >= 14
+    L = N.lib()
+    for n in names:
+        assert getattr(L, n) is not None, n
+    assert sorted(N.SYMBOLS) == names
+
+
+def test_library_is_in_tree():
+    assert os.path.dirname(N.LIB_PATH) == os.path.join(ROOT, "gorp_amd")
+
+
+def test_error_string_and_arg_checks():
+    import ctypes as C
+    L = N.lib()
+    h = C.c_void_p()
+    assert L.gx_create_from_patterns(None, None, 0, N.GX_CREATE_HOST_ONLY, C.byref(h)) == N.GX_E_ARG
+    assert "bad argument" in N.last_error()
+    assert L.gx_create_from_blob(b"xxxxxxxxxxxxxxxx", 16, N.GX_CREATE_HOST_ONLY, C.byref(h)) == N.GX_E_ARG
+    assert "blob" in N.last_error()
+    assert L.gx_num_extractions(None) == 0 and L.gx_max_groups(None) == 0 and L.gx_blob_size(None) == 0
+    L.gx_destroy(None)
+
+
+def test_product_does_not_touch_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use oracle/."""
+    pkg = os.path.join(ROOT, "gorp_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in src.lower(), os.path.join(dirpath, f)

@@ -1,0 +1,273 @@
+"""Parity tests proper: the HIP kernels, called through the C ABI, against the
+oracle on the same seeded inputs.  Integer/byte/index work: the bar is bit-exact."""
+import random
+
+import numpy as np
+import pytest
+
+from gorp_amd import _native as N
+from gorp_amd import workloads as W
+from gorp_amd.gorp import (ExtractionException, FlattenedExtraction, Gorp, PolyMatcher, lines_to_csr)
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_for(definition):
+    built = [e.build() for e in definition]
+    return O.OracleGorp([b[0] for b in built], [b[1] for b in built])
+
+
+def fl(extractions):
+    return [FlattenedExtraction(e["name"], e["pieces"], e.get("append")) for e in extractions]
+
+
+def check_batch(gorp, orc, lines):
+    data, offsets = lines_to_csr(lines)
+    mid, caps = gorp.extract_batch(data, offsets)
+    omid, ocaps = orc.extract_batch(data, offsets)
+    assert np.array_equal(mid, omid)
+    assert np.array_equal(caps, ocaps)
+    m2, _ = gorp.extract_batch(data, offsets, match_only=True)
+    assert np.array_equal(m2, orc.extract_batch(data, offsets, match_only=True)[0])
+    return mid, caps
+
+
+def test_library_is_native_and_sees_gpu():
+    assert N.lib().gx_device_count() >= 1
+
+
+def test_multipattern_golden(golden):
+    g = golden("multipattern")
+    pm = PolyMatcher.create(*g["patterns"])
+    for c in g["cases"]:
+        assert pm.match(c["input"]) == c["match"]
+
+
+def test_polymatch_golden(golden):
+    for t in golden("polymatch")["tests"]:
+        gorp = Gorp.construct(fl(t["extractions"]))
+        for c in t["cases"]:
+            assert gorp.getMatcher().match(c["input"]) == c["match"]
+
+
+def test_full_extraction_golden(golden):
+    """Reads like test/FullExtractionTest.java: extract(), getId(), asMap()."""
+    for t in golden("full_extraction")["tests"]:
+        gorp = Gorp.construct(fl(t["extractions"]))
+        for c in t["cases"]:
+            result = gorp.extract(c["input"])
+            assert result is not None
+            if c.get("not_null"):
+                continue
+            assert result.getId() == c["id"]
+            stuff = result.asMap(c.get("id_as"))
+            for k, v in c["map"].items():
+                assert stuff[k] == v
+            if "map_size" in c:
+                assert len(stuff) == c["map_size"]
+
+
+def test_configs_golden(golden):
+    g = golden("configs")
+    for key in ("simple_grp", "readme_3"):
+        gorp = Gorp.construct(fl(g[key]["extractions"]))
+        for c in g[key]["cases"]:
+            assert gorp.getMatcher().match(c["input"]) == c["match"]
+            r = gorp.extract(c["input"])
+            if not c["match"]:
+                assert r is None
+            else:
+                assert r.getId() == c["id"]
+                for k, v in c.get("map", {}).items():
+                    assert r.asMap()[k] == v
+
+
+def test_append_extras_in_asmap(golden):
+    t = [x for x in golden("full_extraction")["tests"] if x["name"] == "testFull"][0]
+    gorp = Gorp.construct(fl(t["extractions"]))
+    r = gorp.extract(t["cases"][1]["input"])
+    m = r.asMap("id")
+    assert m["id"] == "sshdMatch" and m["service"] == "ssh" and m["logType"] == "security"
+    assert list(m)[0] == "id" and list(m)[-1] == "serviceType"  # id first, extras last (ExtractionResult.java:79-87)
+
+
+def test_exception_null_and_safe():
+    gorp = Gorp.construct([FlattenedExtraction("r", [["text", "a"], ["extractor", "x", [["pattern", ".*"]]], ["text", "b"]])])
+    assert gorp.extract("a--b").asMap() == {"x": "--"}
+    assert gorp.extract("zzz") is None
+    with pytest.raises(ExtractionException, match=r"Internal error: high-level match for extraction #0 \(r\) failed"):
+        gorp.extract("a\rb")
+    assert gorp.extractSafe("a\rb") is None
+    data, offsets = lines_to_csr(["a--b", "zzz", "a\rb", "", "ab"])
+    mid, caps = gorp.extract_batch(data, offsets)
+    assert mid.tolist() == [0, -1, -2, -1, 0]
+    assert caps.tolist() == [[1, 3], [-1, -1], [-1, -1], [-1, -1], [1, 1]]
+
+
+def test_config1_simple_grp_10k():
+    definition = W.simple_grp_definition()
+    gorp, orc = Gorp.construct(definition), oracle_for(definition)
+    lines = W.simple_grp_lines(10000, seed=1)
+    mid, caps = check_batch(gorp, orc, lines)
+    frac = (mid == 0).mean()
+    assert 0.75 < frac < 0.85
+    res = gorp.results(*lines_to_csr(lines[:50]), mid[:50], caps[:50])
+    for ln, r in zip(lines[:50], res):
+        if r is not None:
+            assert r.getId() == "sampleMatch" and r.asMap()["authStatus"] == "Accepted"
+            assert ln.startswith("<") and r.asMap()["eventTimeStamp"] in ln
+
+
+def test_config2_readme3_200k_bit_exact():
+    definition = W.readme3_definition()
+    gorp, orc = Gorp.construct(definition), oracle_for(definition)
+    data, offsets, cat = W.readme3_lines(200000, seed=2)
+    d, o = data.numpy(), offsets.numpy()
+    mid, caps = gorp.extract_batch(d, o)
+    omid, ocaps = orc.extract_batch(d, o, nthreads=8)
+    assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+    assert np.array_equal(mid, cat.numpy().astype(np.int32))
+
+
+def test_config2_full_size_properties():
+    """10 M x 200 B on the device: size-independent checks + an oracle-checked sample."""
+    import torch
+    definition = W.readme3_definition()
+    gorp, orc = Gorp.construct(definition), oracle_for(definition)
+    n = 10_000_000
+    data, offsets, cat = W.readme3_lines(n, seed=2, device="cuda")
+    mid = torch.empty(n, dtype=torch.int32, device="cuda")
+    caps = torch.empty((n, 8), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    # the generator knows the answer for every line
+    assert torch.equal(mid, cat.to(torch.int32))
+    ok = mid >= 0
+    c = caps[ok]
+    assert bool((c[:, 0] == 1).all()) and bool((c[:, 1] == 10).all())     # timestamp = 9 digits after '['
+    assert bool((c[:, 2] == 13).all())                                      # verb starts after "]: "
+    assert bool((c[:, 7] == W.LINE_BYTES).all())                            # path runs to the end of the line
+    assert bool((c[:, 4] == c[:, 3] + 1).all()) and bool((c[:, 6] == c[:, 5] + 3).all())  # " " and "ms "
+    assert bool((caps[~ok] == -1).all())
+    # idempotence
+    mid2 = torch.empty_like(mid)
+    caps2 = torch.empty_like(caps)
+    gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, mid2.data_ptr(), caps2.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    assert torch.equal(mid, mid2) and torch.equal(caps, caps2)
+    # a strided sample against the oracle
+    idx = torch.arange(0, n, 97, device="cuda")[:100000]
+    rows = data.view(n, W.LINE_BYTES)[idx].cpu().numpy().reshape(-1)
+    so = (np.arange(len(idx) + 1) * W.LINE_BYTES).astype(np.uint32)
+    omid, ocaps = orc.extract_batch(rows, so, nthreads=8)
+    assert np.array_equal(mid[idx].cpu().numpy(), omid) and np.array_equal(caps[idx].cpu().numpy(), ocaps)
+
+
+def test_ragged_empty_and_long_lines():
+    definition = W.readme3_definition()
+    gorp, orc = Gorp.construct(definition), oracle_for(definition)
+    long_ok = "[123456789]: GET 5ms /" + "x" * 70000     # longer than 65535: positions need 32 bits
+    long_bad = long_ok + " "
+    lines = ["", "[", "[1]: GET 5ms /x", "", "[1]: PUT 5ms /x", long_ok, long_bad, "x", "[12]: HEAD 7777ms /a?b=c", ""]
+    mid, caps = check_batch(gorp, orc, lines)
+    assert mid.tolist() == [-1, -1, 1, -1, 0, 1, -1, -1, 2, -1]
+    assert caps[5].tolist()[-2:] == [21, len(long_ok)]
+    # empty batch
+    m0, c0 = gorp.extract_batch(np.zeros(0, np.uint8), np.zeros(1, np.uint32))
+    assert m0.shape == (0,) and c0.shape == (0, 8)
+    # 64-bit offsets
+    data, offsets = lines_to_csr(lines, offsets_dtype=np.uint64)
+    m64, c64 = gorp.extract_batch(data, offsets)
+    assert np.array_equal(m64, mid) and np.array_equal(c64, caps)
+
+
+def test_all_byte_values_and_latin1():
+    """Every byte value is a legal Latin-1 code unit; classes above 0x7F follow the automaton's ranges."""
+    definition = [FlattenedExtraction("hi", [["extractor", "a", [["pattern", "[\u0080-\u00ff]+"]]], ["pattern", ".*"]]),
+                  FlattenedExtraction("any", [["extractor", "all", [["pattern", ".+"]]]])]
+    gorp, orc = Gorp.construct(definition), oracle_for(definition)
+    rng = random.Random(5)
+    lines = [bytes(rng.randrange(256) for _ in range(rng.randrange(0, 40))) for _ in range(3000)]
+    lines += [bytes([b]) for b in range(256)]
+    check_batch(gorp, orc, lines)
+
+
+def test_utf16_single_line_api():
+    pm = PolyMatcher.create("[^a]+", "é+", "中.", "[Ā-࿿]x")
+    orc = O.OracleGorp(["[^a]+", "é+", "中.", "[Ā-࿿]x"])
+    for ln in ["éé", "中x", "Āx", "࿿x", "ကx", "a", "", "￿", "😀", "é" * 300]:
+        assert pm.match(ln) == orc.match(ln)
+    gorp = Gorp.construct([FlattenedExtraction("u", [["text", "k="], ["extractor", "v", [["pattern", "[^ ]+"]]]])])
+    r = gorp.extract("k=中文é")
+    assert r.asMap() == {"v": "中文é"}
+
+
+def test_device_pointer_api_and_stream():
+    import torch
+    definition = W.readme3_definition()
+    gorp, orc = Gorp.construct(definition), oracle_for(definition)
+    n = 50000
+    data, offsets, cat = W.readme3_lines(n, seed=9, device="cuda")
+    s = torch.cuda.Stream()
+    mid = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    caps = torch.full((n, 8), -7, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, mid.data_ptr(), caps.data_ptr(),
+                                  stream=s.cuda_stream, no_sync=True)
+    s.synchronize()
+    omid, ocaps = orc.extract_batch(data.cpu().numpy(), offsets.cpu().numpy(), nthreads=4)
+    assert np.array_equal(mid.cpu().numpy(), omid) and np.array_equal(caps.cpu().numpy(), ocaps)
+
+
+def test_blob_roundtrip_on_device():
+    definition = W.readme3_definition()
+    a = Gorp.construct(definition)
+    b = Gorp.from_blob(a.blob(), a.getExtractions())
+    lines = ["[1]: GET 5ms /x", "[1]: PUT 5ms /x", "nope"]
+    data, offsets = lines_to_csr(lines)
+    ma, ca = a.extract_batch(data, offsets)
+    mb, cb = b.extract_batch(data, offsets)
+    assert np.array_equal(ma, mb) and np.array_equal(ca, cb)
+
+
+def test_random_definitions_through_kernels():
+    """The CPU differential test again, through the real kernels (batched per definition)."""
+    import test_compiler_vs_oracle as TC
+    from blob_interp import Blob
+    rng = random.Random(4321)
+    n_defs = n_hits = 0
+    while n_defs < 150:
+        exts = [{"name": "e%d" % i, "pieces": TC.gen_pieces(rng)} for i in range(rng.randint(1, 4))]
+        try:
+            definition = fl(exts)
+            gorp = Gorp.construct(definition)
+            orc = oracle_for(definition)
+        except (ValueError, O.OracleError, Exception) as e:  # noqa: B014
+            if isinstance(e, AssertionError):
+                raise
+            continue
+        n_defs += 1
+        b = Blob(gorp.blob())
+        lines = [TC.gen_line(rng) for _ in range(20)] + [TC.sample_from_match_automaton(b, rng) for _ in range(44)]
+        mid, _ = check_batch(gorp, orc, lines)
+        n_hits += int((mid >= 0).sum())
+    assert n_hits > 1500
+
+
+def test_syslog_16_rules():
+    rules, meta = W.syslog_definition(16, seed=3)
+    gorp, orc = Gorp.construct(rules), oracle_for(rules)
+    data, offsets, cats = W.syslog_lines(meta, 20000, seed=3)
+    mid, caps = gorp.extract_batch(data, offsets)
+    omid, ocaps = orc.extract_batch(data, offsets, nthreads=8)
+    assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+    known = cats != -9
+    assert np.array_equal(mid[known], cats[known])
+    # mixed lengths 50-2000 B
+    data, offsets, cats = W.syslog_lines(meta, 5000, seed=4, min_len=50, max_len=2000)
+    mid, caps = gorp.extract_batch(data, offsets)
+    omid, ocaps = orc.extract_batch(data, offsets, nthreads=8)
+    assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
