@@ -31,21 +31,33 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling 6290
 
 
-def cpu_baseline(definition, data_cpu, offsets_cpu, budget_s=12.0):
+def host_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(cores, 64)
+
+
+def cpu_baseline(definition, data_cpu, offsets_cpu, budget_s=20.0):
     """The oracle (a CPU port of the reference path, not the JVM) timed on a bounded
     sample of the same lines, all host cores."""
     import numpy as np
     from oracle import oracle as O
     built = [e.build() for e in definition]
     orc = O.OracleGorp([b[0] for b in built], [b[1] for b in built])
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     n_all = len(offsets_cpu) - 1
-    # calibrate on a small slice, then size the sample for ~budget_s of wall time
-    probe = min(n_all, 20000 * cores)
+    # calibrate on a small slice, then size the sample for ~20 CPU-seconds (>= 3 s of wall time)
+    probe = min(n_all, 10000 * cores)
     t0 = time.perf_counter()
     orc.extract_batch(data_cpu, offsets_cpu[:probe + 1], nthreads=cores)
     rate = probe / max(time.perf_counter() - t0, 1e-6)
-    n = int(min(n_all, max(probe, rate * budget_s)))
+    n = int(min(n_all, max(probe, rate * max(3.0, budget_s / cores))))
     t0 = time.perf_counter()
     mid, caps = orc.extract_batch(data_cpu, offsets_cpu[:n + 1], nthreads=cores)
     dt = time.perf_counter() - t0
@@ -206,7 +218,7 @@ def main():
             "gather_ms": gather_ms,
         }
         if not args.no_cpu_baseline and world == 1:
-            sample = min(n, 4_000_000)
+            sample = min(n, 10_000_000)
             d_cpu = data[: sample * W.LINE_BYTES].cpu().numpy()
             o_cpu = offsets[: sample + 1].cpu().numpy().astype(np.uint32)
             base, omid, ocaps, ns = cpu_baseline(definition, d_cpu, o_cpu)

@@ -35,11 +35,43 @@ class gx_batch_opts(C.Structure):
         ("match_only", C.c_uint32),
         ("stream", C.c_void_p),
         ("no_sync", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("line_bytes_hint", C.c_uint32),
     ]
 
 
 _lib = None
+_hip_runtime = None
+
+
+def _load_hip_runtime():
+    """libgorp_hip.so is linked without a NEEDED libamdhip64 (see build.py): load the one
+    HIP runtime this process will use, globally, before it.  If PyTorch is installed its
+    bundled runtime is the one torch will insist on, so take that; otherwise ROCm's."""
+    global _hip_runtime
+    if _hip_runtime is not None:
+        return _hip_runtime
+    import importlib.util
+    candidates = []
+    env = os.environ.get("GORP_HIP_RUNTIME")
+    if env:
+        candidates.append(env)
+    try:
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            candidates.append(os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so"))
+    except (ImportError, ValueError):
+        pass
+    candidates += ["/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"]
+    errors = []
+    for path in candidates:
+        if os.path.isabs(path) and not os.path.exists(path):
+            continue
+        try:
+            _hip_runtime = C.CDLL(path, mode=C.RTLD_GLOBAL)
+            return _hip_runtime
+        except OSError as e:
+            errors.append("%s: %s" % (path, e))
+    raise ImportError("gorp_amd: no HIP runtime (libamdhip64) could be loaded: " + "; ".join(errors))
 
 
 def lib():
@@ -50,6 +82,7 @@ def lib():
         raise ImportError(
             "gorp_amd: %s not found. Build it with `python -m gorp_amd.build` (hipcc, gfx950). "
             "There is no CPU fallback for the extract path." % LIB_PATH)
+    _load_hip_runtime()
     L = C.CDLL(LIB_PATH)
     L.gx_create_from_patterns.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int32, C.c_uint32,
                                           C.POINTER(C.c_void_p)]

@@ -47,7 +47,11 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+    # -no-hip-rt: do not record a NEEDED entry for a particular libamdhip64.  The process
+    # must hold exactly ONE HIP runtime; PyTorch wheels bundle their own copy (different
+    # SONAME from /opt/rocm's), so the loader (gorp_amd/_native.py, or the JNI shim)
+    # loads the runtime that the rest of the process uses before loading this library.
+    cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-no-hip-rt", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

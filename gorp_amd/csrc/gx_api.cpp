@@ -51,10 +51,104 @@ struct gx_handle {
     size_t image_bytes = 0;
     GxDev dev{};
     int max_regs = 0;
+    // LDS tier (tile kernel)
+    bool tile_ok = false;
+    GxLds lds{};                 // table part of the layout; staging is sized per batch
+    std::vector<uint8_t> lds_image;
+    void* d_lds_image = nullptr;
+    int num_cus = 256;
     std::mutex mu;  // serialises host-pointer batches that share nothing else
 };
 
 namespace {
+
+const uint32_t LDS_BYTES = 163840;     // 160 KiB per CU on gfx950
+const uint32_t LDS_TABLE_BUDGET = 96 * 1024;
+
+// Longest run of ASCII byte values on which `loops(b)` holds, as lo | hi << 8 (0x00FF = none).
+template <typename F> uint16_t self_loop_interval(F loops) {
+    int best_lo = 0, best_len = 0, run_lo = 0, run = 0;
+    for (int b = 0; b < 128; ++b) {
+        if (loops(b)) { if (run == 0) run_lo = b; ++run; if (run > best_len) { best_len = run; best_lo = run_lo; } }
+        else run = 0;
+    }
+    if (best_len < 4) return 0x00FF;
+    return static_cast<uint16_t>(best_lo | ((best_lo + best_len - 1) << 8));
+}
+
+// Build the LDS-resident table image of the tile kernel (layout: GxLds).
+void build_lds_image(gx_handle* h) {
+    const Tables& T = h->T;
+    h->tile_ok = false;
+    if (T.m_states > 32767 || T.n_rules > 32767) return;
+    size_t c_states = 0;
+    for (auto& r : T.rules) c_states += r.n_states;
+    const size_t est = 256 + static_cast<size_t>(T.m_states) * T.ncls * 2 + T.m_states * 4 + c_states * (T.ncls * 4 + 6) +
+                       T.rules.size() * 8 + T.ops_off.size() * 4 + T.ops.size() * 2 + T.fin_tags.size() * 2 + 256;
+    if (est > LDS_TABLE_BUDGET) return;
+    Image img;
+    GxLds L{};
+    L.cmap = static_cast<uint32_t>(img.put(T.cls256, 256));
+    std::vector<uint16_t> m_tab(T.m_next.begin(), T.m_next.end());
+    L.m_tab = static_cast<uint32_t>(img.put(m_tab));
+    std::vector<int16_t> m_acc(T.m_accept_first.begin(), T.m_accept_first.end());
+    L.m_acc = static_cast<uint32_t>(img.put(m_acc));
+    std::vector<uint16_t> m_accel(T.m_states);
+    for (int s = 0; s < T.m_states; ++s)
+        m_accel[s] = self_loop_interval([&](int b) { return T.m_next[static_cast<size_t>(s) * T.ncls + T.cls256[b]] == static_cast<uint32_t>(s); });
+    L.m_accel = static_cast<uint32_t>(img.put(m_accel));
+    std::vector<uint32_t> c_tab, c_rule;
+    std::vector<uint16_t> c_accel;
+    std::vector<int32_t> c_fin;
+    for (auto& r : T.rules) {
+        c_rule.push_back(static_cast<uint32_t>(c_fin.size()));
+        c_rule.push_back(static_cast<uint32_t>(r.n_groups));
+        c_tab.insert(c_tab.end(), r.trans.begin(), r.trans.end());
+        c_fin.insert(c_fin.end(), r.fin.begin(), r.fin.end());
+        for (int s = 0; s < r.n_states; ++s)
+            c_accel.push_back(self_loop_interval(
+                [&](int b) { return r.trans[static_cast<size_t>(s) * T.ncls + T.cls256[b]] == static_cast<uint32_t>(s); }));
+    }
+    if (c_tab.empty()) { c_tab.push_back(0); c_accel.push_back(0x00FF); c_fin.push_back(-1); c_rule.push_back(0); c_rule.push_back(0); }
+    L.c_tab = static_cast<uint32_t>(img.put(c_tab));
+    L.c_accel = static_cast<uint32_t>(img.put(c_accel));
+    L.c_fin = static_cast<uint32_t>(img.put(c_fin));
+    L.c_rule = static_cast<uint32_t>(img.put(c_rule));
+    L.ops_off = static_cast<uint32_t>(img.put(T.ops_off));
+    std::vector<uint16_t> ops = T.ops;
+    if (ops.empty()) ops.push_back(0);
+    L.ops = static_cast<uint32_t>(img.put(ops));
+    std::vector<uint16_t> fin_tags = T.fin_tags;
+    if (fin_tags.empty()) fin_tags.push_back(0);
+    L.fin_tags = static_cast<uint32_t>(img.put(fin_tags));
+    while (img.bytes.size() % 16) img.bytes.push_back(0);
+    L.table_bytes = static_cast<uint32_t>(img.bytes.size());
+    int max_regs = 0;
+    for (auto& r : T.rules) max_regs = std::max(max_regs, r.n_regs);
+    L.regs_wave_bytes = static_cast<uint32_t>((max_regs * 64 * 2 + 15) & ~15);
+    h->lds = L;
+    h->lds_image.swap(img.bytes);
+    h->tile_ok = true;
+}
+
+// Complete the layout for one batch: staging sized for 64 lines of the hinted length.
+bool plan_tile_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out) {
+    if (!h->tile_ok) return false;
+    GxLds L = h->lds;
+    if (line_bytes_hint == 0) line_bytes_hint = 200;
+    if (line_bytes_hint > 2000) line_bytes_hint = 2000;
+    L.stage_bytes = (64u * line_bytes_hint + 32u + 15u) & ~15u;
+    const uint32_t per_wave = L.stage_bytes + L.regs_wave_bytes;
+    if (L.table_bytes + 4 * per_wave > LDS_BYTES) return false;
+    uint32_t nw = (LDS_BYTES - L.table_bytes) / per_wave;
+    if (nw > 16) nw = 16;
+    L.nwaves = nw;
+    L.regs = L.table_bytes;
+    L.stage = L.regs + nw * L.regs_wave_bytes;
+    L.total_bytes = L.stage + nw * L.stage_bytes;
+    *out = L;
+    return true;
+}
 
 void upload(gx_handle* h) {
     const Tables& T = h->T;
@@ -128,7 +222,25 @@ void upload(gx_handle* h) {
     d.max_groups = T.max_groups;
     d.max_regs = max_regs;
     d.has_capture = T.has_capture ? 1 : 0;
+
+    build_lds_image(h);
+    if (h->tile_ok) {
+        GX_HIP(hipMalloc(&h->d_lds_image, h->lds_image.size()));
+        GX_HIP(hipMemcpy(h->d_lds_image, h->lds_image.data(), h->lds_image.size(), hipMemcpyHostToDevice));
+        GX_HIP(prepare_tile_kernels(LDS_BYTES));
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->num_cus = cus;
+    }
     h->on_device = true;
+}
+
+// One batch on the device: LDS-tier tile kernel when the tables fit, generic kernel otherwise.
+void launch_batch(gx_handle* h, const GxBatch& b, uint32_t line_bytes_hint, hipStream_t stream) {
+    GxLds L;
+    if (!b.wide && !b.state_out && plan_tile_launch(h, line_bytes_hint, &L))
+        GX_HIP(launch_extract_tile(h->dev, L, static_cast<const uint8_t*>(h->d_lds_image), h->num_cus, b, stream));
+    else
+        GX_HIP(launch_extract_generic(h->dev, b, stream));
 }
 
 int finish_create(std::unique_ptr<gx_handle>& h, uint32_t flags, gx_handle** out) {
@@ -196,6 +308,7 @@ int gx_blob_copy(const gx_handle* h, void* dst, size_t cap) {
 void gx_destroy(gx_handle* h) {
     if (!h) return;
     if (h->dimage) (void)hipFree(h->dimage);
+    if (h->d_lds_image) (void)hipFree(h->d_lds_image);
     delete h;
 }
 
@@ -214,7 +327,8 @@ int64_t gx_stat(const gx_handle* h, int32_t which) {
     case 2: { int64_t s = 0; for (auto& r : h->T.rules) s += r.n_states; return s; }
     case 3: { int64_t m = 0; for (auto& r : h->T.rules) m = std::max<int64_t>(m, r.n_regs); return m; }
     case 4: return static_cast<int64_t>(h->blob.size());
-    case 5: return 0;
+    case 5: { GxLds L; return plan_tile_launch(h, 0, &L) ? static_cast<int64_t>(L.total_bytes) : 0; }
+    case 6: { GxLds L; return plan_tile_launch(h, 0, &L) ? static_cast<int64_t>(L.nwaves) : 0; }
     default: return -1;
     }
 }
@@ -229,7 +343,7 @@ int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, ui
         o = *opts;
     }
     const bool match_only = o.match_only || !h->T.has_capture;
-    if (!match_only && !caps) return fail(GX_E_ARG, "gx_extract_batch: caps is NULL");
+    if (!match_only && !caps && n > 0 && h->T.max_groups > 0) return fail(GX_E_ARG, "gx_extract_batch: caps is NULL");
     try {
         GX_HIP(hipSetDevice(h->device));
         hipStream_t stream = static_cast<hipStream_t>(o.stream);
@@ -242,7 +356,7 @@ int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, ui
         const size_t slots = 2 * static_cast<size_t>(h->T.max_groups);
         if (o.device_pointers) {
             b.data = bytes; b.offsets = offsets; b.match_id = match_id; b.caps = match_only ? nullptr : caps;
-            GX_HIP(launch_extract_generic(h->dev, b, stream));
+            launch_batch(h, b, o.line_bytes_hint, stream);
             if (!o.no_sync) GX_HIP(hipStreamSynchronize(stream));
             return GX_OK;
         }
@@ -250,6 +364,8 @@ int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, ui
         std::lock_guard<std::mutex> lock(h->mu);
         uint64_t total = 0;
         if (n) total = o.offsets64 ? static_cast<const uint64_t*>(offsets)[n] : static_cast<const uint32_t*>(offsets)[n];
+        uint32_t hint = o.line_bytes_hint;
+        if (hint == 0 && n) hint = static_cast<uint32_t>((total + n - 1) / n);
         DevBuf d_bytes, d_off, d_mid, d_caps;
         d_bytes.alloc(total); d_off.alloc((n + 1) * off_w); d_mid.alloc(n * 4);
         if (!match_only) d_caps.alloc(n * slots * 4);
@@ -257,7 +373,7 @@ int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, ui
         GX_HIP(hipMemcpyAsync(d_off.p, offsets, (n + 1) * off_w, hipMemcpyHostToDevice, stream));
         b.data = d_bytes.p; b.offsets = d_off.p; b.match_id = static_cast<int32_t*>(d_mid.p);
         b.caps = match_only ? nullptr : static_cast<int32_t*>(d_caps.p);
-        GX_HIP(launch_extract_generic(h->dev, b, stream));
+        launch_batch(h, b, hint, stream);
         if (n) GX_HIP(hipMemcpyAsync(match_id, d_mid.p, n * 4, hipMemcpyDeviceToHost, stream));
         if (!match_only && n && slots) GX_HIP(hipMemcpyAsync(caps, d_caps.p, n * slots * 4, hipMemcpyDeviceToHost, stream));
         GX_HIP(hipStreamSynchronize(stream));

@@ -34,6 +34,31 @@ struct GxDev {
     int32_t has_capture;
 };
 
+// Layout of the LDS-resident table image used by the tile kernel: byte offsets
+// from the start of dynamic LDS.  The image [0, table_bytes) is built on the
+// host, kept in HBM next to the other tables and copied into LDS by every
+// workgroup's prologue.
+struct GxLds {
+    uint32_t cmap;        // u8[256]    byte -> class
+    uint32_t m_tab;       // u16[m_states * ncls]
+    uint32_t m_acc;       // i16[m_states] first accepting extraction or -1
+    uint32_t m_accel;     // u16[m_states] self-loop byte interval lo | hi << 8 (lo > hi: none)
+    uint32_t c_tab;       // u32[c_states * ncls]  next (rule-local) | op-list << 16
+    uint32_t c_accel;     // u16[c_states]
+    uint32_t c_fin;       // i32[c_states]
+    uint32_t c_rule;      // u32[n_rules * 2]: first state of the rule, group count
+    uint32_t ops_off;     // u32[n_oplists + 1]
+    uint32_t ops;         // u16 pairs
+    uint32_t fin_tags;    // u16[]
+    uint32_t table_bytes; // size of the image, multiple of 16
+    uint32_t regs;        // u16[nwaves][max_regs][64]
+    uint32_t regs_wave_bytes;
+    uint32_t stage;       // u8[nwaves][stage_bytes]
+    uint32_t stage_bytes; // multiple of 16
+    uint32_t nwaves;
+    uint32_t total_bytes; // dynamic LDS size to launch with
+};
+
 struct GxBatch {
     const void* data;      // uint8_t (Latin-1) or uint16_t (UTF-16) code units
     const void* offsets;   // uint32_t or uint64_t [n + 1], in code units
@@ -48,5 +73,12 @@ struct GxBatch {
 
 // Generic kernel: any table size, any line length, bytes or UTF-16.
 hipError_t launch_extract_generic(const GxDev& dev, const GxBatch& b, hipStream_t stream);
+
+// Tile kernel (LDS tier): tables resident in LDS, 64-line tiles staged through
+// LDS with coalesced loads, self-loop runs skipped 16 bytes at a time.
+// Byte input only.  `lds_image` is the device copy of the table image.
+hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, int num_cus,
+                               const GxBatch& b, hipStream_t stream);
+hipError_t prepare_tile_kernels(uint32_t lds_bytes);
 
 }  // namespace gx

@@ -30,73 +30,76 @@ __device__ __forceinline__ int class_of(const GxDev& T, CH ch) {
 }
 
 // ---------------------------------------------------------------------------
-// Generic kernel: one lane per line, tables read through L1/L2.  Handles every
-// table size (16- or 32-bit match states), any line length, bytes or UTF-16.
-// It is the correctness backstop; the LDS-tier kernels below are the fast path.
+// One line, tables read through L1/L2 (any table size, any line length).
 // ---------------------------------------------------------------------------
+template <typename CH, typename MS>
+__device__ void extract_line_global(const GxDev& T, const MS* __restrict__ m_next, const CH* __restrict__ s, int64_t len,
+                                    uint64_t i, int32_t* __restrict__ match_id, int32_t* __restrict__ caps,
+                                    int32_t* __restrict__ state_out, int match_only) {
+    const int ncls = T.ncls;
+    const int slots = 2 * T.max_groups;
+    // ---- hot loop #1: walk the match automaton ----
+    uint32_t st = 0;
+    const uint32_t dead = static_cast<uint32_t>(T.m_dead);
+    for (int64_t p = 0; p < len; ++p) {
+        st = m_next[static_cast<size_t>(st) * ncls + class_of(T, s[p])];
+        if (st == dead) break;  // the reference's early return on -1
+    }
+    const int32_t k = T.m_accept_first[st];
+    if (state_out) state_out[i] = (st == dead) ? -1 : static_cast<int32_t>(st);
+    if (match_only || !T.has_capture) { match_id[i] = k; return; }
+
+    int32_t* cp = caps + i * static_cast<uint64_t>(slots);
+    if (k < 0) {
+        match_id[i] = -1;
+        for (int t = 0; t < slots; ++t) cp[t] = -1;
+        return;
+    }
+    // ---- hot loop #2: walk extraction k's tagged automaton ----
+    const uint32_t* tr = T.c_trans + T.c_trans_off[k];
+    int32_t regs[GENERIC_MAX_REGS];
+    uint32_t ts = 0;
+    for (int64_t p = 0; p < len; ++p) {
+        const uint32_t w = tr[static_cast<size_t>(ts) * ncls + class_of(T, s[p])];
+        ts = w & 0xFFFFu;
+        const uint32_t op = w >> 16;
+        if (op) {
+            for (uint32_t j = T.ops_off[op]; j < T.ops_off[op + 1]; ++j) {
+                const uint16_t dst = T.ops[2 * j], src = T.ops[2 * j + 1];
+                regs[dst] = (src == SRC_POS) ? static_cast<int32_t>(p) : regs[src];
+            }
+        }
+    }
+    const int32_t f = (T.c_fin + T.c_fin_off[k])[ts];
+    if (f < 0) {  // DFA said yes, capture regex says no -> ExtractionException
+        match_id[i] = -2 - k;
+        for (int t = 0; t < slots; ++t) cp[t] = -1;
+        return;
+    }
+    const int ng = T.c_ngroups[k];
+    for (int g = 0; g < ng; ++g) {
+        const uint16_t vb = T.fin_tags[f + 2 * g], ve = T.fin_tags[f + 2 * g + 1];
+        int32_t pb = (vb == SRC_POS) ? static_cast<int32_t>(len) : (vb == SRC_NIL ? -1 : regs[vb]);
+        int32_t pe = (ve == SRC_POS) ? static_cast<int32_t>(len) : (ve == SRC_NIL ? -1 : regs[ve]);
+        if (pb < 0 || pe < 0) { pb = -1; pe = -1; }
+        cp[2 * g] = pb;
+        cp[2 * g + 1] = pe;
+    }
+    for (int t = 2 * ng; t < slots; ++t) cp[t] = -1;
+    match_id[i] = k;
+}
+
+// Generic kernel: one lane per line.  The correctness backstop for tables that
+// do not fit LDS, UTF-16 input and 32-bit match states.
 template <typename CH, typename OFF, typename MS>
 __global__ void __launch_bounds__(256)
 k_extract_generic(GxDev T, const CH* __restrict__ data, const OFF* __restrict__ off, uint64_t n,
                   int32_t* __restrict__ match_id, int32_t* __restrict__ caps, int32_t* __restrict__ state_out,
                   int match_only, const MS* __restrict__ m_next) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-    const int ncls = T.ncls;
-    const int slots = 2 * T.max_groups;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint64_t b = off[i], e = off[i + 1];
-        const CH* s = data + b;
-        const int64_t len = static_cast<int64_t>(e - b);
-
-        // ---- hot loop #1: walk the match automaton ----
-        uint32_t st = 0;
-        const uint32_t dead = static_cast<uint32_t>(T.m_dead);
-        for (int64_t p = 0; p < len; ++p) {
-            st = m_next[static_cast<size_t>(st) * ncls + class_of(T, s[p])];
-            if (st == dead) break;  // the reference's early return on -1
-        }
-        const int32_t k = T.m_accept_first[st];
-        if (state_out) state_out[i] = (st == dead) ? -1 : static_cast<int32_t>(st);
-        if (match_only || !T.has_capture) { match_id[i] = k; continue; }
-
-        int32_t* cp = caps + i * static_cast<uint64_t>(slots);
-        if (k < 0) {
-            match_id[i] = -1;
-            for (int t = 0; t < slots; ++t) cp[t] = -1;
-            continue;
-        }
-
-        // ---- hot loop #2: walk extraction k's tagged automaton ----
-        const uint32_t* tr = T.c_trans + T.c_trans_off[k];
-        int32_t regs[GENERIC_MAX_REGS];
-        uint32_t ts = 0;
-        for (int64_t p = 0; p < len; ++p) {
-            const uint32_t w = tr[static_cast<size_t>(ts) * ncls + class_of(T, s[p])];
-            ts = w & 0xFFFFu;
-            const uint32_t op = w >> 16;
-            if (op) {
-                for (uint32_t j = T.ops_off[op]; j < T.ops_off[op + 1]; ++j) {
-                    const uint16_t dst = T.ops[2 * j], src = T.ops[2 * j + 1];
-                    regs[dst] = (src == SRC_POS) ? static_cast<int32_t>(p) : regs[src];
-                }
-            }
-        }
-        const int32_t f = (T.c_fin + T.c_fin_off[k])[ts];
-        if (f < 0) {  // DFA said yes, capture regex says no -> ExtractionException
-            match_id[i] = -2 - k;
-            for (int t = 0; t < slots; ++t) cp[t] = -1;
-            continue;
-        }
-        const int ng = T.c_ngroups[k];
-        for (int g = 0; g < ng; ++g) {
-            const uint16_t vb = T.fin_tags[f + 2 * g], ve = T.fin_tags[f + 2 * g + 1];
-            int32_t pb = (vb == SRC_POS) ? static_cast<int32_t>(len) : (vb == SRC_NIL ? -1 : regs[vb]);
-            int32_t pe = (ve == SRC_POS) ? static_cast<int32_t>(len) : (ve == SRC_NIL ? -1 : regs[ve]);
-            if (pb < 0 || pe < 0) { pb = -1; pe = -1; }
-            cp[2 * g] = pb;
-            cp[2 * g + 1] = pe;
-        }
-        for (int t = 2 * ng; t < slots; ++t) cp[t] = -1;
-        match_id[i] = k;
+        extract_line_global<CH, MS>(T, m_next, data + b, static_cast<int64_t>(e - b), i, match_id, caps, state_out, match_only);
     }
 }
 
@@ -118,6 +121,215 @@ hipError_t launch_generic_t(const GxDev& dev, const GxBatch& b, hipStream_t stre
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Tile kernel (LDS tier)
+// ---------------------------------------------------------------------------
+// One wave owns one tile of 64 consecutive lines at a time.  The tile's bytes
+// are one contiguous span of the CSR buffer: the wave copies it into its own
+// LDS staging area with 16-byte-per-lane coalesced loads (every HBM byte is
+// fetched exactly once, in full cache lines), then each lane walks its line
+// out of LDS.  All automaton tables (byte->class map, class-compressed match
+// table, per-extraction tagged tables, capture programs) live in LDS.
+//
+// Self-loop acceleration: for every automaton state the host precomputes the
+// longest run [lo,hi] of ASCII byte values on which the state loops to itself
+// (with no capture operation).  While a lane sits in such a state it tests 16
+// (or 4) staged bytes at once with SWAR arithmetic and skips them if all lie in
+// [lo,hi]; any other byte falls through to the exact one-byte step.  Log
+// templates are dominated by \S+ / \d+ / .* runs, so most bytes take this path.
+
+extern __shared__ __attribute__((aligned(16))) uint8_t gx_smem[];
+
+__device__ __forceinline__ uint32_t splat_byte0(uint32_t v) { return __builtin_amdgcn_perm(v, v, 0x00000000u); }
+__device__ __forceinline__ uint32_t splat_byte1(uint32_t v) { return __builtin_amdgcn_perm(v, v, 0x01010101u); }
+
+// bit 7 of every byte of the result is set iff that byte of x lies in [lo,hi] (lo,hi < 0x80)
+__device__ __forceinline__ uint32_t inrange_bits(uint32_t x, uint32_t lo4, uint32_t hi4h) {
+    const uint32_t H = 0x80808080u;
+    const uint32_t ge = (x | H) - lo4;   // no inter-byte borrow: every minuend byte >= 0x80 > lo
+    const uint32_t le = hi4h - x;        // hi4h = hi4 | H; exact for bytes < 0x80, and bytes >= 0x80 are vetoed by ~x
+    return ge & le & ~x;
+}
+
+template <typename OFF>
+__global__ void __launch_bounds__(1024)
+k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const uint8_t* __restrict__ data,
+               const OFF* __restrict__ off, uint64_t n, int32_t* __restrict__ match_id, int32_t* __restrict__ caps,
+               int match_only) {
+    // ---- prologue: table image -> LDS ----
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(lds_image);
+        uint4* dst = reinterpret_cast<uint4*>(gx_smem);
+        for (uint32_t c = threadIdx.x; c < L.table_bytes / 16; c += blockDim.x) dst[c] = src[c];
+    }
+    __syncthreads();
+
+    const uint8_t* cmap = gx_smem + L.cmap;
+    const uint16_t* m_tab = reinterpret_cast<const uint16_t*>(gx_smem + L.m_tab);
+    const int16_t* m_acc = reinterpret_cast<const int16_t*>(gx_smem + L.m_acc);
+    const uint16_t* m_accel = reinterpret_cast<const uint16_t*>(gx_smem + L.m_accel);
+    const uint32_t* c_tab = reinterpret_cast<const uint32_t*>(gx_smem + L.c_tab);
+    const uint16_t* c_accel = reinterpret_cast<const uint16_t*>(gx_smem + L.c_accel);
+    const int32_t* c_fin = reinterpret_cast<const int32_t*>(gx_smem + L.c_fin);
+    const uint32_t* c_rule = reinterpret_cast<const uint32_t*>(gx_smem + L.c_rule);
+    const uint32_t* ops_off = reinterpret_cast<const uint32_t*>(gx_smem + L.ops_off);
+    const uint16_t* ops = reinterpret_cast<const uint16_t*>(gx_smem + L.ops);
+    const uint16_t* fin_tags = reinterpret_cast<const uint16_t*>(gx_smem + L.fin_tags);
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint8_t* stage = gx_smem + L.stage + wave * L.stage_bytes;
+    uint16_t* regs = reinterpret_cast<uint16_t*>(gx_smem + L.regs + wave * L.regs_wave_bytes) + lane;  // regs[r * 64]
+
+    const uint32_t ncls = static_cast<uint32_t>(T.ncls);
+    const uint32_t dead = static_cast<uint32_t>(T.m_dead);
+    const int slots = 2 * T.max_groups;
+    const bool want_caps = !match_only && T.has_capture;
+    const uint64_t tiles = (n + 63) >> 6;
+    const uint64_t wstride = static_cast<uint64_t>(gridDim.x) * L.nwaves;
+    const uint8_t* data_end = data + static_cast<uint64_t>(off[n]);
+    const uint32_t H = 0x80808080u;
+
+    for (uint64_t tile = static_cast<uint64_t>(blockIdx.x) * L.nwaves + wave; tile < tiles; tile += wstride) {
+        const uint64_t i = (tile << 6) + lane;
+        const bool valid = i < n;
+        const uint64_t o0 = off[valid ? i : n];
+        const uint64_t o1 = off[valid ? i + 1 : n];
+        // tile span [lo, hi): lane 0 always holds a valid line
+        const uint64_t lo = __shfl(o0, 0);
+        const uint64_t hi = __shfl(o1, 63);
+        const uint8_t* g_lo = data + lo;
+        const uint8_t* g_al = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(g_lo) & ~static_cast<uintptr_t>(15));
+        const uint32_t skew = static_cast<uint32_t>(g_lo - g_al);
+        const uint64_t span = (hi - lo) + skew;
+
+        if (span + 16 > L.stage_bytes) {
+            // tile does not fit the staging area (very long lines): exact per-lane path from global memory
+            if (valid)
+                extract_line_global<uint8_t, uint16_t>(T, T.m_next16, data + o0, static_cast<int64_t>(o1 - o0), i, match_id, caps,
+                                                       nullptr, match_only);
+            continue;
+        }
+
+        // ---- stage the span: coalesced 16 B per lane ----
+        {
+            const uint32_t nch = static_cast<uint32_t>((span + 15) >> 4);
+            for (uint32_t c = lane; c < nch; c += 64) {
+                const uint8_t* src = g_al + (static_cast<uint64_t>(c) << 4);
+                uint4 v;
+                if (src >= data && src + 16 <= data_end) {
+                    v = *reinterpret_cast<const uint4*>(src);
+                } else {
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    for (int q = 0; q < 16; ++q)
+                        if (src + q >= data && src + q < data_end) w[q >> 2] |= static_cast<uint32_t>(src[q]) << ((q & 3) * 8);
+                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                *reinterpret_cast<uint4*>(stage + (c << 4)) = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        const uint32_t start = skew + static_cast<uint32_t>(o0 - lo);
+        const uint32_t end = skew + static_cast<uint32_t>(o1 - lo);
+
+        // ---- hot loop #1: match automaton ----
+        uint32_t st = 0;
+        {
+            uint32_t p = start;
+            while (p < end && st != dead) {
+                const uint32_t acc = m_accel[st];
+                const uint32_t alo = acc & 0xFFu, ahi = acc >> 8;
+                if (alo <= ahi) {
+                    const uint32_t lo4 = splat_byte0(acc), hi4h = splat_byte1(acc) | H;
+                    if ((p & 15u) == 0u && p + 16u <= end) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(stage + p);
+                        const uint32_t r = inrange_bits(v.x, lo4, hi4h) & inrange_bits(v.y, lo4, hi4h) &
+                                           inrange_bits(v.z, lo4, hi4h) & inrange_bits(v.w, lo4, hi4h);
+                        if ((r & H) == H) { p += 16; continue; }
+                    }
+                    if ((p & 3u) == 0u && p + 4u <= end) {
+                        const uint32_t x = *reinterpret_cast<const uint32_t*>(stage + p);
+                        if ((inrange_bits(x, lo4, hi4h) & H) == H) { p += 4; continue; }
+                    }
+                }
+                st = m_tab[st * ncls + cmap[stage[p]]];
+                ++p;
+            }
+        }
+        const int32_t k = m_acc[st];
+        if (!want_caps) {
+            if (valid) match_id[i] = k;
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
+
+        // ---- hot loop #2: extraction k's tagged automaton ----
+        int32_t result = k;
+        uint32_t gstate = 0;
+        uint32_t ng = 0;
+        if (k >= 0) {
+            const uint32_t s0 = c_rule[2 * k];
+            ng = c_rule[2 * k + 1];
+            gstate = s0;
+            uint32_t p = start;
+            while (p < end) {
+                const uint32_t acc = c_accel[gstate];
+                const uint32_t alo = acc & 0xFFu, ahi = acc >> 8;
+                if (alo <= ahi) {
+                    const uint32_t lo4 = splat_byte0(acc), hi4h = splat_byte1(acc) | H;
+                    if ((p & 15u) == 0u && p + 16u <= end) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(stage + p);
+                        const uint32_t r = inrange_bits(v.x, lo4, hi4h) & inrange_bits(v.y, lo4, hi4h) &
+                                           inrange_bits(v.z, lo4, hi4h) & inrange_bits(v.w, lo4, hi4h);
+                        if ((r & H) == H) { p += 16; continue; }
+                    }
+                    if ((p & 3u) == 0u && p + 4u <= end) {
+                        const uint32_t x = *reinterpret_cast<const uint32_t*>(stage + p);
+                        if ((inrange_bits(x, lo4, hi4h) & H) == H) { p += 4; continue; }
+                    }
+                }
+                const uint32_t w = c_tab[gstate * ncls + cmap[stage[p]]];
+                gstate = s0 + (w & 0xFFFFu);
+                const uint32_t op = w >> 16;
+                if (op) {
+                    const uint16_t pos = static_cast<uint16_t>(p - start);
+                    for (uint32_t j = ops_off[op]; j < ops_off[op + 1]; ++j) {
+                        const uint32_t dst = ops[2 * j], src = ops[2 * j + 1];
+                        regs[dst * 64] = (src == SRC_POS) ? pos : regs[src * 64];
+                    }
+                }
+                ++p;
+            }
+        }
+        if (valid) {
+            int32_t* cp = caps + i * static_cast<uint64_t>(slots);
+            int32_t f = -1;
+            if (k >= 0) {
+                f = c_fin[gstate];
+                if (f < 0) result = -2 - k;  // DFA said yes, capture regex says no -> ExtractionException
+            }
+            const int32_t len = static_cast<int32_t>(end - start);
+            for (int g = 0; g < T.max_groups; ++g) {
+                int32_t pb = -1, pe = -1;
+                if (f >= 0 && static_cast<uint32_t>(g) < ng) {
+                    const uint16_t vb = fin_tags[f + 2 * g], ve = fin_tags[f + 2 * g + 1];
+                    pb = (vb == SRC_POS) ? len : (vb == SRC_NIL ? -1 : static_cast<int32_t>(regs[vb * 64]));
+                    pe = (ve == SRC_POS) ? len : (ve == SRC_NIL ? -1 : static_cast<int32_t>(regs[ve * 64]));
+                    if (pb < 0 || pe < 0) { pb = -1; pe = -1; }
+                }
+                cp[2 * g] = pb;
+                cp[2 * g + 1] = pe;
+            }
+            match_id[i] = result;
+        }
+        // the staging area is reused by the next tile: all lanes must be done reading it
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace
 
 hipError_t launch_extract_generic(const GxDev& dev, const GxBatch& b, hipStream_t stream) {
@@ -125,6 +337,35 @@ hipError_t launch_extract_generic(const GxDev& dev, const GxBatch& b, hipStream_
         return b.offsets64 ? launch_generic_t<uint16_t, uint64_t>(dev, b, stream) : launch_generic_t<uint16_t, uint32_t>(dev, b, stream);
     }
     return b.offsets64 ? launch_generic_t<uint8_t, uint64_t>(dev, b, stream) : launch_generic_t<uint8_t, uint32_t>(dev, b, stream);
+}
+
+hipError_t prepare_tile_kernels(uint32_t lds_bytes) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extract_tile<uint32_t>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extract_tile<uint64_t>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+}
+
+hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, int num_cus, const GxBatch& b,
+                               hipStream_t stream) {
+    if (b.n == 0) return hipSuccess;
+    const uint64_t tiles = (b.n + 63) >> 6;
+    uint32_t blocks_per_cu = 163840u / lds.total_bytes;
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    uint64_t blocks = static_cast<uint64_t>(num_cus) * blocks_per_cu;
+    const uint64_t need = (tiles + lds.nwaves - 1) / lds.nwaves;
+    if (blocks > need) blocks = need;
+    dim3 grid(static_cast<unsigned>(blocks)), block(lds.nwaves * 64);
+    if (b.offsets64)
+        hipLaunchKernelGGL((k_extract_tile<uint64_t>), grid, block, lds.total_bytes, stream, dev, lds, lds_image,
+                           static_cast<const uint8_t*>(b.data), static_cast<const uint64_t*>(b.offsets), b.n, b.match_id, b.caps,
+                           b.match_only);
+    else
+        hipLaunchKernelGGL((k_extract_tile<uint32_t>), grid, block, lds.total_bytes, stream, dev, lds, lds_image,
+                           static_cast<const uint8_t*>(b.data), static_cast<const uint32_t*>(b.offsets), b.n, b.match_id, b.caps,
+                           b.match_only);
+    return hipGetLastError();
 }
 
 }  // namespace gx

@@ -87,7 +87,8 @@ typedef struct gx_batch_opts {
     uint32_t match_only;       /* 1: PolyMatcher.match only; caps may be NULL */
     void*    stream;           /* hipStream_t to launch on (NULL = the null stream) */
     uint32_t no_sync;          /* 1 (device pointers only): return after enqueueing */
-    uint32_t reserved;
+    uint32_t line_bytes_hint;  /* typical line length in bytes (0 = 200); sizes the per-wave LDS staging
+                                  area of the batch kernel.  A wrong hint costs speed, never correctness. */
 } gx_batch_opts;
 
 /* Replaces the per-line loop "for each line: Gorp.extract(line)"
