@@ -83,33 +83,37 @@ void build_lds_image(gx_handle* h) {
     if (T.m_states > 32767 || T.n_rules > 32767) return;
     size_t c_states = 0;
     for (auto& r : T.rules) c_states += r.n_states;
-    const size_t est = 256 + static_cast<size_t>(T.m_states) * T.ncls * 2 + T.m_states * 4 + c_states * (T.ncls * 4 + 6) +
+    const size_t est = 256 + static_cast<size_t>(T.m_states) * T.ncls * 4 + T.m_states * 4 + c_states * (T.ncls * 8 + 6) +
                        T.rules.size() * 8 + T.ops_off.size() * 4 + T.ops.size() * 2 + T.fin_tags.size() * 2 + 256;
     if (est > LDS_TABLE_BUDGET) return;
     Image img;
     GxLds L{};
-    L.cmap = static_cast<uint32_t>(img.put(T.cls256, 256));
-    std::vector<uint16_t> m_tab(T.m_next.begin(), T.m_next.end());
-    L.m_tab = static_cast<uint32_t>(img.put(m_tab));
-    std::vector<int16_t> m_acc(T.m_accept_first.begin(), T.m_accept_first.end());
-    L.m_acc = static_cast<uint32_t>(img.put(m_acc));
+    L.cmap = static_cast<uint32_t>(img.put(T.cls256, 256));  // must stay at offset 0 (the kernel indexes LDS by byte value)
     std::vector<uint16_t> m_accel(T.m_states);
     for (int s = 0; s < T.m_states; ++s)
         m_accel[s] = self_loop_interval([&](int b) { return T.m_next[static_cast<size_t>(s) * T.ncls + T.cls256[b]] == static_cast<uint32_t>(s); });
+    // every transition carries its destination's self-loop interval: one LDS read per step
+    std::vector<uint32_t> m_tab(T.m_next.size());
+    for (size_t e = 0; e < T.m_next.size(); ++e) m_tab[e] = T.m_next[e] | (static_cast<uint32_t>(m_accel[T.m_next[e]]) << 16);
+    L.m_tab = static_cast<uint32_t>(img.put(m_tab));
+    std::vector<int16_t> m_acc(T.m_accept_first.begin(), T.m_accept_first.end());
+    L.m_acc = static_cast<uint32_t>(img.put(m_acc));
     L.m_accel = static_cast<uint32_t>(img.put(m_accel));
-    std::vector<uint32_t> c_tab, c_rule;
+    std::vector<uint32_t> c_tab, c_rule;  // c_tab: pairs (next | op << 16, destination's interval)
     std::vector<uint16_t> c_accel;
     std::vector<int32_t> c_fin;
     for (auto& r : T.rules) {
         c_rule.push_back(static_cast<uint32_t>(c_fin.size()));
         c_rule.push_back(static_cast<uint32_t>(r.n_groups));
-        c_tab.insert(c_tab.end(), r.trans.begin(), r.trans.end());
         c_fin.insert(c_fin.end(), r.fin.begin(), r.fin.end());
+        std::vector<uint16_t> acc(r.n_states);
         for (int s = 0; s < r.n_states; ++s)
-            c_accel.push_back(self_loop_interval(
-                [&](int b) { return r.trans[static_cast<size_t>(s) * T.ncls + T.cls256[b]] == static_cast<uint32_t>(s); }));
+            acc[s] = self_loop_interval(
+                [&](int b) { return r.trans[static_cast<size_t>(s) * T.ncls + T.cls256[b]] == static_cast<uint32_t>(s); });
+        for (uint32_t w : r.trans) { c_tab.push_back(w); c_tab.push_back(acc[w & 0xFFFFu]); }
+        c_accel.insert(c_accel.end(), acc.begin(), acc.end());
     }
-    if (c_tab.empty()) { c_tab.push_back(0); c_accel.push_back(0x00FF); c_fin.push_back(-1); c_rule.push_back(0); c_rule.push_back(0); }
+    if (c_tab.empty()) { c_tab.push_back(0); c_tab.push_back(0x00FF); c_accel.push_back(0x00FF); c_fin.push_back(-1); c_rule.push_back(0); c_rule.push_back(0); }
     L.c_tab = static_cast<uint32_t>(img.put(c_tab));
     L.c_accel = static_cast<uint32_t>(img.put(c_accel));
     L.c_fin = static_cast<uint32_t>(img.put(c_fin));

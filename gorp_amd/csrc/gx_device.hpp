@@ -40,10 +40,10 @@ struct GxDev {
 // workgroup's prologue.
 struct GxLds {
     uint32_t cmap;        // u8[256]    byte -> class
-    uint32_t m_tab;       // u16[m_states * ncls]
+    uint32_t m_tab;       // u32[m_states * ncls]  next | self-loop interval of next << 16
     uint32_t m_acc;       // i16[m_states] first accepting extraction or -1
     uint32_t m_accel;     // u16[m_states] self-loop byte interval lo | hi << 8 (lo > hi: none)
-    uint32_t c_tab;       // u32[c_states * ncls]  next (rule-local) | op-list << 16
+    uint32_t c_tab;       // uint2[c_states * ncls] {next (rule-local) | op-list << 16, self-loop interval of next}
     uint32_t c_accel;     // u16[c_states]
     uint32_t c_fin;       // i32[c_states]
     uint32_t c_rule;      // u32[n_rules * 2]: first state of the rule, group count

@@ -140,15 +140,61 @@ hipError_t launch_generic_t(const GxDev& dev, const GxBatch& b, hipStream_t stre
 
 extern __shared__ __attribute__((aligned(16))) uint8_t gx_smem[];
 
+constexpr uint32_t HI_BITS = 0x80808080u;
+
 __device__ __forceinline__ uint32_t splat_byte0(uint32_t v) { return __builtin_amdgcn_perm(v, v, 0x00000000u); }
 __device__ __forceinline__ uint32_t splat_byte1(uint32_t v) { return __builtin_amdgcn_perm(v, v, 0x01010101u); }
 
 // bit 7 of every byte of the result is set iff that byte of x lies in [lo,hi] (lo,hi < 0x80)
 __device__ __forceinline__ uint32_t inrange_bits(uint32_t x, uint32_t lo4, uint32_t hi4h) {
-    const uint32_t H = 0x80808080u;
-    const uint32_t ge = (x | H) - lo4;   // no inter-byte borrow: every minuend byte >= 0x80 > lo
-    const uint32_t le = hi4h - x;        // hi4h = hi4 | H; exact for bytes < 0x80, and bytes >= 0x80 are vetoed by ~x
+    const uint32_t ge = (x | HI_BITS) - lo4;  // no inter-byte borrow: every minuend byte >= 0x80 > lo
+    const uint32_t le = hi4h - x;             // hi4h = hi4 | H; exact for bytes < 0x80; bytes >= 0x80 are vetoed by ~x
     return ge & le & ~x;
+}
+__device__ __forceinline__ bool all16_in(const uint4& v, uint32_t lo4, uint32_t hi4h) {
+    const uint32_t r = inrange_bits(v.x, lo4, hi4h) & inrange_bits(v.y, lo4, hi4h) & inrange_bits(v.z, lo4, hi4h) &
+                       inrange_bits(v.w, lo4, hi4h);
+    return (r & HI_BITS) == HI_BITS;
+}
+__device__ __forceinline__ uint32_t pick_dword(const uint4& v, uint32_t idx) {
+    const uint32_t a = (idx & 1u) ? v.y : v.x;
+    const uint32_t b = (idx & 1u) ? v.w : v.z;
+    return (idx & 2u) ? b : a;
+}
+
+// Wave-cooperative copy of [g_al, g_al + nch*16) into the wave's LDS staging area.
+// All loads of a batch are issued before the first LDS write so that up to 16 KiB
+// per wave is in flight.
+__device__ __forceinline__ void stage_span(const uint8_t* __restrict__ g_al, uint32_t nch, uint8_t* stage, uint32_t lane) {
+    constexpr int B = 8;  // loads in flight per lane (8 KiB per wave)
+    for (uint32_t base = 0; base < nch; base += 64u * B) {
+        uint4 v[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            // clamped, unconditional: keeps v[] in registers; a clamped lane re-reads the last chunk (cache hit)
+            const uint32_t c = min(base + lane + 64u * k, nch - 1u);
+            v[k] = *reinterpret_cast<const uint4*>(g_al + (static_cast<uint64_t>(c) << 4));
+        }
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            // unconditional as well (clamped lanes rewrite the last chunk with identical data): a conditional
+            // store lets the compiler sink each load next to its store and serialise the batch
+            const uint32_t c = min(base + lane + 64u * k, nch - 1u);
+            *reinterpret_cast<uint4*>(stage + (c << 4)) = v[k];
+        }
+    }
+}
+
+// Same copy for a span that touches the first or last bytes of the buffer: never reads outside [data, data_end).
+__device__ void stage_span_guarded(const uint8_t* __restrict__ g_al, uint32_t nch, uint8_t* stage, uint32_t lane,
+                                   const uint8_t* data, const uint8_t* data_end) {
+    for (uint32_t c = lane; c < nch; c += 64) {
+        const uint8_t* src = g_al + (static_cast<uint64_t>(c) << 4);
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int q = 0; q < 16; ++q)
+            if (src + q >= data && src + q < data_end) w[q >> 2] |= static_cast<uint32_t>(src[q]) << ((q & 3) * 8);
+        *reinterpret_cast<uint4*>(stage + (c << 4)) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
 }
 
 template <typename OFF>
@@ -164,11 +210,11 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
     }
     __syncthreads();
 
-    const uint8_t* cmap = gx_smem + L.cmap;
-    const uint16_t* m_tab = reinterpret_cast<const uint16_t*>(gx_smem + L.m_tab);
+    const uint8_t* cmap = gx_smem;  // GxLds::cmap is always 0: a byte value is its own LDS address
+    const uint32_t* m_tab = reinterpret_cast<const uint32_t*>(gx_smem + L.m_tab);
     const int16_t* m_acc = reinterpret_cast<const int16_t*>(gx_smem + L.m_acc);
     const uint16_t* m_accel = reinterpret_cast<const uint16_t*>(gx_smem + L.m_accel);
-    const uint32_t* c_tab = reinterpret_cast<const uint32_t*>(gx_smem + L.c_tab);
+    const uint2* c_tab = reinterpret_cast<const uint2*>(gx_smem + L.c_tab);
     const uint16_t* c_accel = reinterpret_cast<const uint16_t*>(gx_smem + L.c_accel);
     const int32_t* c_fin = reinterpret_cast<const int32_t*>(gx_smem + L.c_fin);
     const uint32_t* c_rule = reinterpret_cast<const uint32_t*>(gx_smem + L.c_rule);
@@ -188,7 +234,6 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
     const uint64_t tiles = (n + 63) >> 6;
     const uint64_t wstride = static_cast<uint64_t>(gridDim.x) * L.nwaves;
     const uint8_t* data_end = data + static_cast<uint64_t>(off[n]);
-    const uint32_t H = 0x80808080u;
 
     for (uint64_t tile = static_cast<uint64_t>(blockIdx.x) * L.nwaves + wave; tile < tiles; tile += wstride) {
         const uint64_t i = (tile << 6) + lane;
@@ -196,11 +241,11 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
         const uint64_t o0 = off[valid ? i : n];
         const uint64_t o1 = off[valid ? i + 1 : n];
         // tile span [lo, hi): lane 0 always holds a valid line
-        const uint64_t lo = __shfl(o0, 0);
-        const uint64_t hi = __shfl(o1, 63);
+        const uint64_t lo = __shfl(static_cast<unsigned long long>(o0), 0);
+        const uint64_t hi = __shfl(static_cast<unsigned long long>(o1), 63);
         const uint8_t* g_lo = data + lo;
-        const uint8_t* g_al = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(g_lo) & ~static_cast<uintptr_t>(15));
-        const uint32_t skew = static_cast<uint32_t>(g_lo - g_al);
+        const uint32_t skew = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(g_lo) & 15u);
+        const uint8_t* g_al = g_lo - skew;  // 16-byte aligned; still a global-address-space pointer for the compiler
         const uint64_t span = (hi - lo) + skew;
 
         if (span + 16 > L.stage_bytes) {
@@ -214,19 +259,8 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
         // ---- stage the span: coalesced 16 B per lane ----
         {
             const uint32_t nch = static_cast<uint32_t>((span + 15) >> 4);
-            for (uint32_t c = lane; c < nch; c += 64) {
-                const uint8_t* src = g_al + (static_cast<uint64_t>(c) << 4);
-                uint4 v;
-                if (src >= data && src + 16 <= data_end) {
-                    v = *reinterpret_cast<const uint4*>(src);
-                } else {
-                    uint32_t w[4] = {0, 0, 0, 0};
-                    for (int q = 0; q < 16; ++q)
-                        if (src + q >= data && src + q < data_end) w[q >> 2] |= static_cast<uint32_t>(src[q]) << ((q & 3) * 8);
-                    v = make_uint4(w[0], w[1], w[2], w[3]);
-                }
-                *reinterpret_cast<uint4*>(stage + (c << 4)) = v;
-            }
+            if (g_al >= data && g_al + (static_cast<uint64_t>(nch) << 4) <= data_end) stage_span(g_al, nch, stage, lane);
+            else stage_span_guarded(g_al, nch, stage, lane, data, data_end);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -238,25 +272,39 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
         // ---- hot loop #1: match automaton ----
         uint32_t st = 0;
         {
+            uint32_t acc = m_accel[0];
             uint32_t p = start;
+            uint4 win = make_uint4(0, 0, 0, 0);
+            if (p < end) win = *reinterpret_cast<const uint4*>(stage + (p & ~15u));
             while (p < end && st != dead) {
-                const uint32_t acc = m_accel[st];
-                const uint32_t alo = acc & 0xFFu, ahi = acc >> 8;
-                if (alo <= ahi) {
-                    const uint32_t lo4 = splat_byte0(acc), hi4h = splat_byte1(acc) | H;
-                    if ((p & 15u) == 0u && p + 16u <= end) {
-                        const uint4 v = *reinterpret_cast<const uint4*>(stage + p);
-                        const uint32_t r = inrange_bits(v.x, lo4, hi4h) & inrange_bits(v.y, lo4, hi4h) &
-                                           inrange_bits(v.z, lo4, hi4h) & inrange_bits(v.w, lo4, hi4h);
-                        if ((r & H) == H) { p += 16; continue; }
-                    }
-                    if ((p & 3u) == 0u && p + 4u <= end) {
-                        const uint32_t x = *reinterpret_cast<const uint32_t*>(stage + p);
-                        if ((inrange_bits(x, lo4, hi4h) & H) == H) { p += 4; continue; }
+                const bool has = (acc & 0xFFu) <= (acc >> 8);
+                const uint32_t lo4 = splat_byte0(acc), hi4h = splat_byte1(acc) | HI_BITS;
+                if (has && (p & 15u) == 0u && p + 16u <= end && all16_in(win, lo4, hi4h)) {
+                    p += 16;
+                    if (p < end) win = *reinterpret_cast<const uint4*>(stage + p);
+                    continue;
+                }
+                const uint32_t d = pick_dword(win, (p >> 2) & 3u);
+                if (has && (p & 3u) == 0u && p + 4u <= end && (inrange_bits(d, lo4, hi4h) & HI_BITS) == HI_BITS) {
+                    p += 4;
+                    if ((p & 15u) == 0u && p < end) win = *reinterpret_cast<const uint4*>(stage + p);
+                    continue;
+                }
+                // exact steps over the rest of this dword; the four class lookups are independent of the state chain
+                const uint32_t c0 = cmap[d & 0xFFu], c1 = cmap[(d >> 8) & 0xFFu], c2 = cmap[(d >> 16) & 0xFFu], c3 = cmap[d >> 24];
+                const uint32_t j0 = p & 3u;
+                const uint32_t pbase = p & ~3u;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    if (j >= j0 && pbase + j < end) {
+                        const uint32_t cj = j == 0 ? c0 : (j == 1 ? c1 : (j == 2 ? c2 : c3));
+                        const uint32_t e = m_tab[st * ncls + cj];
+                        st = e & 0xFFFFu;
+                        acc = e >> 16;
+                        ++p;
                     }
                 }
-                st = m_tab[st * ncls + cmap[stage[p]]];
-                ++p;
+                if ((p & 15u) == 0u && p < end) win = *reinterpret_cast<const uint4*>(stage + p);
             }
         }
         const int32_t k = m_acc[st];
@@ -274,34 +322,46 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
             const uint32_t s0 = c_rule[2 * k];
             ng = c_rule[2 * k + 1];
             gstate = s0;
+            uint32_t acc = c_accel[s0];
             uint32_t p = start;
+            uint4 win = make_uint4(0, 0, 0, 0);
+            if (p < end) win = *reinterpret_cast<const uint4*>(stage + (p & ~15u));
             while (p < end) {
-                const uint32_t acc = c_accel[gstate];
-                const uint32_t alo = acc & 0xFFu, ahi = acc >> 8;
-                if (alo <= ahi) {
-                    const uint32_t lo4 = splat_byte0(acc), hi4h = splat_byte1(acc) | H;
-                    if ((p & 15u) == 0u && p + 16u <= end) {
-                        const uint4 v = *reinterpret_cast<const uint4*>(stage + p);
-                        const uint32_t r = inrange_bits(v.x, lo4, hi4h) & inrange_bits(v.y, lo4, hi4h) &
-                                           inrange_bits(v.z, lo4, hi4h) & inrange_bits(v.w, lo4, hi4h);
-                        if ((r & H) == H) { p += 16; continue; }
-                    }
-                    if ((p & 3u) == 0u && p + 4u <= end) {
-                        const uint32_t x = *reinterpret_cast<const uint32_t*>(stage + p);
-                        if ((inrange_bits(x, lo4, hi4h) & H) == H) { p += 4; continue; }
+                const bool has = (acc & 0xFFu) <= (acc >> 8);
+                const uint32_t lo4 = splat_byte0(acc), hi4h = splat_byte1(acc) | HI_BITS;
+                if (has && (p & 15u) == 0u && p + 16u <= end && all16_in(win, lo4, hi4h)) {
+                    p += 16;
+                    if (p < end) win = *reinterpret_cast<const uint4*>(stage + p);
+                    continue;
+                }
+                const uint32_t d = pick_dword(win, (p >> 2) & 3u);
+                if (has && (p & 3u) == 0u && p + 4u <= end && (inrange_bits(d, lo4, hi4h) & HI_BITS) == HI_BITS) {
+                    p += 4;
+                    if ((p & 15u) == 0u && p < end) win = *reinterpret_cast<const uint4*>(stage + p);
+                    continue;
+                }
+                const uint32_t c0 = cmap[d & 0xFFu], c1 = cmap[(d >> 8) & 0xFFu], c2 = cmap[(d >> 16) & 0xFFu], c3 = cmap[d >> 24];
+                const uint32_t j0 = p & 3u;
+                const uint32_t pbase = p & ~3u;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    if (j >= j0 && pbase + j < end) {
+                        const uint32_t cj = j == 0 ? c0 : (j == 1 ? c1 : (j == 2 ? c2 : c3));
+                        const uint2 e = c_tab[gstate * ncls + cj];
+                        gstate = s0 + (e.x & 0xFFFFu);
+                        acc = e.y;
+                        const uint32_t op = e.x >> 16;
+                        if (op) {
+                            const uint16_t pos = static_cast<uint16_t>(pbase + j - start);
+                            for (uint32_t q = ops_off[op]; q < ops_off[op + 1]; ++q) {
+                                const uint32_t dst = ops[2 * q], src = ops[2 * q + 1];
+                                regs[dst * 64] = (src == SRC_POS) ? pos : regs[src * 64];
+                            }
+                        }
+                        ++p;
                     }
                 }
-                const uint32_t w = c_tab[gstate * ncls + cmap[stage[p]]];
-                gstate = s0 + (w & 0xFFFFu);
-                const uint32_t op = w >> 16;
-                if (op) {
-                    const uint16_t pos = static_cast<uint16_t>(p - start);
-                    for (uint32_t j = ops_off[op]; j < ops_off[op + 1]; ++j) {
-                        const uint32_t dst = ops[2 * j], src = ops[2 * j + 1];
-                        regs[dst * 64] = (src == SRC_POS) ? pos : regs[src * 64];
-                    }
-                }
-                ++p;
+                if ((p & 15u) == 0u && p < end) win = *reinterpret_cast<const uint4*>(stage + p);
             }
         }
         if (valid) {
