@@ -4,6 +4,7 @@
 // every extract/match entry point runs the HIP kernels or fails with GX_E_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <mutex>
 #include <new>
 #include <string>
@@ -110,7 +111,17 @@ void build_lds_image(gx_handle* h) {
         for (int s = 0; s < r.n_states; ++s)
             acc[s] = self_loop_interval(
                 [&](int b) { return r.trans[static_cast<size_t>(s) * T.ncls + T.cls256[b]] == static_cast<uint32_t>(s); });
-        for (uint32_t w : r.trans) { c_tab.push_back(w); c_tab.push_back(acc[w & 0xFFFFu]); }
+        for (uint32_t w : r.trans) {
+            // the common capture program "one tag := position" is folded into the entry as 0x8000 | register
+            uint32_t op = w >> 16;
+            if (op) {
+                const uint32_t b = T.ops_off[op], e = T.ops_off[op + 1];
+                if (e - b == 1 && T.ops[2 * b + 1] == GX_SRC_POS && T.ops[2 * b] < 0x7FFF) op = 0x8000u | T.ops[2 * b];
+                else if (op >= 0x8000u) return;  // too many distinct general programs for the LDS tier
+            }
+            c_tab.push_back((w & 0xFFFFu) | (op << 16));
+            c_tab.push_back(acc[w & 0xFFFFu]);
+        }
         c_accel.insert(c_accel.end(), acc.begin(), acc.end());
     }
     if (c_tab.empty()) { c_tab.push_back(0); c_tab.push_back(0x00FF); c_accel.push_back(0x00FF); c_fin.push_back(-1); c_rule.push_back(0); c_rule.push_back(0); }
@@ -359,6 +370,9 @@ int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, ui
         const size_t off_w = o.offsets64 ? 8 : 4;
         const size_t slots = 2 * static_cast<size_t>(h->T.max_groups);
         if (o.device_pointers) {
+            // developer-only timing ablations of the tile kernel (results are NOT valid when set)
+            static const int ablate = getenv("GX_DEBUG_ABLATE") ? atoi(getenv("GX_DEBUG_ABLATE")) : 0;
+            if (ablate > 1 && !match_only) b.match_only = ablate;
             b.data = bytes; b.offsets = offsets; b.match_id = match_id; b.caps = match_only ? nullptr : caps;
             launch_batch(h, b, o.line_bytes_hint, stream);
             if (!o.no_sync) GX_HIP(hipStreamSynchronize(stream));

@@ -162,6 +162,32 @@ __device__ __forceinline__ uint32_t pick_dword(const uint4& v, uint32_t idx) {
     return (idx & 2u) ? b : a;
 }
 
+// bit j set iff byte j of the 16-byte window at `wb` lies inside the line [start, end)
+__device__ __forceinline__ uint32_t window_mask(uint32_t start, uint32_t end, uint32_t wb) {
+    const uint32_t lo = start > wb ? start - wb : 0u;                 // < 16 for a window that overlaps the line
+    const uint32_t hi = end - wb < 16u ? end - wb : 16u;              // 1..16
+    return ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+}
+
+// the 16 byte->class lookups of a window: independent of the automaton state, so issued back to back
+__device__ __forceinline__ void window_classes(const uint4& win, const uint8_t* cmap, uint32_t (&cls)[16]) {
+    const uint32_t d[4] = {win.x, win.y, win.z, win.w};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cls[j] = cmap[(d[j >> 2] >> ((j & 3) * 8)) & 0xFFu];
+}
+
+// General capture program (anything but a single "tag := position"): executed from the LDS copy of the
+// op lists.  Rare, so kept out of line.  regs_b = byte offset in LDS of this lane's register column.
+__device__ __noinline__ void run_op_list(uint32_t ops_off_b, uint32_t ops_b, uint32_t regs_b, uint32_t op, uint16_t pos) {
+    const uint32_t* ops_off = reinterpret_cast<const uint32_t*>(gx_smem + ops_off_b);
+    const uint16_t* ops = reinterpret_cast<const uint16_t*>(gx_smem + ops_b);
+    uint16_t* regs = reinterpret_cast<uint16_t*>(gx_smem + regs_b);
+    for (uint32_t q = ops_off[op]; q < ops_off[op + 1]; ++q) {
+        const uint32_t dst = ops[2 * q], src = ops[2 * q + 1];
+        regs[dst * 64] = (src == SRC_POS) ? pos : regs[src * 64];
+    }
+}
+
 // Wave-cooperative copy of [g_al, g_al + nch*16) into the wave's LDS staging area.
 // All loads of a batch are issued before the first LDS write so that up to 16 KiB
 // per wave is in flight.
@@ -218,8 +244,6 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
     const uint16_t* c_accel = reinterpret_cast<const uint16_t*>(gx_smem + L.c_accel);
     const int32_t* c_fin = reinterpret_cast<const int32_t*>(gx_smem + L.c_fin);
     const uint32_t* c_rule = reinterpret_cast<const uint32_t*>(gx_smem + L.c_rule);
-    const uint32_t* ops_off = reinterpret_cast<const uint32_t*>(gx_smem + L.ops_off);
-    const uint16_t* ops = reinterpret_cast<const uint16_t*>(gx_smem + L.ops);
     const uint16_t* fin_tags = reinterpret_cast<const uint16_t*>(gx_smem + L.fin_tags);
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -230,7 +254,7 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
     const uint32_t ncls = static_cast<uint32_t>(T.ncls);
     const uint32_t dead = static_cast<uint32_t>(T.m_dead);
     const int slots = 2 * T.max_groups;
-    const bool want_caps = !match_only && T.has_capture;
+    const bool want_caps = (match_only == 0 || match_only == 3) && T.has_capture;
     const uint64_t tiles = (n + 63) >> 6;
     const uint64_t wstride = static_cast<uint64_t>(gridDim.x) * L.nwaves;
     const uint8_t* data_end = data + static_cast<uint64_t>(off[n]);
@@ -259,7 +283,9 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
         // ---- stage the span: coalesced 16 B per lane ----
         {
             const uint32_t nch = static_cast<uint32_t>((span + 15) >> 4);
-            if (g_al >= data && g_al + (static_cast<uint64_t>(nch) << 4) <= data_end) stage_span(g_al, nch, stage, lane);
+            if (match_only == 3) {
+                // timing ablation (GX_DEBUG_ABLATE=3): no staging, walk whatever is in LDS
+            } else if (g_al >= data && g_al + (static_cast<uint64_t>(nch) << 4) <= data_end) stage_span(g_al, nch, stage, lane);
             else stage_span_guarded(g_al, nch, stage, lane, data, data_end);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -268,43 +294,45 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
 
         const uint32_t start = skew + static_cast<uint32_t>(o0 - lo);
         const uint32_t end = skew + static_cast<uint32_t>(o1 - lo);
+        if (match_only == 2) {  // timing ablation (GX_DEBUG_ABLATE=2): staging only
+            if (valid) match_id[i] = stage[start];
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
+
+        // Both hot loops advance in lock step over 16-byte windows of the staged line: the wave
+        // iterates ceil(longest line / 16) times, and in every window a lane either proves with one
+        // SWAR test that all 16 bytes stay inside its state's self-loop interval (state unchanged),
+        // or takes 16 exact, branch-free steps (bytes outside [start,end) are masked out).
+        const bool nonempty = start < end;
+        const uint32_t w_first = start & ~15u;
+        const uint32_t w_last = nonempty ? ((end - 1u) & ~15u) : 0u;
 
         // ---- hot loop #1: match automaton ----
         uint32_t st = 0;
         {
             uint32_t acc = m_accel[0];
-            uint32_t p = start;
-            uint4 win = make_uint4(0, 0, 0, 0);
-            if (p < end) win = *reinterpret_cast<const uint4*>(stage + (p & ~15u));
-            while (p < end && st != dead) {
+            uint32_t wb = w_first;
+            bool more = nonempty;
+            while (__any(more)) {
+                const uint4 win = *reinterpret_cast<const uint4*>(stage + (more ? wb : 0u));
+                const uint32_t mask = more ? window_mask(start, end, wb) : 0u;
                 const bool has = (acc & 0xFFu) <= (acc >> 8);
                 const uint32_t lo4 = splat_byte0(acc), hi4h = splat_byte1(acc) | HI_BITS;
-                if (has && (p & 15u) == 0u && p + 16u <= end && all16_in(win, lo4, hi4h)) {
-                    p += 16;
-                    if (p < end) win = *reinterpret_cast<const uint4*>(stage + p);
-                    continue;
-                }
-                const uint32_t d = pick_dword(win, (p >> 2) & 3u);
-                if (has && (p & 3u) == 0u && p + 4u <= end && (inrange_bits(d, lo4, hi4h) & HI_BITS) == HI_BITS) {
-                    p += 4;
-                    if ((p & 15u) == 0u && p < end) win = *reinterpret_cast<const uint4*>(stage + p);
-                    continue;
-                }
-                // exact steps over the rest of this dword; the four class lookups are independent of the state chain
-                const uint32_t c0 = cmap[d & 0xFFu], c1 = cmap[(d >> 8) & 0xFFu], c2 = cmap[(d >> 16) & 0xFFu], c3 = cmap[d >> 24];
-                const uint32_t j0 = p & 3u;
-                const uint32_t pbase = p & ~3u;
+                const bool fast = mask == 0xFFFFu && has && all16_in(win, lo4, hi4h);
+                if (more && !fast) {
+                    uint32_t cls[16];
+                    window_classes(win, cmap, cls);
 #pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) {
-                    if (j >= j0 && pbase + j < end) {
-                        const uint32_t cj = j == 0 ? c0 : (j == 1 ? c1 : (j == 2 ? c2 : c3));
-                        const uint32_t e = m_tab[st * ncls + cj];
-                        st = e & 0xFFFFu;
-                        acc = e >> 16;
-                        ++p;
+                    for (int j = 0; j < 16; ++j) {
+                        const uint32_t e = m_tab[st * ncls + cls[j]];
+                        const bool take = (mask >> j) & 1u;
+                        st = take ? (e & 0xFFFFu) : st;
+                        acc = take ? (e >> 16) : acc;
                     }
                 }
-                if ((p & 15u) == 0u && p < end) win = *reinterpret_cast<const uint4*>(stage + p);
+                more = more && wb < w_last && st != dead;
+                wb += 16u;
             }
         }
         const int32_t k = m_acc[st];
@@ -318,50 +346,41 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
         int32_t result = k;
         uint32_t gstate = 0;
         uint32_t ng = 0;
-        if (k >= 0) {
-            const uint32_t s0 = c_rule[2 * k];
-            ng = c_rule[2 * k + 1];
+        {
+            uint32_t s0 = 0, acc = 0x00FFu;
+            if (k >= 0) {
+                s0 = c_rule[2 * k];
+                ng = c_rule[2 * k + 1];
+                acc = c_accel[s0];
+            }
             gstate = s0;
-            uint32_t acc = c_accel[s0];
-            uint32_t p = start;
-            uint4 win = make_uint4(0, 0, 0, 0);
-            if (p < end) win = *reinterpret_cast<const uint4*>(stage + (p & ~15u));
-            while (p < end) {
+            uint32_t wb = w_first;
+            bool more = nonempty && k >= 0;
+            while (__any(more)) {
+                const uint4 win = *reinterpret_cast<const uint4*>(stage + (more ? wb : 0u));
+                const uint32_t mask = more ? window_mask(start, end, wb) : 0u;
                 const bool has = (acc & 0xFFu) <= (acc >> 8);
                 const uint32_t lo4 = splat_byte0(acc), hi4h = splat_byte1(acc) | HI_BITS;
-                if (has && (p & 15u) == 0u && p + 16u <= end && all16_in(win, lo4, hi4h)) {
-                    p += 16;
-                    if (p < end) win = *reinterpret_cast<const uint4*>(stage + p);
-                    continue;
-                }
-                const uint32_t d = pick_dword(win, (p >> 2) & 3u);
-                if (has && (p & 3u) == 0u && p + 4u <= end && (inrange_bits(d, lo4, hi4h) & HI_BITS) == HI_BITS) {
-                    p += 4;
-                    if ((p & 15u) == 0u && p < end) win = *reinterpret_cast<const uint4*>(stage + p);
-                    continue;
-                }
-                const uint32_t c0 = cmap[d & 0xFFu], c1 = cmap[(d >> 8) & 0xFFu], c2 = cmap[(d >> 16) & 0xFFu], c3 = cmap[d >> 24];
-                const uint32_t j0 = p & 3u;
-                const uint32_t pbase = p & ~3u;
+                const bool fast = mask == 0xFFFFu && has && all16_in(win, lo4, hi4h);
+                if (more && !fast) {
+                    uint32_t cls[16];
+                    window_classes(win, cmap, cls);
 #pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) {
-                    if (j >= j0 && pbase + j < end) {
-                        const uint32_t cj = j == 0 ? c0 : (j == 1 ? c1 : (j == 2 ? c2 : c3));
-                        const uint2 e = c_tab[gstate * ncls + cj];
-                        gstate = s0 + (e.x & 0xFFFFu);
-                        acc = e.y;
-                        const uint32_t op = e.x >> 16;
+                    for (int j = 0; j < 16; ++j) {
+                        const uint2 e = c_tab[gstate * ncls + cls[j]];
+                        const bool take = (mask >> j) & 1u;
+                        gstate = take ? s0 + (e.x & 0xFFFFu) : gstate;
+                        acc = take ? e.y : acc;
+                        const uint32_t op = take ? (e.x >> 16) : 0u;
                         if (op) {
-                            const uint16_t pos = static_cast<uint16_t>(pbase + j - start);
-                            for (uint32_t q = ops_off[op]; q < ops_off[op + 1]; ++q) {
-                                const uint32_t dst = ops[2 * q], src = ops[2 * q + 1];
-                                regs[dst * 64] = (src == SRC_POS) ? pos : regs[src * 64];
-                            }
+                            const uint16_t pos = static_cast<uint16_t>(wb + j - start);
+                            if (op & 0x8000u) regs[(op & 0x7FFFu) * 64] = pos;  // the common program: one tag := position
+                            else run_op_list(L.ops_off, L.ops, static_cast<uint32_t>(reinterpret_cast<uint8_t*>(regs) - gx_smem), op, pos);
                         }
-                        ++p;
                     }
                 }
-                if ((p & 15u) == 0u && p < end) win = *reinterpret_cast<const uint4*>(stage + p);
+                more = more && wb < w_last;
+                wb += 16u;
             }
         }
         if (valid) {
