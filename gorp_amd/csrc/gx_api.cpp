@@ -81,53 +81,61 @@ template <typename F> uint16_t self_loop_interval(F loops) {
 void build_lds_image(gx_handle* h) {
     const Tables& T = h->T;
     h->tile_ok = false;
-    if (T.m_states > 32767 || T.n_rules > 32767) return;
-    size_t c_states = 0;
-    for (auto& r : T.rules) c_states += r.n_states;
-    const size_t est = 256 + static_cast<size_t>(T.m_states) * T.ncls * 4 + T.m_states * 4 + c_states * (T.ncls * 8 + 6) +
-                       T.rules.size() * 8 + T.ops_off.size() * 4 + T.ops.size() * 2 + T.fin_tags.size() * 2 + 256;
-    if (est > LDS_TABLE_BUDGET) return;
+    if (T.n_rules > 32767) return;
+    const uint32_t cols = static_cast<uint32_t>(T.ncls) + 3u;
+    const uint32_t RS = cols * 4u;
+    size_t rows = static_cast<size_t>(T.m_states);
+    for (auto& r : T.rules) rows += r.n_states;
+    if (rows * RS > 65536u || T.ncls * 4 > 65535) return;  // row offsets are 16-bit
+    if (rows * RS + T.ops_off.size() * 4 + T.ops.size() * 2 + T.fin_tags.size() * 2 + 1024 > LDS_TABLE_BUDGET) return;
+
     Image img;
     GxLds L{};
-    L.cmap = static_cast<uint32_t>(img.put(T.cls256, 256));  // must stay at offset 0 (the kernel indexes LDS by byte value)
-    std::vector<uint16_t> m_accel(T.m_states);
-    for (int s = 0; s < T.m_states; ++s)
-        m_accel[s] = self_loop_interval([&](int b) { return T.m_next[static_cast<size_t>(s) * T.ncls + T.cls256[b]] == static_cast<uint32_t>(s); });
-    // every transition carries its destination's self-loop interval: one LDS read per step
-    std::vector<uint32_t> m_tab(T.m_next.size());
-    for (size_t e = 0; e < T.m_next.size(); ++e) m_tab[e] = T.m_next[e] | (static_cast<uint32_t>(m_accel[T.m_next[e]]) << 16);
-    L.m_tab = static_cast<uint32_t>(img.put(m_tab));
-    std::vector<int16_t> m_acc(T.m_accept_first.begin(), T.m_accept_first.end());
-    L.m_acc = static_cast<uint32_t>(img.put(m_acc));
-    L.m_accel = static_cast<uint32_t>(img.put(m_accel));
-    std::vector<uint32_t> c_tab, c_rule;  // c_tab: pairs (next | op << 16, destination's interval)
-    std::vector<uint16_t> c_accel;
-    std::vector<int32_t> c_fin;
-    for (auto& r : T.rules) {
-        c_rule.push_back(static_cast<uint32_t>(c_fin.size()));
-        c_rule.push_back(static_cast<uint32_t>(r.n_groups));
-        c_fin.insert(c_fin.end(), r.fin.begin(), r.fin.end());
-        std::vector<uint16_t> acc(r.n_states);
-        for (int s = 0; s < r.n_states; ++s)
-            acc[s] = self_loop_interval(
-                [&](int b) { return r.trans[static_cast<size_t>(s) * T.ncls + T.cls256[b]] == static_cast<uint32_t>(s); });
-        for (uint32_t w : r.trans) {
-            // the common capture program "one tag := position" is folded into the entry as 0x8000 | register
-            uint32_t op = w >> 16;
-            if (op) {
-                const uint32_t b = T.ops_off[op], e = T.ops_off[op + 1];
-                if (e - b == 1 && T.ops[2 * b + 1] == GX_SRC_POS && T.ops[2 * b] < 0x7FFF) op = 0x8000u | T.ops[2 * b];
-                else if (op >= 0x8000u) return;  // too many distinct general programs for the LDS tier
-            }
-            c_tab.push_back((w & 0xFFFFu) | (op << 16));
-            c_tab.push_back(acc[w & 0xFFFFu]);
-        }
-        c_accel.insert(c_accel.end(), acc.begin(), acc.end());
+    std::vector<uint16_t> cmap(256);
+    for (int b = 0; b < 256; ++b) cmap[b] = static_cast<uint16_t>(T.cls256[b] * 4);
+    L.cmap = static_cast<uint32_t>(img.put(cmap));  // offset 0
+    L.row_bytes = RS;
+    std::vector<uint32_t> at(rows * cols, 0);
+    const uint32_t IDC = T.ncls, ACC = T.ncls + 1, INFO = T.ncls + 2;
+    // match automaton rows
+    for (int s = 0; s < T.m_states; ++s) {
+        uint32_t* row = &at[static_cast<size_t>(s) * cols];
+        for (int c = 0; c < T.ncls; ++c) row[c] = T.m_next[static_cast<size_t>(s) * T.ncls + c] * RS;
+        row[IDC] = static_cast<uint32_t>(s) * RS;
+        row[ACC] = self_loop_interval([&](int b) { return T.m_next[static_cast<size_t>(s) * T.ncls + T.cls256[b]] == static_cast<uint32_t>(s); });
+        row[INFO] = static_cast<uint32_t>(T.m_accept_first[s]);
     }
-    if (c_tab.empty()) { c_tab.push_back(0); c_tab.push_back(0x00FF); c_accel.push_back(0x00FF); c_fin.push_back(-1); c_rule.push_back(0); c_rule.push_back(0); }
-    L.c_tab = static_cast<uint32_t>(img.put(c_tab));
-    L.c_accel = static_cast<uint32_t>(img.put(c_accel));
-    L.c_fin = static_cast<uint32_t>(img.put(c_fin));
+    L.m_start = 0;
+    L.m_dead = static_cast<uint32_t>(T.m_dead) * RS;
+    // capture automata rows
+    std::vector<uint32_t> c_rule;
+    size_t base_row = static_cast<size_t>(T.m_states);
+    for (auto& r : T.rules) {
+        const uint32_t base = static_cast<uint32_t>(base_row) * RS;
+        c_rule.push_back(base);
+        c_rule.push_back(static_cast<uint32_t>(r.n_groups));
+        for (int s = 0; s < r.n_states; ++s) {
+            uint32_t* row = &at[(base_row + s) * cols];
+            for (int c = 0; c < T.ncls; ++c) {
+                const uint32_t w = r.trans[static_cast<size_t>(s) * T.ncls + c];
+                // the common capture program "one tag := position" is folded into the entry as 0x8000 | register
+                uint32_t op = w >> 16;
+                if (op) {
+                    const uint32_t b = T.ops_off[op], e = T.ops_off[op + 1];
+                    if (e - b == 1 && T.ops[2 * b + 1] == GX_SRC_POS && T.ops[2 * b] < 0x7FFF) op = 0x8000u | T.ops[2 * b];
+                    else if (op >= 0x8000u) return;  // too many distinct general programs for the LDS tier
+                }
+                row[c] = (base + (w & 0xFFFFu) * RS) | (op << 16);
+            }
+            row[IDC] = base + static_cast<uint32_t>(s) * RS;
+            row[ACC] = self_loop_interval(
+                [&](int b) { return r.trans[static_cast<size_t>(s) * T.ncls + T.cls256[b]] == static_cast<uint32_t>(s); });
+            row[INFO] = static_cast<uint32_t>(r.fin[s]);
+        }
+        base_row += r.n_states;
+    }
+    if (c_rule.empty()) { c_rule.push_back(0); c_rule.push_back(0); }
+    L.at = static_cast<uint32_t>(img.put(at));
     L.c_rule = static_cast<uint32_t>(img.put(c_rule));
     L.ops_off = static_cast<uint32_t>(img.put(T.ops_off));
     std::vector<uint16_t> ops = T.ops;

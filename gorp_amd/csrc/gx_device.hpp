@@ -39,14 +39,17 @@ struct GxDev {
 // host, kept in HBM next to the other tables and copied into LDS by every
 // workgroup's prologue.
 struct GxLds {
-    uint32_t cmap;        // u8[256]    byte -> class
-    uint32_t m_tab;       // u32[m_states * ncls]  next | self-loop interval of next << 16
-    uint32_t m_acc;       // i16[m_states] first accepting extraction or -1
-    uint32_t m_accel;     // u16[m_states] self-loop byte interval lo | hi << 8 (lo > hi: none)
-    uint32_t c_tab;       // uint2[c_states * ncls] {next (rule-local) | op-list << 16, self-loop interval of next}
-    uint32_t c_accel;     // u16[c_states]
-    uint32_t c_fin;       // i32[c_states]
-    uint32_t c_rule;      // u32[n_rules * 2]: first state of the rule, group count
+    uint32_t cmap;        // u16[256] byte -> class * 4; always at offset 0 (the kernel indexes LDS by byte value)
+    uint32_t at;          // automaton rows, u32[rows][ncls + 3]: one row per state of the match automaton and of
+                          // every extraction's capture automaton.  Columns 0..ncls-1: next row byte offset (from
+                          // `at`) | capture program << 16; column ncls: identity (self, no program); column
+                          // ncls+1: self-loop byte interval lo | hi << 8 (lo > hi: none); column ncls+2: info
+                          // (match automaton: first accepting extraction or -1; capture automaton: offset of the
+                          // state's final tag list in fin_tags or -1)
+    uint32_t row_bytes;   // (ncls + 3) * 4
+    uint32_t m_start;     // row offset of the match automaton's start state
+    uint32_t m_dead;      // row offset of its absorbing dead state
+    uint32_t c_rule;      // u32[n_rules * 2]: row offset of the rule's start state, group count
     uint32_t ops_off;     // u32[n_oplists + 1]
     uint32_t ops;         // u16 pairs
     uint32_t fin_tags;    // u16[]

@@ -156,10 +156,14 @@ __device__ __forceinline__ bool all16_in(const uint4& v, uint32_t lo4, uint32_t 
                        inrange_bits(v.w, lo4, hi4h);
     return (r & HI_BITS) == HI_BITS;
 }
-__device__ __forceinline__ uint32_t pick_dword(const uint4& v, uint32_t idx) {
-    const uint32_t a = (idx & 1u) ? v.y : v.x;
-    const uint32_t b = (idx & 1u) ? v.w : v.z;
-    return (idx & 2u) ? b : a;
+// Partial window (first / last of a line): a dword passes when it lies wholly outside the line, or wholly
+// inside and in range; a dword the line boundary cuts through fails (the exact steps handle it).
+__device__ __forceinline__ bool dword_ok(uint32_t x, uint32_t nib, uint32_t lo4, uint32_t hi4h) {
+    return nib == 0u || (nib == 15u && (inrange_bits(x, lo4, hi4h) & HI_BITS) == HI_BITS);
+}
+__device__ __forceinline__ bool partial16_in(const uint4& v, uint32_t mask, uint32_t lo4, uint32_t hi4h) {
+    return dword_ok(v.x, mask & 15u, lo4, hi4h) && dword_ok(v.y, (mask >> 4) & 15u, lo4, hi4h) &&
+           dword_ok(v.z, (mask >> 8) & 15u, lo4, hi4h) && dword_ok(v.w, mask >> 12, lo4, hi4h);
 }
 
 // bit j set iff byte j of the 16-byte window at `wb` lies inside the line [start, end)
@@ -167,13 +171,6 @@ __device__ __forceinline__ uint32_t window_mask(uint32_t start, uint32_t end, ui
     const uint32_t lo = start > wb ? start - wb : 0u;                 // < 16 for a window that overlaps the line
     const uint32_t hi = end - wb < 16u ? end - wb : 16u;              // 1..16
     return ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-}
-
-// the 16 byte->class lookups of a window: independent of the automaton state, so issued back to back
-__device__ __forceinline__ void window_classes(const uint4& win, const uint8_t* cmap, uint32_t (&cls)[16]) {
-    const uint32_t d[4] = {win.x, win.y, win.z, win.w};
-#pragma unroll
-    for (int j = 0; j < 16; ++j) cls[j] = cmap[(d[j >> 2] >> ((j & 3) * 8)) & 0xFFu];
 }
 
 // General capture program (anything but a single "tag := position"): executed from the LDS copy of the
@@ -186,6 +183,72 @@ __device__ __noinline__ void run_op_list(uint32_t ops_off_b, uint32_t ops_b, uin
         const uint32_t dst = ops[2 * q], src = ops[2 * q + 1];
         regs[dst * 64] = (src == SRC_POS) ? pos : regs[src * 64];
     }
+}
+
+// 16 exact automaton steps over one staged window.  `row` is the byte offset of the current state's row in
+// the LDS automaton table; an entry is (next row offset | capture program << 16), so the dependent chain per
+// byte is one LDS read plus one add.  The byte->class lookups do not depend on the state and are issued up
+// front.  MASKED windows (first/last of a line) send out-of-line bytes through the identity column, which
+// maps every state to itself with no capture program.
+template <bool CAPTURE, bool MASKED>
+__device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, const uint8_t* at, uint32_t row, uint32_t idc4,
+                                            uint32_t wb_rel, uint16_t* regs, const GxLds& L) {
+    const uint8_t* cmap = gx_smem;  // GxLds: the byte->class*4 map sits at LDS offset 0
+    const uint32_t d[4] = {win.x, win.y, win.z, win.w};
+    uint32_t c4[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t b = (d[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+        uint32_t c = reinterpret_cast<const uint16_t*>(cmap)[b];
+        if (MASKED) c = ((mask >> j) & 1u) ? c : idc4;
+        c4[j] = c;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t e = *reinterpret_cast<const uint32_t*>(at + row + c4[j]);
+        row = e & 0xFFFFu;
+        if (CAPTURE) {
+            const uint32_t op = e >> 16;
+            if (op) {
+                const uint16_t pos = static_cast<uint16_t>(wb_rel + j);
+                if (op & 0x8000u) regs[(op & 0x7FFFu) * 64] = pos;  // the common program: one tag := position
+                else run_op_list(L.ops_off, L.ops, static_cast<uint32_t>(reinterpret_cast<uint8_t*>(regs) - gx_smem), op, pos);
+            }
+        }
+    }
+    return row;
+}
+
+// Walk one automaton over the staged line [start, end), all lanes in lock step over 16-byte windows: in every
+// window a lane either proves with one SWAR test that all its bytes stay inside the current state's self-loop
+// interval (state unchanged), or takes 16 exact steps.  Returns the row offset of the final state.
+template <bool CAPTURE>
+__device__ __forceinline__ uint32_t walk(const uint8_t* stage, const uint8_t* at, uint32_t row, uint32_t start, uint32_t end,
+                                         bool on, uint32_t dead_row, uint16_t* regs, const GxLds& L) {
+    const uint32_t idc4 = L.row_bytes - 12u;   // identity column
+    const uint32_t acc_off = L.row_bytes - 8u; // self-loop interval column
+    const bool nonempty = on && start < end;
+    const uint32_t w_last = nonempty ? ((end - 1u) & ~15u) : 0u;
+    uint32_t wb = start & ~15u;
+    uint32_t acc = *reinterpret_cast<const uint32_t*>(at + row + acc_off);
+    bool more = nonempty;
+    while (__any(more)) {
+        const uint4 win = *reinterpret_cast<const uint4*>(stage + (more ? wb : 0u));
+        const uint32_t mask = more ? window_mask(start, end, wb) : 0u;
+        const bool has = (acc & 0xFFu) <= ((acc >> 8) & 0xFFu);
+        const uint32_t lo4 = splat_byte0(acc), hi4h = splat_byte1(acc) | HI_BITS;
+        const bool full = mask == 0xFFFFu;
+        bool fast = has && full && all16_in(win, lo4, hi4h);
+        if (more && has && !full) fast = partial16_in(win, mask, lo4, hi4h);
+        if (more && !fast) {
+            if (full) row = steps16<CAPTURE, false>(win, mask, at, row, idc4, wb - start, regs, L);
+            else row = steps16<CAPTURE, true>(win, mask, at, row, idc4, wb - start, regs, L);
+            acc = *reinterpret_cast<const uint32_t*>(at + row + acc_off);
+        }
+        more = more && wb < w_last && row != dead_row;
+        wb += 16u;
+    }
+    return row;
 }
 
 // Wave-cooperative copy of [g_al, g_al + nch*16) into the wave's LDS staging area.
@@ -236,23 +299,16 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
     }
     __syncthreads();
 
-    const uint8_t* cmap = gx_smem;  // GxLds::cmap is always 0: a byte value is its own LDS address
-    const uint32_t* m_tab = reinterpret_cast<const uint32_t*>(gx_smem + L.m_tab);
-    const int16_t* m_acc = reinterpret_cast<const int16_t*>(gx_smem + L.m_acc);
-    const uint16_t* m_accel = reinterpret_cast<const uint16_t*>(gx_smem + L.m_accel);
-    const uint2* c_tab = reinterpret_cast<const uint2*>(gx_smem + L.c_tab);
-    const uint16_t* c_accel = reinterpret_cast<const uint16_t*>(gx_smem + L.c_accel);
-    const int32_t* c_fin = reinterpret_cast<const int32_t*>(gx_smem + L.c_fin);
+    const uint8_t* at = gx_smem + L.at;
     const uint32_t* c_rule = reinterpret_cast<const uint32_t*>(gx_smem + L.c_rule);
     const uint16_t* fin_tags = reinterpret_cast<const uint16_t*>(gx_smem + L.fin_tags);
+    const uint32_t info_off = L.row_bytes - 4u;  // per-state info column: accept / final-tags offset
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     uint8_t* stage = gx_smem + L.stage + wave * L.stage_bytes;
     uint16_t* regs = reinterpret_cast<uint16_t*>(gx_smem + L.regs + wave * L.regs_wave_bytes) + lane;  // regs[r * 64]
 
-    const uint32_t ncls = static_cast<uint32_t>(T.ncls);
-    const uint32_t dead = static_cast<uint32_t>(T.m_dead);
     const int slots = 2 * T.max_groups;
     const bool want_caps = (match_only == 0 || match_only == 3) && T.has_capture;
     const uint64_t tiles = (n + 63) >> 6;
@@ -300,42 +356,9 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
             continue;
         }
 
-        // Both hot loops advance in lock step over 16-byte windows of the staged line: the wave
-        // iterates ceil(longest line / 16) times, and in every window a lane either proves with one
-        // SWAR test that all 16 bytes stay inside its state's self-loop interval (state unchanged),
-        // or takes 16 exact, branch-free steps (bytes outside [start,end) are masked out).
-        const bool nonempty = start < end;
-        const uint32_t w_first = start & ~15u;
-        const uint32_t w_last = nonempty ? ((end - 1u) & ~15u) : 0u;
-
         // ---- hot loop #1: match automaton ----
-        uint32_t st = 0;
-        {
-            uint32_t acc = m_accel[0];
-            uint32_t wb = w_first;
-            bool more = nonempty;
-            while (__any(more)) {
-                const uint4 win = *reinterpret_cast<const uint4*>(stage + (more ? wb : 0u));
-                const uint32_t mask = more ? window_mask(start, end, wb) : 0u;
-                const bool has = (acc & 0xFFu) <= (acc >> 8);
-                const uint32_t lo4 = splat_byte0(acc), hi4h = splat_byte1(acc) | HI_BITS;
-                const bool fast = mask == 0xFFFFu && has && all16_in(win, lo4, hi4h);
-                if (more && !fast) {
-                    uint32_t cls[16];
-                    window_classes(win, cmap, cls);
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const uint32_t e = m_tab[st * ncls + cls[j]];
-                        const bool take = (mask >> j) & 1u;
-                        st = take ? (e & 0xFFFFu) : st;
-                        acc = take ? (e >> 16) : acc;
-                    }
-                }
-                more = more && wb < w_last && st != dead;
-                wb += 16u;
-            }
-        }
-        const int32_t k = m_acc[st];
+        const uint32_t mrow = walk<false>(stage, at, L.m_start, start, end, true, L.m_dead, regs, L);
+        const int32_t k = *reinterpret_cast<const int32_t*>(at + mrow + info_off);
         if (!want_caps) {
             if (valid) match_id[i] = k;
             __builtin_amdgcn_wave_barrier();
@@ -344,50 +367,17 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
 
         // ---- hot loop #2: extraction k's tagged automaton ----
         int32_t result = k;
-        uint32_t gstate = 0;
-        uint32_t ng = 0;
-        {
-            uint32_t s0 = 0, acc = 0x00FFu;
-            if (k >= 0) {
-                s0 = c_rule[2 * k];
-                ng = c_rule[2 * k + 1];
-                acc = c_accel[s0];
-            }
-            gstate = s0;
-            uint32_t wb = w_first;
-            bool more = nonempty && k >= 0;
-            while (__any(more)) {
-                const uint4 win = *reinterpret_cast<const uint4*>(stage + (more ? wb : 0u));
-                const uint32_t mask = more ? window_mask(start, end, wb) : 0u;
-                const bool has = (acc & 0xFFu) <= (acc >> 8);
-                const uint32_t lo4 = splat_byte0(acc), hi4h = splat_byte1(acc) | HI_BITS;
-                const bool fast = mask == 0xFFFFu && has && all16_in(win, lo4, hi4h);
-                if (more && !fast) {
-                    uint32_t cls[16];
-                    window_classes(win, cmap, cls);
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const uint2 e = c_tab[gstate * ncls + cls[j]];
-                        const bool take = (mask >> j) & 1u;
-                        gstate = take ? s0 + (e.x & 0xFFFFu) : gstate;
-                        acc = take ? e.y : acc;
-                        const uint32_t op = take ? (e.x >> 16) : 0u;
-                        if (op) {
-                            const uint16_t pos = static_cast<uint16_t>(wb + j - start);
-                            if (op & 0x8000u) regs[(op & 0x7FFFu) * 64] = pos;  // the common program: one tag := position
-                            else run_op_list(L.ops_off, L.ops, static_cast<uint32_t>(reinterpret_cast<uint8_t*>(regs) - gx_smem), op, pos);
-                        }
-                    }
-                }
-                more = more && wb < w_last;
-                wb += 16u;
-            }
+        uint32_t ng = 0, crow = L.m_dead;
+        if (k >= 0) {
+            crow = c_rule[2 * k];
+            ng = c_rule[2 * k + 1];
         }
+        crow = walk<true>(stage, at, crow, start, end, k >= 0, 0xFFFFFFFFu, regs, L);
         if (valid) {
             int32_t* cp = caps + i * static_cast<uint64_t>(slots);
             int32_t f = -1;
             if (k >= 0) {
-                f = c_fin[gstate];
+                f = *reinterpret_cast<const int32_t*>(at + crow + info_off);
                 if (f < 0) result = -2 - k;  // DFA said yes, capture regex says no -> ExtractionException
             }
             const int32_t len = static_cast<int32_t>(end - start);
