@@ -402,6 +402,19 @@ Dfa product(const std::vector<Dfa>& parts, int ncls, std::vector<std::vector<int
 // it crossed since the last consumed symbol ("pending"); pending tags are
 // written with the current position by the NEXT transition (or by the final
 // step at end of input).
+//
+// Registers are allocated by VALUE: every tag written by one transition
+// receives the same value (the current position), so all of them -- across
+// threads and, in the union automaton, across extractions -- share ONE
+// register.  A register stays live while any surviving thread refers to it.
+// A transition therefore carries at most one "register := position" plus
+// copies on state merges, and the register count tracks the number of distinct
+// live positions rather than (extractions x tags).
+//
+// The builder accepts a program holding several extractions (rule k's code ends
+// in MATCH k, entered through a priority chain of SPLITs): the resulting "union"
+// automaton finds the first-declared extraction that matches the whole line AND
+// its captures in a single pass.
 const int MAX_TAGS = 64;
 const int TDFA_STATE_LIMIT = 60000;
 const int16_t R_NIL = -1, R_NEW = -2;
@@ -409,7 +422,7 @@ const int16_t R_NIL = -1, R_NEW = -2;
 struct Thread {
     int pc;
     uint64_t pending;
-    std::vector<int16_t> reg;  // per tag: register id, R_NIL, or (while building) R_NEW
+    std::vector<int16_t> reg;  // per tag of the thread's rule: register id, R_NIL, or (while building) R_NEW
     bool operator==(const Thread& o) const { return pc == o.pc && pending == o.pending && reg == o.reg; }
     bool operator<(const Thread& o) const {
         if (pc != o.pc) return pc < o.pc;
@@ -417,7 +430,14 @@ struct Thread {
         return reg < o.reg;
     }
 };
-typedef std::vector<Thread> TState;
+// A tagged-DFA state: the ordered thread list, plus (fused automaton only) the state of the match
+// automaton that runs in product with it.
+struct TState {
+    int d = 0;
+    std::vector<Thread> th;
+    bool operator==(const TState& o) const { return d == o.d && th == o.th; }
+    bool operator<(const TState& o) const { return d != o.d ? d < o.d : th < o.th; }
+};
 
 struct OpListPool {
     std::map<std::vector<uint16_t>, int> index;
@@ -434,24 +454,61 @@ struct OpListPool {
     }
 };
 
+// One or more extractions in one program.
+struct MultiProg {
+    std::vector<Inst> code;
+    std::vector<int> rule_of_pc;  // -1 for the SPLIT prelude
+    std::vector<int> ntags;       // per rule
+    std::vector<int> ngroups;     // per rule
+};
+
+MultiProg join_programs(const std::vector<const Prog*>& progs) {
+    MultiProg mp;
+    const int n = static_cast<int>(progs.size());
+    for (int k = 0; k + 1 < n; ++k) { Inst sp; sp.op = Inst::SPLIT; mp.code.push_back(sp); mp.rule_of_pc.push_back(-1); }
+    std::vector<int> start(n);
+    for (int k = 0; k < n; ++k) {
+        const int base = static_cast<int>(mp.code.size());
+        start[k] = base;
+        for (Inst in : progs[k]->code) {
+            if (in.op == Inst::SPLIT) { in.x += base; in.y += base; }
+            else if (in.op == Inst::JMP) in.x += base;
+            else if (in.op == Inst::MATCH) in.x = k;
+            mp.code.push_back(in);
+            mp.rule_of_pc.push_back(k);
+        }
+        mp.ntags.push_back(2 * progs[k]->ngroups);
+        mp.ngroups.push_back(progs[k]->ngroups);
+        if (mp.code.size() > PROG_LIMIT) throw GxError(GX_E_LIMIT, "combined program too large");
+    }
+    for (int k = 0; k + 1 < n; ++k) {
+        mp.code[k].x = start[k];
+        mp.code[k].y = (k + 2 < n) ? k + 1 : start[n - 1];
+    }
+    return mp;
+}
+
 class TdfaBuilder {
 public:
-    TdfaBuilder(const Prog& p, const Classes& C, OpListPool& ops, std::vector<uint16_t>& fin_tags)
-        : p_(p), C_(C), ops_(ops), fin_tags_(fin_tags), ntags_(2 * p.ngroups) {
-        if (ntags_ > MAX_TAGS) throw GxError(GX_E_LIMIT, "more than 32 capture groups in one extraction");
-        pool_.resize(ntags_);
+    // with_rule_id: final-tag records start with the extraction index (union automaton)
+    // fused != nullptr: run in product with the match automaton of *fused (see Tables::uni);
+    // final-tag records then start with the extraction index.
+    TdfaBuilder(const MultiProg& p, const Classes& C, OpListPool& ops, std::vector<uint16_t>& fin_tags, const Tables* fused)
+        : p_(p), C_(C), ops_(ops), fin_tags_(fin_tags), with_rule_id_(fused != nullptr), fused_(fused) {
+        for (int t : p.ntags) if (t > MAX_TAGS) throw GxError(GX_E_LIMIT, "more than 32 capture groups in one extraction");
     }
 
     RuleTables build() {
         RuleTables R;
-        R.n_groups = p_.ngroups;
+        for (int g : p_.ngroups) R.n_groups = std::max(R.n_groups, g);
         seen_.assign(p_.code.size(), 0);
         TState init;
         {
             Thread seed;
-            seed.pc = 0; seed.pending = 0; seed.reg.assign(ntags_, R_NIL);
+            seed.pc = 0; seed.pending = 0;
             std::vector<Thread> seeds{seed};
-            init = close(seeds);
+            init.th = close(seeds);
+            init.d = 0;
         }
         add_state(init);
         for (size_t i = 0; i < states_.size(); ++i) {
@@ -479,30 +536,25 @@ public:
 
 private:
     static const uint32_t DEAD_MARK = 0xFFFFFFFFu;
-    const Prog& p_;
+    const MultiProg& p_;
     const Classes& C_;
     OpListPool& ops_;
     std::vector<uint16_t>& fin_tags_;
-    int ntags_;
+    bool with_rule_id_;
+    const Tables* fused_;
     int nregs_ = 0;
-    std::vector<std::vector<int>> pool_;  // per tag: global register ids in allocation order
+    int scratch_ = -1;
     std::vector<TState> states_;
     std::map<TState, int> exact_;
     std::map<std::vector<std::pair<int, uint64_t>>, std::vector<int>> by_shape_;
     std::vector<uint32_t> trans_;
     std::vector<char> seen_;
 
-    int pool_reg(int tag, size_t idx) {
-        while (pool_[tag].size() <= idx) {
-            if (nregs_ >= 0x7FF0) throw GxError(GX_E_LIMIT, "capture automaton needs too many registers");
-            pool_[tag].push_back(nregs_++);
-        }
-        return pool_[tag][idx];
-    }
+    int ntags_at(int pc) const { return p_.ntags[p_.rule_of_pc[pc]]; }
 
     // Ordered epsilon-closure of a list of seed threads (highest priority first).
-    TState close(const std::vector<Thread>& seeds) {
-        TState out;
+    std::vector<Thread> close(const std::vector<Thread>& seeds) {
+        std::vector<Thread> out;
         std::fill(seen_.begin(), seen_.end(), 0);
         std::vector<std::pair<int, uint64_t>> stack;
         for (const Thread& seed : seeds) {
@@ -518,8 +570,10 @@ private:
                 case Inst::CHAR: case Inst::MATCH: {
                     Thread t;
                     t.pc = q; t.pending = top.second; t.reg = seed.reg;
+                    const int nt = ntags_at(q);
+                    if (t.reg.empty()) t.reg.assign(nt, R_NIL);  // the initial seed enters its rule here
                     // a pending tag's old value is dead: the next step overwrites it
-                    for (int g = 0; g < ntags_; ++g) if ((t.pending >> g) & 1) t.reg[g] = R_NIL;
+                    for (int g = 0; g < nt; ++g) if ((t.pending >> g) & 1) t.reg[g] = R_NIL;
                     out.push_back(std::move(t));
                     break;
                 }
@@ -535,9 +589,10 @@ private:
 
     std::vector<std::pair<int, uint64_t>> shape_of(const TState& s) const {
         std::vector<std::pair<int, uint64_t>> k;
-        for (auto& t : s) {
+        k.push_back({-2, static_cast<uint64_t>(s.d)});
+        for (auto& t : s.th) {
             uint64_t nil = 0;
-            for (int g = 0; g < ntags_; ++g) if (t.reg[g] == R_NIL) nil |= 1ull << g;
+            for (size_t g = 0; g < t.reg.size(); ++g) if (t.reg[g] == R_NIL) nil |= 1ull << g;
             k.push_back({t.pc, t.pending});
             k.push_back({-1, nil});
         }
@@ -553,10 +608,9 @@ private:
         return id;
     }
 
-    // Sequentialise a set of parallel moves dst <- src (src may be GX_SRC_POS).
+    // Sequentialise a set of parallel moves dst <- src (src < 0: the current position).
     std::vector<uint16_t> order_moves(std::vector<std::pair<int, int>> moves) {
         std::vector<uint16_t> out;
-        // drop no-ops
         moves.erase(std::remove_if(moves.begin(), moves.end(), [](const std::pair<int, int>& m) { return m.first == m.second; }), moves.end());
         while (!moves.empty()) {
             bool progress = false;
@@ -582,45 +636,48 @@ private:
         }
         return out;
     }
-    int scratch_ = -1;
 
     uint32_t step(const TState& cur, int cls) {
+        int nd = 0;
+        if (fused_) {
+            nd = static_cast<int>(fused_->m_next[static_cast<size_t>(cur.d) * C_.ncls + cls]);
+            if (nd == fused_->m_dead) return DEAD_MARK;  // no extraction can match any more: the line's result is null
+        }
         std::vector<Thread> seeds;
-        uint64_t new_tags = 0;
-        for (const Thread& t : cur) {
+        for (const Thread& t : cur.th) {
             const Inst& in = p_.code[t.pc];
             if (in.op != Inst::CHAR || !C_.set_has(in.x, cls)) continue;
             Thread s;
             s.pc = t.pc + 1; s.pending = 0; s.reg = t.reg;
-            for (int g = 0; g < ntags_; ++g) if ((t.pending >> g) & 1) s.reg[g] = R_NEW;
+            for (size_t g = 0; g < s.reg.size(); ++g) if ((t.pending >> g) & 1) s.reg[g] = R_NEW;
             seeds.push_back(std::move(s));
         }
-        if (seeds.empty()) return DEAD_MARK;
-        TState nxt = close(seeds);
-        if (nxt.empty()) return DEAD_MARK;
-        // choose a concrete register for every tag written by this transition:
-        // the lowest register of the tag's pool that no surviving thread still reads
-        std::vector<int> new_reg(ntags_, -1);
-        for (int g = 0; g < ntags_; ++g) {
-            bool used = false;
-            for (auto& t : nxt) if (t.reg[g] == R_NEW) { used = true; break; }
-            if (!used) continue;
-            new_tags |= 1ull << g;
-            for (size_t idx = 0;; ++idx) {
-                int r = pool_reg(g, idx);
-                bool busy = false;
-                for (auto& t : nxt) if (t.reg[g] == r) { busy = true; break; }
-                if (!busy) { new_reg[g] = r; break; }
+        std::vector<Thread> nxt;
+        if (!seeds.empty()) nxt = close(seeds);
+        if (nxt.empty() && !fused_) return DEAD_MARK;
+        // one register receives the current position: the lowest one no surviving thread still reads
+        int new_reg = -1;
+        {
+            bool any_new = false;
+            std::vector<char> busy(static_cast<size_t>(nregs_) + 1, 0);
+            for (auto& t : nxt) for (int16_t r : t.reg) { if (r == R_NEW) any_new = true; else if (r >= 0) busy[r] = 1; }
+            if (any_new) {
+                new_reg = 0;
+                while (new_reg < nregs_ && (busy[new_reg] || new_reg == scratch_)) ++new_reg;
+                if (new_reg >= 0x7FF0) throw GxError(GX_E_LIMIT, "capture automaton needs too many registers");
+                if (new_reg >= nregs_) nregs_ = new_reg + 1;
             }
         }
-        TState resolved = nxt;
-        for (auto& t : resolved) for (int g = 0; g < ntags_; ++g) if (t.reg[g] == R_NEW) t.reg[g] = static_cast<int16_t>(new_reg[g]);
+        TState resolved;
+        resolved.d = nd;
+        resolved.th = nxt;
+        for (auto& t : resolved.th) for (auto& r : t.reg) if (r == R_NEW) r = static_cast<int16_t>(new_reg);
         std::vector<std::pair<int, int>> moves;
         auto it = exact_.find(resolved);
         int target = -1;
         if (it != exact_.end()) {
             target = it->second;
-            for (int g = 0; g < ntags_; ++g) if (new_reg[g] >= 0) moves.push_back({new_reg[g], -1});
+            if (new_reg >= 0) moves.push_back({new_reg, -1});
         } else {
             // an existing state of the same shape whose registers can be produced from ours by moves?
             auto sh = by_shape_.find(shape_of(resolved));
@@ -629,9 +686,9 @@ private:
                     const TState& z = states_[cand];
                     std::map<int, int> src_of;  // z register -> our register
                     bool ok = true;
-                    for (size_t j = 0; j < z.size() && ok; ++j)
-                        for (int g = 0; g < ntags_ && ok; ++g) {
-                            int rz = z[j].reg[g], ry = resolved[j].reg[g];
+                    for (size_t j = 0; j < z.th.size() && ok; ++j)
+                        for (size_t g = 0; g < z.th[j].reg.size() && ok; ++g) {
+                            int rz = z.th[j].reg[g], ry = resolved.th[j].reg[g];
                             if (rz == R_NIL) continue;
                             auto f = src_of.find(rz);
                             if (f == src_of.end()) src_of[rz] = ry;
@@ -639,38 +696,44 @@ private:
                         }
                     if (!ok) continue;
                     target = cand;
-                    for (auto& kv : src_of) {
-                        bool is_new = false;
-                        for (int g = 0; g < ntags_; ++g) if (new_reg[g] == kv.second) is_new = true;
-                        moves.push_back({kv.first, is_new ? -1 : kv.second});
-                    }
+                    for (auto& kv : src_of) moves.push_back({kv.first, kv.second == new_reg ? -1 : kv.second});
                     break;
                 }
             }
             if (target < 0) {
                 target = add_state(resolved);
-                for (int g = 0; g < ntags_; ++g) if (new_reg[g] >= 0) moves.push_back({new_reg[g], -1});
+                if (new_reg >= 0) moves.push_back({new_reg, -1});
             }
         }
-        (void)new_tags;
         if (target > 0xFFFE) throw GxError(GX_E_LIMIT, "capture automaton too large");
         int op_id = ops_.intern(order_moves(moves));
         return static_cast<uint32_t>(target) | (static_cast<uint32_t>(op_id) << 16);
     }
 
+    // Info word of a state.  Per-extraction automaton: offset of its final tag record, or -1 (reject).
+    // Fused automaton: offset of the record (which starts with the extraction index), -1 when no
+    // extraction matches (Gorp.extract returns null), -2-k when the match automaton chose extraction k
+    // but k's capture regex has no accepting thread (ExtractionException, core/Gorp.java:173-177).
     int32_t final_of(const TState& s) {
-        for (const Thread& t : s) {
+        int want = -1;
+        if (fused_) {
+            want = fused_->m_accept_first[s.d];
+            if (want < 0) return -1;
+        }
+        for (const Thread& t : s.th) {
             if (p_.code[t.pc].op != Inst::MATCH) continue;
+            if (fused_ && p_.code[t.pc].x != want) continue;
             int32_t off = static_cast<int32_t>(fin_tags_.size());
-            for (int g = 0; g < ntags_; ++g) {
+            if (with_rule_id_) fin_tags_.push_back(static_cast<uint16_t>(p_.code[t.pc].x));
+            for (size_t g = 0; g < t.reg.size(); ++g) {
                 if ((t.pending >> g) & 1) fin_tags_.push_back(GX_SRC_POS);
                 else if (t.reg[g] == R_NIL) fin_tags_.push_back(GX_SRC_NIL);
                 else fin_tags_.push_back(static_cast<uint16_t>(t.reg[g]));
             }
-            if (ntags_ == 0) { fin_tags_.push_back(GX_SRC_NIL); }  // keep offsets distinct from -1
+            if (!with_rule_id_ && t.reg.empty()) fin_tags_.push_back(GX_SRC_NIL);  // keep offsets distinct from -1
             return off;
         }
-        return -1;
+        return fused_ ? -2 - want : -1;
     }
 };
 
@@ -728,8 +791,8 @@ Tables compile_tables(const std::vector<ustr>& automaton_rx, const std::vector<u
         }
     }
     // match automaton
+    std::vector<Dfa> parts;
     {
-        std::vector<Dfa> parts;
         parts.reserve(n);
         for (size_t k = 0; k < n; ++k) parts.push_back(minimize(subset_construct(aprog[k], C)));
         std::vector<std::vector<int32_t>> accept_sets;
@@ -752,12 +815,34 @@ Tables compile_tables(const std::vector<ustr>& automaton_rx, const std::vector<u
         }
     }
     // capture automata
+    T.union_ok = false;
     if (jdk_rx) {
         OpListPool ops;
         for (size_t k = 0; k < n; ++k) {
-            TdfaBuilder b(jprog[k], C, ops, T.fin_tags);
+            MultiProg mp = join_programs({&jprog[k]});
+            TdfaBuilder b(mp, C, ops, T.fin_tags, nullptr);
             T.rules.push_back(b.build());
             T.max_groups = std::max(T.max_groups, T.rules.back().n_groups);
+        }
+        // Fused automaton (single pass): every extraction's capture automaton, joined in priority order,
+        // run in product with the match automaton.  The match component decides WHICH extraction wins
+        // (automaton dialect, exactly as PolyMatcher does), the tagged component supplies that
+        // extraction's captures (JDK dialect) or proves that its regex rejects the line.
+        if (n <= 4096) {
+            try {
+                std::vector<const Prog*> ps;
+                for (auto& p : jprog) ps.push_back(&p);
+                MultiProg mp = join_programs(ps);
+                std::vector<uint16_t> fin = T.fin_tags;  // commit only on success
+                OpListPool ops2 = ops;
+                TdfaBuilder b(mp, C, ops2, fin, &T);
+                T.uni = b.build();
+                T.fin_tags.swap(fin);
+                ops = ops2;
+                T.union_ok = true;
+            } catch (GxError& e) {
+                if (e.code != GX_E_LIMIT) throw;
+            }
         }
         T.ops_off.push_back(0);
         for (auto& l : ops.lists) {
@@ -775,7 +860,7 @@ Tables compile_tables(const std::vector<ustr>& automaton_rx, const std::vector<u
 // ===========================================================================
 namespace {
 const uint32_t BLOB_MAGIC = 0x31425847u;  // "GXB1"
-const uint32_t BLOB_VERSION = 1;
+const uint32_t BLOB_VERSION = 2;
 
 struct Writer {
     std::vector<uint8_t> buf;
@@ -821,6 +906,12 @@ std::vector<uint8_t> pack_blob(const Tables& t) {
         w.vec(r.trans); w.vec(r.fin);
     }
     w.vec(t.ops_off); w.vec(t.ops); w.vec(t.fin_tags);
+    w.pod<int32_t>(t.union_ok ? 1 : 0);
+    w.pod<int32_t>(0);  // keeps the following vectors 8-byte aligned
+    if (t.union_ok) {
+        w.pod<int32_t>(t.uni.n_groups); w.pod<int32_t>(t.uni.n_states); w.pod<int32_t>(t.uni.n_regs); w.pod<int32_t>(t.uni.dead);
+        w.vec(t.uni.trans); w.vec(t.uni.fin);
+    }
     return w.buf;
 }
 
@@ -847,6 +938,14 @@ Tables unpack_blob(const void* data, size_t size) {
         t.rules.push_back(std::move(rt));
     }
     t.ops_off = r.vec<uint32_t>(); t.ops = r.vec<uint16_t>(); t.fin_tags = r.vec<uint16_t>();
+    t.union_ok = r.pod<int32_t>() != 0;
+    (void)r.pod<int32_t>();
+    if (t.union_ok) {
+        t.uni.n_groups = r.pod<int32_t>(); t.uni.n_states = r.pod<int32_t>(); t.uni.n_regs = r.pod<int32_t>(); t.uni.dead = r.pod<int32_t>();
+        t.uni.trans = r.vec<uint32_t>(); t.uni.fin = r.vec<int32_t>();
+        if (t.uni.trans.size() != static_cast<size_t>(t.uni.n_states) * t.ncls || t.uni.fin.size() != static_cast<size_t>(t.uni.n_states))
+            throw GxError(GX_E_ARG, "corrupt table blob");
+    }
     if (t.m_next.size() != static_cast<size_t>(t.m_states) * t.ncls || t.hi_lo.size() != t.hi_cls.size() || t.hi_lo.empty())
         throw GxError(GX_E_ARG, "corrupt table blob");
     return t;

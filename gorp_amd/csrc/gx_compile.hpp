@@ -44,6 +44,13 @@ struct Tables {
     std::vector<int32_t> m_accept_list;    // ascending extraction indexes per state
 
     std::vector<RuleTables> rules;
+    // Fused automaton: all extractions' capture automata joined in priority order, in product with the
+    // match automaton -- one pass yields the winning extraction AND its captures.  fin[s] >= 0: offset of
+    // a final-tag record that starts with the extraction index; -1: no match (null); -2-k: the match
+    // automaton chose k but k's regex rejects (ExtractionException).  Absent (union_ok false) only when
+    // it exceeds a size limit.
+    bool union_ok = false;
+    RuleTables uni;
     std::vector<uint32_t> ops_off;   // [n_oplists + 1]; list 0 is empty
     std::vector<uint16_t> ops;       // (dst, src) pairs, executed in order
     std::vector<uint16_t> fin_tags;  // register id | GX_SRC_POS (= line length) | GX_SRC_NIL

@@ -36,7 +36,7 @@ class Blob:
     def __init__(self, buf):
         r = _Reader(buf)
         assert r.pod("I") == 0x31425847, "bad magic"
-        assert r.pod("I") == 1, "bad version"
+        assert r.pod("I") == 2, "bad version"
         self.n_rules = r.pod("i")
         self.ncls = r.pod("i")
         self.max_groups = r.pod("i")
@@ -59,6 +59,14 @@ class Blob:
         self.ops_off = r.vec(np.uint32)
         self.ops = r.vec(np.uint16)
         self.fin_tags = r.vec(np.uint16)
+        self.union_ok = r.pod("i") != 0
+        r.pod("i")  # padding
+        self.uni = None
+        if self.union_ok:
+            u = {"n_groups": r.pod("i"), "n_states": r.pod("i"), "n_regs": r.pod("i"), "dead": r.pod("i")}
+            u["trans"] = r.vec(np.uint32).reshape(u["n_states"], self.ncls)
+            u["fin"] = r.vec(np.int32)
+            self.uni = u
 
     # -- kernel contract ---------------------------------------------------
     def class_of(self, c):
@@ -115,6 +123,38 @@ class Blob:
             pe = n if ve == SRC_POS else (-1 if ve == SRC_NIL else regs[ve])
             caps.append(None if pb < 0 or pe < 0 else (pb, pe))
         return k, caps
+
+
+def _extract_union(self, units):
+    """Single pass over the fused automaton (match automaton x joined capture automata): same result encoding."""
+    assert self.union_ok
+    u = self.uni
+    cls = self.classes(units)
+    regs = {}
+    ts = 0
+    for p, c in enumerate(cls):
+        w = int(u["trans"][ts, c])
+        ts = w & 0xFFFF
+        op = w >> 16
+        if op:
+            for j in range(int(self.ops_off[op]), int(self.ops_off[op + 1])):
+                dst, src = int(self.ops[2 * j]), int(self.ops[2 * j + 1])
+                regs[dst] = p if src == SRC_POS else regs[src]
+    f = int(u["fin"][ts])
+    if f < 0:
+        return f, []
+    k = int(self.fin_tags[f])
+    caps = []
+    n = len(cls)
+    for g in range(self.rules[k]["n_groups"]):
+        vb, ve = int(self.fin_tags[f + 1 + 2 * g]), int(self.fin_tags[f + 2 + 2 * g])
+        pb = n if vb == SRC_POS else (-1 if vb == SRC_NIL else regs[vb])
+        pe = n if ve == SRC_POS else (-1 if ve == SRC_NIL else regs[ve])
+        caps.append(None if pb < 0 or pe < 0 else (pb, pe))
+    return k, caps
+
+
+Blob.extract_union = _extract_union
 
 
 def units_of(s):

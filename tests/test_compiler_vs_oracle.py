@@ -22,6 +22,14 @@ def product_blob(autom, jdk):
     return Blob(out)
 
 
+def extract_both_ways(b, units):
+    """Two-phase tables and, when present, the fused single-pass automaton must agree."""
+    got = b.extract(units)
+    if b.union_ok:
+        assert b.extract_union(units) == got, units
+    return got
+
+
 def both(extractions):
     fl = [FlattenedExtraction(e["name"], e["pieces"], e.get("append")) for e in extractions]
     built = [f.build() for f in fl]
@@ -81,7 +89,7 @@ def test_full_extraction_golden(golden):
     for t in golden("full_extraction")["tests"]:
         b, orc = both(t["extractions"])
         for c in t["cases"]:
-            got = b.extract(units_of(c["input"]))
+            got = extract_both_ways(b, units_of(c["input"]))
             assert got == orc.extract(c["input"]), (t["name"], c["input"])
             assert got[0] >= 0
             if "id" in c:
@@ -95,7 +103,15 @@ def test_configs_golden(golden):
         for c in g[key]["cases"]:
             u = units_of(c["input"])
             assert b.match(u) == c["match"]
-            assert b.extract(u) == orc.extract(c["input"])
+            assert extract_both_ways(b, u) == orc.extract(c["input"])
+
+
+def test_fused_automaton_is_built_for_the_benchmark_definitions(golden):
+    g = golden("configs")
+    for key in ("simple_grp", "readme_3"):
+        b, _ = both(g[key]["extractions"])
+        assert b.union_ok
+        assert b.uni["n_regs"] <= 8  # value-shared registers: one per distinct live position
 
 
 def test_blob_roundtrip(golden):
@@ -229,7 +245,7 @@ def test_random_definitions_match_and_extract():
         for ln in lines:
             u = units_of(ln)
             assert b.match(u) == orc.match(ln), (exts, ln)
-            got, exp = b.extract(u), orc.extract(ln)
+            got, exp = extract_both_ways(b, u), orc.extract(ln)
             assert got == exp, (exts, ln, got, exp)
             n_lines += 1
             n_hits += got[0] >= 0
@@ -266,7 +282,7 @@ def test_random_raw_regex_pairs_capture_parity():
         n += 1
         lines = [gen_line(rng) for _ in range(15)] + _sample_accepted(rng, jdk)
         for ln in lines:
-            got, exp = b.extract(units_of(ln)), orc.extract(ln)
+            got, exp = extract_both_ways(b, units_of(ln)), orc.extract(ln)
             assert got == exp, (jdk, ln, got, exp)
             checked += 1
             matched += got[0] >= 0
@@ -290,6 +306,6 @@ def test_dialect_disagreement_yields_exception_code():
         ([["pattern", "[(]x"]], "?x", -1),
     ]:
         b, orc = both([{"name": "r", "pieces": pieces}])
-        got = b.extract(units_of(line))
+        got = extract_both_ways(b, units_of(line))
         assert got == orc.extract(line)
         assert got[0] == want, (pieces, line)
