@@ -84,8 +84,11 @@ void build_lds_image(gx_handle* h) {
     if (T.n_rules > 32767) return;
     const uint32_t cols = static_cast<uint32_t>(T.ncls) + 3u;
     const uint32_t RS = cols * 4u;
+    // with the fused automaton present the per-extraction capture rows are not needed on the device
+    const bool fused = T.union_ok;
     size_t rows = static_cast<size_t>(T.m_states);
-    for (auto& r : T.rules) rows += r.n_states;
+    if (fused) rows += T.uni.n_states;
+    else for (auto& r : T.rules) rows += r.n_states;
     if (rows * RS > 65536u || T.ncls * 4 > 65535) return;  // row offsets are 16-bit
     if (rows * RS + T.ops_off.size() * 4 + T.ops.size() * 2 + T.fin_tags.size() * 2 + 1024 > LDS_TABLE_BUDGET) return;
 
@@ -107,23 +110,22 @@ void build_lds_image(gx_handle* h) {
     }
     L.m_start = 0;
     L.m_dead = static_cast<uint32_t>(T.m_dead) * RS;
-    // capture automata rows
+    // capture automata rows: the fused automaton, or one automaton per extraction
     std::vector<uint32_t> c_rule;
     size_t base_row = static_cast<size_t>(T.m_states);
-    for (auto& r : T.rules) {
+    bool too_many_programs = false;
+    auto emit_rows = [&](const RuleTables& r) {
         const uint32_t base = static_cast<uint32_t>(base_row) * RS;
-        c_rule.push_back(base);
-        c_rule.push_back(static_cast<uint32_t>(r.n_groups));
         for (int s = 0; s < r.n_states; ++s) {
             uint32_t* row = &at[(base_row + s) * cols];
             for (int c = 0; c < T.ncls; ++c) {
                 const uint32_t w = r.trans[static_cast<size_t>(s) * T.ncls + c];
-                // the common capture program "one tag := position" is folded into the entry as 0x8000 | register
+                // the common capture program "one register := position" is folded into the entry as 0x8000 | register
                 uint32_t op = w >> 16;
                 if (op) {
                     const uint32_t b = T.ops_off[op], e = T.ops_off[op + 1];
                     if (e - b == 1 && T.ops[2 * b + 1] == GX_SRC_POS && T.ops[2 * b] < 0x7FFF) op = 0x8000u | T.ops[2 * b];
-                    else if (op >= 0x8000u) return;  // too many distinct general programs for the LDS tier
+                    else if (op >= 0x8000u) too_many_programs = true;
                 }
                 row[c] = (base + (w & 0xFFFFu) * RS) | (op << 16);
             }
@@ -133,7 +135,23 @@ void build_lds_image(gx_handle* h) {
             row[INFO] = static_cast<uint32_t>(r.fin[s]);
         }
         base_row += r.n_states;
+        return base;
+    };
+    L.u_start = 0xFFFFFFFFu;
+    L.u_dead = 0xFFFFFFFFu;
+    if (fused) {
+        const uint32_t base = emit_rows(T.uni);
+        L.u_start = base;
+        L.u_dead = base + static_cast<uint32_t>(T.uni.dead) * RS;
+        for (auto& r : T.rules) { c_rule.push_back(0); c_rule.push_back(static_cast<uint32_t>(r.n_groups)); }
+    } else {
+        for (auto& r : T.rules) {
+            const uint32_t base = emit_rows(r);
+            c_rule.push_back(base);
+            c_rule.push_back(static_cast<uint32_t>(r.n_groups));
+        }
     }
+    if (too_many_programs) return;  // too many distinct general programs for the LDS tier
     if (c_rule.empty()) { c_rule.push_back(0); c_rule.push_back(0); }
     L.at = static_cast<uint32_t>(img.put(at));
     L.c_rule = static_cast<uint32_t>(img.put(c_rule));
@@ -148,6 +166,7 @@ void build_lds_image(gx_handle* h) {
     L.table_bytes = static_cast<uint32_t>(img.bytes.size());
     int max_regs = 0;
     for (auto& r : T.rules) max_regs = std::max(max_regs, r.n_regs);
+    if (fused) max_regs = T.uni.n_regs;
     L.regs_wave_bytes = static_cast<uint32_t>((max_regs * 64 * 2 + 15) & ~15);
     h->lds = L;
     h->lds_image.swap(img.bytes);

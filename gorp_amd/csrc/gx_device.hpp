@@ -50,6 +50,8 @@ struct GxLds {
     uint32_t m_start;     // row offset of the match automaton's start state
     uint32_t m_dead;      // row offset of its absorbing dead state
     uint32_t c_rule;      // u32[n_rules * 2]: row offset of the rule's start state, group count
+    uint32_t u_start;     // row offset of the fused automaton's start state, or 0xFFFFFFFF when absent
+    uint32_t u_dead;      // row offset of its dead state
     uint32_t ops_off;     // u32[n_oplists + 1]
     uint32_t ops;         // u16 pairs
     uint32_t fin_tags;    // u16[]

@@ -356,35 +356,55 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
             continue;
         }
 
-        // ---- hot loop #1: match automaton ----
-        const uint32_t mrow = walk<false>(stage, at, L.m_start, start, end, true, L.m_dead, regs, L);
-        const int32_t k = *reinterpret_cast<const int32_t*>(at + mrow + info_off);
+        // ---- hot loop #1: match automaton (skipped when the fused automaton answers both questions) ----
+        const bool need_match = !want_caps || L.u_start == 0xFFFFFFFFu;
+        int32_t k = -1;
+        if (need_match) {
+            const uint32_t mrow = walk<false>(stage, at, L.m_start, start, end, true, L.m_dead, regs, L);
+            k = *reinterpret_cast<const int32_t*>(at + mrow + info_off);
+        }
         if (!want_caps) {
             if (valid) match_id[i] = k;
             __builtin_amdgcn_wave_barrier();
             continue;
         }
+        const int mrow_unused = 0;
 
-        // ---- hot loop #2: extraction k's tagged automaton ----
-        int32_t result = k;
-        uint32_t ng = 0, crow = L.m_dead;
-        if (k >= 0) {
-            crow = c_rule[2 * k];
-            ng = c_rule[2 * k + 1];
-        }
-        crow = walk<true>(stage, at, crow, start, end, k >= 0, 0xFFFFFFFFu, regs, L);
-        if (valid) {
-            int32_t* cp = caps + i * static_cast<uint64_t>(slots);
-            int32_t f = -1;
+        int32_t result, f = -1, tag0 = 0;
+        uint32_t ng = 0;
+        if (L.u_start != 0xFFFFFFFFu) {
+            // ---- fused pass: match automaton x joined capture automata, one walk ----
+            (void)mrow_unused;
+            const uint32_t urow = walk<true>(stage, at, L.u_start, start, end, true, L.u_dead, regs, L);
+            const int32_t info = *reinterpret_cast<const int32_t*>(at + urow + info_off);
+            result = info;  // -1: null, -2-k: ExtractionException
+            if (info >= 0) {
+                result = fin_tags[info];  // the record starts with the winning extraction
+                ng = c_rule[2 * result + 1];
+                f = info;
+                tag0 = 1;
+            }
+        } else {
+            // ---- hot loop #2: extraction k's tagged automaton ----
+            result = k;
+            uint32_t crow = L.m_dead;
+            if (k >= 0) {
+                crow = c_rule[2 * k];
+                ng = c_rule[2 * k + 1];
+            }
+            crow = walk<true>(stage, at, crow, start, end, k >= 0, 0xFFFFFFFFu, regs, L);
             if (k >= 0) {
                 f = *reinterpret_cast<const int32_t*>(at + crow + info_off);
                 if (f < 0) result = -2 - k;  // DFA said yes, capture regex says no -> ExtractionException
             }
+        }
+        if (valid) {
+            int32_t* cp = caps + i * static_cast<uint64_t>(slots);
             const int32_t len = static_cast<int32_t>(end - start);
             for (int g = 0; g < T.max_groups; ++g) {
                 int32_t pb = -1, pe = -1;
                 if (f >= 0 && static_cast<uint32_t>(g) < ng) {
-                    const uint16_t vb = fin_tags[f + 2 * g], ve = fin_tags[f + 2 * g + 1];
+                    const uint16_t vb = fin_tags[f + tag0 + 2 * g], ve = fin_tags[f + tag0 + 2 * g + 1];
                     pb = (vb == SRC_POS) ? len : (vb == SRC_NIL ? -1 : static_cast<int32_t>(regs[vb * 64]));
                     pe = (ve == SRC_POS) ? len : (ve == SRC_NIL ? -1 : static_cast<int32_t>(regs[ve * 64]));
                     if (pb < 0 || pe < 0) { pb = -1; pe = -1; }
