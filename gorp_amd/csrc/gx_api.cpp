@@ -180,10 +180,12 @@ bool plan_tile_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out) 
     if (line_bytes_hint == 0) line_bytes_hint = 200;
     if (line_bytes_hint > 2000) line_bytes_hint = 2000;
     L.stage_bytes = (64u * line_bytes_hint + 32u + 15u) & ~15u;
+    if (L.stage_bytes > 16384u) L.stage_bytes = 16384u;  // the kernel prefetches a tile into <= 64 VGPRs per lane;
+                                                          // tiles that do not fit take the per-lane global path
     const uint32_t per_wave = L.stage_bytes + L.regs_wave_bytes;
     if (L.table_bytes + 4 * per_wave > LDS_BYTES) return false;
     uint32_t nw = (LDS_BYTES - L.table_bytes) / per_wave;
-    if (nw > 16) nw = 16;
+    if (nw > 12) nw = 12;  // 768 threads: leaves 170 VGPRs per lane for the prefetch registers
     L.nwaves = nw;
     L.regs = L.table_bytes;
     L.stage = L.regs + nw * L.regs_wave_bytes;

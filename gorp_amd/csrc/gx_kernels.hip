@@ -174,8 +174,9 @@ __device__ __forceinline__ uint32_t window_mask(uint32_t start, uint32_t end, ui
 }
 
 // General capture program (anything but a single "tag := position"): executed from the LDS copy of the
-// op lists.  Rare, so kept out of line.  regs_b = byte offset in LDS of this lane's register column.
-__device__ __noinline__ void run_op_list(uint32_t ops_off_b, uint32_t ops_b, uint32_t regs_b, uint32_t op, uint16_t pos) {
+// op lists (rare).  Inlined on purpose: a real call would force the prefetch registers, which are live
+// across the whole walk, to be spilled around it.  regs_b = byte offset in LDS of this lane's register column.
+__device__ __forceinline__ void run_op_list(uint32_t ops_off_b, uint32_t ops_b, uint32_t regs_b, uint32_t op, uint16_t pos) {
     const uint32_t* ops_off = reinterpret_cast<const uint32_t*>(gx_smem + ops_off_b);
     const uint16_t* ops = reinterpret_cast<const uint16_t*>(gx_smem + ops_b);
     uint16_t* regs = reinterpret_cast<uint16_t*>(gx_smem + regs_b);
@@ -286,8 +287,58 @@ __device__ void stage_span_guarded(const uint8_t* __restrict__ g_al, uint32_t nc
     }
 }
 
-template <typename OFF>
-__global__ void __launch_bounds__(1024)
+// What one wave needs to know about a tile (64 consecutive lines).
+struct TileInfo {
+    uint64_t i;            // this lane's line index
+    uint64_t o0, o1;       // its byte range in the CSR buffer
+    const uint8_t* g_al;   // 16-byte aligned start of the tile's span in global memory
+    uint32_t nch;          // 16-byte chunks in the span
+    uint32_t start, end;   // this lane's line inside the staging area
+    int mode;              // 0: prefetched into registers; 1: touches the buffer edge (guarded copy);
+                           // 2: does not fit the staging area (per-lane global path)
+    bool valid;
+};
+
+// Clamped, unconditional accesses on both sides: a lane beyond the span re-reads / rewrites the last chunk
+// with identical data.  (Per-lane conditions make the compiler spill the array and serialise the batch.)
+// native vector type: a plain 128-bit value the optimiser keeps in registers (HIP's uint4 struct is copied with
+// memcpy, which pins the prefetch array in scratch memory)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int KCH>
+__device__ __forceinline__ void tile_issue_loads(const TileInfo& t, uint32_t lane, u32x4 (&pre)[KCH]) {
+    if (t.mode == 0) {
+#pragma unroll
+        for (int k = 0; k < KCH; ++k) {
+            const uint32_t c = min(lane + 64u * k, t.nch - 1u);
+            pre[k] = *reinterpret_cast<const u32x4*>(t.g_al + (static_cast<uint64_t>(c) << 4));
+        }
+    }
+}
+template <int KCH>
+__device__ __forceinline__ void tile_commit(const TileInfo& t, uint32_t lane, const u32x4 (&pre)[KCH], uint8_t* stage,
+                                            const uint8_t* data, const uint8_t* data_end, bool copy) {
+    if (t.mode == 0) {
+        if (copy) {
+#pragma unroll
+            for (int k = 0; k < KCH; ++k) {
+                const uint32_t c = min(lane + 64u * k, t.nch - 1u);
+                *reinterpret_cast<u32x4*>(stage + (c << 4)) = pre[k];
+            }
+        }
+    } else if (t.mode == 1) {
+        stage_span_guarded(t.g_al, t.nch, stage, lane, data, data_end);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// KCH: 16-byte chunks per lane that cover the staging area (stage_bytes <= KCH * 1024).  A tile's span is
+// fetched into KCH*4 VGPRs per lane one tile AHEAD: the loads are issued before the current tile is walked
+// and land while the wave computes out of LDS, so HBM latency is hidden without a second LDS buffer.
+template <typename OFF, int KCH>
+__global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(1, 3)))
 k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const uint8_t* __restrict__ data,
                const OFF* __restrict__ off, uint64_t n, int32_t* __restrict__ match_id, int32_t* __restrict__ caps,
                int match_only) {
@@ -315,107 +366,125 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
     const uint64_t wstride = static_cast<uint64_t>(gridDim.x) * L.nwaves;
     const uint8_t* data_end = data + static_cast<uint64_t>(off[n]);
 
-    for (uint64_t tile = static_cast<uint64_t>(blockIdx.x) * L.nwaves + wave; tile < tiles; tile += wstride) {
+    auto load_offsets = [&](uint64_t tile, uint64_t& o0, uint64_t& o1) {
         const uint64_t i = (tile << 6) + lane;
         const bool valid = i < n;
-        const uint64_t o0 = off[valid ? i : n];
-        const uint64_t o1 = off[valid ? i + 1 : n];
+        o0 = off[valid ? i : n];
+        o1 = off[valid ? i + 1 : n];
+    };
+    auto make_tile = [&](uint64_t tile, uint64_t o0, uint64_t o1) {
+        TileInfo t;
+        t.i = (tile << 6) + lane;
+        t.valid = t.i < n;
+        t.o0 = o0; t.o1 = o1;
         // tile span [lo, hi): lane 0 always holds a valid line
         const uint64_t lo = __shfl(static_cast<unsigned long long>(o0), 0);
         const uint64_t hi = __shfl(static_cast<unsigned long long>(o1), 63);
         const uint8_t* g_lo = data + lo;
         const uint32_t skew = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(g_lo) & 15u);
-        const uint8_t* g_al = g_lo - skew;  // 16-byte aligned; still a global-address-space pointer for the compiler
+        t.g_al = g_lo - skew;  // 16-byte aligned; still a global-address-space pointer for the compiler
         const uint64_t span = (hi - lo) + skew;
+        t.nch = static_cast<uint32_t>((span + 15) >> 4);
+        t.start = skew + static_cast<uint32_t>(o0 - lo);
+        t.end = skew + static_cast<uint32_t>(o1 - lo);
+        if (span + 16 > L.stage_bytes) t.mode = 2;
+        else if (!(t.g_al >= data && t.g_al + (static_cast<uint64_t>(t.nch) << 4) <= data_end)) t.mode = 1;
+        else t.mode = 0;
+        return t;
+    };
 
-        if (span + 16 > L.stage_bytes) {
+    uint64_t tile = static_cast<uint64_t>(blockIdx.x) * L.nwaves + wave;
+    if (tile >= tiles) return;
+    u32x4 pre[KCH];  // the next tile's bytes, in flight or landed
+    uint64_t o0, o1, no0 = 0, no1 = 0;
+    load_offsets(tile, o0, o1);
+    TileInfo cur = make_tile(tile, o0, o1);
+    if (match_only != 3) tile_issue_loads<KCH>(cur, lane, pre);
+    uint64_t ntile = tile + wstride;
+    load_offsets(min(ntile, tiles - 1), no0, no1);
+
+    for (;;) {
+        tile_commit<KCH>(cur, lane, pre, stage, data, data_end, match_only != 3);
+        // ---- software pipeline: start fetching the next tile (and the offsets of the one after) ----
+        const bool has_next = ntile < tiles;
+        TileInfo nxt = cur;
+        if (has_next) {
+            nxt = make_tile(ntile, no0, no1);
+            if (match_only != 3) tile_issue_loads<KCH>(nxt, lane, pre);
+        }
+        // unconditional (index clamped): a conditional load would need a register copy at the join, and
+        // that copy would wait for every load issued before it -- including the prefetch above
+        uint64_t nno0, nno1;
+        load_offsets(min(ntile + wstride, tiles - 1), nno0, nno1);
+
+        const uint64_t i = cur.i;
+        const bool valid = cur.valid;
+        const uint32_t start = cur.start, end = cur.end;
+        if (cur.mode == 2) {
             // tile does not fit the staging area (very long lines): exact per-lane path from global memory
             if (valid)
-                extract_line_global<uint8_t, uint16_t>(T, T.m_next16, data + o0, static_cast<int64_t>(o1 - o0), i, match_id, caps,
-                                                       nullptr, match_only);
-            continue;
-        }
-
-        // ---- stage the span: coalesced 16 B per lane ----
-        {
-            const uint32_t nch = static_cast<uint32_t>((span + 15) >> 4);
-            if (match_only == 3) {
-                // timing ablation (GX_DEBUG_ABLATE=3): no staging, walk whatever is in LDS
-            } else if (g_al >= data && g_al + (static_cast<uint64_t>(nch) << 4) <= data_end) stage_span(g_al, nch, stage, lane);
-            else stage_span_guarded(g_al, nch, stage, lane, data, data_end);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        const uint32_t start = skew + static_cast<uint32_t>(o0 - lo);
-        const uint32_t end = skew + static_cast<uint32_t>(o1 - lo);
-        if (match_only == 2) {  // timing ablation (GX_DEBUG_ABLATE=2): staging only
+                extract_line_global<uint8_t, uint16_t>(T, T.m_next16, data + cur.o0, static_cast<int64_t>(cur.o1 - cur.o0), i, match_id,
+                                                       caps, nullptr, match_only);
+        } else if (match_only == 2) {  // timing ablation (GX_DEBUG_ABLATE=2): staging only
             if (valid) match_id[i] = stage[start];
-            __builtin_amdgcn_wave_barrier();
-            continue;
-        }
-
-        // ---- hot loop #1: match automaton (skipped when the fused automaton answers both questions) ----
-        const bool need_match = !want_caps || L.u_start == 0xFFFFFFFFu;
-        int32_t k = -1;
-        if (need_match) {
+        } else if (!want_caps) {
+            // ---- hot loop #1 alone: PolyMatcher.match ----
             const uint32_t mrow = walk<false>(stage, at, L.m_start, start, end, true, L.m_dead, regs, L);
-            k = *reinterpret_cast<const int32_t*>(at + mrow + info_off);
-        }
-        if (!want_caps) {
-            if (valid) match_id[i] = k;
-            __builtin_amdgcn_wave_barrier();
-            continue;
-        }
-        const int mrow_unused = 0;
-
-        int32_t result, f = -1, tag0 = 0;
-        uint32_t ng = 0;
-        if (L.u_start != 0xFFFFFFFFu) {
-            // ---- fused pass: match automaton x joined capture automata, one walk ----
-            (void)mrow_unused;
-            const uint32_t urow = walk<true>(stage, at, L.u_start, start, end, true, L.u_dead, regs, L);
-            const int32_t info = *reinterpret_cast<const int32_t*>(at + urow + info_off);
-            result = info;  // -1: null, -2-k: ExtractionException
-            if (info >= 0) {
-                result = fin_tags[info];  // the record starts with the winning extraction
-                ng = c_rule[2 * result + 1];
-                f = info;
-                tag0 = 1;
-            }
+            if (valid) match_id[i] = *reinterpret_cast<const int32_t*>(at + mrow + info_off);
         } else {
-            // ---- hot loop #2: extraction k's tagged automaton ----
-            result = k;
-            uint32_t crow = L.m_dead;
-            if (k >= 0) {
-                crow = c_rule[2 * k];
-                ng = c_rule[2 * k + 1];
-            }
-            crow = walk<true>(stage, at, crow, start, end, k >= 0, 0xFFFFFFFFu, regs, L);
-            if (k >= 0) {
-                f = *reinterpret_cast<const int32_t*>(at + crow + info_off);
-                if (f < 0) result = -2 - k;  // DFA said yes, capture regex says no -> ExtractionException
-            }
-        }
-        if (valid) {
-            int32_t* cp = caps + i * static_cast<uint64_t>(slots);
-            const int32_t len = static_cast<int32_t>(end - start);
-            for (int g = 0; g < T.max_groups; ++g) {
-                int32_t pb = -1, pe = -1;
-                if (f >= 0 && static_cast<uint32_t>(g) < ng) {
-                    const uint16_t vb = fin_tags[f + tag0 + 2 * g], ve = fin_tags[f + tag0 + 2 * g + 1];
-                    pb = (vb == SRC_POS) ? len : (vb == SRC_NIL ? -1 : static_cast<int32_t>(regs[vb * 64]));
-                    pe = (ve == SRC_POS) ? len : (ve == SRC_NIL ? -1 : static_cast<int32_t>(regs[ve * 64]));
-                    if (pb < 0 || pe < 0) { pb = -1; pe = -1; }
+            int32_t result, f = -1, tag0 = 0;
+            uint32_t ng = 0;
+            if (L.u_start != 0xFFFFFFFFu) {
+                // ---- fused pass: match automaton x joined capture automata, one walk ----
+                const uint32_t urow = walk<true>(stage, at, L.u_start, start, end, true, L.u_dead, regs, L);
+                const int32_t info = *reinterpret_cast<const int32_t*>(at + urow + info_off);
+                result = info;  // -1: null, -2-k: ExtractionException
+                if (info >= 0) {
+                    result = fin_tags[info];  // the record starts with the winning extraction
+                    ng = c_rule[2 * result + 1];
+                    f = info;
+                    tag0 = 1;
                 }
-                cp[2 * g] = pb;
-                cp[2 * g + 1] = pe;
+            } else {
+                // ---- hot loop #1, then hot loop #2 on extraction k's tagged automaton ----
+                const uint32_t mrow = walk<false>(stage, at, L.m_start, start, end, true, L.m_dead, regs, L);
+                const int32_t k = *reinterpret_cast<const int32_t*>(at + mrow + info_off);
+                result = k;
+                uint32_t crow = L.m_dead;
+                if (k >= 0) {
+                    crow = c_rule[2 * k];
+                    ng = c_rule[2 * k + 1];
+                }
+                crow = walk<true>(stage, at, crow, start, end, k >= 0, 0xFFFFFFFFu, regs, L);
+                if (k >= 0) {
+                    f = *reinterpret_cast<const int32_t*>(at + crow + info_off);
+                    if (f < 0) result = -2 - k;  // DFA said yes, capture regex says no -> ExtractionException
+                }
             }
-            match_id[i] = result;
+            if (valid) {
+                int32_t* cp = caps + i * static_cast<uint64_t>(slots);
+                const int32_t len = static_cast<int32_t>(end - start);
+                for (int g = 0; g < T.max_groups; ++g) {
+                    int32_t pb = -1, pe = -1;
+                    if (f >= 0 && static_cast<uint32_t>(g) < ng) {
+                        const uint16_t vb = fin_tags[f + tag0 + 2 * g], ve = fin_tags[f + tag0 + 2 * g + 1];
+                        pb = (vb == SRC_POS) ? len : (vb == SRC_NIL ? -1 : static_cast<int32_t>(regs[vb * 64]));
+                        pe = (ve == SRC_POS) ? len : (ve == SRC_NIL ? -1 : static_cast<int32_t>(regs[ve * 64]));
+                        if (pb < 0 || pe < 0) { pb = -1; pe = -1; }
+                    }
+                    cp[2 * g] = pb;
+                    cp[2 * g + 1] = pe;
+                }
+                match_id[i] = result;
+            }
         }
         // the staging area is reused by the next tile: all lanes must be done reading it
         __builtin_amdgcn_wave_barrier();
+        if (!has_next) break;
+        cur = nxt;
+        no0 = nno0;
+        no1 = nno1;
+        ntile += wstride;
     }
 }
 
@@ -428,13 +497,34 @@ hipError_t launch_extract_generic(const GxDev& dev, const GxBatch& b, hipStream_
     return b.offsets64 ? launch_generic_t<uint8_t, uint64_t>(dev, b, stream) : launch_generic_t<uint8_t, uint32_t>(dev, b, stream);
 }
 
-hipError_t prepare_tile_kernels(uint32_t lds_bytes) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extract_tile<uint32_t>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extract_tile<uint64_t>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+namespace {
+template <typename OFF, int KCH>
+hipError_t launch_tile_t(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, dim3 grid, dim3 block, const GxBatch& b,
+                         hipStream_t stream) {
+    static bool prepared = false;  // per instantiation; the attribute is sticky for the process
+    if (!prepared) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extract_tile<OFF, KCH>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        if (e != hipSuccess) return e;
+        prepared = true;
+    }
+    hipLaunchKernelGGL((k_extract_tile<OFF, KCH>), grid, block, lds.total_bytes, stream, dev, lds, lds_image,
+                       static_cast<const uint8_t*>(b.data), static_cast<const OFF*>(b.offsets), b.n, b.match_id, b.caps, b.match_only);
+    return hipGetLastError();
 }
+template <typename OFF>
+hipError_t launch_tile_o(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, dim3 grid, dim3 block, const GxBatch& b,
+                         hipStream_t stream) {
+    const uint32_t kch = (lds.stage_bytes + 1023u) / 1024u;
+    if (kch <= 4) return launch_tile_t<OFF, 4>(dev, lds, lds_image, grid, block, b, stream);
+    if (kch <= 8) return launch_tile_t<OFF, 8>(dev, lds, lds_image, grid, block, b, stream);
+    if (kch <= 13) return launch_tile_t<OFF, 13>(dev, lds, lds_image, grid, block, b, stream);
+    if (kch <= 16) return launch_tile_t<OFF, 16>(dev, lds, lds_image, grid, block, b, stream);
+    return hipErrorInvalidValue;
+}
+}  // namespace
+
+hipError_t prepare_tile_kernels(uint32_t) { return hipSuccess; }
 
 hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, int num_cus, const GxBatch& b,
                                hipStream_t stream) {
@@ -446,15 +536,8 @@ hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t
     const uint64_t need = (tiles + lds.nwaves - 1) / lds.nwaves;
     if (blocks > need) blocks = need;
     dim3 grid(static_cast<unsigned>(blocks)), block(lds.nwaves * 64);
-    if (b.offsets64)
-        hipLaunchKernelGGL((k_extract_tile<uint64_t>), grid, block, lds.total_bytes, stream, dev, lds, lds_image,
-                           static_cast<const uint8_t*>(b.data), static_cast<const uint64_t*>(b.offsets), b.n, b.match_id, b.caps,
-                           b.match_only);
-    else
-        hipLaunchKernelGGL((k_extract_tile<uint32_t>), grid, block, lds.total_bytes, stream, dev, lds, lds_image,
-                           static_cast<const uint8_t*>(b.data), static_cast<const uint32_t*>(b.offsets), b.n, b.match_id, b.caps,
-                           b.match_only);
-    return hipGetLastError();
+    if (b.offsets64) return launch_tile_o<uint64_t>(dev, lds, lds_image, grid, block, b, stream);
+    return launch_tile_o<uint32_t>(dev, lds, lds_image, grid, block, b, stream);
 }
 
 }  // namespace gx
