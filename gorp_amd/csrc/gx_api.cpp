@@ -114,22 +114,36 @@ void build_lds_image(gx_handle* h) {
     std::vector<uint32_t> c_rule;
     size_t base_row = static_cast<size_t>(T.m_states);
     bool too_many_programs = false;
+    // are all capture programs of the tables we ship "one register := position"?
+    auto is_single_set = [&](uint32_t op) {
+        const uint32_t b = T.ops_off[op], e = T.ops_off[op + 1];
+        return e - b == 1 && T.ops[2 * b + 1] == GX_SRC_POS && T.ops[2 * b] < 0x7FFE;
+    };
+    bool simple = true;
+    auto scan_simple = [&](const RuleTables& r) {
+        for (uint32_t w : r.trans) if ((w >> 16) && !is_single_set(w >> 16)) simple = false;
+    };
+    if (fused) scan_simple(T.uni);
+    else for (auto& r : T.rules) scan_simple(r);
+    L.simple_ops = simple ? 1u : 0u;
     auto emit_rows = [&](const RuleTables& r) {
         const uint32_t base = static_cast<uint32_t>(base_row) * RS;
         for (int s = 0; s < r.n_states; ++s) {
             uint32_t* row = &at[(base_row + s) * cols];
             for (int c = 0; c < T.ncls; ++c) {
                 const uint32_t w = r.trans[static_cast<size_t>(s) * T.ncls + c];
-                // the common capture program "one register := position" is folded into the entry as 0x8000 | register
                 uint32_t op = w >> 16;
-                if (op) {
-                    const uint32_t b = T.ops_off[op], e = T.ops_off[op + 1];
-                    if (e - b == 1 && T.ops[2 * b + 1] == GX_SRC_POS && T.ops[2 * b] < 0x7FFF) op = 0x8000u | T.ops[2 * b];
+                if (simple) {
+                    // register column directly: 0 = dummy ("no program"), r + 1 = register r
+                    op = 0x8000u | (op ? T.ops[2 * T.ops_off[op]] + 1u : 0u);
+                } else if (op) {
+                    // the common capture program "one register := position" is folded into the entry as 0x8000 | register
+                    if (is_single_set(op)) op = 0x8000u | T.ops[2 * T.ops_off[op]];
                     else if (op >= 0x8000u) too_many_programs = true;
                 }
                 row[c] = (base + (w & 0xFFFFu) * RS) | (op << 16);
             }
-            row[IDC] = base + static_cast<uint32_t>(s) * RS;
+            row[IDC] = (base + static_cast<uint32_t>(s) * RS) | (simple ? 0x80000000u : 0u);
             row[ACC] = self_loop_interval(
                 [&](int b) { return r.trans[static_cast<size_t>(s) * T.ncls + T.cls256[b]] == static_cast<uint32_t>(s); });
             row[INFO] = static_cast<uint32_t>(r.fin[s]);
@@ -167,7 +181,7 @@ void build_lds_image(gx_handle* h) {
     int max_regs = 0;
     for (auto& r : T.rules) max_regs = std::max(max_regs, r.n_regs);
     if (fused) max_regs = T.uni.n_regs;
-    L.regs_wave_bytes = static_cast<uint32_t>((max_regs * 64 * 2 + 15) & ~15);
+    L.regs_wave_bytes = static_cast<uint32_t>(((max_regs + 1) * 64 * 2 + 15) & ~15);  // + the dummy column
     h->lds = L;
     h->lds_image.swap(img.bytes);
     h->tile_ok = true;

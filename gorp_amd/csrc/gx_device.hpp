@@ -56,7 +56,9 @@ struct GxLds {
     uint32_t ops;         // u16 pairs
     uint32_t fin_tags;    // u16[]
     uint32_t table_bytes; // size of the image, multiple of 16
-    uint32_t regs;        // u16[nwaves][max_regs][64]
+    uint32_t simple_ops;  // 1: every capture program is one "register := position"; entries then carry
+                          // 0x8000 | (register + 1) (0x8000 alone = no program) and steps are branch-free
+    uint32_t regs;        // u16[nwaves][1 + max_regs][64]; column 0 is a write-only dummy
     uint32_t regs_wave_bytes;
     uint32_t stage;       // u8[nwaves][stage_bytes]
     uint32_t stage_bytes; // multiple of 16

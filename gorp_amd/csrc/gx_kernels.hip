@@ -151,19 +151,22 @@ __device__ __forceinline__ uint32_t inrange_bits(uint32_t x, uint32_t lo4, uint3
     const uint32_t le = hi4h - x;             // hi4h = hi4 | H; exact for bytes < 0x80; bytes >= 0x80 are vetoed by ~x
     return ge & le & ~x;
 }
-__device__ __forceinline__ bool all16_in(const uint4& v, uint32_t lo4, uint32_t hi4h) {
-    const uint32_t r = inrange_bits(v.x, lo4, hi4h) & inrange_bits(v.y, lo4, hi4h) & inrange_bits(v.z, lo4, hi4h) &
-                       inrange_bits(v.w, lo4, hi4h);
-    return (r & HI_BITS) == HI_BITS;
-}
-// Partial window (first / last of a line): a dword passes when it lies wholly outside the line, or wholly
-// inside and in range; a dword the line boundary cuts through fails (the exact steps handle it).
-__device__ __forceinline__ bool dword_ok(uint32_t x, uint32_t nib, uint32_t lo4, uint32_t hi4h) {
-    return nib == 0u || (nib == 15u && (inrange_bits(x, lo4, hi4h) & HI_BITS) == HI_BITS);
-}
-__device__ __forceinline__ bool partial16_in(const uint4& v, uint32_t mask, uint32_t lo4, uint32_t hi4h) {
-    return dword_ok(v.x, mask & 15u, lo4, hi4h) && dword_ok(v.y, (mask >> 4) & 15u, lo4, hi4h) &&
-           dword_ok(v.z, (mask >> 8) & 15u, lo4, hi4h) && dword_ok(v.w, mask >> 12, lo4, hi4h);
+// Window test, branch-free.  Full window: all 16 bytes in range.  Partial window (first / last of a line):
+// every dword must lie wholly outside the line, or wholly inside and in range; a dword that the line
+// boundary cuts through fails (the exact steps handle it).
+__device__ __forceinline__ bool window_in_range(const uint4& v, uint32_t mask, uint32_t lo4, uint32_t hi4h) {
+    const uint32_t rx = inrange_bits(v.x, lo4, hi4h), ry = inrange_bits(v.y, lo4, hi4h);
+    const uint32_t rz = inrange_bits(v.z, lo4, hi4h), rw = inrange_bits(v.w, lo4, hi4h);
+    if (mask == 0xFFFFu) return ((rx & ry & rz & rw) & HI_BITS) == HI_BITS;
+    // spread each nibble of the byte mask over a dword: 0x80 per byte that belongs to the line
+    auto spread = [](uint32_t nib) { return ((nib * 0x00204081u) & 0x01010101u) << 7; };
+    const uint32_t mx = spread(mask & 15u), my = spread((mask >> 4) & 15u), mz = spread((mask >> 8) & 15u), mw = spread(mask >> 12);
+    // per dword: (no byte inside) or (all bytes inside and all in range)
+    const bool ox = mx == 0u || (mx == HI_BITS && (rx & HI_BITS) == HI_BITS);
+    const bool oy = my == 0u || (my == HI_BITS && (ry & HI_BITS) == HI_BITS);
+    const bool oz = mz == 0u || (mz == HI_BITS && (rz & HI_BITS) == HI_BITS);
+    const bool ow = mw == 0u || (mw == HI_BITS && (rw & HI_BITS) == HI_BITS);
+    return ox & oy & oz & ow;
 }
 
 // bit j set iff byte j of the 16-byte window at `wb` lies inside the line [start, end)
@@ -191,7 +194,7 @@ __device__ __forceinline__ void run_op_list(uint32_t ops_off_b, uint32_t ops_b, 
 // byte is one LDS read plus one add.  The byte->class lookups do not depend on the state and are issued up
 // front.  MASKED windows (first/last of a line) send out-of-line bytes through the identity column, which
 // maps every state to itself with no capture program.
-template <bool CAPTURE, bool MASKED>
+template <bool CAPTURE, bool MASKED, bool SIMPLE>
 __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, const uint8_t* at, uint32_t row, uint32_t idc4,
                                             uint32_t wb_rel, uint16_t* regs, const GxLds& L) {
     const uint8_t* cmap = gx_smem;  // GxLds: the byte->class*4 map sits at LDS offset 0
@@ -209,11 +212,18 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
         const uint32_t e = *reinterpret_cast<const uint32_t*>(at + row + c4[j]);
         row = e & 0xFFFFu;
         if (CAPTURE) {
-            const uint32_t op = e >> 16;
-            if (op) {
-                const uint16_t pos = static_cast<uint16_t>(wb_rel + j);
-                if (op & 0x8000u) regs[(op & 0x7FFFu) * 64] = pos;  // the common program: one tag := position
-                else run_op_list(L.ops_off, L.ops, static_cast<uint32_t>(reinterpret_cast<uint8_t*>(regs) - gx_smem), op, pos);
+            const uint16_t pos = static_cast<uint16_t>(wb_rel + j);
+            if (SIMPLE) {
+                // every program of this definition is "one register := position": the entry names the register
+                // column directly (column 0 of the wave's register block is a write-only dummy for "no program"),
+                // so the step is branch-free
+                regs[static_cast<int>((e >> 16) & 0x7FFFu) * 64 - 64] = pos;
+            } else {
+                const uint32_t op = e >> 16;
+                if (op) {
+                    if (op & 0x8000u) regs[(op & 0x7FFFu) * 64] = pos;  // the common program: one register := position
+                    else run_op_list(L.ops_off, L.ops, static_cast<uint32_t>(reinterpret_cast<uint8_t*>(regs) - gx_smem), op, pos);
+                }
             }
         }
     }
@@ -239,11 +249,23 @@ __device__ __forceinline__ uint32_t walk(const uint8_t* stage, const uint8_t* at
         const bool has = (acc & 0xFFu) <= ((acc >> 8) & 0xFFu);
         const uint32_t lo4 = splat_byte0(acc), hi4h = splat_byte1(acc) | HI_BITS;
         const bool full = mask == 0xFFFFu;
-        bool fast = has && full && all16_in(win, lo4, hi4h);
-        if (more && has && !full) fast = partial16_in(win, mask, lo4, hi4h);
+        bool fast;
+        if (__all(full || !more)) {
+            // every live lane has a full window (the steady state): one fused test
+            const uint32_t r = inrange_bits(win.x, lo4, hi4h) & inrange_bits(win.y, lo4, hi4h) &
+                               inrange_bits(win.z, lo4, hi4h) & inrange_bits(win.w, lo4, hi4h);
+            fast = has & ((r & HI_BITS) == HI_BITS);
+        } else {
+            fast = has & window_in_range(win, mask, lo4, hi4h);
+        }
         if (more && !fast) {
-            if (full) row = steps16<CAPTURE, false>(win, mask, at, row, idc4, wb - start, regs, L);
-            else row = steps16<CAPTURE, true>(win, mask, at, row, idc4, wb - start, regs, L);
+            if (CAPTURE && L.simple_ops) {
+                if (full) row = steps16<CAPTURE, false, true>(win, mask, at, row, idc4, wb - start, regs, L);
+                else row = steps16<CAPTURE, true, true>(win, mask, at, row, idc4, wb - start, regs, L);
+            } else {
+                if (full) row = steps16<CAPTURE, false, false>(win, mask, at, row, idc4, wb - start, regs, L);
+                else row = steps16<CAPTURE, true, false>(win, mask, at, row, idc4, wb - start, regs, L);
+            }
             acc = *reinterpret_cast<const uint32_t*>(at + row + acc_off);
         }
         more = more && wb < w_last && row != dead_row;
@@ -358,7 +380,8 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     uint8_t* stage = gx_smem + L.stage + wave * L.stage_bytes;
-    uint16_t* regs = reinterpret_cast<uint16_t*>(gx_smem + L.regs + wave * L.regs_wave_bytes) + lane;  // regs[r * 64]
+    // register r of this lane = regs[r * 64]; the column before register 0 is a write-only dummy
+    uint16_t* regs = reinterpret_cast<uint16_t*>(gx_smem + L.regs + wave * L.regs_wave_bytes) + 64 + lane;
 
     const int slots = 2 * T.max_groups;
     const bool want_caps = (match_only == 0 || match_only == 3) && T.has_capture;
