@@ -97,25 +97,16 @@ def main():
     # ---- tables: compile on rank 0, broadcast the blob (RCCL), build everywhere ----
     definition = W.readme3_definition()
     t0 = time.perf_counter()
-    if rank == 0:
-        gorp = Gorp.construct(definition)
-        blob = torch.from_numpy(gorp.blob()).to(dev)
-        size = torch.tensor([blob.numel()], dtype=torch.int64, device=dev)
-    else:
-        size = torch.zeros(1, dtype=torch.int64, device=dev)
-    bcast_ms = 0.0
+    bcast_ms = None
     if distributed:
-        dist.broadcast(size, src=0)
-        if rank != 0:
-            blob = torch.empty(int(size.item()), dtype=torch.uint8, device=dev)
+        from gorp_amd import dist as gdist
         torch.cuda.synchronize()
         tb = time.perf_counter()
-        dist.broadcast(blob, src=0)
+        gorp, _ = gdist.broadcast_gorp(definition, dev, src=0)
         torch.cuda.synchronize()
-        bcast_ms = (time.perf_counter() - tb) * 1e3
-        if rank != 0:
-            cooked = Gorp.construct(definition, host_only=True).getExtractions()
-            gorp = Gorp.from_blob(blob.cpu().numpy(), cooked)
+        bcast_ms = (time.perf_counter() - tb) * 1e3   # includes rank 0's compile
+    else:
+        gorp = Gorp.construct(definition)
     setup_s = time.perf_counter() - t0
 
     # ---- this rank's shard, generated on the device ----
@@ -166,17 +157,15 @@ def main():
     # ---- final gather of results to rank 0 over xGMI (reported, not in `value`) ----
     gather_ms = None
     if distributed and not args.no_gather:
-        packed = torch.cat([mid.view(n, 1), caps], dim=1).contiguous()
-        bufs = [torch.empty_like(packed) for _ in range(world)] if rank == 0 else None
         torch.cuda.synchronize()
         dist.barrier()
         tg = time.perf_counter()
-        dist.gather(packed, bufs, dst=0)
+        gm, gc = gdist.gather_results(mid, caps, dst=0)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
         if rank == 0:
-            assert torch.equal(bufs[0], packed)
-        del bufs, packed
+            assert gm.shape[0] == n * world and torch.equal(gm[:n], mid) and torch.equal(gc[:n], caps)
+        del gm, gc
 
     if rank == 0:
         steps = args.steps
@@ -214,7 +203,7 @@ def main():
                          "algorithmic_read_bytes": algo_read, "algorithmic_write_bytes": algo_write,
                          "frac_of_measured_copy_ceiling": achieved / 6290.0},
             "setup_s": setup_s,
-            "table_bcast_ms": bcast_ms if distributed else None,
+            "table_bcast_ms": bcast_ms,
             "gather_ms": gather_ms,
         }
         if not args.no_cpu_baseline and world == 1:
