@@ -271,3 +271,31 @@ def test_syslog_16_rules():
     mid, caps = gorp.extract_batch(data, offsets)
     omid, ocaps = orc.extract_batch(data, offsets, nthreads=8)
     assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+
+
+def test_config3_64_rules_parity():
+    """BASELINE.json configs[2]: 64 extractions (tables beyond the LDS tier -> generic kernel)."""
+    rules, meta = W.syslog_definition(64, seed=3)
+    gorp, orc = Gorp.construct(rules), oracle_for(rules)
+    assert gorp.stat(0) > 1000  # match-automaton states
+    data, offsets, cats = W.syslog_lines(meta, 30000, seed=3)
+    mid, caps = gorp.extract_batch(data, offsets)
+    omid, ocaps = orc.extract_batch(data, offsets, nthreads=8)
+    assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+    known = cats != -9
+    assert np.array_equal(mid[known], cats[known])
+    assert len(set(mid[mid >= 0].tolist())) == 64  # every extraction wins somewhere
+
+
+def test_config5_512_rules_mixed_lengths_parity():
+    """BASELINE.json configs[4]: 512 extractions, lines of 50-2000 bytes."""
+    rules, meta = W.syslog_definition(512, seed=3)
+    gorp, orc = Gorp.construct(rules), oracle_for(rules)
+    data, offsets, cats = W.syslog_lines(meta, 6000, seed=5, min_len=50, max_len=2000)
+    mid, caps = gorp.extract_batch(data, offsets)
+    omid, ocaps = orc.extract_batch(data, offsets, nthreads=8)
+    assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+    known = cats != -9
+    assert np.array_equal(mid[known], cats[known])
+    m2, _ = gorp.extract_batch(data, offsets, match_only=True)
+    assert np.array_equal(m2, orc.extract_batch(data, offsets, match_only=True, nthreads=8)[0])
