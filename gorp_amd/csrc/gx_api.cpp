@@ -193,17 +193,21 @@ bool plan_tile_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out) 
     GxLds L = h->lds;
     if (line_bytes_hint == 0) line_bytes_hint = 200;
     if (line_bytes_hint > 2000) line_bytes_hint = 2000;
-    L.stage_bytes = (64u * line_bytes_hint + 32u + 15u) & ~15u;
+    L.stage_bytes = (64u * line_bytes_hint + 64u + 15u) & ~15u;  // + slack: the walk reads two windows ahead
     if (L.stage_bytes > 16384u) L.stage_bytes = 16384u;  // the kernel prefetches a tile into <= 64 VGPRs per lane;
                                                           // tiles that do not fit take the per-lane global path
     const uint32_t per_wave = L.stage_bytes + L.regs_wave_bytes;
     if (L.table_bytes + 4 * per_wave > LDS_BYTES) return false;
     uint32_t nw = (LDS_BYTES - L.table_bytes) / per_wave;
     if (nw > 12) nw = 12;  // 768 threads: leaves 170 VGPRs per lane for the prefetch registers
+    static const int force_nw = getenv("GX_DEBUG_NWAVES") ? atoi(getenv("GX_DEBUG_NWAVES")) : 0;  // developer sweep
+    if (force_nw > 0 && static_cast<uint32_t>(force_nw) < nw) nw = static_cast<uint32_t>(force_nw);
     L.nwaves = nw;
     L.regs = L.table_bytes;
     L.stage = L.regs + nw * L.regs_wave_bytes;
     L.total_bytes = L.stage + nw * L.stage_bytes;
+    static const int ablate = getenv("GX_DEBUG_ABLATE") ? atoi(getenv("GX_DEBUG_ABLATE")) : 0;
+    L.debug_ablate = ablate >= 4 ? static_cast<uint32_t>(ablate) : 0u;
     *out = L;
     return true;
 }

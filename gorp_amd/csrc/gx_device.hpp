@@ -64,6 +64,7 @@ struct GxLds {
     uint32_t stage_bytes; // multiple of 16
     uint32_t nwaves;
     uint32_t total_bytes; // dynamic LDS size to launch with
+    uint32_t debug_ablate; // developer timing ablations (GX_DEBUG_ABLATE >= 4); 0 in production
 };
 
 struct GxBatch {

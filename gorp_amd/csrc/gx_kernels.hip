@@ -151,21 +151,17 @@ __device__ __forceinline__ uint32_t inrange_bits(uint32_t x, uint32_t lo4, uint3
     const uint32_t le = hi4h - x;             // hi4h = hi4 | H; exact for bytes < 0x80; bytes >= 0x80 are vetoed by ~x
     return ge & le & ~x;
 }
-// Window test, branch-free.  Full window: all 16 bytes in range.  Partial window (first / last of a line):
-// every dword must lie wholly outside the line, or wholly inside and in range; a dword that the line
-// boundary cuts through fails (the exact steps handle it).
-__device__ __forceinline__ bool window_in_range(const uint4& v, uint32_t mask, uint32_t lo4, uint32_t hi4h) {
-    const uint32_t rx = inrange_bits(v.x, lo4, hi4h), ry = inrange_bits(v.y, lo4, hi4h);
-    const uint32_t rz = inrange_bits(v.z, lo4, hi4h), rw = inrange_bits(v.w, lo4, hi4h);
-    if (mask == 0xFFFFu) return ((rx & ry & rz & rw) & HI_BITS) == HI_BITS;
+// Partial window (first / last of a line), given the per-dword range bits: every dword must lie wholly
+// outside the line, or wholly inside and in range; a dword that the line boundary cuts through fails (the
+// exact steps handle it).
+__device__ __forceinline__ bool partial_window_ok(uint32_t rx, uint32_t ry, uint32_t rz, uint32_t rw, uint32_t mask) {
     // spread each nibble of the byte mask over a dword: 0x80 per byte that belongs to the line
     auto spread = [](uint32_t nib) { return ((nib * 0x00204081u) & 0x01010101u) << 7; };
     const uint32_t mx = spread(mask & 15u), my = spread((mask >> 4) & 15u), mz = spread((mask >> 8) & 15u), mw = spread(mask >> 12);
-    // per dword: (no byte inside) or (all bytes inside and all in range)
-    const bool ox = mx == 0u || (mx == HI_BITS && (rx & HI_BITS) == HI_BITS);
-    const bool oy = my == 0u || (my == HI_BITS && (ry & HI_BITS) == HI_BITS);
-    const bool oz = mz == 0u || (mz == HI_BITS && (rz & HI_BITS) == HI_BITS);
-    const bool ow = mw == 0u || (mw == HI_BITS && (rw & HI_BITS) == HI_BITS);
+    const bool ox = (mx == 0u) | ((mx == HI_BITS) & ((rx & HI_BITS) == HI_BITS));
+    const bool oy = (my == 0u) | ((my == HI_BITS) & ((ry & HI_BITS) == HI_BITS));
+    const bool oz = (mz == 0u) | ((mz == HI_BITS) & ((rz & HI_BITS) == HI_BITS));
+    const bool ow = (mw == 0u) | ((mw == HI_BITS) & ((rw & HI_BITS) == HI_BITS));
     return ox & oy & oz & ow;
 }
 
@@ -230,46 +226,49 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
     return row;
 }
 
-// Walk one automaton over the staged line [start, end), all lanes in lock step over 16-byte windows: in every
-// window a lane either proves with one SWAR test that all its bytes stay inside the current state's self-loop
-// interval (state unchanged), or takes 16 exact steps.  Returns the row offset of the final state.
+// Walk one automaton over the staged line [start, end), all lanes in lock step over 16-byte windows of their own
+// line.  In every window a lane either proves with one SWAR test that all its bytes stay inside the current
+// state's self-loop interval (state unchanged, 16 bytes skipped), or takes 16 exact steps (partial windows at
+// the ends of a line go through the identity column or, when they pass the range test dword by dword, are
+// skipped too).  Returns the row offset of the final state.
+// (A 32-byte look-ahead variant was measured slower: the extra test is paid in the header windows too.)
 template <bool CAPTURE>
 __device__ __forceinline__ uint32_t walk(const uint8_t* stage, const uint8_t* at, uint32_t row, uint32_t start, uint32_t end,
                                          bool on, uint32_t dead_row, uint16_t* regs, const GxLds& L) {
     const uint32_t idc4 = L.row_bytes - 12u;   // identity column
     const uint32_t acc_off = L.row_bytes - 8u; // self-loop interval column
-    const bool nonempty = on && start < end;
-    const uint32_t w_last = nonempty ? ((end - 1u) & ~15u) : 0u;
     uint32_t wb = start & ~15u;
     uint32_t acc = *reinterpret_cast<const uint32_t*>(at + row + acc_off);
-    bool more = nonempty;
+    bool has = (acc & 0xFFu) <= ((acc >> 8) & 0xFFu);
+    uint32_t lo4 = splat_byte0(acc), hi4h = splat_byte1(acc) | HI_BITS;
+    bool more = on && start < end;
     while (__any(more)) {
-        const uint4 win = *reinterpret_cast<const uint4*>(stage + (more ? wb : 0u));
-        const uint32_t mask = more ? window_mask(start, end, wb) : 0u;
-        const bool has = (acc & 0xFFu) <= ((acc >> 8) & 0xFFu);
-        const uint32_t lo4 = splat_byte0(acc), hi4h = splat_byte1(acc) | HI_BITS;
-        const bool full = mask == 0xFFFFu;
-        bool fast;
-        if (__all(full || !more)) {
-            // every live lane has a full window (the steady state): one fused test
-            const uint32_t r = inrange_bits(win.x, lo4, hi4h) & inrange_bits(win.y, lo4, hi4h) &
-                               inrange_bits(win.z, lo4, hi4h) & inrange_bits(win.w, lo4, hi4h);
-            fast = has & ((r & HI_BITS) == HI_BITS);
-        } else {
-            fast = has & window_in_range(win, mask, lo4, hi4h);
-        }
-        if (more && !fast) {
-            if (CAPTURE && L.simple_ops) {
-                if (full) row = steps16<CAPTURE, false, true>(win, mask, at, row, idc4, wb - start, regs, L);
-                else row = steps16<CAPTURE, true, true>(win, mask, at, row, idc4, wb - start, regs, L);
-            } else {
-                if (full) row = steps16<CAPTURE, false, false>(win, mask, at, row, idc4, wb - start, regs, L);
-                else row = steps16<CAPTURE, true, false>(win, mask, at, row, idc4, wb - start, regs, L);
+        const uint4 w0 = *reinterpret_cast<const uint4*>(stage + (more ? wb : 0u));
+        const bool full0 = wb >= start && wb + 16u <= end;
+        const uint32_t rx = inrange_bits(w0.x, lo4, hi4h), ry = inrange_bits(w0.y, lo4, hi4h);
+        const uint32_t rz = inrange_bits(w0.z, lo4, hi4h), rw = inrange_bits(w0.w, lo4, hi4h);
+        bool ok0 = has & full0 & (((rx & ry & rz & rw) & HI_BITS) == HI_BITS);
+        if (L.debug_ablate == 4) ok0 = true;  // timing ablation: no exact steps at all
+        if (more && !ok0) {
+            const uint32_t mask = window_mask(start, end, wb);
+            bool skip = false;
+            if (!full0) skip = has & partial_window_ok(rx, ry, rz, rw, mask);
+            if (!skip) {
+                if (CAPTURE && L.simple_ops) {
+                    if (full0) row = steps16<CAPTURE, false, true>(w0, mask, at, row, idc4, wb - start, regs, L);
+                    else row = steps16<CAPTURE, true, true>(w0, mask, at, row, idc4, wb - start, regs, L);
+                } else {
+                    if (full0) row = steps16<CAPTURE, false, false>(w0, mask, at, row, idc4, wb - start, regs, L);
+                    else row = steps16<CAPTURE, true, false>(w0, mask, at, row, idc4, wb - start, regs, L);
+                }
+                acc = *reinterpret_cast<const uint32_t*>(at + row + acc_off);
+                has = (acc & 0xFFu) <= ((acc >> 8) & 0xFFu);
+                lo4 = splat_byte0(acc);
+                hi4h = splat_byte1(acc) | HI_BITS;
             }
-            acc = *reinterpret_cast<const uint32_t*>(at + row + acc_off);
         }
-        more = more && wb < w_last && row != dead_row;
         wb += 16u;
+        more = more && wb < end && row != dead_row;
     }
     return row;
 }
@@ -410,7 +409,7 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
         t.nch = static_cast<uint32_t>((span + 15) >> 4);
         t.start = skew + static_cast<uint32_t>(o0 - lo);
         t.end = skew + static_cast<uint32_t>(o1 - lo);
-        if (span + 16 > L.stage_bytes) t.mode = 2;
+        if (span + 48 > L.stage_bytes) t.mode = 2;  // keep room for the two-window look-ahead of the walk
         else if (!(t.g_al >= data && t.g_al + (static_cast<uint64_t>(t.nch) << 4) <= data_end)) t.mode = 1;
         else t.mode = 0;
         return t;
@@ -487,16 +486,35 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
             if (valid) {
                 int32_t* cp = caps + i * static_cast<uint64_t>(slots);
                 const int32_t len = static_cast<int32_t>(end - start);
-                for (int g = 0; g < T.max_groups; ++g) {
-                    int32_t pb = -1, pe = -1;
-                    if (f >= 0 && static_cast<uint32_t>(g) < ng) {
-                        const uint16_t vb = fin_tags[f + tag0 + 2 * g], ve = fin_tags[f + tag0 + 2 * g + 1];
-                        pb = (vb == SRC_POS) ? len : (vb == SRC_NIL ? -1 : static_cast<int32_t>(regs[vb * 64]));
-                        pe = (ve == SRC_POS) ? len : (ve == SRC_NIL ? -1 : static_cast<int32_t>(regs[ve * 64]));
-                        if (pb < 0 || pe < 0) { pb = -1; pe = -1; }
+                const int G = T.max_groups;
+                for (int g0 = 0; g0 < G; g0 += 2) {
+                    // two groups = four values = one 16-byte store
+                    int32_t v[4];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int g = g0 + q;
+                        int32_t pb = -1, pe = -1;
+                        if (f >= 0 && static_cast<uint32_t>(g) < ng) {
+                            const uint16_t vb = fin_tags[f + tag0 + 2 * g], ve = fin_tags[f + tag0 + 2 * g + 1];
+                            pb = (vb == SRC_POS) ? len : (vb == SRC_NIL ? -1 : static_cast<int32_t>(regs[vb * 64]));
+                            pe = (ve == SRC_POS) ? len : (ve == SRC_NIL ? -1 : static_cast<int32_t>(regs[ve * 64]));
+                            if (pb < 0 || pe < 0) { pb = -1; pe = -1; }
+                        }
+                        v[2 * q] = pb;
+                        v[2 * q + 1] = pe;
                     }
-                    cp[2 * g] = pb;
-                    cp[2 * g + 1] = pe;
+                    if ((slots & 3) == 0) {
+                        // slots % 4 == 0 implies g0 + 1 < G and a 16-byte aligned row: one 16-byte store.  Plain, not
+                        // nontemporal: a lane's row is finished by a second store, and only L2 can merge the two halves
+                        // of a cache line (measured: nt raises WRITE_SIZE from 1.4x to 2.2x the algorithmic bytes)
+                        u32x4 q4 = {static_cast<uint32_t>(v[0]), static_cast<uint32_t>(v[1]), static_cast<uint32_t>(v[2]),
+                                    static_cast<uint32_t>(v[3])};
+                        *reinterpret_cast<u32x4*>(cp + 2 * g0) = q4;
+                    } else {
+                        cp[2 * g0] = v[0];
+                        cp[2 * g0 + 1] = v[1];
+                        if (g0 + 1 < G) { cp[2 * g0 + 2] = v[2]; cp[2 * g0 + 3] = v[3]; }
+                    }
                 }
                 match_id[i] = result;
             }
