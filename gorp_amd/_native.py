@@ -16,6 +16,7 @@ GX_E_DEVICE = 3
 GX_E_ARG = 4
 GX_E_NOMEM = 5
 GX_E_LIMIT = 6
+GX_E_DEFINITION = 7
 GX_CREATE_HOST_ONLY = 1
 
 # every symbol include/gorp_hip.h declares
@@ -24,6 +25,7 @@ SYMBOLS = [
     "gx_num_extractions", "gx_num_groups", "gx_max_groups", "gx_stat", "gx_extract_batch",
     "gx_extract_one_utf16", "gx_match_one_utf16", "gx_last_error", "gx_device_count",
     "gx_quote_literal_as_regexp", "gx_massage_regexp_for_automaton", "gx_massage_regexp_for_jdk",
+    "gx_create_from_definition", "gx_definition_to_json",
 ]
 
 
@@ -117,6 +119,10 @@ def lib():
     for f in ("gx_quote_literal_as_regexp", "gx_massage_regexp_for_automaton", "gx_massage_regexp_for_jdk"):
         getattr(L, f).argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
         getattr(L, f).restype = C.c_int
+    L.gx_create_from_definition.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.gx_create_from_definition.restype = C.c_int
+    L.gx_definition_to_json.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.gx_definition_to_json.restype = C.c_int
     _lib = L
     return L
 

@@ -12,8 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgorp_hip.so")
-SOURCES = ["gx_regex.cpp", "gx_compile.cpp", "gx_host.cpp", "gx_api.cpp", "gx_kernels.hip"]
-HEADERS = ["gx_common.hpp", "gx_compile.hpp", "gx_device.hpp", os.path.join("..", "..", "include", "gorp_hip.h")]
+SOURCES = ["gx_regex.cpp", "gx_compile.cpp", "gx_host.cpp", "gx_dsl.cpp", "gx_api.cpp", "gx_kernels.hip"]
+HEADERS = ["gx_common.hpp", "gx_compile.hpp", "gx_device.hpp", "gx_dsl.hpp", os.path.join("..", "..", "include", "gorp_hip.h")]
 
 
 def _hipcc():

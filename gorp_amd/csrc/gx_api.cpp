@@ -11,6 +11,7 @@
 
 #include "gx_compile.hpp"
 #include "gx_device.hpp"
+#include "gx_dsl.hpp"
 
 using namespace gx;
 
@@ -514,6 +515,45 @@ int gx_massage_regexp_for_jdk(const char* pattern, char* out, size_t cap, size_t
     if (!pattern) return fail(GX_E_ARG, "null pattern");
     try { return string_result(massage_regexp_for_jdk(utf8_to_u16(pattern)), out, cap, out_len); }
     catch (GxError& e) { return fail(e.code, e.what()); }
+}
+
+int gx_create_from_definition(const char* definition_text, const char* source_ref, uint32_t flags, gx_handle** out) {
+    if (!definition_text || !out) return fail(GX_E_ARG, "gx_create_from_definition: bad argument");
+    try {
+        std::vector<dsl::Extraction> xs = dsl::read_definition(definition_text, source_ref ? source_ref : "<input string>");
+        std::vector<ustr> a, j;
+        for (auto& x : xs) {
+            std::string as, js;
+            dsl::build_regex_strings(x, as, js);
+            a.push_back(utf8_to_u16(as.c_str()));
+            j.push_back(utf8_to_u16(js.c_str()));
+        }
+        std::unique_ptr<gx_handle> h(new gx_handle());
+        try {
+            h->T = compile_tables(a, &j);
+        } catch (GxError& e) {
+            // core/Gorp.java:84-90
+            if (e.code == GX_E_DEVICE || e.code == GX_E_NOMEM) throw;
+            throw GxError(e.code, std::string("(N/A): Internal error: problem with PolyMatcher construction: ") + e.what());
+        }
+        return finish_create(h, flags, out);
+    } catch (GxError& e) { return fail(e.code, e.what()); }
+    catch (std::bad_alloc&) { return fail(GX_E_NOMEM, "out of memory"); }
+    catch (std::exception& e) { return fail(GX_E_ARG, e.what()); }
+}
+
+int gx_definition_to_json(const char* definition_text, const char* source_ref, const char* stage, char* out, size_t cap,
+                          size_t* out_len) {
+    if (!definition_text || !stage) return fail(GX_E_ARG, "gx_definition_to_json: bad argument");
+    try {
+        std::string js = dsl::dump_json(definition_text, source_ref ? source_ref : "<input string>", stage);
+        if (out_len) *out_len = js.size();
+        if (!out || cap < js.size() + 1) return fail(GX_E_ARG, "output buffer too small");
+        memcpy(out, js.c_str(), js.size() + 1);
+        return GX_OK;
+    } catch (GxError& e) { return fail(e.code, e.what()); }
+    catch (std::bad_alloc&) { return fail(GX_E_NOMEM, "out of memory"); }
+    catch (std::exception& e) { return fail(GX_E_ARG, e.what()); }
 }
 
 }  // extern "C"

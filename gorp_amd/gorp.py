@@ -372,3 +372,66 @@ def lines_to_csr(lines, offsets_dtype=np.uint32):
         offsets[1:] = np.cumsum([len(b) for b in bs])
     data = np.frombuffer(b"".join(bs), dtype=np.uint8) if bs else np.zeros(0, np.uint8)
     return data, offsets
+
+
+# ---------------------------------------------------------------------------
+# DefinitionReader (core/DefinitionReader.java) -- the definition language, parsed natively (gx_dsl.cpp)
+# ---------------------------------------------------------------------------
+def _definition_json(text, source_ref, stage):
+    import json
+    L = N.lib()
+    raw = text.encode("utf-8")
+    cap = 64 * len(raw) + 4096
+    n = C.c_size_t(0)
+    buf = C.create_string_buffer(cap)
+    rc = L.gx_definition_to_json(raw, source_ref.encode("utf-8"), stage.encode("ascii"), buf, cap, C.byref(n))
+    if rc == N.GX_E_ARG and n.value + 1 > cap:
+        cap = n.value + 1
+        buf = C.create_string_buffer(cap)
+        rc = L.gx_definition_to_json(raw, source_ref.encode("utf-8"), stage.encode("ascii"), buf, cap, C.byref(n))
+    if rc == N.GX_E_DEFINITION:
+        raise DefinitionParseException(rc, N.last_error())
+    _check(rc)
+    return json.loads(buf.raw[:n.value].decode("utf-8"))
+
+
+class DefinitionReader:
+    """core/DefinitionReader.java: reads an extraction definition and builds a Gorp."""
+
+    def __init__(self, text, source_ref):
+        self._text = text
+        self._source_ref = source_ref
+
+    @staticmethod
+    def reader(source):
+        """`source`: definition text, or a path-like object / open file (DefinitionReader.reader(File|String))."""
+        import os
+        if hasattr(source, "read"):
+            return DefinitionReader(source.read(), "<input stream>")
+        if isinstance(source, os.PathLike):
+            path = os.fspath(source)
+            with open(path, encoding="utf-8") as f:
+                return DefinitionReader(f.read(), "file '%s'" % os.path.abspath(path))
+        return DefinitionReader(source, "<input string>")
+
+    def readUncooked(self):
+        """Tokenised but unresolved definitions (dict view of UncookedDefinitions)."""
+        return _definition_json(self._text, self._source_ref, "uncooked")
+
+    def resolveTemplates(self):
+        """Resolved patterns and templates (dict view of CookedDefinitions after resolveTemplates)."""
+        return _definition_json(self._text, self._source_ref, "cooked")
+
+    def flatten(self):
+        """List of FlattenedExtraction (CookedDefinitions.getExtractions())."""
+        d = _definition_json(self._text, self._source_ref, "flattened")
+        return [FlattenedExtraction(x["name"], x["pieces"], x["append"]) for x in d["extractions"]], d
+
+    def read(self, host_only=False):
+        fl, d = self.flatten()
+        autom = [x["automaton_rx"] for x in d["extractions"]]
+        jdk = [x["jdk_rx"] for x in d["extractions"]]
+        cooked = [CookedExtraction(i, x["name"], x["jdk_rx"], x["extractor_names"], x["append"])
+                  for i, x in enumerate(d["extractions"])]
+        h = _create(autom, jdk, N.GX_CREATE_HOST_ONLY if host_only else 0)
+        return Gorp(h, cooked)

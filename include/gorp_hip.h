@@ -43,7 +43,8 @@ enum {
     GX_E_DEVICE = 3,               /* no gfx950 device / HIP runtime failure */
     GX_E_ARG = 4,                  /* bad argument */
     GX_E_NOMEM = 5,
-    GX_E_LIMIT = 6                 /* automaton exceeds a compile-time limit */
+    GX_E_LIMIT = 6,                /* automaton exceeds a compile-time limit */
+    GX_E_DEFINITION = 7            /* definition text rejected: DefinitionParseException (core/DefinitionParseException.java) */
 };
 
 /* gx_create flags */
@@ -118,6 +119,20 @@ int gx_match_one_utf16(gx_handle* h, const uint16_t* s, int32_t len, int32_t* in
 int gx_quote_literal_as_regexp(const char* text, char* out, size_t cap, size_t* out_len);
 int gx_massage_regexp_for_automaton(const char* pattern, char* out, size_t cap, size_t* out_len);
 int gx_massage_regexp_for_jdk(const char* pattern, char* out, size_t cap, size_t* out_len);
+
+/* Native front-end for the definition language (.grp text): replaces
+ * DefinitionReader.reader(String).read() (core/DefinitionReader.java:58-84) -- tokenising
+ * (:126-181,189-640), pattern / template / extraction resolution (core/model/CookedDefinitions.java:57-453)
+ * and Gorp.construct (core/Gorp.java:50-92).  GX_E_DEFINITION carries the reference's
+ * DefinitionParseException text, "([source (row,col)]): message".
+ * gx_definition_to_json returns what the reference keeps in Java objects: stage "flattened" = per
+ * extraction its name, flattened pieces, extractor names (capture-group order), `append` object and the two
+ * regex strings; stages "uncooked" / "cooked" expose the intermediate piece lists that the reference's own
+ * parser tests assert on.  NUL-terminated UTF-8 out; *out_len = length without the NUL (GX_E_ARG with
+ * *out_len set when cap is too small). */
+int gx_create_from_definition(const char* definition_text, const char* source_ref, uint32_t flags, gx_handle** out);
+int gx_definition_to_json(const char* definition_text, const char* source_ref, const char* stage,
+                          char* out, size_t cap, size_t* out_len);
 
 /* Thread-local message for the last failing call on this thread. */
 const char* gx_last_error(void);

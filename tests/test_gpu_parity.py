@@ -299,3 +299,21 @@ def test_config5_512_rules_mixed_lengths_parity():
     assert np.array_equal(mid[known], cats[known])
     m2, _ = gorp.extract_batch(data, offsets, match_only=True)
     assert np.array_equal(m2, orc.extract_batch(data, offsets, match_only=True, nthreads=8)[0])
+
+
+def test_config1_from_definition_text(tmp_path):
+    """BASELINE.json configs[0] driven by the .grp text itself (native DSL front-end), 10 k lines."""
+    from gorp_amd.gorp import DefinitionReader
+    text = (
+        "pattern %phrase \\S+\npattern %num \\d+\npattern %ts %phrase\n"
+        "template @base <%num>$eventTimeStamp(%ts)\n\n"
+        "extract sampleMatch {\n  template @base ($authStatus(Accepted)) \n}\n")
+    p = tmp_path / "simple.grp"
+    p.write_text(text)
+    gorp = DefinitionReader.reader(p).read()
+    orc = oracle_for(W.simple_grp_definition())
+    lines = W.simple_grp_lines(10000, seed=1)
+    mid, caps = check_batch(gorp, orc, lines)
+    assert 0.75 < (mid == 0).mean() < 0.85
+    r = gorp.extract(lines[int(np.argmax(mid == 0))])
+    assert r.getId() == "sampleMatch" and r.asMap()["authStatus"] == "Accepted"
