@@ -26,6 +26,7 @@ SYMBOLS = [
     "gx_extract_one_utf16", "gx_match_one_utf16", "gx_last_error", "gx_device_count",
     "gx_quote_literal_as_regexp", "gx_massage_regexp_for_automaton", "gx_massage_regexp_for_jdk",
     "gx_create_from_definition", "gx_definition_to_json",
+    "gx_extraction_name", "gx_extractor_name", "gx_extraction_append_json",
 ]
 
 
@@ -123,6 +124,12 @@ def lib():
     L.gx_create_from_definition.restype = C.c_int
     L.gx_definition_to_json.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.gx_definition_to_json.restype = C.c_int
+    L.gx_extraction_name.argtypes = [C.c_void_p, C.c_int32]
+    L.gx_extraction_name.restype = C.c_char_p
+    L.gx_extractor_name.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    L.gx_extractor_name.restype = C.c_char_p
+    L.gx_extraction_append_json.argtypes = [C.c_void_p, C.c_int32]
+    L.gx_extraction_append_json.restype = C.c_char_p
     _lib = L
     return L
 

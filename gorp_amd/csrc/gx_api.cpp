@@ -59,6 +59,7 @@ struct gx_handle {
     std::vector<uint8_t> lds_image;
     void* d_lds_image = nullptr;
     int num_cus = 256;
+    std::vector<dsl::Extraction> meta;  // names / extractor names / append (only when built from definition text)
     std::mutex mu;  // serialises host-pointer batches that share nothing else
 };
 
@@ -536,10 +537,25 @@ int gx_create_from_definition(const char* definition_text, const char* source_re
             if (e.code == GX_E_DEVICE || e.code == GX_E_NOMEM) throw;
             throw GxError(e.code, std::string("(N/A): Internal error: problem with PolyMatcher construction: ") + e.what());
         }
+        h->meta = xs;
         return finish_create(h, flags, out);
     } catch (GxError& e) { return fail(e.code, e.what()); }
     catch (std::bad_alloc&) { return fail(GX_E_NOMEM, "out of memory"); }
     catch (std::exception& e) { return fail(GX_E_ARG, e.what()); }
+}
+
+const char* gx_extraction_name(const gx_handle* h, int32_t k) {
+    if (!h || k < 0 || k >= static_cast<int32_t>(h->meta.size())) return nullptr;
+    return h->meta[k].name.c_str();
+}
+const char* gx_extractor_name(const gx_handle* h, int32_t k, int32_t g) {
+    if (!h || k < 0 || k >= static_cast<int32_t>(h->meta.size())) return nullptr;
+    if (g < 0 || g >= static_cast<int32_t>(h->meta[k].extractor_names.size())) return nullptr;
+    return h->meta[k].extractor_names[g].c_str();
+}
+const char* gx_extraction_append_json(const gx_handle* h, int32_t k) {
+    if (!h || k < 0 || k >= static_cast<int32_t>(h->meta.size()) || h->meta[k].append_json.empty()) return nullptr;
+    return h->meta[k].append_json.c_str();
 }
 
 int gx_definition_to_json(const char* definition_text, const char* source_ref, const char* stage, char* out, size_t cap,

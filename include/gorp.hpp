@@ -1,0 +1,215 @@
+// gorp.hpp -- C++ host-side mirror of the reference's API for the match-and-extract path, header-only over the
+// C ABI of libgorp_hip.so (include/gorp_hip.h).  Same names, argument meaning and error behaviour as
+// salesforce/gorp (core/ = gorp-core/src/main/java/com/salesforce/gorp/):
+//
+//   gorp::DefinitionReader::reader(text).read()  core/DefinitionReader.java:58-84
+//   gorp::Gorp::extract / extractSafe            core/Gorp.java:145-186
+//   gorp::ExtractionResult::getId / asMap        core/ExtractionResult.java:39-88
+//   gorp::ExtractionException                    core/ExtractionException.java:15-34
+//   gorp::DefinitionParseException               core/DefinitionParseException.java
+//   gorp::RegexHelper                            core/util/RegexHelper.java
+//
+// plus the batch entry point the GPU needs (Gorp::extractBatch over a CSR byte buffer).  All matching runs in the
+// HIP kernels; nothing here computes a match on the CPU.  Link: -lgorp_hip -lamdhip64.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "gorp_hip.h"
+
+namespace gorp {
+
+struct DefinitionParseException : std::runtime_error {
+    int code;
+    DefinitionParseException(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+struct ExtractionException : std::runtime_error {
+    std::string input;
+    ExtractionException(std::string in, const std::string& m) : std::runtime_error(m), input(std::move(in)) {}
+    const std::string& getInput() const { return input; }
+};
+
+struct GorpError : std::runtime_error {
+    int code;
+    GorpError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+// core/model/CookedExtraction.java (data only)
+struct CookedExtraction {
+    std::string name;
+    std::vector<std::string> extractorNames;
+    std::string appendJson;  // getExtra() as JSON object text; empty when there is none
+    const std::string& getName() const { return name; }
+};
+
+// core/ExtractionResult.java.  Values are (present, text) because Matcher.group may return null.
+class ExtractionResult {
+public:
+    ExtractionResult(const CookedExtraction* x, std::string input, std::vector<std::pair<bool, std::string>> values)
+        : x_(x), input_(std::move(input)), values_(std::move(values)) {}
+    const std::string& getId() const { return x_->name; }
+    const std::string& getInput() const { return input_; }
+    const CookedExtraction& getMatchedExtraction() const { return *x_; }
+    // id (optional) first, captures in group order; `append` extras are exposed separately as JSON
+    // (getMatchedExtraction().appendJson) because their values are typed (core/ExtractionResult.java:65-88)
+    std::vector<std::pair<std::string, std::string>> asMap(const char* idAs = nullptr) const {
+        std::vector<std::pair<std::string, std::string>> m;
+        if (idAs) m.emplace_back(idAs, x_->name);
+        for (size_t i = 0; i < values_.size(); ++i)
+            if (values_[i].first) m.emplace_back(x_->extractorNames[i], values_[i].second);
+        return m;
+    }
+    bool has(size_t group) const { return group < values_.size() && values_[group].first; }
+    const std::string& value(size_t group) const { return values_[group].second; }
+
+private:
+    const CookedExtraction* x_;
+    std::string input_;
+    std::vector<std::pair<bool, std::string>> values_;
+};
+
+struct RegexHelper {
+    static std::string quoteLiteralAsRegexp(const std::string& t) { return call(gx_quote_literal_as_regexp, t); }
+    static std::string massageRegexpForAutomaton(const std::string& p) { return call(gx_massage_regexp_for_automaton, p); }
+    static std::string massageRegexpForJDK(const std::string& p) { return call(gx_massage_regexp_for_jdk, p); }
+
+private:
+    typedef int (*Fn)(const char*, char*, size_t, size_t*);
+    static std::string call(Fn fn, const std::string& in) {
+        size_t n = 0;
+        std::string out(8 * in.size() + 64, '\0');
+        int rc = fn(in.c_str(), &out[0], out.size(), &n);
+        if (rc == GX_E_ARG && n + 1 > out.size()) { out.assign(n + 1, '\0'); rc = fn(in.c_str(), &out[0], out.size(), &n); }
+        if (rc == GX_E_REGEX_SYNTAX) throw std::invalid_argument(gx_last_error());  // IllegalArgumentException
+        if (rc != GX_OK) throw GorpError(rc, gx_last_error());
+        out.resize(n);
+        return out;
+    }
+};
+
+// core/Gorp.java
+class Gorp {
+public:
+    ~Gorp() { gx_destroy(h_); }
+    Gorp(const Gorp&) = delete;
+    Gorp& operator=(const Gorp&) = delete;
+
+    const std::vector<CookedExtraction>& getExtractions() const { return extractions_; }
+
+    // Gorp.extract(String): the line as UTF-8 (converted to UTF-16 code units, which is what the reference walks).
+    // Returns nullptr for "no match"; throws ExtractionException when the matcher and the capture regexp disagree.
+    std::unique_ptr<ExtractionResult> extract(const std::string& input, bool allowFallbacks = false) const {
+        std::u16string u = to_utf16(input);
+        int32_t id = 0;
+        std::vector<int32_t> caps(2 * static_cast<size_t>(gx_max_groups(h_)) + 2, -1);
+        int rc = gx_extract_one_utf16(h_, reinterpret_cast<const uint16_t*>(u.data()), static_cast<int32_t>(u.size()), &id, caps.data());
+        if (rc != GX_OK) throw GorpError(rc, gx_last_error());
+        return materialise(input, u, id, caps.data(), allowFallbacks);
+    }
+    std::unique_ptr<ExtractionResult> extractSafe(const std::string& input) const { return extract(input, true); }
+
+    // The batch path: lines as one Latin-1 byte buffer + offsets[n+1]; match_id[n], caps[n * 2*maxGroups()].
+    void extractBatch(const uint8_t* bytes, const uint32_t* offsets, uint64_t n, int32_t* match_id, int32_t* caps,
+                      const gx_batch_opts* opts = nullptr) const {
+        int rc = gx_extract_batch(h_, bytes, offsets, n, match_id, caps, opts);
+        if (rc != GX_OK) throw GorpError(rc, gx_last_error());
+    }
+    int maxGroups() const { return gx_max_groups(h_); }
+    gx_handle* handle() const { return h_; }
+
+private:
+    friend class DefinitionReader;
+    Gorp(gx_handle* h, std::vector<CookedExtraction> x) : h_(h), extractions_(std::move(x)) {}
+    gx_handle* h_;
+    std::vector<CookedExtraction> extractions_;
+
+    std::unique_ptr<ExtractionResult> materialise(const std::string& input, const std::u16string& u, int32_t id, const int32_t* caps,
+                                                  bool safe) const {
+        if (id == -1) return nullptr;
+        if (id <= -2) {
+            const CookedExtraction& x = extractions_[static_cast<size_t>(-2 - id)];
+            if (safe) return nullptr;  // core/Gorp.java:178-185
+            throw ExtractionException(input, "Internal error: high-level match for extraction #" + std::to_string(-2 - id) + " (" + x.name +
+                                                 ") failed to match generated regexp");
+        }
+        const CookedExtraction& x = extractions_[static_cast<size_t>(id)];
+        std::vector<std::pair<bool, std::string>> values;
+        const int ng = gx_num_groups(h_, id);
+        for (int g = 0; g < ng; ++g) {
+            const int32_t b = caps[2 * g], e = caps[2 * g + 1];
+            if (b < 0) values.emplace_back(false, std::string());
+            else values.emplace_back(true, to_utf8(u.substr(static_cast<size_t>(b), static_cast<size_t>(e - b))));
+        }
+        return std::unique_ptr<ExtractionResult>(new ExtractionResult(&x, input, std::move(values)));
+    }
+
+    static std::u16string to_utf16(const std::string& s) {
+        std::u16string out;
+        for (size_t i = 0; i < s.size();) {
+            uint32_t cp = static_cast<unsigned char>(s[i]);
+            int extra = cp < 0x80 ? 0 : (cp >> 5) == 6 ? 1 : (cp >> 4) == 14 ? 2 : 3;
+            cp = extra == 0 ? cp : cp & (0x3F >> extra);
+            ++i;
+            for (int k = 0; k < extra && i < s.size(); ++k, ++i) cp = (cp << 6) | (static_cast<unsigned char>(s[i]) & 0x3F);
+            if (cp > 0xFFFF) {
+                cp -= 0x10000;
+                out.push_back(static_cast<char16_t>(0xD800 | (cp >> 10)));
+                out.push_back(static_cast<char16_t>(0xDC00 | (cp & 0x3FF)));
+            } else out.push_back(static_cast<char16_t>(cp));
+        }
+        return out;
+    }
+    static std::string to_utf8(const std::u16string& s) {
+        std::string out;
+        for (size_t i = 0; i < s.size(); ++i) {
+            uint32_t cp = s[i];
+            if (cp >= 0xD800 && cp <= 0xDBFF && i + 1 < s.size()) { cp = 0x10000 + ((cp & 0x3FF) << 10) + (s[i + 1] & 0x3FF); ++i; }
+            if (cp < 0x80) out += static_cast<char>(cp);
+            else if (cp < 0x800) { out += static_cast<char>(0xC0 | (cp >> 6)); out += static_cast<char>(0x80 | (cp & 0x3F)); }
+            else if (cp < 0x10000) {
+                out += static_cast<char>(0xE0 | (cp >> 12)); out += static_cast<char>(0x80 | ((cp >> 6) & 0x3F)); out += static_cast<char>(0x80 | (cp & 0x3F));
+            } else {
+                out += static_cast<char>(0xF0 | (cp >> 18)); out += static_cast<char>(0x80 | ((cp >> 12) & 0x3F));
+                out += static_cast<char>(0x80 | ((cp >> 6) & 0x3F)); out += static_cast<char>(0x80 | (cp & 0x3F));
+            }
+        }
+        return out;
+    }
+};
+
+// core/DefinitionReader.java
+class DefinitionReader {
+public:
+    static DefinitionReader reader(const std::string& contents, const std::string& sourceRef = "<input string>") {
+        return DefinitionReader(contents, sourceRef);
+    }
+    // flags: 0, or GX_CREATE_HOST_ONLY to parse and compile without touching a GPU
+    std::unique_ptr<Gorp> read(uint32_t flags = 0) const {
+        gx_handle* h = nullptr;
+        int rc = gx_create_from_definition(text_.c_str(), ref_.c_str(), flags, &h);
+        if (rc == GX_E_DEFINITION || rc == GX_E_REGEX_SYNTAX || rc == GX_E_UNSUPPORTED_CONSTRUCT || rc == GX_E_LIMIT)
+            throw DefinitionParseException(rc, gx_last_error());
+        if (rc != GX_OK) throw GorpError(rc, gx_last_error());
+        std::vector<CookedExtraction> xs;
+        for (int32_t k = 0; k < gx_num_extractions(h); ++k) {
+            CookedExtraction x;
+            x.name = gx_extraction_name(h, k);
+            for (int32_t g = 0; gx_extractor_name(h, k, g); ++g) x.extractorNames.push_back(gx_extractor_name(h, k, g));
+            if (const char* a = gx_extraction_append_json(h, k)) x.appendJson = a;
+            xs.push_back(std::move(x));
+        }
+        return std::unique_ptr<Gorp>(new Gorp(h, std::move(xs)));
+    }
+
+private:
+    DefinitionReader(std::string t, std::string r) : text_(std::move(t)), ref_(std::move(r)) {}
+    std::string text_, ref_;
+};
+
+}  // namespace gorp
