@@ -53,11 +53,14 @@ struct gx_handle {
     size_t image_bytes = 0;
     GxDev dev{};
     int max_regs = 0;
-    // LDS tier (tile kernel)
+    // tile kernel: LDS tier (automaton rows in LDS) or L2 tier (rows in global memory, l2_image)
     bool tile_ok = false;
+    bool tile_global = false;
     GxLds lds{};                 // table part of the layout; staging is sized per batch
     std::vector<uint8_t> lds_image;
     void* d_lds_image = nullptr;
+    std::vector<uint8_t> l2_image;
+    void* d_l2_image = nullptr;
     int num_cus = 256;
     std::vector<dsl::Extraction> meta;  // names / extractor names / append (only when built from definition text)
     std::mutex mu;  // serialises host-pointer batches that share nothing else
@@ -79,20 +82,34 @@ template <typename F> uint16_t self_loop_interval(F loops) {
     return static_cast<uint16_t>(best_lo | ((best_lo + best_len - 1) << 8));
 }
 
-// Build the LDS-resident table image of the tile kernel (layout: GxLds).
-void build_lds_image(gx_handle* h) {
+// Build the table image of the tile kernel (layout: GxLds).  global == false: LDS tier, everything in one
+// LDS-resident image, rows addressed by byte offset.  global == true: L2 tier, the automaton rows go to a
+// separate global-memory image (h->l2_image: match rows at 0, capture rows at GxLds::c_base) and are addressed
+// by state index; LDS keeps only the byte->class map, the per-extraction start rows and the capture programs.
+bool build_tile_image(gx_handle* h, bool global) {
     const Tables& T = h->T;
     h->tile_ok = false;
-    if (T.n_rules > 32767) return;
+    h->tile_global = global;
+    if (T.n_rules > 32767) return false;
     const uint32_t cols = static_cast<uint32_t>(T.ncls) + 3u;
     const uint32_t RS = cols * 4u;
     // with the fused automaton present the per-extraction capture rows are not needed on the device
     const bool fused = T.union_ok;
-    size_t rows = static_cast<size_t>(T.m_states);
-    if (fused) rows += T.uni.n_states;
-    else for (auto& r : T.rules) rows += r.n_states;
-    if (rows * RS > 65536u || T.ncls * 4 > 65535) return;  // row offsets are 16-bit
-    if (rows * RS + T.ops_off.size() * 4 + T.ops.size() * 2 + T.fin_tags.size() * 2 + 1024 > LDS_TABLE_BUDGET) return;
+    const size_t m_rows = static_cast<size_t>(T.m_states);
+    size_t c_rows = 0;
+    if (fused) c_rows = T.uni.n_states;
+    else for (auto& r : T.rules) c_rows += r.n_states;
+    const size_t rows = m_rows + c_rows;
+    if (T.ncls * 4 > 65535) return false;
+    if (!global) {
+        if (rows * RS > 65536u) return false;  // row offsets are 16-bit
+        if (rows * RS + T.ops_off.size() * 4 + T.ops.size() * 2 + T.fin_tags.size() * 2 + 1024 > LDS_TABLE_BUDGET) return false;
+    } else {
+        if (m_rows > 65536u || c_rows > 65536u) return false;  // state indexes are 16-bit per automaton table
+        if (T.n_rules * 8 + T.ops_off.size() * 4 + T.ops.size() * 2 + 1024 > LDS_TABLE_BUDGET) return false;
+    }
+    // a state's successor field: LDS tier = byte offset of the row, L2 tier = state index
+    const uint32_t UNIT = global ? 1u : RS;
 
     Image img;
     GxLds L{};
@@ -105,13 +122,14 @@ void build_lds_image(gx_handle* h) {
     // match automaton rows
     for (int s = 0; s < T.m_states; ++s) {
         uint32_t* row = &at[static_cast<size_t>(s) * cols];
-        for (int c = 0; c < T.ncls; ++c) row[c] = T.m_next[static_cast<size_t>(s) * T.ncls + c] * RS;
-        row[IDC] = static_cast<uint32_t>(s) * RS;
+        for (int c = 0; c < T.ncls; ++c) row[c] = T.m_next[static_cast<size_t>(s) * T.ncls + c] * UNIT;
+        row[IDC] = static_cast<uint32_t>(s) * UNIT;
         row[ACC] = self_loop_interval([&](int b) { return T.m_next[static_cast<size_t>(s) * T.ncls + T.cls256[b]] == static_cast<uint32_t>(s); });
         row[INFO] = static_cast<uint32_t>(T.m_accept_first[s]);
     }
     L.m_start = 0;
-    L.m_dead = static_cast<uint32_t>(T.m_dead) * RS;
+    L.m_dead = static_cast<uint32_t>(T.m_dead) * UNIT;
+    L.c_base = global ? static_cast<uint32_t>(m_rows * RS) : 0u;
     // capture automata rows: the fused automaton, or one automaton per extraction
     std::vector<uint32_t> c_rule;
     size_t base_row = static_cast<size_t>(T.m_states);
@@ -129,7 +147,8 @@ void build_lds_image(gx_handle* h) {
     else for (auto& r : T.rules) scan_simple(r);
     L.simple_ops = simple ? 1u : 0u;
     auto emit_rows = [&](const RuleTables& r) {
-        const uint32_t base = static_cast<uint32_t>(base_row) * RS;
+        // LDS tier: offsets from the start of all rows; L2 tier: state indexes within the capture rows
+        const uint32_t base = static_cast<uint32_t>(global ? base_row - m_rows : base_row) * UNIT;
         for (int s = 0; s < r.n_states; ++s) {
             uint32_t* row = &at[(base_row + s) * cols];
             for (int c = 0; c < T.ncls; ++c) {
@@ -143,9 +162,9 @@ void build_lds_image(gx_handle* h) {
                     if (is_single_set(op)) op = 0x8000u | T.ops[2 * T.ops_off[op]];
                     else if (op >= 0x8000u) too_many_programs = true;
                 }
-                row[c] = (base + (w & 0xFFFFu) * RS) | (op << 16);
+                row[c] = (base + (w & 0xFFFFu) * UNIT) | (op << 16);
             }
-            row[IDC] = (base + static_cast<uint32_t>(s) * RS) | (simple ? 0x80000000u : 0u);
+            row[IDC] = (base + static_cast<uint32_t>(s) * UNIT) | (simple ? 0x80000000u : 0u);
             row[ACC] = self_loop_interval(
                 [&](int b) { return r.trans[static_cast<size_t>(s) * T.ncls + T.cls256[b]] == static_cast<uint32_t>(s); });
             row[INFO] = static_cast<uint32_t>(r.fin[s]);
@@ -158,7 +177,7 @@ void build_lds_image(gx_handle* h) {
     if (fused) {
         const uint32_t base = emit_rows(T.uni);
         L.u_start = base;
-        L.u_dead = base + static_cast<uint32_t>(T.uni.dead) * RS;
+        L.u_dead = base + static_cast<uint32_t>(T.uni.dead) * UNIT;
         for (auto& r : T.rules) { c_rule.push_back(0); c_rule.push_back(static_cast<uint32_t>(r.n_groups)); }
     } else {
         for (auto& r : T.rules) {
@@ -167,9 +186,14 @@ void build_lds_image(gx_handle* h) {
             c_rule.push_back(static_cast<uint32_t>(r.n_groups));
         }
     }
-    if (too_many_programs) return;  // too many distinct general programs for the LDS tier
+    if (too_many_programs) return false;  // too many distinct general programs for the 15-bit program field
     if (c_rule.empty()) { c_rule.push_back(0); c_rule.push_back(0); }
-    L.at = static_cast<uint32_t>(img.put(at));
+    if (global) {
+        L.at = 0;
+        h->l2_image.assign(reinterpret_cast<const uint8_t*>(at.data()), reinterpret_cast<const uint8_t*>(at.data() + at.size()));
+    } else {
+        L.at = static_cast<uint32_t>(img.put(at));
+    }
     L.c_rule = static_cast<uint32_t>(img.put(c_rule));
     L.ops_off = static_cast<uint32_t>(img.put(T.ops_off));
     std::vector<uint16_t> ops = T.ops;
@@ -177,7 +201,7 @@ void build_lds_image(gx_handle* h) {
     L.ops = static_cast<uint32_t>(img.put(ops));
     std::vector<uint16_t> fin_tags = T.fin_tags;
     if (fin_tags.empty()) fin_tags.push_back(0);
-    L.fin_tags = static_cast<uint32_t>(img.put(fin_tags));
+    L.fin_tags = global ? 0u : static_cast<uint32_t>(img.put(fin_tags));  // L2 tier reads GxDev::fin_tags
     while (img.bytes.size() % 16) img.bytes.push_back(0);
     L.table_bytes = static_cast<uint32_t>(img.bytes.size());
     int max_regs = 0;
@@ -187,6 +211,7 @@ void build_lds_image(gx_handle* h) {
     h->lds = L;
     h->lds_image.swap(img.bytes);
     h->tile_ok = true;
+    return true;
 }
 
 // Complete the layout for one batch: staging sized for 64 lines of the hinted length.
@@ -287,10 +312,15 @@ void upload(gx_handle* h) {
     d.max_regs = max_regs;
     d.has_capture = T.has_capture ? 1 : 0;
 
-    build_lds_image(h);
+    const int force_tier = getenv("GX_DEBUG_TIER") ? atoi(getenv("GX_DEBUG_TIER")) : 0;  // developer/tests: 2 = L2 tier, 3 = generic
+    if (force_tier == 3 || !((force_tier != 2 && build_tile_image(h, false)) || build_tile_image(h, true))) h->tile_ok = false;
     if (h->tile_ok) {
         GX_HIP(hipMalloc(&h->d_lds_image, h->lds_image.size()));
         GX_HIP(hipMemcpy(h->d_lds_image, h->lds_image.data(), h->lds_image.size(), hipMemcpyHostToDevice));
+        if (h->tile_global) {
+            GX_HIP(hipMalloc(&h->d_l2_image, h->l2_image.size()));
+            GX_HIP(hipMemcpy(h->d_l2_image, h->l2_image.data(), h->l2_image.size(), hipMemcpyHostToDevice));
+        }
         GX_HIP(prepare_tile_kernels(LDS_BYTES));
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->num_cus = cus;
@@ -298,11 +328,12 @@ void upload(gx_handle* h) {
     h->on_device = true;
 }
 
-// One batch on the device: LDS-tier tile kernel when the tables fit, generic kernel otherwise.
+// One batch on the device: tile kernel (LDS tier when the tables fit LDS, else L2 tier), generic kernel otherwise.
 void launch_batch(gx_handle* h, const GxBatch& b, uint32_t line_bytes_hint, hipStream_t stream) {
     GxLds L;
     if (!b.wide && !b.state_out && plan_tile_launch(h, line_bytes_hint, &L))
-        GX_HIP(launch_extract_tile(h->dev, L, static_cast<const uint8_t*>(h->d_lds_image), h->num_cus, b, stream));
+        GX_HIP(launch_extract_tile(h->dev, L, static_cast<const uint8_t*>(h->d_lds_image),
+                                   h->tile_global ? static_cast<const uint8_t*>(h->d_l2_image) : nullptr, h->num_cus, b, stream));
     else
         GX_HIP(launch_extract_generic(h->dev, b, stream));
 }
@@ -373,6 +404,7 @@ void gx_destroy(gx_handle* h) {
     if (!h) return;
     if (h->dimage) (void)hipFree(h->dimage);
     if (h->d_lds_image) (void)hipFree(h->d_lds_image);
+    if (h->d_l2_image) (void)hipFree(h->d_l2_image);
     delete h;
 }
 
@@ -393,6 +425,7 @@ int64_t gx_stat(const gx_handle* h, int32_t which) {
     case 4: return static_cast<int64_t>(h->blob.size());
     case 5: { GxLds L; return plan_tile_launch(h, 0, &L) ? static_cast<int64_t>(L.total_bytes) : 0; }
     case 6: { GxLds L; return plan_tile_launch(h, 0, &L) ? static_cast<int64_t>(L.nwaves) : 0; }
+    case 7: return !h->tile_ok ? 0 : h->tile_global ? 2 : 1;
     default: return -1;
     }
 }

@@ -47,6 +47,7 @@ struct GxLds {
                           // (match automaton: first accepting extraction or -1; capture automaton: offset of the
                           // state's final tag list in fin_tags or -1)
     uint32_t row_bytes;   // (ncls + 3) * 4
+    uint32_t c_base;      // L2 tier: byte offset of the capture rows inside the global row image (0 in the LDS tier)
     uint32_t m_start;     // row offset of the match automaton's start state
     uint32_t m_dead;      // row offset of its absorbing dead state
     uint32_t c_rule;      // u32[n_rules * 2]: row offset of the rule's start state, group count
@@ -85,7 +86,9 @@ hipError_t launch_extract_generic(const GxDev& dev, const GxBatch& b, hipStream_
 // Tile kernel (LDS tier): tables resident in LDS, 64-line tiles staged through
 // LDS with coalesced loads, self-loop runs skipped 16 bytes at a time.
 // Byte input only.  `lds_image` is the device copy of the table image.
-hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, int num_cus,
+// at_global != nullptr selects the L2 tier: automaton rows are read from that global-memory table (row =
+// state index, GxLds::row_bytes per row) instead of from LDS.
+hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
                                const GxBatch& b, hipStream_t stream);
 hipError_t prepare_tile_kernels(uint32_t lds_bytes);
 

@@ -190,7 +190,16 @@ __device__ __forceinline__ void run_op_list(uint32_t ops_off_b, uint32_t ops_b, 
 // byte is one LDS read plus one add.  The byte->class lookups do not depend on the state and are issued up
 // front.  MASKED windows (first/last of a line) send out-of-line bytes through the identity column, which
 // maps every state to itself with no capture program.
-template <bool CAPTURE, bool MASKED, bool SIMPLE>
+// One automaton-table word.  LDS tier (GT = false): `row` is the byte offset of the state's row inside the LDS
+// table.  L2 tier (GT = true): the table lives in global memory (it stays resident in the XCD's L2), `row` is
+// the state index and the row address is state * row_bytes.
+template <bool GT>
+__device__ __forceinline__ uint32_t tab_read(const uint8_t* at, uint32_t row, uint32_t off, uint32_t rs) {
+    if (GT) return *reinterpret_cast<const uint32_t*>(at + (static_cast<uint64_t>(row) * rs + off));
+    return *reinterpret_cast<const uint32_t*>(at + row + off);
+}
+
+template <bool CAPTURE, bool MASKED, bool SIMPLE, bool GT>
 __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, const uint8_t* at, uint32_t row, uint32_t idc4,
                                             uint32_t wb_rel, uint16_t* regs, const GxLds& L) {
     const uint8_t* cmap = gx_smem;  // GxLds: the byte->class*4 map sits at LDS offset 0
@@ -205,7 +214,7 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const uint32_t e = *reinterpret_cast<const uint32_t*>(at + row + c4[j]);
+        const uint32_t e = tab_read<GT>(at, row, c4[j], L.row_bytes);
         row = e & 0xFFFFu;
         if (CAPTURE) {
             const uint16_t pos = static_cast<uint16_t>(wb_rel + j);
@@ -232,13 +241,13 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
 // the ends of a line go through the identity column or, when they pass the range test dword by dword, are
 // skipped too).  Returns the row offset of the final state.
 // (A 32-byte look-ahead variant was measured slower: the extra test is paid in the header windows too.)
-template <bool CAPTURE>
+template <bool CAPTURE, bool GT>
 __device__ __forceinline__ uint32_t walk(const uint8_t* stage, const uint8_t* at, uint32_t row, uint32_t start, uint32_t end,
                                          bool on, uint32_t dead_row, uint16_t* regs, const GxLds& L) {
     const uint32_t idc4 = L.row_bytes - 12u;   // identity column
     const uint32_t acc_off = L.row_bytes - 8u; // self-loop interval column
     uint32_t wb = start & ~15u;
-    uint32_t acc = *reinterpret_cast<const uint32_t*>(at + row + acc_off);
+    uint32_t acc = tab_read<GT>(at, row, acc_off, L.row_bytes);
     bool has = (acc & 0xFFu) <= ((acc >> 8) & 0xFFu);
     uint32_t lo4 = splat_byte0(acc), hi4h = splat_byte1(acc) | HI_BITS;
     bool more = on && start < end;
@@ -255,13 +264,13 @@ __device__ __forceinline__ uint32_t walk(const uint8_t* stage, const uint8_t* at
             if (!full0) skip = has & partial_window_ok(rx, ry, rz, rw, mask);
             if (!skip) {
                 if (CAPTURE && L.simple_ops) {
-                    if (full0) row = steps16<CAPTURE, false, true>(w0, mask, at, row, idc4, wb - start, regs, L);
-                    else row = steps16<CAPTURE, true, true>(w0, mask, at, row, idc4, wb - start, regs, L);
+                    if (full0) row = steps16<CAPTURE, false, true, GT>(w0, mask, at, row, idc4, wb - start, regs, L);
+                    else row = steps16<CAPTURE, true, true, GT>(w0, mask, at, row, idc4, wb - start, regs, L);
                 } else {
-                    if (full0) row = steps16<CAPTURE, false, false>(w0, mask, at, row, idc4, wb - start, regs, L);
-                    else row = steps16<CAPTURE, true, false>(w0, mask, at, row, idc4, wb - start, regs, L);
+                    if (full0) row = steps16<CAPTURE, false, false, GT>(w0, mask, at, row, idc4, wb - start, regs, L);
+                    else row = steps16<CAPTURE, true, false, GT>(w0, mask, at, row, idc4, wb - start, regs, L);
                 }
-                acc = *reinterpret_cast<const uint32_t*>(at + row + acc_off);
+                acc = tab_read<GT>(at, row, acc_off, L.row_bytes);
                 has = (acc & 0xFFu) <= ((acc >> 8) & 0xFFu);
                 lo4 = splat_byte0(acc);
                 hi4h = splat_byte1(acc) | HI_BITS;
@@ -358,9 +367,10 @@ __device__ __forceinline__ void tile_commit(const TileInfo& t, uint32_t lane, co
 // KCH: 16-byte chunks per lane that cover the staging area (stage_bytes <= KCH * 1024).  A tile's span is
 // fetched into KCH*4 VGPRs per lane one tile AHEAD: the loads are issued before the current tile is walked
 // and land while the wave computes out of LDS, so HBM latency is hidden without a second LDS buffer.
-template <typename OFF, int KCH>
+template <typename OFF, int KCH, bool GT>
 __global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(1, 3)))
-k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const uint8_t* __restrict__ data,
+k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const uint8_t* __restrict__ at_global,
+               const uint8_t* __restrict__ data,
                const OFF* __restrict__ off, uint64_t n, int32_t* __restrict__ match_id, int32_t* __restrict__ caps,
                int match_only) {
     // ---- prologue: table image -> LDS ----
@@ -371,9 +381,12 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
     }
     __syncthreads();
 
-    const uint8_t* at = gx_smem + L.at;
+    // LDS tier: automaton rows, final-tag records and group counts sit in LDS.  L2 tier: they are read from
+    // global memory (the uploaded table image); only the byte->class map and the capture programs are in LDS.
+    const uint8_t* at = GT ? at_global : gx_smem + L.at;       // match automaton rows
+    const uint8_t* at_c = GT ? at_global + L.c_base : at;      // fused / per-extraction capture rows
     const uint32_t* c_rule = reinterpret_cast<const uint32_t*>(gx_smem + L.c_rule);
-    const uint16_t* fin_tags = reinterpret_cast<const uint16_t*>(gx_smem + L.fin_tags);
+    const uint16_t* fin_tags = GT ? T.fin_tags : reinterpret_cast<const uint16_t*>(gx_smem + L.fin_tags);
     const uint32_t info_off = L.row_bytes - 4u;  // per-state info column: accept / final-tags offset
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -451,35 +464,35 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
             if (valid) match_id[i] = stage[start];
         } else if (!want_caps) {
             // ---- hot loop #1 alone: PolyMatcher.match ----
-            const uint32_t mrow = walk<false>(stage, at, L.m_start, start, end, true, L.m_dead, regs, L);
-            if (valid) match_id[i] = *reinterpret_cast<const int32_t*>(at + mrow + info_off);
+            const uint32_t mrow = walk<false, GT>(stage, at, L.m_start, start, end, true, L.m_dead, regs, L);
+            if (valid) match_id[i] = static_cast<int32_t>(tab_read<GT>(at, mrow, info_off, L.row_bytes));
         } else {
             int32_t result, f = -1, tag0 = 0;
             uint32_t ng = 0;
             if (L.u_start != 0xFFFFFFFFu) {
                 // ---- fused pass: match automaton x joined capture automata, one walk ----
-                const uint32_t urow = walk<true>(stage, at, L.u_start, start, end, true, L.u_dead, regs, L);
-                const int32_t info = *reinterpret_cast<const int32_t*>(at + urow + info_off);
+                const uint32_t urow = walk<true, GT>(stage, at_c, L.u_start, start, end, true, L.u_dead, regs, L);
+                const int32_t info = static_cast<int32_t>(tab_read<GT>(at_c, urow, info_off, L.row_bytes));
                 result = info;  // -1: null, -2-k: ExtractionException
                 if (info >= 0) {
                     result = fin_tags[info];  // the record starts with the winning extraction
-                    ng = c_rule[2 * result + 1];
+                    ng = GT ? static_cast<uint32_t>(T.c_ngroups[result]) : c_rule[2 * result + 1];
                     f = info;
                     tag0 = 1;
                 }
             } else {
                 // ---- hot loop #1, then hot loop #2 on extraction k's tagged automaton ----
-                const uint32_t mrow = walk<false>(stage, at, L.m_start, start, end, true, L.m_dead, regs, L);
-                const int32_t k = *reinterpret_cast<const int32_t*>(at + mrow + info_off);
+                const uint32_t mrow = walk<false, GT>(stage, at, L.m_start, start, end, true, L.m_dead, regs, L);
+                const int32_t k = static_cast<int32_t>(tab_read<GT>(at, mrow, info_off, L.row_bytes));
                 result = k;
-                uint32_t crow = L.m_dead;
+                uint32_t crow = GT ? 0u : L.m_dead;  // any valid row: the walk below is off for lanes without a match
                 if (k >= 0) {
                     crow = c_rule[2 * k];
                     ng = c_rule[2 * k + 1];
                 }
-                crow = walk<true>(stage, at, crow, start, end, k >= 0, 0xFFFFFFFFu, regs, L);
+                crow = walk<true, GT>(stage, at_c, crow, start, end, k >= 0, 0xFFFFFFFFu, regs, L);
                 if (k >= 0) {
-                    f = *reinterpret_cast<const int32_t*>(at + crow + info_off);
+                    f = static_cast<int32_t>(tab_read<GT>(at_c, crow, info_off, L.row_bytes));
                     if (f < 0) result = -2 - k;  // DFA said yes, capture regex says no -> ExtractionException
                 }
             }
@@ -539,46 +552,51 @@ hipError_t launch_extract_generic(const GxDev& dev, const GxBatch& b, hipStream_
 }
 
 namespace {
-template <typename OFF, int KCH>
-hipError_t launch_tile_t(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, dim3 grid, dim3 block, const GxBatch& b,
-                         hipStream_t stream) {
+template <typename OFF, int KCH, bool GT>
+hipError_t launch_tile_t(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, dim3 grid, dim3 block,
+                         const GxBatch& b, hipStream_t stream) {
     static bool prepared = false;  // per instantiation; the attribute is sticky for the process
     if (!prepared) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extract_tile<OFF, KCH>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extract_tile<OFF, KCH, GT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         if (e != hipSuccess) return e;
         prepared = true;
     }
-    hipLaunchKernelGGL((k_extract_tile<OFF, KCH>), grid, block, lds.total_bytes, stream, dev, lds, lds_image,
+    hipLaunchKernelGGL((k_extract_tile<OFF, KCH, GT>), grid, block, lds.total_bytes, stream, dev, lds, lds_image, at_global,
                        static_cast<const uint8_t*>(b.data), static_cast<const OFF*>(b.offsets), b.n, b.match_id, b.caps, b.match_only);
     return hipGetLastError();
 }
-template <typename OFF>
-hipError_t launch_tile_o(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, dim3 grid, dim3 block, const GxBatch& b,
-                         hipStream_t stream) {
+template <typename OFF, bool GT>
+hipError_t launch_tile_o(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, dim3 grid, dim3 block,
+                         const GxBatch& b, hipStream_t stream) {
     const uint32_t kch = (lds.stage_bytes + 1023u) / 1024u;
-    if (kch <= 4) return launch_tile_t<OFF, 4>(dev, lds, lds_image, grid, block, b, stream);
-    if (kch <= 8) return launch_tile_t<OFF, 8>(dev, lds, lds_image, grid, block, b, stream);
-    if (kch <= 13) return launch_tile_t<OFF, 13>(dev, lds, lds_image, grid, block, b, stream);
-    if (kch <= 16) return launch_tile_t<OFF, 16>(dev, lds, lds_image, grid, block, b, stream);
+    if (kch <= 4) return launch_tile_t<OFF, 4, GT>(dev, lds, lds_image, at_global, grid, block, b, stream);
+    if (kch <= 8) return launch_tile_t<OFF, 8, GT>(dev, lds, lds_image, at_global, grid, block, b, stream);
+    if (kch <= 13) return launch_tile_t<OFF, 13, GT>(dev, lds, lds_image, at_global, grid, block, b, stream);
+    if (kch <= 16) return launch_tile_t<OFF, 16, GT>(dev, lds, lds_image, at_global, grid, block, b, stream);
     return hipErrorInvalidValue;
 }
 }  // namespace
 
 hipError_t prepare_tile_kernels(uint32_t) { return hipSuccess; }
 
-hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, int num_cus, const GxBatch& b,
-                               hipStream_t stream) {
+hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
+                               const GxBatch& b, hipStream_t stream) {
     if (b.n == 0) return hipSuccess;
     const uint64_t tiles = (b.n + 63) >> 6;
     uint32_t blocks_per_cu = 163840u / lds.total_bytes;
     if (blocks_per_cu < 1) blocks_per_cu = 1;
+    if (blocks_per_cu * lds.nwaves > 12) blocks_per_cu = 1;  // the kernel is built for <= 3 waves per SIMD
     uint64_t blocks = static_cast<uint64_t>(num_cus) * blocks_per_cu;
     const uint64_t need = (tiles + lds.nwaves - 1) / lds.nwaves;
     if (blocks > need) blocks = need;
     dim3 grid(static_cast<unsigned>(blocks)), block(lds.nwaves * 64);
-    if (b.offsets64) return launch_tile_o<uint64_t>(dev, lds, lds_image, grid, block, b, stream);
-    return launch_tile_o<uint32_t>(dev, lds, lds_image, grid, block, b, stream);
+    if (at_global) {
+        if (b.offsets64) return launch_tile_o<uint64_t, true>(dev, lds, lds_image, at_global, grid, block, b, stream);
+        return launch_tile_o<uint32_t, true>(dev, lds, lds_image, at_global, grid, block, b, stream);
+    }
+    if (b.offsets64) return launch_tile_o<uint64_t, false>(dev, lds, lds_image, nullptr, grid, block, b, stream);
+    return launch_tile_o<uint32_t, false>(dev, lds, lds_image, nullptr, grid, block, b, stream);
 }
 
 }  // namespace gx

@@ -78,7 +78,9 @@ int32_t gx_num_extractions(const gx_handle* h);
 int32_t gx_num_groups(const gx_handle* h, int32_t k);
 int32_t gx_max_groups(const gx_handle* h);
 /* table statistics: 0 = match-DFA states, 1 = char classes, 2 = capture-automaton states (sum),
- * 3 = capture registers (max over extractions), 4 = blob bytes, 5 = LDS bytes the batch kernel stages */
+ * 3 = capture registers (max over extractions), 4 = blob bytes, 5 = LDS bytes the batch kernel stages,
+ * 6 = waves per workgroup of the batch kernel, 7 = table tier of the batch kernel (1 = automaton rows in LDS,
+ * 2 = rows in global memory / L2, 0 = per-line generic kernel) */
 int64_t gx_stat(const gx_handle* h, int32_t which);
 
 typedef struct gx_batch_opts {

@@ -273,11 +273,61 @@ def test_syslog_16_rules():
     assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
 
 
+@pytest.mark.parametrize("tier", [2, 3])
+def test_table_tiers_agree_with_oracle(tier, monkeypatch):
+    """The same definitions through the L2-tier tile kernel (automaton rows in global memory) and through the
+    per-line generic kernel; the default for these small definitions is the LDS tier, covered everywhere else."""
+    monkeypatch.setenv("GX_DEBUG_TIER", str(tier))
+    want = {2: 2, 3: 0}[tier]
+    # config 1
+    definition = W.simple_grp_definition()
+    gorp, orc = Gorp.construct(definition), oracle_for(definition)
+    assert gorp.stat(7) == want
+    check_batch(gorp, orc, W.simple_grp_lines(5000, seed=11))
+    # config 2 + ragged / empty / very long lines + 64-bit offsets + match-only
+    definition = W.readme3_definition()
+    gorp, orc = Gorp.construct(definition), oracle_for(definition)
+    assert gorp.stat(7) == want
+    data, offsets, cat = W.readme3_lines(60000, seed=12)
+    d, o = data.numpy(), offsets.numpy()
+    mid, caps = gorp.extract_batch(d, o)
+    omid, ocaps = orc.extract_batch(d, o, nthreads=8)
+    assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+    m2, _ = gorp.extract_batch(d, o, match_only=True)
+    assert np.array_equal(m2, orc.extract_batch(d, o, match_only=True, nthreads=8)[0])
+    long_ok = "[123456789]: GET 5ms /" + "x" * 70000
+    lines = ["", "[", "[1]: GET 5ms /x", "", "[1]: PUT 5ms /x", long_ok, long_ok + " ", "x", "[12]: HEAD 7777ms /a?b=c", ""]
+    mid, caps = check_batch(gorp, orc, lines)
+    d64, o64 = lines_to_csr(lines, offsets_dtype=np.uint64)
+    m64, c64 = gorp.extract_batch(d64, o64)
+    assert np.array_equal(m64, mid) and np.array_equal(c64, caps)
+    # exception outcome (-2-k) and a definition without the fused automaton's "simple programs" shortcut
+    import test_compiler_vs_oracle as TC
+    from blob_interp import Blob
+    rng = random.Random(777 + tier)
+    n_defs = 0
+    while n_defs < 40:
+        exts = [{"name": "e%d" % i, "pieces": TC.gen_pieces(rng)} for i in range(rng.randint(1, 4))]
+        try:
+            definition = fl(exts)
+            gorp = Gorp.construct(definition)
+            orc = oracle_for(definition)
+        except AssertionError:
+            raise
+        except Exception:
+            continue
+        n_defs += 1
+        b = Blob(gorp.blob())
+        lines = [TC.gen_line(rng) for _ in range(20)] + [TC.sample_from_match_automaton(b, rng) for _ in range(44)]
+        check_batch(gorp, orc, lines)
+
+
 def test_config3_64_rules_parity():
-    """BASELINE.json configs[2]: 64 extractions (tables beyond the LDS tier -> generic kernel)."""
+    """BASELINE.json configs[2]: 64 extractions (tables beyond the LDS tier -> L2-tier tile kernel)."""
     rules, meta = W.syslog_definition(64, seed=3)
     gorp, orc = Gorp.construct(rules), oracle_for(rules)
     assert gorp.stat(0) > 1000  # match-automaton states
+    assert gorp.stat(7) == 2    # automaton rows in global memory
     data, offsets, cats = W.syslog_lines(meta, 30000, seed=3)
     mid, caps = gorp.extract_batch(data, offsets)
     omid, ocaps = orc.extract_batch(data, offsets, nthreads=8)
@@ -291,6 +341,7 @@ def test_config5_512_rules_mixed_lengths_parity():
     """BASELINE.json configs[4]: 512 extractions, lines of 50-2000 bytes."""
     rules, meta = W.syslog_definition(512, seed=3)
     gorp, orc = Gorp.construct(rules), oracle_for(rules)
+    assert gorp.stat(7) == 2
     data, offsets, cats = W.syslog_lines(meta, 6000, seed=5, min_len=50, max_len=2000)
     mid, caps = gorp.extract_batch(data, offsets)
     omid, ocaps = orc.extract_batch(data, offsets, nthreads=8)
