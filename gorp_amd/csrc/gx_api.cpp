@@ -71,15 +71,16 @@ namespace {
 const uint32_t LDS_BYTES = 163840;     // 160 KiB per CU on gfx950
 const uint32_t LDS_TABLE_BUDGET = 96 * 1024;
 
-// Longest run of ASCII byte values on which `loops(b)` holds, as lo | hi << 8 (0x00FF = none).
+// Longest run of ASCII byte values on which `loops(b)` holds, as lo | (0x7F - hi) << 8 (0x8000 = none): the
+// form the kernel's SWAR range test consumes.
 template <typename F> uint16_t self_loop_interval(F loops) {
     int best_lo = 0, best_len = 0, run_lo = 0, run = 0;
     for (int b = 0; b < 128; ++b) {
         if (loops(b)) { if (run == 0) run_lo = b; ++run; if (run > best_len) { best_len = run; best_lo = run_lo; } }
         else run = 0;
     }
-    if (best_len < 4) return 0x00FF;
-    return static_cast<uint16_t>(best_lo | ((best_lo + best_len - 1) << 8));
+    if (best_len < 4) return 0x8000;
+    return static_cast<uint16_t>(best_lo | ((0x7F - (best_lo + best_len - 1)) << 8));
 }
 
 // Build the table image of the tile kernel (layout: GxLds).  global == false: LDS tier, everything in one
@@ -100,35 +101,38 @@ bool build_tile_image(gx_handle* h, bool global) {
     if (fused) c_rows = T.uni.n_states;
     else for (auto& r : T.rules) c_rows += r.n_states;
     const size_t rows = m_rows + c_rows;
-    if (T.ncls * 4 > 65535) return false;
+    if (T.ncls > 252) return false;  // classes (+ the identity column) are bytes in the LDS class map
+    const uint32_t AT = 272;         // LDS tier: the rows follow the class map (256 bytes + the identity entry, padded)
     if (!global) {
-        if (rows * RS > 65536u) return false;  // row offsets are 16-bit
+        if (AT + rows * RS > 65536u) return false;  // successors are 16-bit LDS addresses
         if (rows * RS + T.ops_off.size() * 4 + T.ops.size() * 2 + T.fin_tags.size() * 2 + 1024 > LDS_TABLE_BUDGET) return false;
     } else {
         if (m_rows > 65536u || c_rows > 65536u) return false;  // state indexes are 16-bit per automaton table
         if (T.n_rules * 8 + T.ops_off.size() * 4 + T.ops.size() * 2 + 1024 > LDS_TABLE_BUDGET) return false;
     }
-    // a state's successor field: LDS tier = byte offset of the row, L2 tier = state index
+    // a state's successor field: LDS tier = LDS address of the row, L2 tier = state index
     const uint32_t UNIT = global ? 1u : RS;
+    const uint32_t ORG = global ? 0u : AT;
 
     Image img;
     GxLds L{};
-    std::vector<uint16_t> cmap(256);
-    for (int b = 0; b < 256; ++b) cmap[b] = static_cast<uint16_t>(T.cls256[b] * 4);
+    std::vector<uint8_t> cmap(T.cls256, T.cls256 + 256);
+    cmap.resize(272, static_cast<uint8_t>(T.ncls));  // entry 256: the identity column, for bytes outside the line
     L.cmap = static_cast<uint32_t>(img.put(cmap));  // offset 0
+    L.ncls = static_cast<uint32_t>(T.ncls);
     L.row_bytes = RS;
     std::vector<uint32_t> at(rows * cols, 0);
     const uint32_t IDC = T.ncls, ACC = T.ncls + 1, INFO = T.ncls + 2;
     // match automaton rows
     for (int s = 0; s < T.m_states; ++s) {
         uint32_t* row = &at[static_cast<size_t>(s) * cols];
-        for (int c = 0; c < T.ncls; ++c) row[c] = T.m_next[static_cast<size_t>(s) * T.ncls + c] * UNIT;
-        row[IDC] = static_cast<uint32_t>(s) * UNIT;
+        for (int c = 0; c < T.ncls; ++c) row[c] = ORG + T.m_next[static_cast<size_t>(s) * T.ncls + c] * UNIT;
+        row[IDC] = ORG + static_cast<uint32_t>(s) * UNIT;
         row[ACC] = self_loop_interval([&](int b) { return T.m_next[static_cast<size_t>(s) * T.ncls + T.cls256[b]] == static_cast<uint32_t>(s); });
         row[INFO] = static_cast<uint32_t>(T.m_accept_first[s]);
     }
-    L.m_start = 0;
-    L.m_dead = static_cast<uint32_t>(T.m_dead) * UNIT;
+    L.m_start = ORG;
+    L.m_dead = ORG + static_cast<uint32_t>(T.m_dead) * UNIT;
     L.c_base = global ? static_cast<uint32_t>(m_rows * RS) : 0u;
     // capture automata rows: the fused automaton, or one automaton per extraction
     std::vector<uint32_t> c_rule;
@@ -137,7 +141,7 @@ bool build_tile_image(gx_handle* h, bool global) {
     // are all capture programs of the tables we ship "one register := position"?
     auto is_single_set = [&](uint32_t op) {
         const uint32_t b = T.ops_off[op], e = T.ops_off[op + 1];
-        return e - b == 1 && T.ops[2 * b + 1] == GX_SRC_POS && T.ops[2 * b] < 0x7FFE;
+        return e - b == 1 && T.ops[2 * b + 1] == GX_SRC_POS && T.ops[2 * b] < 500;
     };
     bool simple = true;
     auto scan_simple = [&](const RuleTables& r) {
@@ -147,16 +151,17 @@ bool build_tile_image(gx_handle* h, bool global) {
     else for (auto& r : T.rules) scan_simple(r);
     L.simple_ops = simple ? 1u : 0u;
     auto emit_rows = [&](const RuleTables& r) {
-        // LDS tier: offsets from the start of all rows; L2 tier: state indexes within the capture rows
-        const uint32_t base = static_cast<uint32_t>(global ? base_row - m_rows : base_row) * UNIT;
+        // LDS tier: LDS addresses; L2 tier: state indexes within the capture rows
+        const uint32_t base = ORG + static_cast<uint32_t>(global ? base_row - m_rows : base_row) * UNIT;
         for (int s = 0; s < r.n_states; ++s) {
             uint32_t* row = &at[(base_row + s) * cols];
             for (int c = 0; c < T.ncls; ++c) {
                 const uint32_t w = r.trans[static_cast<size_t>(s) * T.ncls + c];
                 uint32_t op = w >> 16;
                 if (simple) {
-                    // register column directly: 0 = dummy ("no program"), r + 1 = register r
-                    op = 0x8000u | (op ? T.ops[2 * T.ops_off[op]] + 1u : 0u);
+                    // byte offset of the register's column in the wave's register block: 0 = the dummy column
+                    // ("no program"), (r + 1) * 128 = register r
+                    op = op ? (T.ops[2 * T.ops_off[op]] + 1u) * 128u : 0u;
                 } else if (op) {
                     // the common capture program "one register := position" is folded into the entry as 0x8000 | register
                     if (is_single_set(op)) op = 0x8000u | T.ops[2 * T.ops_off[op]];
@@ -164,7 +169,7 @@ bool build_tile_image(gx_handle* h, bool global) {
                 }
                 row[c] = (base + (w & 0xFFFFu) * UNIT) | (op << 16);
             }
-            row[IDC] = (base + static_cast<uint32_t>(s) * UNIT) | (simple ? 0x80000000u : 0u);
+            row[IDC] = base + static_cast<uint32_t>(s) * UNIT;
             row[ACC] = self_loop_interval(
                 [&](int b) { return r.trans[static_cast<size_t>(s) * T.ncls + T.cls256[b]] == static_cast<uint32_t>(s); });
             row[INFO] = static_cast<uint32_t>(r.fin[s]);
@@ -193,6 +198,7 @@ bool build_tile_image(gx_handle* h, bool global) {
         h->l2_image.assign(reinterpret_cast<const uint8_t*>(at.data()), reinterpret_cast<const uint8_t*>(at.data() + at.size()));
     } else {
         L.at = static_cast<uint32_t>(img.put(at));
+        if (L.at != AT) throw GxError(GX_E_ARG, "internal: LDS table image layout");
     }
     L.c_rule = static_cast<uint32_t>(img.put(c_rule));
     L.ops_off = static_cast<uint32_t>(img.put(T.ops_off));

@@ -39,26 +39,32 @@ struct GxDev {
 // host, kept in HBM next to the other tables and copied into LDS by every
 // workgroup's prologue.
 struct GxLds {
-    uint32_t cmap;        // u16[256] byte -> class * 4; always at offset 0 (the kernel indexes LDS by byte value)
+    uint32_t cmap;        // u8[272] byte -> class, entry 256 = the identity column; always at offset 0 (the kernel
+                          // indexes LDS by byte value)
+    uint32_t ncls;        // number of classes = index of the identity column
     uint32_t at;          // automaton rows, u32[rows][ncls + 3]: one row per state of the match automaton and of
-                          // every extraction's capture automaton.  Columns 0..ncls-1: next row byte offset (from
-                          // `at`) | capture program << 16; column ncls: identity (self, no program); column
-                          // ncls+1: self-loop byte interval lo | hi << 8 (lo > hi: none); column ncls+2: info
-                          // (match automaton: first accepting extraction or -1; capture automaton: offset of the
-                          // state's final tag list in fin_tags or -1)
+                          // the fused automaton (or of every extraction's capture automaton).  Columns
+                          // 0..ncls-1: successor | capture program << 16, where the successor is the LDS byte
+                          // address of its row (LDS tier; always < 65536) or its state index (L2 tier); column
+                          // ncls: identity (self, no program); column ncls+1: self-loop byte interval as
+                          // lo | (0x7F - hi) << 8 (0x8000: none); column ncls+2: info (match automaton: first
+                          // accepting extraction or -1; capture automaton: offset of the state's final tag
+                          // record in fin_tags, or -1 / -2-k)
     uint32_t row_bytes;   // (ncls + 3) * 4
     uint32_t c_base;      // L2 tier: byte offset of the capture rows inside the global row image (0 in the LDS tier)
-    uint32_t m_start;     // row offset of the match automaton's start state
-    uint32_t m_dead;      // row offset of its absorbing dead state
-    uint32_t c_rule;      // u32[n_rules * 2]: row offset of the rule's start state, group count
-    uint32_t u_start;     // row offset of the fused automaton's start state, or 0xFFFFFFFF when absent
-    uint32_t u_dead;      // row offset of its dead state
+    uint32_t m_start;     // row (LDS address / state index) of the match automaton's start state
+    uint32_t m_dead;      // row of its absorbing dead state
+    uint32_t c_rule;      // u32[n_rules * 2]: row of the rule's start state, group count
+    uint32_t u_start;     // row of the fused automaton's start state, or 0xFFFFFFFF when absent
+    uint32_t u_dead;      // row of its dead state
     uint32_t ops_off;     // u32[n_oplists + 1]
     uint32_t ops;         // u16 pairs
     uint32_t fin_tags;    // u16[]
     uint32_t table_bytes; // size of the image, multiple of 16
-    uint32_t simple_ops;  // 1: every capture program is one "register := position"; entries then carry
-                          // 0x8000 | (register + 1) (0x8000 alone = no program) and steps are branch-free
+    uint32_t simple_ops;  // 1: every capture program is one "register := position"; the program field is then
+                          // (register + 1) * 128 = byte offset of the register's column in the wave's register
+                          // block (0 = the dummy column = no program) and steps are branch-free;
+                          // 0: program field 0 = none, 0x8000 | register = single set, else op-list index
     uint32_t regs;        // u16[nwaves][1 + max_regs][64]; column 0 is a write-only dummy
     uint32_t regs_wave_bytes;
     uint32_t stage;       // u8[nwaves][stage_bytes]

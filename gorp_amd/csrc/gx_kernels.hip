@@ -145,23 +145,35 @@ constexpr uint32_t HI_BITS = 0x80808080u;
 __device__ __forceinline__ uint32_t splat_byte0(uint32_t v) { return __builtin_amdgcn_perm(v, v, 0x00000000u); }
 __device__ __forceinline__ uint32_t splat_byte1(uint32_t v) { return __builtin_amdgcn_perm(v, v, 0x01010101u); }
 
-// bit 7 of every byte of the result is set iff that byte of x lies in [lo,hi] (lo,hi < 0x80)
-__device__ __forceinline__ uint32_t inrange_bits(uint32_t x, uint32_t lo4, uint32_t hi4h) {
-    const uint32_t ge = (x | HI_BITS) - lo4;  // no inter-byte borrow: every minuend byte >= 0x80 > lo
-    const uint32_t le = hi4h - x;             // hi4h = hi4 | H; exact for bytes < 0x80; bytes >= 0x80 are vetoed by ~x
-    return ge & le & ~x;
+// Bit 7 of some byte of the result is set iff some byte of x lies outside [lo, hi] (lo, hi < 0x80), where
+// lo4 = lo in every byte and k4 = 0x7F - hi in every byte.  An "any byte" test only: a borrow or carry can
+// only leave a byte that is itself out of range, so the lowest offending byte is always reported.
+// k = 0x80 encodes "no interval" (every byte fails).
+__device__ __forceinline__ uint32_t or3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_or3_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
-// Partial window (first / last of a line), given the per-dword range bits: every dword must lie wholly
+__device__ __forceinline__ uint32_t outside_bits(uint32_t x, uint32_t lo4, uint32_t k4) {
+    return or3(x - lo4, x + k4, x);
+}
+// (a << 2) + b in one instruction: the address of column a in the row at b
+__device__ __forceinline__ uint32_t lshl2_add(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// Partial window (first / last of a line), given the per-dword outside bits: every dword must lie wholly
 // outside the line, or wholly inside and in range; a dword that the line boundary cuts through fails (the
 // exact steps handle it).
-__device__ __forceinline__ bool partial_window_ok(uint32_t rx, uint32_t ry, uint32_t rz, uint32_t rw, uint32_t mask) {
+__device__ __forceinline__ bool partial_window_ok(uint32_t bx, uint32_t by, uint32_t bz, uint32_t bw, uint32_t mask) {
     // spread each nibble of the byte mask over a dword: 0x80 per byte that belongs to the line
     auto spread = [](uint32_t nib) { return ((nib * 0x00204081u) & 0x01010101u) << 7; };
     const uint32_t mx = spread(mask & 15u), my = spread((mask >> 4) & 15u), mz = spread((mask >> 8) & 15u), mw = spread(mask >> 12);
-    const bool ox = (mx == 0u) | ((mx == HI_BITS) & ((rx & HI_BITS) == HI_BITS));
-    const bool oy = (my == 0u) | ((my == HI_BITS) & ((ry & HI_BITS) == HI_BITS));
-    const bool oz = (mz == 0u) | ((mz == HI_BITS) & ((rz & HI_BITS) == HI_BITS));
-    const bool ow = (mw == 0u) | ((mw == HI_BITS) & ((rw & HI_BITS) == HI_BITS));
+    const bool ox = (mx == 0u) | ((mx == HI_BITS) & ((bx & HI_BITS) == 0u));
+    const bool oy = (my == 0u) | ((my == HI_BITS) & ((by & HI_BITS) == 0u));
+    const bool oz = (mz == 0u) | ((mz == HI_BITS) & ((bz & HI_BITS) == 0u));
+    const bool ow = (mw == 0u) | ((mw == HI_BITS) & ((bw & HI_BITS) == 0u));
     return ox & oy & oz & ow;
 }
 
@@ -185,50 +197,63 @@ __device__ __forceinline__ void run_op_list(uint32_t ops_off_b, uint32_t ops_b, 
     }
 }
 
-// 16 exact automaton steps over one staged window.  `row` is the byte offset of the current state's row in
-// the LDS automaton table; an entry is (next row offset | capture program << 16), so the dependent chain per
-// byte is one LDS read plus one add.  The byte->class lookups do not depend on the state and are issued up
-// front.  MASKED windows (first/last of a line) send out-of-line bytes through the identity column, which
-// maps every state to itself with no capture program.
-// One automaton-table word.  LDS tier (GT = false): `row` is the byte offset of the state's row inside the LDS
-// table.  L2 tier (GT = true): the table lives in global memory (it stays resident in the XCD's L2), `row` is
-// the state index and the row address is state * row_bytes.
+// One automaton-table word.  LDS tier (GT = false): `row` is the LDS byte address of the state's row (the host
+// bakes the table's position into every successor field, so `at` is the start of LDS).  L2 tier (GT = true):
+// the table lives in global memory (it stays resident in the XCD's L2), `row` is the state index and the row
+// address is state * row_bytes.
 template <bool GT>
 __device__ __forceinline__ uint32_t tab_read(const uint8_t* at, uint32_t row, uint32_t off, uint32_t rs) {
     if (GT) return *reinterpret_cast<const uint32_t*>(at + (static_cast<uint64_t>(row) * rs + off));
-    return *reinterpret_cast<const uint32_t*>(at + row + off);
+    return *reinterpret_cast<const uint32_t*>(gx_smem + row + off);
 }
 
+// 16 exact automaton steps over one staged window.  An entry is (successor | capture program << 16).  In the
+// LDS tier the two halves are read as two 16-bit LDS loads, so the dependent chain per byte is one LDS read
+// plus one shift-add (successor address + class * 4) and nothing has to be unpacked.  The byte->class lookups
+// do not depend on the state and are issued up front.  MASKED windows (first/last of a line) send out-of-line
+// bytes through the identity column, which maps every state to itself with no capture program.
+// SIMPLE: every program of the definition is "one register := position"; the program field is then the byte
+// offset of that register's column in the wave's register block (0 = a write-only dummy column), so a step is
+// branch-free.  regs = this lane's slot in register column 0 (one column = 64 lanes x u16, after the dummy).
 template <bool CAPTURE, bool MASKED, bool SIMPLE, bool GT>
-__device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, const uint8_t* at, uint32_t row, uint32_t idc4,
-                                            uint32_t wb_rel, uint16_t* regs, const GxLds& L) {
-    const uint8_t* cmap = gx_smem;  // GxLds: the byte->class*4 map sits at LDS offset 0
+__device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, const uint8_t* at, uint32_t row, uint32_t rel,
+                                            uint16_t* regs, const GxLds& L) {
+    const uint8_t* cmap = gx_smem;  // GxLds: the byte->class map sits at LDS offset 0; cmap[256] = identity column
     const uint32_t d[4] = {win.x, win.y, win.z, win.w};
-    uint32_t c4[16];
+    uint32_t cls[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const uint32_t b = (d[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
-        uint32_t c = reinterpret_cast<const uint16_t*>(cmap)[b];
-        if (MASKED) c = ((mask >> j) & 1u) ? c : idc4;
-        c4[j] = c;
+        uint32_t b = (d[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+        if (MASKED) {
+            // out-of-line bytes look up entry 256; selecting the index (not the class) keeps the 16 lookups
+            // independent of each other, so they are issued back to back
+            // (written as two instructions; the compiler's own choice is and + compare + select)
+            uint32_t in_line;
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(in_line) : "v"(mask), "n"(j));
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(b) : "v"(in_line), "v"(b), "v"(256u));
+        }
+        cls[j] = cmap[b];
     }
+    uint8_t* dummy_col = reinterpret_cast<uint8_t*>(regs) - 128;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const uint32_t e = tab_read<GT>(at, row, c4[j], L.row_bytes);
-        row = e & 0xFFFFu;
+        uint32_t op = 0;
+        if (GT) {
+            const uint32_t e = *reinterpret_cast<const uint32_t*>(at + (static_cast<uint64_t>(row) * L.row_bytes + cls[j] * 4u));
+            row = e & 0xFFFFu;
+            op = e >> 16;
+        } else {
+            const uint16_t* p = reinterpret_cast<const uint16_t*>(gx_smem + lshl2_add(cls[j], row));
+            row = p[0];
+            if (CAPTURE) op = p[1];
+        }
         if (CAPTURE) {
-            const uint16_t pos = static_cast<uint16_t>(wb_rel + j);
+            const uint16_t pos = static_cast<uint16_t>(rel + j);
             if (SIMPLE) {
-                // every program of this definition is "one register := position": the entry names the register
-                // column directly (column 0 of the wave's register block is a write-only dummy for "no program"),
-                // so the step is branch-free
-                regs[static_cast<int>((e >> 16) & 0x7FFFu) * 64 - 64] = pos;
-            } else {
-                const uint32_t op = e >> 16;
-                if (op) {
-                    if (op & 0x8000u) regs[(op & 0x7FFFu) * 64] = pos;  // the common program: one register := position
-                    else run_op_list(L.ops_off, L.ops, static_cast<uint32_t>(reinterpret_cast<uint8_t*>(regs) - gx_smem), op, pos);
-                }
+                *reinterpret_cast<uint16_t*>(dummy_col + op) = pos;
+            } else if (op) {
+                if (op & 0x8000u) regs[(op & 0x7FFFu) * 64] = pos;  // the common program: one register := position
+                else run_op_list(L.ops_off, L.ops, static_cast<uint32_t>(reinterpret_cast<uint8_t*>(regs) - gx_smem), op, pos);
             }
         }
     }
@@ -239,73 +264,55 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
 // line.  In every window a lane either proves with one SWAR test that all its bytes stay inside the current
 // state's self-loop interval (state unchanged, 16 bytes skipped), or takes 16 exact steps (partial windows at
 // the ends of a line go through the identity column or, when they pass the range test dword by dword, are
-// skipped too).  Returns the row offset of the final state.
+// skipped too).  Returns the row of the final state.
 // (A 32-byte look-ahead variant was measured slower: the extra test is paid in the header windows too.)
 template <bool CAPTURE, bool GT>
 __device__ __forceinline__ uint32_t walk(const uint8_t* stage, const uint8_t* at, uint32_t row, uint32_t start, uint32_t end,
                                          bool on, uint32_t dead_row, uint16_t* regs, const GxLds& L) {
-    const uint32_t idc4 = L.row_bytes - 12u;   // identity column
-    const uint32_t acc_off = L.row_bytes - 8u; // self-loop interval column
+    const uint32_t acc_off = L.row_bytes - 8u; // self-loop interval column: lo | (0x7F - hi) << 8
     uint32_t wb = start & ~15u;
+    const uint32_t len = end - start;
+    const uint32_t full_lim = len >= 16u ? len - 15u : 0u;  // window at line offset rel is full iff rel < full_lim (unsigned)
     uint32_t acc = tab_read<GT>(at, row, acc_off, L.row_bytes);
-    bool has = (acc & 0xFFu) <= ((acc >> 8) & 0xFFu);
-    uint32_t lo4 = splat_byte0(acc), hi4h = splat_byte1(acc) | HI_BITS;
+    uint32_t lo4 = splat_byte0(acc), k4 = splat_byte1(acc);
     bool more = on && start < end;
     while (__any(more)) {
-        const uint4 w0 = *reinterpret_cast<const uint4*>(stage + (more ? wb : 0u));
-        const bool full0 = wb >= start && wb + 16u <= end;
-        const uint32_t rx = inrange_bits(w0.x, lo4, hi4h), ry = inrange_bits(w0.y, lo4, hi4h);
-        const uint32_t rz = inrange_bits(w0.z, lo4, hi4h), rw = inrange_bits(w0.w, lo4, hi4h);
-        bool ok0 = has & full0 & (((rx & ry & rz & rw) & HI_BITS) == HI_BITS);
+        // a finished lane keeps its last window: the address stays inside the staged tile
+        const uint4 w0 = *reinterpret_cast<const uint4*>(stage + wb);
+        const uint32_t rel = wb - start;  // "negative" (huge) for the first window of a line that starts inside it
+        const bool full0 = rel < full_lim;
+        const uint32_t bx = outside_bits(w0.x, lo4, k4), by = outside_bits(w0.y, lo4, k4);
+        const uint32_t bz = outside_bits(w0.z, lo4, k4), bw = outside_bits(w0.w, lo4, k4);
+        bool ok0 = full0 & (((or3(bx, by, bz) | bw) & HI_BITS) == 0u);
         if (L.debug_ablate == 4) ok0 = true;  // timing ablation: no exact steps at all
-        if (more && !ok0) {
-            const uint32_t mask = window_mask(start, end, wb);
-            bool skip = false;
-            if (!full0) skip = has & partial_window_ok(rx, ry, rz, rw, mask);
-            if (!skip) {
-                if (CAPTURE && L.simple_ops) {
-                    if (full0) row = steps16<CAPTURE, false, true, GT>(w0, mask, at, row, idc4, wb - start, regs, L);
-                    else row = steps16<CAPTURE, true, true, GT>(w0, mask, at, row, idc4, wb - start, regs, L);
-                } else {
-                    if (full0) row = steps16<CAPTURE, false, false, GT>(w0, mask, at, row, idc4, wb - start, regs, L);
-                    else row = steps16<CAPTURE, true, false, GT>(w0, mask, at, row, idc4, wb - start, regs, L);
-                }
-                acc = tab_read<GT>(at, row, acc_off, L.row_bytes);
-                has = (acc & 0xFFu) <= ((acc >> 8) & 0xFFu);
-                lo4 = splat_byte0(acc);
-                hi4h = splat_byte1(acc) | HI_BITS;
-            }
+        bool step = more && !ok0;
+        uint32_t mask = 0xFFFFu;
+        if (step && !full0) {
+            mask = window_mask(start, end, wb);
+            step = !partial_window_ok(bx, by, bz, bw, mask);
         }
-        wb += 16u;
+        // one variant per wave: if any stepping lane has a partial window, every stepping lane takes the masked
+        // steps (its mask is all ones) instead of the wave running both variants one after the other
+        const bool masked = __any(step && !full0);
+        if (step) {
+            if (CAPTURE && L.simple_ops) {
+                if (!masked) row = steps16<CAPTURE, false, true, GT>(w0, mask, at, row, rel, regs, L);
+                else row = steps16<CAPTURE, true, true, GT>(w0, mask, at, row, rel, regs, L);
+            } else {
+                if (!masked) row = steps16<CAPTURE, false, false, GT>(w0, mask, at, row, rel, regs, L);
+                else row = steps16<CAPTURE, true, false, GT>(w0, mask, at, row, rel, regs, L);
+            }
+            acc = tab_read<GT>(at, row, acc_off, L.row_bytes);
+            lo4 = splat_byte0(acc);
+            k4 = splat_byte1(acc);
+        }
+        if (more) wb += 16u;
         more = more && wb < end && row != dead_row;
     }
     return row;
 }
 
-// Wave-cooperative copy of [g_al, g_al + nch*16) into the wave's LDS staging area.
-// All loads of a batch are issued before the first LDS write so that up to 16 KiB
-// per wave is in flight.
-__device__ __forceinline__ void stage_span(const uint8_t* __restrict__ g_al, uint32_t nch, uint8_t* stage, uint32_t lane) {
-    constexpr int B = 8;  // loads in flight per lane (8 KiB per wave)
-    for (uint32_t base = 0; base < nch; base += 64u * B) {
-        uint4 v[B];
-#pragma unroll
-        for (int k = 0; k < B; ++k) {
-            // clamped, unconditional: keeps v[] in registers; a clamped lane re-reads the last chunk (cache hit)
-            const uint32_t c = min(base + lane + 64u * k, nch - 1u);
-            v[k] = *reinterpret_cast<const uint4*>(g_al + (static_cast<uint64_t>(c) << 4));
-        }
-#pragma unroll
-        for (int k = 0; k < B; ++k) {
-            // unconditional as well (clamped lanes rewrite the last chunk with identical data): a conditional
-            // store lets the compiler sink each load next to its store and serialise the batch
-            const uint32_t c = min(base + lane + 64u * k, nch - 1u);
-            *reinterpret_cast<uint4*>(stage + (c << 4)) = v[k];
-        }
-    }
-}
-
-// Same copy for a span that touches the first or last bytes of the buffer: never reads outside [data, data_end).
+// Staging copy for a span that touches the first or last bytes of the buffer: never reads outside [data, data_end).
 __device__ void stage_span_guarded(const uint8_t* __restrict__ g_al, uint32_t nch, uint8_t* stage, uint32_t lane,
                                    const uint8_t* data, const uint8_t* data_end) {
     for (uint32_t c = lane; c < nch; c += 64) {
@@ -383,7 +390,7 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
 
     // LDS tier: automaton rows, final-tag records and group counts sit in LDS.  L2 tier: they are read from
     // global memory (the uploaded table image); only the byte->class map and the capture programs are in LDS.
-    const uint8_t* at = GT ? at_global : gx_smem + L.at;       // match automaton rows
+    const uint8_t* at = GT ? at_global : gx_smem;              // match automaton rows (LDS tier: rows are LDS addresses)
     const uint8_t* at_c = GT ? at_global + L.c_base : at;      // fused / per-extraction capture rows
     const uint32_t* c_rule = reinterpret_cast<const uint32_t*>(gx_smem + L.c_rule);
     const uint16_t* fin_tags = GT ? T.fin_tags : reinterpret_cast<const uint16_t*>(gx_smem + L.fin_tags);

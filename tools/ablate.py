@@ -23,3 +23,15 @@ for mo in (False, True):
         g.extract_batch_device(data.data_ptr(), off.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), match_only=mo, stream=st, no_sync=True)
     e1.record(); torch.cuda.synchronize()
     print("ablate=%s match_only=%s: %.3f ms" % (os.environ.get("GX_DEBUG_ABLATE", "0"), mo, e0.elapsed_time(e1) / 10))
+# box calibration: a plain device-to-device copy of the same buffer (read + write bytes / time)
+dst = torch.empty_like(data)
+for _ in range(3):
+    dst.copy_(data)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    dst.copy_(data)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 10
+print("copy %d B: %.3f ms -> %.2f TB/s (read+write)" % (data.numel(), ms, 2 * data.numel() / ms / 1e9))
