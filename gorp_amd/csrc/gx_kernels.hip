@@ -331,9 +331,10 @@ struct TileInfo {
     const uint8_t* g_al;   // 16-byte aligned start of the tile's span in global memory
     uint32_t nch;          // 16-byte chunks in the span
     uint32_t start, end;   // this lane's line inside the staging area
-    int mode;              // 0: prefetched into registers; 1: touches the buffer edge (guarded copy);
+    uint32_t mode;         // 0: prefetched into registers; 1: touches the buffer edge (guarded copy);
                            // 2: does not fit the staging area (per-lane global path)
-    bool valid;
+    uint32_t valid;        // (32-bit flags and no padding: a struct with padding bytes is copied through scratch
+    uint32_t pad_;         //  memory, which costs a store + load per tile and stalls on the prefetch loads)
 };
 
 // Clamped, unconditional accesses on both sides: a lane beyond the span re-reads / rewrites the last chunk
@@ -404,6 +405,7 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
 
     const int slots = 2 * T.max_groups;
     const bool want_caps = (match_only == 0 || match_only == 3) && T.has_capture;
+    const bool caps_aligned = ((reinterpret_cast<uintptr_t>(caps) | reinterpret_cast<uintptr_t>(match_id)) & 15u) == 0u;
     const uint64_t tiles = (n + 63) >> 6;
     const uint64_t wstride = static_cast<uint64_t>(gridDim.x) * L.nwaves;
     const uint8_t* data_end = data + static_cast<uint64_t>(off[n]);
@@ -417,7 +419,8 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
     auto make_tile = [&](uint64_t tile, uint64_t o0, uint64_t o1) {
         TileInfo t;
         t.i = (tile << 6) + lane;
-        t.valid = t.i < n;
+        t.valid = t.i < n ? 1u : 0u;
+        t.pad_ = 0;
         t.o0 = o0; t.o1 = o1;
         // tile span [lo, hi): lane 0 always holds a valid line
         const uint64_t lo = __shfl(static_cast<unsigned long long>(o0), 0);
@@ -460,7 +463,7 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
         load_offsets(min(ntile + wstride, tiles - 1), nno0, nno1);
 
         const uint64_t i = cur.i;
-        const bool valid = cur.valid;
+        const bool valid = cur.valid != 0u;
         const uint32_t start = cur.start, end = cur.end;
         if (cur.mode == 2) {
             // tile does not fit the staging area (very long lines): exact per-lane path from global memory
@@ -503,38 +506,46 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
                     if (f < 0) result = -2 - k;  // DFA said yes, capture regex says no -> ExtractionException
                 }
             }
-            if (valid) {
+            // capture offsets of this lane's line: group g -> (begin, end), (-1, -1) when unset
+            auto group_span = [&](int g, int32_t& pb, int32_t& pe) {
+                pb = -1; pe = -1;
+                if (f >= 0 && static_cast<uint32_t>(g) < ng) {
+                    const int32_t len = static_cast<int32_t>(end - start);
+                    const uint16_t vb = fin_tags[f + tag0 + 2 * g], ve = fin_tags[f + tag0 + 2 * g + 1];
+                    pb = (vb == SRC_POS) ? len : (vb == SRC_NIL ? -1 : static_cast<int32_t>(regs[vb * 64]));
+                    pe = (ve == SRC_POS) ? len : (ve == SRC_NIL ? -1 : static_cast<int32_t>(regs[ve * 64]));
+                    if (pb < 0 || pe < 0) { pb = -1; pe = -1; }
+                }
+            };
+            const int G = T.max_groups;
+            const uint32_t row_b = static_cast<uint32_t>(slots) * 4u;
+            const bool full_tile = ((cur.i - lane) + 64u) <= n;
+            if (full_tile && caps_aligned && 64u * row_b + 256u <= L.stage_bytes) {
+                // The tile's 64 capture rows are one contiguous block of the output.  Transpose through the staging
+                // area (free now: every lane has finished its walk) so that each store instruction writes 1 KiB of
+                // consecutive bytes, instead of every lane writing pieces of its own row.
+                uint8_t* my_row = stage + lane * row_b;
+                for (int g = 0; g < G; ++g) {
+                    int32_t pb, pe;
+                    group_span(g, pb, pe);
+                    *reinterpret_cast<int2*>(my_row + g * 8) = make_int2(pb, pe);
+                }
+                int32_t* ids = reinterpret_cast<int32_t*>(stage + 64u * row_b);  // the tile's 64 match ids = 256 bytes
+                ids[lane] = result;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                uint8_t* out = reinterpret_cast<uint8_t*>(caps + (cur.i - lane) * static_cast<uint64_t>(slots));
+                for (uint32_t c = lane; c < 4u * row_b; c += 64u)  // 64 * row_b / 16 chunks
+                    *reinterpret_cast<u32x4*>(out + (c << 4)) = *reinterpret_cast<const u32x4*>(stage + (c << 4));
+                if (lane < 16u)
+                    *reinterpret_cast<u32x4*>(match_id + (cur.i - lane) + 4u * lane) = *reinterpret_cast<const u32x4*>(ids + 4u * lane);
+            } else if (valid) {
                 int32_t* cp = caps + i * static_cast<uint64_t>(slots);
-                const int32_t len = static_cast<int32_t>(end - start);
-                const int G = T.max_groups;
-                for (int g0 = 0; g0 < G; g0 += 2) {
-                    // two groups = four values = one 16-byte store
-                    int32_t v[4];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int g = g0 + q;
-                        int32_t pb = -1, pe = -1;
-                        if (f >= 0 && static_cast<uint32_t>(g) < ng) {
-                            const uint16_t vb = fin_tags[f + tag0 + 2 * g], ve = fin_tags[f + tag0 + 2 * g + 1];
-                            pb = (vb == SRC_POS) ? len : (vb == SRC_NIL ? -1 : static_cast<int32_t>(regs[vb * 64]));
-                            pe = (ve == SRC_POS) ? len : (ve == SRC_NIL ? -1 : static_cast<int32_t>(regs[ve * 64]));
-                            if (pb < 0 || pe < 0) { pb = -1; pe = -1; }
-                        }
-                        v[2 * q] = pb;
-                        v[2 * q + 1] = pe;
-                    }
-                    if ((slots & 3) == 0) {
-                        // slots % 4 == 0 implies g0 + 1 < G and a 16-byte aligned row: one 16-byte store.  Plain, not
-                        // nontemporal: a lane's row is finished by a second store, and only L2 can merge the two halves
-                        // of a cache line (measured: nt raises WRITE_SIZE from 1.4x to 2.2x the algorithmic bytes)
-                        u32x4 q4 = {static_cast<uint32_t>(v[0]), static_cast<uint32_t>(v[1]), static_cast<uint32_t>(v[2]),
-                                    static_cast<uint32_t>(v[3])};
-                        *reinterpret_cast<u32x4*>(cp + 2 * g0) = q4;
-                    } else {
-                        cp[2 * g0] = v[0];
-                        cp[2 * g0 + 1] = v[1];
-                        if (g0 + 1 < G) { cp[2 * g0 + 2] = v[2]; cp[2 * g0 + 3] = v[3]; }
-                    }
+                for (int g = 0; g < G; ++g) {
+                    int32_t pb, pe;
+                    group_span(g, pb, pe);
+                    cp[2 * g] = pb;
+                    cp[2 * g + 1] = pe;
                 }
                 match_id[i] = result;
             }

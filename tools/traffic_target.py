@@ -8,6 +8,7 @@ from gorp_amd import workloads as W
 from gorp_amd.gorp import Gorp
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+match_only = len(sys.argv) > 2 and sys.argv[2] == "match_only"
 g = Gorp.construct(W.readme3_definition())
 data, off, cat = W.readme3_lines(n, seed=2, device="cuda")
 mid = torch.empty(n, dtype=torch.int32, device="cuda")
@@ -15,7 +16,7 @@ caps = torch.empty((n, 8), dtype=torch.int32, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 torch.cuda.synchronize()
 for _ in range(3):
-    g.extract_batch_device(data.data_ptr(), off.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=st, no_sync=True)
+    g.extract_batch_device(data.data_ptr(), off.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), match_only=match_only, stream=st, no_sync=True)
 torch.cuda.synchronize()
 # calibration: a copy kernel that reads and writes exactly data.numel() bytes, 16 B per lane
 src = data.view(torch.int32).view(-1, 4)
