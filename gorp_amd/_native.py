@@ -27,6 +27,7 @@ SYMBOLS = [
     "gx_quote_literal_as_regexp", "gx_massage_regexp_for_automaton", "gx_massage_regexp_for_jdk",
     "gx_create_from_definition", "gx_definition_to_json",
     "gx_extraction_name", "gx_extractor_name", "gx_extraction_append_json",
+    "gx_split_lines",
 ]
 
 
@@ -39,6 +40,8 @@ class gx_batch_opts(C.Structure):
         ("stream", C.c_void_p),
         ("no_sync", C.c_uint32),
         ("line_bytes_hint", C.c_uint32),
+        ("strip_eol", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -130,6 +133,9 @@ def lib():
     L.gx_extractor_name.restype = C.c_char_p
     L.gx_extraction_append_json.argtypes = [C.c_void_p, C.c_int32]
     L.gx_extraction_append_json.restype = C.c_char_p
+    L.gx_split_lines.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p,
+                                 C.POINTER(gx_batch_opts)]
+    L.gx_split_lines.restype = C.c_int
     _lib = L
     return L
 

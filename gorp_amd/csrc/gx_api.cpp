@@ -4,6 +4,7 @@
 // every extract/match entry point runs the HIP kernels or fails with GX_E_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdlib>
 #include <mutex>
 #include <new>
@@ -233,6 +234,7 @@ bool plan_tile_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out) 
     if (L.table_bytes + 4 * per_wave > LDS_BYTES) return false;
     uint32_t nw = (LDS_BYTES - L.table_bytes) / per_wave;
     if (nw > 12) nw = 12;  // 768 threads: leaves 170 VGPRs per lane for the prefetch registers
+    if (L.stage_bytes > 13u * 1024u && nw > 8) nw = 8;  // the 16 KB variant prefetches 64 VGPRs: 2 waves per SIMD
     static const int force_nw = getenv("GX_DEBUG_NWAVES") ? atoi(getenv("GX_DEBUG_NWAVES")) : 0;  // developer sweep
     if (force_nw > 0 && static_cast<uint32_t>(force_nw) < nw) nw = static_cast<uint32_t>(force_nw);
     L.nwaves = nw;
@@ -436,15 +438,66 @@ int64_t gx_stat(const gx_handle* h, int32_t which) {
     }
 }
 
+// Accepts the current gx_batch_opts and the shorter first version of it (struct_size says which).
+static bool read_opts(const gx_batch_opts* opts, gx_batch_opts* o) {
+    *o = gx_batch_opts{};
+    if (!opts) return true;
+    const size_t v1 = offsetof(gx_batch_opts, strip_eol);
+    if (opts->struct_size != sizeof(gx_batch_opts) && opts->struct_size != v1) return false;
+    memcpy(o, opts, opts->struct_size);
+    return true;
+}
+
+int gx_split_lines(const uint8_t* bytes, uint64_t size, void* offsets, uint64_t cap_lines, uint64_t* n_lines, uint8_t* line_flags,
+                   const gx_batch_opts* opts) {
+    if (!offsets || !n_lines || (size && !bytes)) return fail(GX_E_ARG, "gx_split_lines: bad argument");
+    gx_batch_opts o{};
+    if (!read_opts(opts, &o)) return fail(GX_E_ARG, "gx_batch_opts.struct_size mismatch");
+    if (!o.offsets64 && size > 0xFFFFFFFFull) return fail(GX_E_ARG, "gx_split_lines: buffers of 4 GiB and more need offsets64");
+    try {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+            throw GxError(GX_E_DEVICE, "no HIP device available (libgorp_hip needs a gfx950 GPU; there is no CPU fallback)");
+        hipStream_t stream = static_cast<hipStream_t>(o.stream);
+        const size_t off_w = o.offsets64 ? 8 : 4;
+        DevBuf ws, d_bytes, d_off, d_flags;
+        ws.alloc(split_workspace_bytes(size));
+        const uint8_t* src = bytes;
+        void* dst_off = offsets;
+        uint8_t* dst_flags = line_flags;
+        if (o.device_pointers) {
+            if (reinterpret_cast<uintptr_t>(bytes) & 15u) return fail(GX_E_ARG, "gx_split_lines: device buffer must be 16-byte aligned");
+        } else {
+            d_bytes.alloc(size);
+            d_off.alloc((cap_lines + 1) * off_w);
+            if (line_flags) d_flags.alloc(cap_lines);
+            if (size) GX_HIP(hipMemcpyAsync(d_bytes.p, bytes, size, hipMemcpyHostToDevice, stream));
+            src = static_cast<const uint8_t*>(d_bytes.p);
+            dst_off = d_off.p;
+            dst_flags = line_flags ? static_cast<uint8_t*>(d_flags.p) : nullptr;
+        }
+        uint64_t* d_n = nullptr;
+        GX_HIP(launch_split_lines(src, size, dst_off, o.offsets64 ? 1 : 0, cap_lines, dst_flags, ws.p, &d_n, stream));
+        uint64_t n = 0;
+        GX_HIP(hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, stream));
+        GX_HIP(hipStreamSynchronize(stream));
+        *n_lines = n;
+        if (n > cap_lines) return fail(GX_E_LIMIT, "gx_split_lines: the buffer holds more lines than cap_lines");
+        if (!o.device_pointers) {
+            GX_HIP(hipMemcpy(offsets, d_off.p, (n + 1) * off_w, hipMemcpyDeviceToHost));
+            if (line_flags && n) GX_HIP(hipMemcpy(line_flags, d_flags.p, n, hipMemcpyDeviceToHost));
+        }
+        return GX_OK;
+    } catch (GxError& e) { return fail(e.code, e.what()); }
+    catch (std::bad_alloc&) { return fail(GX_E_NOMEM, "out of memory"); }
+}
+
 int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, uint64_t n, int32_t* match_id, int32_t* caps,
                      const gx_batch_opts* opts) {
     if (!h || !offsets || !match_id || (n && !bytes && false)) return fail(GX_E_ARG, "gx_extract_batch: bad argument");
     if (!h->on_device) return fail(GX_E_DEVICE, "handle was created host-only; no device tables (there is no CPU fallback)");
     gx_batch_opts o{};
-    if (opts) {
-        if (opts->struct_size != sizeof(gx_batch_opts)) return fail(GX_E_ARG, "gx_batch_opts.struct_size mismatch");
-        o = *opts;
-    }
+    if (!read_opts(opts, &o)) return fail(GX_E_ARG, "gx_batch_opts.struct_size mismatch");
     const bool match_only = o.match_only || !h->T.has_capture;
     if (!match_only && !caps && n > 0 && h->T.max_groups > 0) return fail(GX_E_ARG, "gx_extract_batch: caps is NULL");
     try {
@@ -455,6 +508,7 @@ int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, ui
         b.wide = 0;
         b.offsets64 = o.offsets64 ? 1 : 0;
         b.match_only = match_only ? 1 : 0;
+        b.strip_eol = o.strip_eol ? 1 : 0;
         const size_t off_w = o.offsets64 ? 8 : 4;
         const size_t slots = 2 * static_cast<size_t>(h->T.max_groups);
         if (o.device_pointers) {
@@ -462,7 +516,18 @@ int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, ui
             static const int ablate = getenv("GX_DEBUG_ABLATE") ? atoi(getenv("GX_DEBUG_ABLATE")) : 0;
             if (ablate > 1 && !match_only) b.match_only = ablate;
             b.data = bytes; b.offsets = offsets; b.match_id = match_id; b.caps = match_only ? nullptr : caps;
-            launch_batch(h, b, o.line_bytes_hint, stream);
+            uint32_t hint = o.line_bytes_hint;
+            if (hint == 0 && n && !o.no_sync) {
+                // no hint: the mean line length, from the two ends of the offsets array (a small synchronous read;
+                // asynchronous callers pass line_bytes_hint themselves)
+                uint64_t first = 0, last = 0;
+                GX_HIP(hipMemcpyAsync(&first, offsets, off_w, hipMemcpyDeviceToHost, stream));
+                GX_HIP(hipMemcpyAsync(&last, static_cast<const uint8_t*>(offsets) + n * off_w, off_w, hipMemcpyDeviceToHost, stream));
+                GX_HIP(hipStreamSynchronize(stream));
+                hint = static_cast<uint32_t>(std::min<uint64_t>((last - first + n - 1) / n, 4096));
+                if (hint == 0) hint = 1;
+            }
+            launch_batch(h, b, hint, stream);
             if (!o.no_sync) GX_HIP(hipStreamSynchronize(stream));
             return GX_OK;
         }

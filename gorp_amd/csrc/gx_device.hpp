@@ -84,6 +84,7 @@ struct GxBatch {
     int32_t wide;          // 1: data is uint16_t
     int32_t offsets64;
     int32_t match_only;
+    int32_t strip_eol;     // 1: every line carries its terminator ("\n", "\r\n" or "\r"), to be ignored
 };
 
 // Generic kernel: any table size, any line length, bytes or UTF-16.
@@ -97,5 +98,11 @@ hipError_t launch_extract_generic(const GxDev& dev, const GxBatch& b, hipStream_
 hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
                                const GxBatch& b, hipStream_t stream);
 hipError_t prepare_tile_kernels(uint32_t lds_bytes);
+
+// Line ingestion (gx_ingest.hip): raw bytes -> CSR offsets of readLine()-style lines, terminators included.
+// `workspace` holds split_workspace_bytes(size) bytes; *d_n_lines receives the device address of the line count.
+size_t split_workspace_bytes(uint64_t size);
+hipError_t launch_split_lines(const uint8_t* data, uint64_t size, void* offsets, int offsets64, uint64_t cap_lines, uint8_t* flags,
+                              void* workspace, uint64_t** d_n_lines, hipStream_t stream);
 
 }  // namespace gx

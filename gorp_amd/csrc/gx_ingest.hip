@@ -1,0 +1,235 @@
+// gx_ingest.hip -- line ingestion on the device: raw log bytes -> CSR offsets.
+//
+// The reference has no equivalent: its callers hand in java.lang.Strings "often coming from a line-oriented
+// input source" (README.md:26), i.e. BufferedReader.readLine(): a line ends at '\n', at '\r', or at "\r\n"
+// (one terminator), and a final line without terminator still counts.  This file produces, for a byte buffer
+// in HBM, offsets[0..n] such that line i = bytes[offsets[i], offsets[i+1]) *including* its terminator; the
+// extract kernels strip the terminator when gx_batch_opts.strip_eol is set (gx_kernels.hip: trim_eol), so
+// match offsets stay relative to the start of the line exactly as for a Java String.
+//
+// Three bandwidth-bound passes (the buffer is read twice): count line ends per block -> exclusive scan of the
+// block counts -> write offsets (and, optionally, a per-line flag "contains a byte >= 0x80": such a line is
+// only Latin-1 if the file is; UTF-8 input needs the UTF-16 route).
+#include <cstdint>
+#include <hip/hip_runtime.h>
+
+#include "gx_device.hpp"
+
+namespace gx {
+namespace {
+
+constexpr int SPLIT_THREADS = 256;
+constexpr int SPLIT_ITERS = 8;                                   // 16-byte chunks per thread
+constexpr uint64_t SPLIT_BLOCK_BYTES = static_cast<uint64_t>(SPLIT_THREADS) * SPLIT_ITERS * 16;  // 32 KiB
+
+// 0x80 in every byte of v that is zero (exact, no cross-byte carries)
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t v) {
+    const uint32_t t = (v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(t | v | 0x7F7F7F7Fu);
+}
+// bit j of the result = bit 7 of byte j of the four dwords (16 bytes -> 16 bits)
+__device__ __forceinline__ uint32_t pack_hi_bits(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    auto nib = [](uint32_t v) { return ((((v >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu; };  // byte j -> bit j
+    return nib(a) | (nib(b) << 4) | (nib(c) << 8) | (nib(d) << 12);
+}
+
+struct Chunk {
+    uint32_t ends;    // bit j: byte j ends a line
+    uint32_t high;    // bit j: byte j >= 0x80
+};
+
+// Classify the 16 bytes at `pos` (pos is a multiple of 16; bytes at and beyond `size` do not exist).
+// next_byte = the byte at pos + 16 (or 0 when there is none): decides whether a '\r' in the last slot stands alone.
+__device__ __forceinline__ Chunk classify(const uint8_t* __restrict__ data, uint64_t pos, uint64_t size) {
+    Chunk c{0, 0};
+    if (pos >= size) return c;
+    uint32_t w[4];
+    uint32_t next_byte = 0;
+    if (pos + 16 <= size) {
+        const uint4 v = *reinterpret_cast<const uint4*>(data + pos);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        if (pos + 16 < size) next_byte = data[pos + 16];
+    } else {
+        w[0] = w[1] = w[2] = w[3] = 0;
+        for (uint64_t q = pos; q < size; ++q) w[(q - pos) >> 2] |= static_cast<uint32_t>(data[q]) << (((q - pos) & 3) * 8);
+    }
+    const uint32_t lf = pack_hi_bits(zero_bytes(w[0] ^ 0x0A0A0A0Au), zero_bytes(w[1] ^ 0x0A0A0A0Au), zero_bytes(w[2] ^ 0x0A0A0A0Au),
+                                     zero_bytes(w[3] ^ 0x0A0A0A0Au));
+    const uint32_t cr = pack_hi_bits(zero_bytes(w[0] ^ 0x0D0D0D0Du), zero_bytes(w[1] ^ 0x0D0D0D0Du), zero_bytes(w[2] ^ 0x0D0D0D0Du),
+                                     zero_bytes(w[3] ^ 0x0D0D0D0Du));
+    uint32_t valid = 0xFFFFu;
+    if (pos + 16 > size) valid = (1u << (size - pos)) - 1u;  // the zero padding above is neither LF nor CR
+    // a CR ends a line unless the next byte is LF
+    const uint32_t lf_after = (lf >> 1) | (next_byte == 0x0Au ? 0x8000u : 0u);
+    c.ends = (lf | (cr & ~lf_after)) & valid;
+    c.high = pack_hi_bits(w[0], w[1], w[2], w[3]) & valid;
+    return c;
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d);
+        if (lane >= static_cast<uint32_t>(d)) v += o;
+    }
+    return v;
+}
+
+// pass 1: line ends per block
+__global__ void __launch_bounds__(SPLIT_THREADS) k_split_count(const uint8_t* __restrict__ data, uint64_t size, uint32_t* __restrict__ block_counts) {
+    __shared__ uint32_t wsum[SPLIT_THREADS / 64];
+    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * SPLIT_BLOCK_BYTES;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int it = 0; it < SPLIT_ITERS; ++it) {
+        const uint64_t pos = base + (static_cast<uint64_t>(it) * SPLIT_THREADS + threadIdx.x) * 16;
+        cnt += __popc(classify(data, pos, size).ends);
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t inc = wave_inclusive_sum(cnt, lane);
+    if (lane == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < SPLIT_THREADS / 64; ++w) t += wsum[w];
+        block_counts[blockIdx.x] = t;
+    }
+}
+
+// pass 2: exclusive scan of the block counts (one workgroup), total -> *total_ends
+__global__ void __launch_bounds__(1024) k_split_scan(const uint32_t* __restrict__ counts, uint64_t* __restrict__ prefix, uint64_t nblocks,
+                                                    uint64_t* __restrict__ total_ends) {
+    __shared__ uint64_t wsum[16];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint64_t b0 = 0; b0 < nblocks; b0 += 1024) {
+        const uint64_t b = b0 + threadIdx.x;
+        const uint64_t v = b < nblocks ? counts[b] : 0;
+        uint64_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t o = __shfl_up(static_cast<unsigned long long>(inc), d);
+            if (lane >= static_cast<uint32_t>(d)) inc += o;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint64_t wbase = 0;
+        for (uint32_t w = 0; w < wave; ++w) wbase += wsum[w];
+        const uint64_t c = carry;
+        if (b < nblocks) prefix[b] = c + wbase + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + wbase + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_ends = carry;
+}
+
+// pass 3: offsets[1 + rank(p)] = p + 1 for every line end p; flags[line] = 1 for lines with a byte >= 0x80
+template <typename OFF>
+__global__ void __launch_bounds__(SPLIT_THREADS) k_split_write(const uint8_t* __restrict__ data, uint64_t size, const uint64_t* __restrict__ prefix,
+                                                               OFF* __restrict__ offsets, uint64_t cap_lines, uint8_t* __restrict__ flags) {
+    __shared__ uint32_t wsum[SPLIT_THREADS / 64];
+    __shared__ uint32_t running;
+    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * SPLIT_BLOCK_BYTES;
+    const uint64_t block_rank = prefix[blockIdx.x];
+    if (threadIdx.x == 0) running = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) offsets[0] = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (int it = 0; it < SPLIT_ITERS; ++it) {
+        const uint64_t pos = base + (static_cast<uint64_t>(it) * SPLIT_THREADS + threadIdx.x) * 16;
+        const Chunk c = classify(data, pos, size);
+        const uint32_t cnt = __popc(c.ends);
+        const uint32_t inc = wave_inclusive_sum(cnt, lane);
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (uint32_t w = 0; w < wave; ++w) wbase += wsum[w];
+        const uint32_t r0 = running;
+        // number of line ends before this thread's first byte = index of the line that byte belongs to
+        const uint64_t rank = block_rank + r0 + wbase + inc - cnt;
+        uint32_t e = c.ends;
+        uint64_t k = rank;
+        while (e) {
+            const uint32_t j = __ffs(e) - 1u;
+            e &= e - 1u;
+            ++k;  // the line that starts after this end
+            if (k <= cap_lines) offsets[k] = static_cast<OFF>(pos + j + 1);
+        }
+        if (flags) {
+            uint32_t hb = c.high;
+            while (hb) {
+                const uint32_t j = __ffs(hb) - 1u;
+                hb &= hb - 1u;
+                const uint64_t line = rank + __popc(c.ends & ((1u << j) - 1u));
+                if (line < cap_lines) flags[line] = 1;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == SPLIT_THREADS - 1) running = r0 + wbase + inc;
+        __syncthreads();
+    }
+}
+
+// the last line has no terminator: close it with offsets[n] = size
+template <typename OFF>
+__global__ void k_split_finish(const uint8_t* __restrict__ data, uint64_t size, const uint64_t* __restrict__ total_ends, OFF* __restrict__ offsets,
+                               uint64_t cap_lines, uint64_t* __restrict__ n_lines) {
+    const uint64_t ends = *total_ends;
+    uint64_t n = ends;
+    if (size > 0) {
+        const uint8_t last = data[size - 1];
+        if (!(last == 0x0Au || last == 0x0Du)) {  // a trailing CR always ends a line (nothing follows it)
+            n = ends + 1;
+            if (n <= cap_lines) offsets[n] = static_cast<OFF>(size);
+        }
+    }
+    *n_lines = n;
+}
+
+}  // namespace
+
+size_t split_workspace_bytes(uint64_t size) {
+    const uint64_t nblocks = (size + SPLIT_BLOCK_BYTES - 1) / SPLIT_BLOCK_BYTES;
+    return static_cast<size_t>((nblocks + 1) * 4 + (nblocks + 1) * 8 + 64);
+}
+
+// workspace: [total_ends u64][n_lines u64][prefix u64 * nblocks][counts u32 * nblocks]
+hipError_t launch_split_lines(const uint8_t* data, uint64_t size, void* offsets, int offsets64, uint64_t cap_lines, uint8_t* flags,
+                              void* workspace, uint64_t** d_n_lines, hipStream_t stream) {
+    const uint64_t nblocks = (size + SPLIT_BLOCK_BYTES - 1) / SPLIT_BLOCK_BYTES;
+    uint64_t* total_ends = static_cast<uint64_t*>(workspace);
+    uint64_t* n_lines = total_ends + 1;
+    uint64_t* prefix = total_ends + 2;
+    uint32_t* counts = reinterpret_cast<uint32_t*>(prefix + nblocks + 1);
+    *d_n_lines = n_lines;
+    hipError_t e;
+    if (flags && cap_lines) {
+        e = hipMemsetAsync(flags, 0, cap_lines, stream);
+        if (e != hipSuccess) return e;
+    }
+    if (nblocks == 0) {
+        e = hipMemsetAsync(workspace, 0, 16, stream);  // no ends, no lines
+        if (e != hipSuccess) return e;
+        return hipMemsetAsync(offsets, 0, offsets64 ? 8 : 4, stream);
+    }
+    if (nblocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_split_count, dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, counts);
+    hipLaunchKernelGGL(k_split_scan, dim3(1), dim3(1024), 0, stream, counts, prefix, nblocks, total_ends);
+    if (offsets64) {
+        hipLaunchKernelGGL(k_split_write<uint64_t>, dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, prefix,
+                           static_cast<uint64_t*>(offsets), cap_lines, flags);
+        hipLaunchKernelGGL(k_split_finish<uint64_t>, dim3(1), dim3(1), 0, stream, data, size, total_ends, static_cast<uint64_t*>(offsets), cap_lines,
+                           n_lines);
+    } else {
+        hipLaunchKernelGGL(k_split_write<uint32_t>, dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, prefix,
+                           static_cast<uint32_t*>(offsets), cap_lines, flags);
+        hipLaunchKernelGGL(k_split_finish<uint32_t>, dim3(1), dim3(1), 0, stream, data, size, total_ends, static_cast<uint32_t*>(offsets), cap_lines,
+                           n_lines);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace gx

@@ -89,17 +89,28 @@ __device__ void extract_line_global(const GxDev& T, const MS* __restrict__ m_nex
     match_id[i] = k;
 }
 
+// gx_batch_opts.strip_eol: a line handed over with its terminator (gx_split_lines) loses one trailing '\n' and
+// then one trailing '\r' -- "\n", "\r\n" and a lone "\r" are BufferedReader.readLine's three terminators.
+template <typename CH>
+__device__ __forceinline__ int64_t trim_eol(const CH* __restrict__ s, int64_t len) {
+    if (len > 0 && s[len - 1] == 0x0A) --len;
+    if (len > 0 && s[len - 1] == 0x0D) --len;
+    return len;
+}
+
 // Generic kernel: one lane per line.  The correctness backstop for tables that
 // do not fit LDS, UTF-16 input and 32-bit match states.
 template <typename CH, typename OFF, typename MS>
 __global__ void __launch_bounds__(256)
 k_extract_generic(GxDev T, const CH* __restrict__ data, const OFF* __restrict__ off, uint64_t n,
                   int32_t* __restrict__ match_id, int32_t* __restrict__ caps, int32_t* __restrict__ state_out,
-                  int match_only, const MS* __restrict__ m_next) {
+                  int match_only, const MS* __restrict__ m_next, int strip_eol) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint64_t b = off[i], e = off[i + 1];
-        extract_line_global<CH, MS>(T, m_next, data + b, static_cast<int64_t>(e - b), i, match_id, caps, state_out, match_only);
+        int64_t len = static_cast<int64_t>(e - b);
+        if (strip_eol) len = trim_eol(data + b, len);
+        extract_line_global<CH, MS>(T, m_next, data + b, len, i, match_id, caps, state_out, match_only);
     }
 }
 
@@ -113,11 +124,11 @@ hipError_t launch_generic_t(const GxDev& dev, const GxBatch& b, hipStream_t stre
     if (dev.m_next16)
         hipLaunchKernelGGL((k_extract_generic<CH, OFF, uint16_t>), grid, dim3(block), 0, stream, dev,
                            static_cast<const CH*>(b.data), static_cast<const OFF*>(b.offsets), b.n, b.match_id, b.caps,
-                           b.state_out, b.match_only, dev.m_next16);
+                           b.state_out, b.match_only, dev.m_next16, b.strip_eol);
     else
         hipLaunchKernelGGL((k_extract_generic<CH, OFF, uint32_t>), grid, dim3(block), 0, stream, dev,
                            static_cast<const CH*>(b.data), static_cast<const OFF*>(b.offsets), b.n, b.match_id, b.caps,
-                           b.state_out, b.match_only, dev.m_next32);
+                           b.state_out, b.match_only, dev.m_next32, b.strip_eol);
     return hipGetLastError();
 }
 
@@ -324,17 +335,22 @@ __device__ void stage_span_guarded(const uint8_t* __restrict__ g_al, uint32_t nc
     }
 }
 
-// What one wave needs to know about a tile (64 consecutive lines).
+// What one wave needs to know about a round: the lines of a 64-line group (lane = line) that are staged and
+// walked together.  Normally one round covers the whole group; when the group's bytes do not fit the staging
+// area (lines longer than the hint, mixed lengths) the group is taken in several rounds of consecutive lanes.
+// (32-bit flags and no padding: a struct with padding bytes is copied through scratch memory, which costs a
+// store + load per round and stalls on the prefetch loads.)
 struct TileInfo {
     uint64_t i;            // this lane's line index
     uint64_t o0, o1;       // its byte range in the CSR buffer
-    const uint8_t* g_al;   // 16-byte aligned start of the tile's span in global memory
+    const uint8_t* g_al;   // 16-byte aligned start of the round's span in global memory
     uint32_t nch;          // 16-byte chunks in the span
-    uint32_t start, end;   // this lane's line inside the staging area
+    uint32_t start, end;   // this lane's line inside the staging area (0, 0 for a lane outside the round)
     uint32_t mode;         // 0: prefetched into registers; 1: touches the buffer edge (guarded copy);
-                           // 2: does not fit the staging area (per-lane global path)
-    uint32_t valid;        // (32-bit flags and no padding: a struct with padding bytes is copied through scratch
-    uint32_t pad_;         //  memory, which costs a store + load per tile and stalls on the prefetch loads)
+                           // 2: one line that does not fit the staging area (per-lane global path)
+    uint32_t active;       // this lane's line belongs to the round
+    uint32_t a, b;         // the round covers lanes [a, b) of the group (wave-uniform)
+    uint32_t pad_;
 };
 
 // Clamped, unconditional accesses on both sides: a lane beyond the span re-reads / rewrites the last chunk
@@ -376,11 +392,11 @@ __device__ __forceinline__ void tile_commit(const TileInfo& t, uint32_t lane, co
 // fetched into KCH*4 VGPRs per lane one tile AHEAD: the loads are issued before the current tile is walked
 // and land while the wave computes out of LDS, so HBM latency is hidden without a second LDS buffer.
 template <typename OFF, int KCH, bool GT>
-__global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(1, 3)))
+__global__ void __launch_bounds__(KCH > 13 ? 512 : 768) __attribute__((amdgpu_waves_per_eu(1, KCH > 13 ? 2 : 3)))
 k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const uint8_t* __restrict__ at_global,
                const uint8_t* __restrict__ data,
                const OFF* __restrict__ off, uint64_t n, int32_t* __restrict__ match_id, int32_t* __restrict__ caps,
-               int match_only) {
+               int match_only, int strip_eol) {
     // ---- prologue: table image -> LDS ----
     {
         const uint4* src = reinterpret_cast<const uint4*>(lds_image);
@@ -416,60 +432,84 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
         o0 = off[valid ? i : n];
         o1 = off[valid ? i + 1 : n];
     };
-    auto make_tile = [&](uint64_t tile, uint64_t o0, uint64_t o1) {
+    // Round of group `tile` starting at lane a: as many consecutive lines as fit the staging area.
+    auto make_round = [&](uint64_t tile, uint32_t a, uint64_t o0, uint64_t o1) {
         TileInfo t;
         t.i = (tile << 6) + lane;
-        t.valid = t.i < n ? 1u : 0u;
+        const bool valid = t.i < n;
         t.pad_ = 0;
         t.o0 = o0; t.o1 = o1;
-        // tile span [lo, hi): lane 0 always holds a valid line
-        const uint64_t lo = __shfl(static_cast<unsigned long long>(o0), 0);
-        const uint64_t hi = __shfl(static_cast<unsigned long long>(o1), 63);
+        t.a = a;
+        const uint64_t lo = __shfl(static_cast<unsigned long long>(o0), static_cast<int>(a));  // lane a holds a valid line
         const uint8_t* g_lo = data + lo;
         const uint32_t skew = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(g_lo) & 15u);
         t.g_al = g_lo - skew;  // 16-byte aligned; still a global-address-space pointer for the compiler
-        const uint64_t span = (hi - lo) + skew;
-        t.nch = static_cast<uint32_t>((span + 15) >> 4);
-        t.start = skew + static_cast<uint32_t>(o0 - lo);
-        t.end = skew + static_cast<uint32_t>(o1 - lo);
-        if (span + 48 > L.stage_bytes) t.mode = 2;  // keep room for the two-window look-ahead of the walk
-        else if (!(t.g_al >= data && t.g_al + (static_cast<uint64_t>(t.nch) << 4) <= data_end)) t.mode = 1;
-        else t.mode = 0;
+        // offsets ascend, so the lines that fit are a run of lanes starting at a (+48: the walk looks two windows ahead)
+        const bool fits = lane >= a && valid && (o1 - lo) + skew + 48u <= L.stage_bytes;
+        const uint32_t cnt = static_cast<uint32_t>(__popcll(__ballot(fits)));
+        if (cnt == 0) {  // line a alone is longer than the staging area
+            t.b = a + 1u;
+            t.mode = 2;
+            t.nch = 1;
+        } else {
+            t.b = a + cnt;
+            const uint64_t hi = __shfl(static_cast<unsigned long long>(o1), static_cast<int>(t.b - 1u));
+            const uint64_t span = (hi - lo) + skew;
+            t.nch = max(static_cast<uint32_t>((span + 15) >> 4), 1u);
+            t.mode = (t.g_al >= data && t.g_al + (static_cast<uint64_t>(t.nch) << 4) <= data_end) ? 0u : 1u;
+        }
+        t.active = (lane >= a && lane < t.b) ? 1u : 0u;
+        t.start = t.active ? skew + static_cast<uint32_t>(o0 - lo) : 0u;
+        t.end = t.active ? skew + static_cast<uint32_t>(o1 - lo) : 0u;
         return t;
     };
 
     uint64_t tile = static_cast<uint64_t>(blockIdx.x) * L.nwaves + wave;
     if (tile >= tiles) return;
-    u32x4 pre[KCH];  // the next tile's bytes, in flight or landed
-    uint64_t o0, o1, no0 = 0, no1 = 0;
-    load_offsets(tile, o0, o1);
-    TileInfo cur = make_tile(tile, o0, o1);
+    u32x4 pre[KCH];  // the next round's bytes, in flight or landed
+    uint64_t no0 = 0, no1 = 0;
+    TileInfo cur;
+    {
+        uint64_t o0, o1;
+        load_offsets(tile, o0, o1);
+        cur = make_round(tile, 0, o0, o1);
+    }
     if (match_only != 3) tile_issue_loads<KCH>(cur, lane, pre);
-    uint64_t ntile = tile + wstride;
-    load_offsets(min(ntile, tiles - 1), no0, no1);
+    load_offsets(min(tile + wstride, tiles - 1), no0, no1);
 
     for (;;) {
         tile_commit<KCH>(cur, lane, pre, stage, data, data_end, match_only != 3);
-        // ---- software pipeline: start fetching the next tile (and the offsets of the one after) ----
+        // ---- software pipeline: start fetching the next round (and the offsets of the group after it) ----
+        const uint32_t group_lines = static_cast<uint32_t>(min(static_cast<uint64_t>(64), n - (tile << 6)));
+        const bool same_group = cur.b < group_lines;
+        const uint64_t ntile = same_group ? tile : tile + wstride;
         const bool has_next = ntile < tiles;
         TileInfo nxt = cur;
         if (has_next) {
-            nxt = make_tile(ntile, no0, no1);
+            nxt = make_round(ntile, same_group ? cur.b : 0u, same_group ? cur.o0 : no0, same_group ? cur.o1 : no1);
             if (match_only != 3) tile_issue_loads<KCH>(nxt, lane, pre);
         }
-        // unconditional (index clamped): a conditional load would need a register copy at the join, and
-        // that copy would wait for every load issued before it -- including the prefetch above
+        // unconditional (index clamped; the same values again while the group is unchanged): a conditional load
+        // would need a register copy at the join, and that copy would wait for every load issued before it --
+        // including the prefetch above
         uint64_t nno0, nno1;
         load_offsets(min(ntile + wstride, tiles - 1), nno0, nno1);
 
         const uint64_t i = cur.i;
-        const bool valid = cur.valid != 0u;
-        const uint32_t start = cur.start, end = cur.end;
+        const bool valid = cur.active != 0u;
+        const uint32_t start = cur.start;
+        uint32_t end = cur.end;
+        if (strip_eol && cur.mode != 2) {  // the terminator is staged with the line (trim_eol, from LDS)
+            if (end > start && stage[end - 1u] == 0x0Au) --end;
+            if (end > start && stage[end - 1u] == 0x0Du) --end;
+        }
         if (cur.mode == 2) {
             // tile does not fit the staging area (very long lines): exact per-lane path from global memory
-            if (valid)
-                extract_line_global<uint8_t, uint16_t>(T, T.m_next16, data + cur.o0, static_cast<int64_t>(cur.o1 - cur.o0), i, match_id,
-                                                       caps, nullptr, match_only);
+            if (valid) {
+                int64_t len = static_cast<int64_t>(cur.o1 - cur.o0);
+                if (strip_eol) len = trim_eol(data + cur.o0, len);
+                extract_line_global<uint8_t, uint16_t>(T, T.m_next16, data + cur.o0, len, i, match_id, caps, nullptr, match_only);
+            }
         } else if (match_only == 2) {  // timing ablation (GX_DEBUG_ABLATE=2): staging only
             if (valid) match_id[i] = stage[start];
         } else if (!want_caps) {
@@ -519,7 +559,7 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
             };
             const int G = T.max_groups;
             const uint32_t row_b = static_cast<uint32_t>(slots) * 4u;
-            const bool full_tile = ((cur.i - lane) + 64u) <= n;
+            const bool full_tile = cur.a == 0u && cur.b == 64u;
             if (full_tile && caps_aligned && 64u * row_b + 256u <= L.stage_bytes) {
                 // The tile's 64 capture rows are one contiguous block of the output.  Transpose through the staging
                 // area (free now: every lane has finished its walk) so that each store instruction writes 1 KiB of
@@ -554,9 +594,9 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
         __builtin_amdgcn_wave_barrier();
         if (!has_next) break;
         cur = nxt;
+        tile = ntile;
         no0 = nno0;
         no1 = nno1;
-        ntile += wstride;
     }
 }
 
@@ -581,7 +621,7 @@ hipError_t launch_tile_t(const GxDev& dev, const GxLds& lds, const uint8_t* lds_
         prepared = true;
     }
     hipLaunchKernelGGL((k_extract_tile<OFF, KCH, GT>), grid, block, lds.total_bytes, stream, dev, lds, lds_image, at_global,
-                       static_cast<const uint8_t*>(b.data), static_cast<const OFF*>(b.offsets), b.n, b.match_id, b.caps, b.match_only);
+                       static_cast<const uint8_t*>(b.data), static_cast<const OFF*>(b.offsets), b.n, b.match_id, b.caps, b.match_only, b.strip_eol);
     return hipGetLastError();
 }
 template <typename OFF, bool GT>

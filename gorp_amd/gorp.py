@@ -324,7 +324,7 @@ class Gorp:
         return ExtractionResult(extr.getName(), line, extr, extr._extractorNames, values)
 
     # -- batch API -----------------------------------------------------------
-    def extract_batch(self, data, offsets, match_only=False):
+    def extract_batch(self, data, offsets, match_only=False, strip_eol=False):
         """Host buffers: data uint8[total], offsets uint32|uint64[n+1].
         Returns (match_id int32[n], caps int32[n, 2*max_groups])."""
         data = np.ascontiguousarray(data, dtype=np.uint8)
@@ -338,13 +338,15 @@ class Gorp:
         o.struct_size = C.sizeof(N.gx_batch_opts)
         o.offsets64 = 1 if offsets.dtype == np.uint64 else 0
         o.match_only = 1 if match_only else 0
+        o.strip_eol = 1 if strip_eol else 0
         _check(N.lib().gx_extract_batch(self._h.ptr, data.ctypes.data if data.size else None, offsets.ctypes.data, n,
                                         mid.ctypes.data, caps.ctypes.data if caps.size else None, C.byref(o)))
         return mid, caps
 
     def extract_batch_device(self, data_ptr, offsets_ptr, n, match_id_ptr, caps_ptr, offsets64=False, match_only=False,
-                             stream=None, no_sync=False):
-        """Device pointers (ints), e.g. torch tensors' data_ptr(); results stay in HBM."""
+                             stream=None, no_sync=False, strip_eol=False, line_bytes_hint=0):
+        """Device pointers (ints), e.g. torch tensors' data_ptr(); results stay in HBM.  line_bytes_hint sizes
+        the kernel's staging area (0: 200 bytes with no_sync, else the batch's mean line length)."""
         o = N.gx_batch_opts()
         o.struct_size = C.sizeof(N.gx_batch_opts)
         o.device_pointers = 1
@@ -352,6 +354,8 @@ class Gorp:
         o.match_only = 1 if match_only else 0
         o.stream = stream
         o.no_sync = 1 if no_sync else 0
+        o.strip_eol = 1 if strip_eol else 0
+        o.line_bytes_hint = int(line_bytes_hint)
         _check(N.lib().gx_extract_batch(self._h.ptr, data_ptr, offsets_ptr, n, match_id_ptr, caps_ptr, C.byref(o)))
 
     def results(self, data, offsets, match_id, caps, safe=False):
@@ -362,6 +366,35 @@ class Gorp:
             line = raw[int(offsets[i]):int(offsets[i + 1])].decode("latin-1")
             out.append(self._materialise(line, int(match_id[i]), caps[i], safe))
         return out
+
+
+def split_lines(data, cap_lines=None, offsets_dtype=np.uint32, want_flags=False):
+    """gx_split_lines on a host buffer: raw bytes -> (offsets[n+1], flags[n] or None) with readLine() line
+    boundaries; every line keeps its terminator (pass strip_eol=True to extract_batch)."""
+    data = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else data, dtype=np.uint8)
+    if cap_lines is None:
+        cap_lines = int(data.size) + 1
+    offsets = np.zeros(cap_lines + 1, offsets_dtype)
+    flags = np.zeros(cap_lines, np.uint8) if want_flags else None
+    o = N.gx_batch_opts()
+    o.struct_size = C.sizeof(N.gx_batch_opts)
+    o.offsets64 = 1 if np.dtype(offsets_dtype) == np.uint64 else 0
+    n = C.c_uint64(0)
+    _check(N.lib().gx_split_lines(data.ctypes.data if data.size else None, data.size, offsets.ctypes.data, cap_lines, C.byref(n),
+                                  flags.ctypes.data if want_flags and cap_lines else None, C.byref(o)))
+    return offsets[:n.value + 1], (flags[:n.value] if want_flags else None)
+
+
+def split_lines_device(data_ptr, size, offsets_ptr, cap_lines, flags_ptr=None, offsets64=False, stream=None):
+    """gx_split_lines on device buffers (ints, e.g. torch data_ptr()); returns the number of lines."""
+    o = N.gx_batch_opts()
+    o.struct_size = C.sizeof(N.gx_batch_opts)
+    o.device_pointers = 1
+    o.offsets64 = 1 if offsets64 else 0
+    o.stream = stream
+    n = C.c_uint64(0)
+    _check(N.lib().gx_split_lines(data_ptr, size, offsets_ptr, cap_lines, C.byref(n), flags_ptr, C.byref(o)))
+    return n.value
 
 
 def lines_to_csr(lines, offsets_dtype=np.uint32):

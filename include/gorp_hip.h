@@ -92,6 +92,10 @@ typedef struct gx_batch_opts {
     uint32_t no_sync;          /* 1 (device pointers only): return after enqueueing */
     uint32_t line_bytes_hint;  /* typical line length in bytes (0 = 200); sizes the per-wave LDS staging
                                   area of the batch kernel.  A wrong hint costs speed, never correctness. */
+    uint32_t strip_eol;        /* 1: every line carries its terminator ("\n", "\r\n" or "\r", as produced by
+                                  gx_split_lines); it is not part of the String the reference would see, so
+                                  it is ignored and capture offsets stay relative to the start of the line */
+    uint32_t reserved;         /* 0 */
 } gx_batch_opts;
 
 /* Replaces the per-line loop "for each line: Gorp.extract(line)"
@@ -101,6 +105,20 @@ typedef struct gx_batch_opts {
  * each byte one Latin-1 code unit.  match_id[n]; caps[n * 2*gx_max_groups(h)] dense. */
 int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, uint64_t n,
                      int32_t* match_id, int32_t* caps, const gx_batch_opts* opts);
+
+/* Line ingestion, the step before the path.  The reference has no counterpart: its callers pass
+ * java.lang.Strings read from "a line-oriented input source" (README.md:26) -- BufferedReader.readLine(),
+ * whose lines end at "\n", "\r" or "\r\n", the last line needing no terminator.  For a raw byte buffer this
+ * writes offsets[0..n] with line i = bytes[offsets[i], offsets[i+1]) INCLUDING its terminator, ready for
+ * gx_extract_batch with strip_eol = 1.  offsets holds cap_lines + 1 entries (uint32_t, or uint64_t with
+ * opts->offsets64; a uint32_t buffer must be < 4 GiB).  line_flags (optional, cap_lines bytes) receives 1 for
+ * every line containing a byte >= 0x80: such a line is Latin-1 only if the file is; UTF-8 text needs the
+ * UTF-16 entry points.  Runs on the GPU (three bandwidth-bound passes); with opts->device_pointers = 1
+ * bytes / offsets / line_flags are device pointers (bytes 16-byte aligned) and *n_lines (host) is written
+ * after a stream synchronisation.  GX_E_LIMIT when the buffer holds more than cap_lines lines (*n_lines is
+ * still set, so the caller can retry with a larger offsets array). */
+int gx_split_lines(const uint8_t* bytes, uint64_t size, void* offsets, uint64_t cap_lines, uint64_t* n_lines,
+                   uint8_t* line_flags, const gx_batch_opts* opts);
 
 /* Replaces one Gorp.extract(String) call (core/Gorp.java:145-147): s is the
  * String's UTF-16 code units.  Runs on the GPU like the batch path.

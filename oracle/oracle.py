@@ -246,3 +246,22 @@ def jdk_matches(rx, s):
     if r == 0:
         return None
     return [None if caps[2 * i] < 0 else (int(caps[2 * i]), int(caps[2 * i + 1])) for i in range(ng.value)]
+
+
+def read_lines(data):
+    """Line ingestion restated on the CPU: what java.io.BufferedReader.readLine() yields for `data`
+    (the "line-oriented input source" of the reference's README.md:26): lines end at "\\n", "\\r" or
+    "\\r\\n"; a final line needs no terminator; there is no empty line after a final terminator.
+
+    Returns (offsets[n+1] uint64, lines: list of bytes without terminators, flags uint8[n]) where line i
+    occupies data[offsets[i]:offsets[i+1]] INCLUDING its terminator and flags[i] = 1 iff the line holds a
+    byte >= 0x80.  bytes.splitlines() has exactly these three terminators.
+    """
+    data = bytes(data)
+    kept = data.splitlines(keepends=True)
+    offsets = np.zeros(len(kept) + 1, np.uint64)
+    if kept:
+        offsets[1:] = np.cumsum([len(k) for k in kept], dtype=np.uint64)
+    lines = data.splitlines()
+    flags = np.array([1 if any(b >= 0x80 for b in k) else 0 for k in kept], np.uint8)
+    return offsets, lines, flags

@@ -368,3 +368,34 @@ def test_config1_from_definition_text(tmp_path):
     assert 0.75 < (mid == 0).mean() < 0.85
     r = gorp.extract(lines[int(np.argmax(mid == 0))])
     assert r.getId() == "sampleMatch" and r.asMap()["authStatus"] == "Accepted"
+
+
+@pytest.mark.parametrize("tier", [1, 2])
+def test_mixed_lengths_take_several_rounds_per_group(tier, monkeypatch):
+    """Lines of 0-3000 bytes against a staging area sized for the mean: groups are walked in several rounds of
+    consecutive lanes, a line longer than the staging area alone takes the per-lane path; all bit-exact."""
+    if tier == 2:
+        monkeypatch.setenv("GX_DEBUG_TIER", "2")
+    definition = W.readme3_definition()
+    gorp, orc = Gorp.construct(definition), oracle_for(definition)
+    rng = random.Random(99)
+    lines = []
+    for k in range(6000):
+        r = rng.random()
+        body = "".join(rng.choice("abc/-_.=?&%09") for _ in range(int(3000 ** rng.random())))
+        if r < 0.05:
+            lines.append("")
+        elif r < 0.5:
+            lines.append("[%09d]: GET %dms /%s" % (rng.randrange(10 ** 9), rng.randrange(9999), body))
+        elif r < 0.8:
+            lines.append("[%09d]: PUT %dms /%s" % (rng.randrange(10 ** 9), rng.randrange(9999), body))
+        elif r < 0.9:
+            lines.append("[%09d]: HEAD %dms /%s" % (rng.randrange(10 ** 9), rng.randrange(9999), body))
+        else:
+            lines.append(body)
+    lines[100] = "[1]: GET 5ms /" + "y" * 20000   # longer than the 16 KB staging maximum
+    lines[101] = "[1]: GET 5ms /" + "y" * 16300   # just around it
+    mid, caps = check_batch(gorp, orc, lines)
+    assert len(set(mid.tolist())) == 4
+    m2, _ = gorp.extract_batch(*lines_to_csr(lines), match_only=True)
+    assert np.array_equal(m2, mid)

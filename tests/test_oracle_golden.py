@@ -189,3 +189,16 @@ def test_minimisation_regression_all_accepting_states():
     assert g.match("_x") == [0]
     assert g.match("[9[8__") == [0]
     assert g.match("[98") == []
+
+
+def test_read_lines_is_buffered_reader_readline():
+    """oracle.read_lines (the ingestion checker): the three readLine() terminators, no line after a final one."""
+    off, lines, flags = O.read_lines(b"a\r\nb\rc\n\nd")
+    assert lines == [b"a", b"b", b"c", b"", b"d"]
+    assert off.tolist() == [0, 3, 5, 7, 8, 9]
+    assert flags.tolist() == [0, 0, 0, 0, 0]
+    off, lines, flags = O.read_lines(b"\xe9\n\r")
+    assert lines == [b"\xe9", b""] and off.tolist() == [0, 2, 3] and flags.tolist() == [1, 0]
+    assert O.read_lines(b"")[1] == [] and O.read_lines(b"\n")[1] == [b""]
+    # a vertical tab / form feed / NEL are ordinary bytes of a line, as for readLine()
+    assert O.read_lines(b"a\x0bb\x0cc\x85d")[1] == [b"a\x0bb\x0cc\x85d"]
