@@ -27,7 +27,7 @@ SYMBOLS = [
     "gx_quote_literal_as_regexp", "gx_massage_regexp_for_automaton", "gx_massage_regexp_for_jdk",
     "gx_create_from_definition", "gx_definition_to_json",
     "gx_extraction_name", "gx_extractor_name", "gx_extraction_append_json",
-    "gx_split_lines",
+    "gx_split_lines", "gx_results_to_jsonl", "gx_set_extraction_meta",
 ]
 
 
@@ -41,7 +41,7 @@ class gx_batch_opts(C.Structure):
         ("no_sync", C.c_uint32),
         ("line_bytes_hint", C.c_uint32),
         ("strip_eol", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("utf8_passthrough", C.c_uint32),
     ]
 
 
@@ -136,6 +136,11 @@ def lib():
     L.gx_split_lines.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p,
                                  C.POINTER(gx_batch_opts)]
     L.gx_split_lines.restype = C.c_int
+    L.gx_results_to_jsonl.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_char_p,
+                                      C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(gx_batch_opts)]
+    L.gx_results_to_jsonl.restype = C.c_int
+    L.gx_set_extraction_meta.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.POINTER(C.c_char_p), C.c_int32, C.c_char_p]
+    L.gx_set_extraction_meta.restype = C.c_int
     _lib = L
     return L
 

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgorp_hip.so")
-SOURCES = ["gx_regex.cpp", "gx_compile.cpp", "gx_host.cpp", "gx_dsl.cpp", "gx_api.cpp", "gx_kernels.hip", "gx_ingest.hip"]
+SOURCES = ["gx_regex.cpp", "gx_compile.cpp", "gx_host.cpp", "gx_dsl.cpp", "gx_api.cpp", "gx_kernels.hip", "gx_ingest.hip", "gx_jsonl.hip"]
 HEADERS = ["gx_common.hpp", "gx_compile.hpp", "gx_device.hpp", "gx_dsl.hpp", os.path.join("..", "..", "include", "gorp_hip.h")]
 
 

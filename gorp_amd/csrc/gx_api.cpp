@@ -6,6 +6,7 @@
 
 #include <cstddef>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
@@ -63,7 +64,9 @@ struct gx_handle {
     std::vector<uint8_t> l2_image;
     void* d_l2_image = nullptr;
     int num_cus = 256;
-    std::vector<dsl::Extraction> meta;  // names / extractor names / append (only when built from definition text)
+    std::vector<dsl::Extraction> meta;  // names / extractor names / append (from definition text or gx_set_extraction_meta)
+    struct JsonlImage { void* d = nullptr; GxJsonl dev{}; };
+    std::map<std::string, JsonlImage> jsonl;  // device templates per id_as ("0" = none, "1" + id_as)
     std::mutex mu;  // serialises host-pointer batches that share nothing else
 };
 
@@ -413,6 +416,7 @@ void gx_destroy(gx_handle* h) {
     if (h->dimage) (void)hipFree(h->dimage);
     if (h->d_lds_image) (void)hipFree(h->d_lds_image);
     if (h->d_l2_image) (void)hipFree(h->d_l2_image);
+    for (auto& e : h->jsonl) if (e.second.d) (void)hipFree(e.second.d);
     delete h;
 }
 
@@ -490,6 +494,144 @@ int gx_split_lines(const uint8_t* bytes, uint64_t size, void* offsets, uint64_t 
         return GX_OK;
     } catch (GxError& e) { return fail(e.code, e.what()); }
     catch (std::bad_alloc&) { return fail(GX_E_NOMEM, "out of memory"); }
+}
+
+// One JSON template per extraction for ExtractionResult.asMap(idAs) (core/ExtractionResult.java:65-88), uploaded once
+// per distinct id_as.
+static const GxJsonl& jsonl_templates(gx_handle* h, const char* id_as) {
+    const std::string key = id_as ? std::string("1") + id_as : std::string("0");
+    auto it = h->jsonl.find(key);
+    if (it != h->jsonl.end()) return it->second.dev;
+    const Tables& T = h->T;
+    if (static_cast<int>(h->meta.size()) != T.n_rules)
+        throw GxError(GX_E_ARG, "extraction names are unknown: create the handle with gx_create_from_definition or call "
+                                "gx_set_extraction_meta for every extraction");
+    std::vector<uint32_t> seg_off(1, 0), lit_off, lit_len, fixed_len;
+    std::vector<int32_t> group;
+    std::vector<uint8_t> lits;
+    for (int k = 0; k < T.n_rules; ++k) {
+        const dsl::Extraction& x = h->meta[k];
+        if (static_cast<int>(x.extractor_names.size()) != T.rules[k].n_groups)
+            throw GxError(GX_E_ARG, "extractor names of extraction '" + x.name + "' do not match its capture groups");
+        // LinkedHashMap: a key put again keeps its position and takes the new value
+        struct Entry { std::string key; int g; std::string raw; };
+        std::vector<Entry> entries;
+        auto put = [&](const std::string& key_utf8, int g, const std::string& raw) {
+            for (auto& e : entries) if (e.key == key_utf8) { e.g = g; e.raw = raw; return; }
+            entries.push_back({key_utf8, g, raw});
+        };
+        if (id_as) put(id_as, -1, dsl::json_quote(x.name));
+        for (size_t g = 0; g < x.extractor_names.size(); ++g) put(x.extractor_names[g], static_cast<int>(g), "");
+        if (!x.append_json.empty())
+            for (auto& kv : dsl::json_object_entries(x.append_json)) put(kv.first, -1, kv.second);
+        std::string lit = "{";
+        uint32_t fixed = 0;
+        auto close_segment = [&](int g) {
+            lit_off.push_back(static_cast<uint32_t>(lits.size()));
+            lit_len.push_back(static_cast<uint32_t>(lit.size()));
+            group.push_back(g);
+            lits.insert(lits.end(), lit.begin(), lit.end());
+            fixed += static_cast<uint32_t>(lit.size());
+            lit.clear();
+        };
+        for (size_t e = 0; e < entries.size(); ++e) {
+            lit += (e ? "," : "") + dsl::json_quote(entries[e].key) + ":";
+            if (entries[e].g >= 0) close_segment(entries[e].g);
+            else lit += entries[e].raw;
+        }
+        lit += "}\n";
+        close_segment(-1);
+        seg_off.push_back(static_cast<uint32_t>(group.size()));
+        fixed_len.push_back(fixed);
+    }
+    if (lits.empty()) lits.push_back(0);
+    Image img;
+    const size_t o_seg = img.put(seg_off), o_lo = img.put(lit_off), o_ll = img.put(lit_len), o_g = img.put(group), o_f = img.put(fixed_len),
+                 o_l = img.put(lits);
+    gx_handle::JsonlImage ji;
+    GX_HIP(hipMalloc(&ji.d, img.bytes.size()));
+    GX_HIP(hipMemcpy(ji.d, img.bytes.data(), img.bytes.size(), hipMemcpyHostToDevice));
+    const uint8_t* base = static_cast<const uint8_t*>(ji.d);
+    ji.dev.seg_off = reinterpret_cast<const uint32_t*>(base + o_seg);
+    ji.dev.lit_off = reinterpret_cast<const uint32_t*>(base + o_lo);
+    ji.dev.lit_len = reinterpret_cast<const uint32_t*>(base + o_ll);
+    ji.dev.group = reinterpret_cast<const int32_t*>(base + o_g);
+    ji.dev.fixed_len = reinterpret_cast<const uint32_t*>(base + o_f);
+    ji.dev.lits = base + o_l;
+    return h->jsonl.emplace(key, ji).first->second.dev;
+}
+
+int gx_results_to_jsonl(gx_handle* h, const uint8_t* bytes, const void* offsets, uint64_t n, const int32_t* match_id, const int32_t* caps,
+                        const char* id_as, uint8_t* out, uint64_t out_cap, uint64_t* out_size, uint64_t* line_out_offsets,
+                        const gx_batch_opts* opts) {
+    if (!h || !offsets || !out_size || (n && !match_id)) return fail(GX_E_ARG, "gx_results_to_jsonl: bad argument");
+    if (!h->on_device) return fail(GX_E_DEVICE, "handle was created host-only; no device tables (there is no CPU fallback)");
+    gx_batch_opts o{};
+    if (!read_opts(opts, &o)) return fail(GX_E_ARG, "gx_batch_opts.struct_size mismatch");
+    const size_t slots = 2 * static_cast<size_t>(h->T.max_groups);
+    if (n && slots && !caps) return fail(GX_E_ARG, "gx_results_to_jsonl: caps is NULL");
+    try {
+        GX_HIP(hipSetDevice(h->device));
+        std::lock_guard<std::mutex> lock(h->mu);
+        const GxJsonl& tm = jsonl_templates(h, id_as);
+        hipStream_t stream = static_cast<hipStream_t>(o.stream);
+        const size_t off_w = o.offsets64 ? 8 : 4;
+        DevBuf ws, d_bytes, d_off, d_mid, d_caps, d_loff, d_out;
+        ws.alloc(jsonl_workspace_bytes(n));
+        GxBatch b{};
+        b.n = n;
+        b.offsets64 = o.offsets64 ? 1 : 0;
+        uint64_t* loff = line_out_offsets;
+        if (o.device_pointers) {
+            b.data = bytes; b.offsets = offsets; b.match_id = const_cast<int32_t*>(match_id); b.caps = const_cast<int32_t*>(caps);
+            if (!loff) { d_loff.alloc((n + 1) * 8); loff = static_cast<uint64_t*>(d_loff.p); }
+        } else {
+            uint64_t total_in = 0;
+            if (n) total_in = o.offsets64 ? static_cast<const uint64_t*>(offsets)[n] : static_cast<const uint32_t*>(offsets)[n];
+            d_bytes.alloc(total_in); d_off.alloc((n + 1) * off_w); d_mid.alloc(n * 4); d_caps.alloc(n * slots * 4); d_loff.alloc((n + 1) * 8);
+            if (total_in) GX_HIP(hipMemcpyAsync(d_bytes.p, bytes, total_in, hipMemcpyHostToDevice, stream));
+            GX_HIP(hipMemcpyAsync(d_off.p, offsets, (n + 1) * off_w, hipMemcpyHostToDevice, stream));
+            if (n) GX_HIP(hipMemcpyAsync(d_mid.p, match_id, n * 4, hipMemcpyHostToDevice, stream));
+            if (n && slots) GX_HIP(hipMemcpyAsync(d_caps.p, caps, n * slots * 4, hipMemcpyHostToDevice, stream));
+            b.data = d_bytes.p; b.offsets = d_off.p; b.match_id = static_cast<int32_t*>(d_mid.p); b.caps = static_cast<int32_t*>(d_caps.p);
+            loff = static_cast<uint64_t*>(d_loff.p);
+        }
+        GX_HIP(launch_jsonl_sizes(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, loff, ws.p, stream));
+        uint64_t total = 0;
+        GX_HIP(hipMemcpyAsync(&total, loff + n, 8, hipMemcpyDeviceToHost, stream));
+        GX_HIP(hipStreamSynchronize(stream));
+        *out_size = total;
+        if (!o.device_pointers && line_out_offsets) GX_HIP(hipMemcpy(line_out_offsets, loff, (n + 1) * 8, hipMemcpyDeviceToHost));
+        if (!out) return GX_OK;  // size query
+        if (total > out_cap) return fail(GX_E_LIMIT, "gx_results_to_jsonl: out_cap is smaller than the text (see *out_size)");
+        uint8_t* dst = out;
+        if (!o.device_pointers) { d_out.alloc(total); dst = static_cast<uint8_t*>(d_out.p); }
+        GX_HIP(launch_jsonl_write(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, loff, dst, stream));
+        if (!o.device_pointers && total) GX_HIP(hipMemcpyAsync(out, dst, total, hipMemcpyDeviceToHost, stream));
+        GX_HIP(hipStreamSynchronize(stream));
+        return GX_OK;
+    } catch (GxError& e) { return fail(e.code, e.what()); }
+    catch (std::bad_alloc&) { return fail(GX_E_NOMEM, "out of memory"); }
+    catch (std::exception& e) { return fail(GX_E_ARG, e.what()); }
+}
+
+int gx_set_extraction_meta(gx_handle* h, int32_t k, const char* name, const char* const* extractor_names, int32_t n_names,
+                           const char* append_json) {
+    if (!h || !name || k < 0 || k >= h->T.n_rules || n_names < 0 || (n_names && !extractor_names))
+        return fail(GX_E_ARG, "gx_set_extraction_meta: bad argument");
+    if (n_names != h->T.rules[k].n_groups) return fail(GX_E_ARG, "gx_set_extraction_meta: n_names must equal gx_num_groups(h, k)");
+    try {
+        std::lock_guard<std::mutex> lock(h->mu);
+        if (static_cast<int>(h->meta.size()) != h->T.n_rules) h->meta.assign(h->T.n_rules, dsl::Extraction());
+        dsl::Extraction& x = h->meta[k];
+        x.name = name;
+        x.extractor_names.assign(extractor_names, extractor_names + n_names);
+        x.append_json = append_json ? dsl::canonical_json_object(append_json) : std::string();
+        for (auto& e : h->jsonl) if (e.second.d) (void)hipFree(e.second.d);
+        h->jsonl.clear();
+        return GX_OK;
+    } catch (GxError& e) { return fail(e.code, e.what()); }
+    catch (std::exception& e) { return fail(GX_E_ARG, e.what()); }
 }
 
 int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, uint64_t n, int32_t* match_id, int32_t* caps,

@@ -105,4 +105,21 @@ size_t split_workspace_bytes(uint64_t size);
 hipError_t launch_split_lines(const uint8_t* data, uint64_t size, void* offsets, int offsets64, uint64_t cap_lines, uint8_t* flags,
                               void* workspace, uint64_t** d_n_lines, hipStream_t stream);
 
+
+// Result materialisation (gx_jsonl.hip): per-extraction JSON templates on the device.  A template is a list of
+// segments; segment s = literal bytes lits[lit_off[s] .. +lit_len[s]) followed by capture group group[s] (-1: none).
+struct GxJsonl {
+    const uint32_t* seg_off;    // [n_rules + 1]
+    const uint32_t* lit_off;    // [n_segs]
+    const uint32_t* lit_len;    // [n_segs]
+    const int32_t* group;       // [n_segs]
+    const uint32_t* fixed_len;  // [n_rules] sum of the template's literal lengths
+    const uint8_t* lits;
+};
+size_t jsonl_workspace_bytes(uint64_t n);
+hipError_t launch_jsonl_sizes(const GxJsonl& tm, const GxBatch& b, int slots, int passthrough, uint64_t* line_out_off, void* workspace,
+                              hipStream_t stream);
+hipError_t launch_jsonl_write(const GxJsonl& tm, const GxBatch& b, int slots, int passthrough, const uint64_t* line_out_off, uint8_t* out,
+                              hipStream_t stream);
+
 }  // namespace gx

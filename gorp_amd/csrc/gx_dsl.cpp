@@ -1028,6 +1028,112 @@ void build_regex_strings(const Extraction& x, std::string& automaton_rx, std::st
 
 
 // ---------------------------------------------------------------------------
+// JSON helpers for result materialisation
+// ---------------------------------------------------------------------------
+std::string json_quote(const std::string& s) {
+    static const char* HEX = "0123456789ABCDEF";
+    std::string o = "\"";
+    for (unsigned char c : s) {
+        switch (c) {
+        case '"': o += "\\\""; break;
+        case '\\': o += "\\\\"; break;
+        case '\b': o += "\\b"; break;
+        case '\t': o += "\\t"; break;
+        case '\n': o += "\\n"; break;
+        case '\f': o += "\\f"; break;
+        case '\r': o += "\\r"; break;
+        default:
+            if (c < 0x20) { o += "\\u00"; o += HEX[c >> 4]; o += HEX[c & 15]; }
+            else o += static_cast<char>(c);
+        }
+    }
+    return o + "\"";
+}
+
+namespace {
+void append_utf8(std::string& o, uint32_t cp) {
+    if (cp < 0x80) o += static_cast<char>(cp);
+    else if (cp < 0x800) { o += static_cast<char>(0xC0 | (cp >> 6)); o += static_cast<char>(0x80 | (cp & 0x3F)); }
+    else if (cp < 0x10000) {
+        o += static_cast<char>(0xE0 | (cp >> 12)); o += static_cast<char>(0x80 | ((cp >> 6) & 0x3F)); o += static_cast<char>(0x80 | (cp & 0x3F));
+    } else {
+        o += static_cast<char>(0xF0 | (cp >> 18)); o += static_cast<char>(0x80 | ((cp >> 12) & 0x3F));
+        o += static_cast<char>(0x80 | ((cp >> 6) & 0x3F)); o += static_cast<char>(0x80 | (cp & 0x3F));
+    }
+}
+// raw = a JSON string literal including its quotes
+std::string json_unquote(const std::string& raw) {
+    std::string o;
+    auto hex4 = [&](size_t at) {
+        uint32_t v = 0;
+        for (size_t q = at; q < at + 4 && q < raw.size(); ++q) {
+            const char c = raw[q];
+            v = v * 16 + (c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : 0);
+        }
+        return v;
+    };
+    for (size_t i = 1; i + 1 < raw.size(); ++i) {
+        char c = raw[i];
+        if (c != '\\') { o += c; continue; }
+        c = raw[++i];
+        switch (c) {
+        case 'b': o += '\b'; break;
+        case 'f': o += '\f'; break;
+        case 'n': o += '\n'; break;
+        case 'r': o += '\r'; break;
+        case 't': o += '\t'; break;
+        case 'u': {
+            uint32_t cp = hex4(i + 1);
+            i += 4;
+            if (cp >= 0xD800 && cp <= 0xDBFF && i + 6 < raw.size() && raw[i + 1] == '\\' && raw[i + 2] == 'u') {
+                const uint32_t lo = hex4(i + 3);
+                if (lo >= 0xDC00 && lo <= 0xDFFF) { cp = 0x10000 + ((cp & 0x3FF) << 10) + (lo & 0x3FF); i += 6; }
+            }
+            append_utf8(o, cp);
+            break;
+        }
+        default: o += c;  // \" \\ \/
+        }
+    }
+    return o;
+}
+}  // namespace
+
+std::string canonical_json_object(const std::string& text) {
+    try {
+        Json j(text);
+        j.ws();
+        if (j.at >= text.size() || text[j.at] != '{') throw std::runtime_error("not a JSON object");
+        std::string canon = j.value();
+        j.ws();
+        if (j.at != text.size()) throw std::runtime_error("trailing content after the JSON object");
+        return canon;
+    } catch (std::runtime_error& e) {
+        if (dynamic_cast<GxError*>(&e)) throw;
+        throw GxError(GX_E_ARG, std::string("invalid JSON object: ") + e.what());
+    }
+}
+
+std::vector<std::pair<std::string, std::string>> json_object_entries(const std::string& canon) {
+    std::vector<std::pair<std::string, std::string>> out;
+    if (canon.size() <= 2) return out;
+    Json j(canon);
+    ++j.at;  // '{'
+    for (;;) {
+        j.ws();
+        const std::string k = j.string();
+        j.ws();
+        ++j.at;  // ':'
+        const std::string v = j.value();
+        out.push_back({json_unquote(k), v});
+        j.ws();
+        if (j.at < canon.size() && canon[j.at] == ',') { ++j.at; continue; }
+        break;
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------
 // JSON views (test support)
 // ---------------------------------------------------------------------------
 namespace {

@@ -2,6 +2,7 @@
 #pragma once
 #include <functional>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "gx_common.hpp"
@@ -34,6 +35,15 @@ void build_regex_strings(const Extraction& x, std::string& automaton_rx, std::st
 // reference's own DSL unit tests: "uncooked" (readUncooked), "cooked" (resolvePatterns + resolveTemplates),
 // "flattened" (everything, plus the two regex strings per extraction).
 std::string dump_json(const std::string& utf8_text, const std::string& source_ref, const std::string& stage);
+
+// JSON helpers shared with result materialisation (gx_api.cpp: gx_results_to_jsonl).
+// Entries of a canonical JSON object text in order: (key decoded to UTF-8, value as raw JSON text).
+std::vector<std::pair<std::string, std::string>> json_object_entries(const std::string& canonical_object);
+// JSON string literal with Jackson's default escaping: \" \\ \b \t \n \f \r, other controls as \u00XX (upper-case
+// hex), everything else (including non-ASCII UTF-8) verbatim.
+std::string json_quote(const std::string& utf8);
+// Parses a JSON object text and returns it in canonical (compact, duplicate keys merged) form; throws GxError(GX_E_ARG).
+std::string canonical_json_object(const std::string& text);
 
 }  // namespace dsl
 }  // namespace gx

@@ -250,6 +250,58 @@ class Gorp:
         self._h = handle
         self._matcher = PolyMatcher(handle)
         self._extractions = extractions
+        self._meta_sent = False
+
+    def _send_meta(self):
+        """gx_set_extraction_meta for handles built from regex strings (names live on this side)."""
+        if self._meta_sent:
+            return
+        import json
+        for k, x in enumerate(self._extractions):
+            names = [s.encode("utf-8") for s in x._extractorNames]
+            arr = (C.c_char_p * max(1, len(names)))(*names)
+            app = json.dumps(x.getExtra(), ensure_ascii=False).encode("utf-8") if x.getExtra() else None
+            _check(N.lib().gx_set_extraction_meta(self._h.ptr, k, x.getName().encode("utf-8"), arr, len(names), app))
+        self._meta_sent = True
+
+    def results_to_jsonl(self, data, offsets, match_id, caps, id_as=None, utf8_passthrough=False, want_line_offsets=False):
+        """gx_results_to_jsonl on host buffers: asMap(id_as) of every matched line as JSON Lines (bytes)."""
+        self._send_meta()
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets)
+        match_id = np.ascontiguousarray(match_id, dtype=np.int32)
+        caps = np.ascontiguousarray(caps, dtype=np.int32)
+        n = len(offsets) - 1
+        o = N.gx_batch_opts()
+        o.struct_size = C.sizeof(N.gx_batch_opts)
+        o.offsets64 = 1 if offsets.dtype == np.uint64 else 0
+        o.utf8_passthrough = 1 if utf8_passthrough else 0
+        ida = id_as.encode("utf-8") if id_as is not None else None
+        size = C.c_uint64(0)
+        args = (self._h.ptr, data.ctypes.data if data.size else None, offsets.ctypes.data, n, match_id.ctypes.data if n else None,
+                caps.ctypes.data if caps.size else None, ida)
+        _check(N.lib().gx_results_to_jsonl(*args, None, 0, C.byref(size), None, C.byref(o)))
+        out = np.zeros(max(1, size.value), np.uint8)
+        loff = np.zeros(n + 1, np.uint64)
+        _check(N.lib().gx_results_to_jsonl(*args, out.ctypes.data, size.value, C.byref(size), loff.ctypes.data, C.byref(o)))
+        text = out[:size.value].tobytes()
+        return (text, loff) if want_line_offsets else text
+
+    def results_to_jsonl_device(self, data_ptr, offsets_ptr, n, match_id_ptr, caps_ptr, out_ptr, out_cap, line_offsets_ptr=None,
+                                id_as=None, offsets64=False, utf8_passthrough=False, stream=None):
+        """Device pointers; returns the size of the text (out_ptr=None only asks for it)."""
+        self._send_meta()
+        o = N.gx_batch_opts()
+        o.struct_size = C.sizeof(N.gx_batch_opts)
+        o.device_pointers = 1
+        o.offsets64 = 1 if offsets64 else 0
+        o.utf8_passthrough = 1 if utf8_passthrough else 0
+        o.stream = stream
+        size = C.c_uint64(0)
+        _check(N.lib().gx_results_to_jsonl(self._h.ptr, data_ptr, offsets_ptr, n, match_id_ptr, caps_ptr,
+                                           id_as.encode("utf-8") if id_as is not None else None, out_ptr, out_cap, C.byref(size),
+                                           line_offsets_ptr, C.byref(o)))
+        return size.value
 
     # -- construction ------------------------------------------------------
     @staticmethod
@@ -461,10 +513,17 @@ class DefinitionReader:
         return [FlattenedExtraction(x["name"], x["pieces"], x["append"]) for x in d["extractions"]], d
 
     def read(self, host_only=False):
+        """DefinitionReader.read() (core/DefinitionReader.java:74-84): the native front-end parses, resolves and
+        compiles the definition in one call (gx_create_from_definition)."""
         fl, d = self.flatten()
-        autom = [x["automaton_rx"] for x in d["extractions"]]
-        jdk = [x["jdk_rx"] for x in d["extractions"]]
         cooked = [CookedExtraction(i, x["name"], x["jdk_rx"], x["extractor_names"], x["append"])
                   for i, x in enumerate(d["extractions"])]
-        h = _create(autom, jdk, N.GX_CREATE_HOST_ONLY if host_only else 0)
-        return Gorp(h, cooked)
+        hp = C.c_void_p()
+        rc = N.lib().gx_create_from_definition(self._text.encode("utf-8"), self._source_ref.encode("utf-8"),
+                                               N.GX_CREATE_HOST_ONLY if host_only else 0, C.byref(hp))
+        if rc in (N.GX_E_DEFINITION, N.GX_E_REGEX_SYNTAX, N.GX_E_UNSUPPORTED_CONSTRUCT, N.GX_E_LIMIT):
+            raise DefinitionParseException(rc, N.last_error())
+        _check(rc)
+        g = Gorp(_Handle(hp), cooked)
+        g._meta_sent = True  # the native front-end kept the names itself
+        return g

@@ -95,7 +95,9 @@ typedef struct gx_batch_opts {
     uint32_t strip_eol;        /* 1: every line carries its terminator ("\n", "\r\n" or "\r", as produced by
                                   gx_split_lines); it is not part of the String the reference would see, so
                                   it is ignored and capture offsets stay relative to the start of the line */
-    uint32_t reserved;         /* 0 */
+    uint32_t utf8_passthrough; /* gx_results_to_jsonl only.  0: line bytes are Latin-1 code units (the batch path's input
+                                  model) and bytes >= 0x80 leave as two-byte UTF-8; 1: copy them unchanged (the
+                                  input was UTF-8 all along and the patterns only look at its ASCII structure) */
 } gx_batch_opts;
 
 /* Replaces the per-line loop "for each line: Gorp.extract(line)"
@@ -119,6 +121,26 @@ int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, ui
  * still set, so the caller can retry with a larger offsets array). */
 int gx_split_lines(const uint8_t* bytes, uint64_t size, void* offsets, uint64_t cap_lines, uint64_t* n_lines,
                    uint8_t* line_flags, const gx_batch_opts* opts);
+
+/* Result materialisation, the step after the path: ExtractionResult.asMap(idAs)
+ * (core/ExtractionResult.java:65-88) for every matched line of a finished batch, written as one JSON object per
+ * line ("JSON Lines") the way Jackson serialises the LinkedHashMap: the id first when id_as != NULL, then
+ * extractor name -> captured text in group order (null where Matcher.group() is null), then the extraction's
+ * `append` entries (core/DefinitionReader.java:602-640); a key put twice keeps its first position and its last
+ * value.  Lines with match_id < 0 produce no text.  bytes/offsets/match_id/caps are the arguments and results
+ * of gx_extract_batch.  line_out_offsets (optional, n + 1 entries) receives where each line's text starts
+ * (equal neighbours = no text).  *out_size receives the total; out == NULL only asks for the size; GX_E_LIMIT
+ * when out_cap is too small.  With opts->device_pointers = 1 every buffer except out_size is a device pointer.
+ * Needs the extraction names: a handle from gx_create_from_definition, or gx_set_extraction_meta first. */
+int gx_results_to_jsonl(gx_handle* h, const uint8_t* bytes, const void* offsets, uint64_t n, const int32_t* match_id,
+                        const int32_t* caps, const char* id_as, uint8_t* out, uint64_t out_cap, uint64_t* out_size,
+                        uint64_t* line_out_offsets, const gx_batch_opts* opts);
+
+/* Names for a handle built from regex strings (the caller did DefinitionReader's work itself and holds the
+ * CookedExtraction data, core/model/CookedExtraction.java:18-66): extraction name, extractor names in group
+ * order (n_names == gx_num_groups(h, k)), and the `append` object as JSON text (NULL = none). */
+int gx_set_extraction_meta(gx_handle* h, int32_t k, const char* name, const char* const* extractor_names, int32_t n_names,
+                           const char* append_json);
 
 /* Replaces one Gorp.extract(String) call (core/Gorp.java:145-147): s is the
  * String's UTF-16 code units.  Runs on the GPU like the batch path.

@@ -265,3 +265,50 @@ def read_lines(data):
     lines = data.splitlines()
     flags = np.array([1 if any(b >= 0x80 for b in k) else 0 for k in kept], np.uint8)
     return offsets, lines, flags
+
+
+def _json_string(text):
+    """Jackson's default string escaping (what ObjectMapper writes for a Map value): \\" \\\\ \\b \\t \\n \\f \\r,
+    other controls < 0x20 as \\u00XX with upper-case hex, everything else verbatim."""
+    out = ['"']
+    short = {'"': '\\"', "\\": "\\\\", "\b": "\\b", "\t": "\\t", "\n": "\\n", "\f": "\\f", "\r": "\\r"}
+    for ch in text:
+        if ch in short:
+            out.append(short[ch])
+        elif ord(ch) < 0x20:
+            out.append("\\u00%02X" % ord(ch))
+        else:
+            out.append(ch)
+    out.append('"')
+    return "".join(out)
+
+
+def results_to_jsonl(lines, match_id, caps, names, extractor_names, appends, id_as=None, utf8_passthrough=False):
+    """Result materialisation restated on the CPU: ExtractionResult.asMap(idAs) (core/ExtractionResult.java:65-88)
+    per matched line -- a LinkedHashMap (a key put again keeps its position, takes the new value): id first,
+    extractor name -> captured text or null, then the append entries -- serialised compactly, one object per line.
+
+    lines: list of bytes (Latin-1 code units); appends: per extraction a dict or None (values are written with
+    json.dumps, compact).  Returns (text bytes, line offsets uint64[n+1]).
+    """
+    import json
+    out = bytearray()
+    offs = [0]
+    for ln, k, cp in zip(lines, match_id, caps):
+        if k >= 0:
+            m = {}
+            if id_as is not None:
+                m[id_as] = _json_string(names[k])
+            for g, nm in enumerate(extractor_names[k]):
+                b, e = int(cp[2 * g]), int(cp[2 * g + 1])
+                if b < 0:
+                    m[nm] = "null"
+                else:
+                    raw = ln[b:e]
+                    m[nm] = _json_string(raw.decode("utf-8", "surrogateescape") if utf8_passthrough else raw.decode("latin-1"))
+            for key, v in (appends[k] or {}).items():
+                m[key] = json.dumps(v, ensure_ascii=False, separators=(",", ":"))
+            text = "{" + ",".join(_json_string(key) + ":" + v for key, v in m.items()) + "}\n"
+            out += text.encode("utf-8", "surrogateescape")
+        offs.append(len(out))
+    return bytes(out), np.array(offs, np.uint64)

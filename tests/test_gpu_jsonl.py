@@ -1,0 +1,94 @@
+"""GPU tests of result materialisation (gx_results_to_jsonl) against oracle.results_to_jsonl
+(ExtractionResult.asMap restated) -- byte-exact, and every line parses back to asMap()."""
+import json
+import random
+
+import numpy as np
+import pytest
+
+from gorp_amd import workloads as W
+from gorp_amd.gorp import DefinitionReader, FlattenedExtraction, Gorp, lines_to_csr
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def run(gorp, lines, id_as=None, utf8_passthrough=False):
+    raw = [ln if isinstance(ln, bytes) else ln.encode("latin-1") for ln in lines]
+    data, offsets = lines_to_csr(raw)
+    mid, caps = gorp.extract_batch(data, offsets)
+    text, loff = gorp.results_to_jsonl(data, offsets, mid, caps, id_as=id_as, utf8_passthrough=utf8_passthrough, want_line_offsets=True)
+    xs = gorp.getExtractions()
+    want, woff = O.results_to_jsonl(raw, mid, caps, [x.getName() for x in xs], [x._extractorNames for x in xs],
+                                    [x.getExtra() for x in xs], id_as=id_as, utf8_passthrough=utf8_passthrough)
+    assert text == want, (text[:300], want[:300])
+    assert np.array_equal(loff, woff)
+    return raw, mid, caps, text
+
+
+def test_readme3_lines_and_asmap_roundtrip():
+    gorp = Gorp.construct(W.readme3_definition())
+    data, offsets, cat = W.readme3_lines(5000, seed=31)
+    d, o = data.numpy(), offsets.numpy()
+    lines = [bytes(d[o[i]:o[i + 1]]) for i in range(len(o) - 1)]
+    raw, mid, caps, text = run(gorp, lines, id_as="rule")
+    objs = [json.loads(t) for t in text.decode("utf-8").split("\n")[:-1]]
+    res = [r for r in gorp.results(*lines_to_csr(raw), mid, caps) if r is not None]
+    assert len(objs) == len(res) == int((mid >= 0).sum())
+    for obj, r in zip(objs[:500], res[:500]):
+        assert obj == r.asMap("rule") and list(obj) == list(r.asMap("rule"))
+    run(gorp, lines)  # without the id
+
+
+def test_escaping_nulls_append_and_key_collisions():
+    definition = [
+        # optional group -> null; nested extractors -> a byte written twice; append with typed values
+        FlattenedExtraction("opt", [["text", "a="], ["extractor", "outer", [["extractor", "inner", [["pattern", "[^;]*"]]], ["pattern", ";?"]]],
+                                    ["pattern", "(x"], ["extractor", "maybe", [["pattern", "y+"]]], ["pattern", ")?"]],
+                            {"env": "prod", "n": 3, "ok": True, "nested": {"k": [1, 2.5, None]}, "quote\"d": "v\\"}),
+        # duplicate extractor name, append overriding an extractor name and the id key
+        FlattenedExtraction("dup", [["text", "b="], ["extractor", "v", [["pattern", "[0-9]+"]]], ["text", ","],
+                                    ["extractor", "v", [["pattern", "[a-z]+"]]], ["text", ","], ["extractor", "w", [["pattern", ".*"]]]],
+                            {"w": "fixed", "id": "from-append"}),
+        FlattenedExtraction("bare", [["text", "c"]]),
+    ]
+    gorp = Gorp.construct(definition)
+    every = bytes(range(256))
+    lines = [b"a=" + every.replace(b";", b"") + b";", b"a=;", b"a=plain", b"a=q\"uo\\te\tTab\x00nul\x1f\x7f\x80\xff;xyyy", b"a=;x",
+             b"b=12,ab,rest \"of\" line", b"b=1,z,", b"c", b"no match", b""]
+    for id_as in (None, "id", "outer"):
+        raw, mid, caps, text = run(gorp, lines, id_as=id_as)
+        assert mid.tolist()[:9] == [0, 0, 0, 0, -1, 1, 1, 2, -1]  # "a=;x": the optional (xy+) needs a y
+        for t in text.decode("utf-8").split("\n")[:-1]:  # (str.splitlines would also split at NEL etc. inside strings)
+            json.loads(t)
+    # utf8_passthrough copies high bytes unchanged
+    run(gorp, [b"a=caf\xc3\xa9;", b"b=1,z,\xe2\x82\xac"], utf8_passthrough=True)
+
+
+def test_from_definition_text_with_append_and_device_buffers():
+    import torch
+    text = ("pattern %num \\d+\npattern %w \\S+\npattern %verb (GET|PUT)\npattern %any .*\n"
+            "extract Req {\n  template [$ts(%num)]: $verb(%verb) $ms(%num)ms $path(%w)\n  append \"kind\":\"request\", \"v\":1\n}\n"
+            "extract Other {\n  template [$ts(%num)]: $rest(%any)\n}\n")
+    gorp = DefinitionReader.reader(text).read()
+    rng = random.Random(8)
+    lines = []
+    for _ in range(20000):
+        verb = rng.choice(["GET", "PUT", "HEAD"])
+        lines.append(("[%d]: %s %dms /%s" % (rng.randrange(10 ** 9), verb, rng.randrange(5000), "p" * rng.randrange(1, 120))).encode())
+    raw, mid, caps, text_out = run(gorp, lines, id_as="_id")
+    assert (mid == 0).sum() > 10000 and (mid == 1).sum() > 5000
+    first = json.loads(text_out.decode().split("\n")[0])
+    assert first["_id"] in ("Req", "Other") and ("kind" in first) == (first["_id"] == "Req")
+    # device pointers: same bytes
+    data, offsets = lines_to_csr(raw)
+    d = torch.from_numpy(data).cuda(); o = torch.from_numpy(offsets.view(np.int32)).cuda()
+    m = torch.from_numpy(mid).cuda(); c = torch.from_numpy(caps).cuda()
+    size = gorp.results_to_jsonl_device(d.data_ptr(), o.data_ptr(), len(raw), m.data_ptr(), c.data_ptr(), None, 0, id_as="_id")
+    assert size == len(text_out)
+    out = torch.empty(size, dtype=torch.uint8, device="cuda")
+    loff = torch.empty(len(raw) + 1, dtype=torch.int64, device="cuda")
+    size2 = gorp.results_to_jsonl_device(d.data_ptr(), o.data_ptr(), len(raw), m.data_ptr(), c.data_ptr(), out.data_ptr(), size,
+                                         line_offsets_ptr=loff.data_ptr(), id_as="_id")
+    assert size2 == size and out.cpu().numpy().tobytes() == text_out
+    assert int(loff[-1]) == size
