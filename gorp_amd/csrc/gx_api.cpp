@@ -570,6 +570,7 @@ int gx_results_to_jsonl(gx_handle* h, const uint8_t* bytes, const void* offsets,
     if (!read_opts(opts, &o)) return fail(GX_E_ARG, "gx_batch_opts.struct_size mismatch");
     const size_t slots = 2 * static_cast<size_t>(h->T.max_groups);
     if (n && slots && !caps) return fail(GX_E_ARG, "gx_results_to_jsonl: caps is NULL");
+    if (slots > 128) return fail(GX_E_LIMIT, "gx_results_to_jsonl: more than 64 capture groups per extraction");
     try {
         GX_HIP(hipSetDevice(h->device));
         std::lock_guard<std::mutex> lock(h->mu);

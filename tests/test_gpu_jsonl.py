@@ -92,3 +92,50 @@ def test_from_definition_text_with_append_and_device_buffers():
                                          line_offsets_ptr=loff.data_ptr(), id_as="_id")
     assert size2 == size and out.cpu().numpy().tobytes() == text_out
     assert int(loff[-1]) == size
+
+
+def test_more_lines_than_waves_in_the_grid():
+    """The kernels walk the batch with a grid-stride loop of waves (8192 blocks x 4 waves): with 100 k lines every
+    wave takes several lines, mixing matched, unmatched, escaped and verbatim ones."""
+    gorp = Gorp.construct(W.readme3_definition())
+    data, offsets, cat = W.readme3_lines(100_000, seed=77)
+    d, o = data.numpy(), offsets.numpy()
+    lines = [bytes(d[o[i]:o[i + 1]]) for i in range(len(o) - 1)]
+    run(gorp, lines, id_as="id")
+
+
+def test_output_beyond_2_gib_properties():
+    """8 M lines -> 2.3 GB of text (offsets cross 2^31 and 2^32 is not far): size-independent checks + samples."""
+    import torch
+    gorp = Gorp.construct(W.readme3_definition())
+    n = 8_000_000
+    data, off, cat = W.readme3_lines(n, seed=2, device="cuda")
+    mid = torch.empty(n, dtype=torch.int32, device="cuda")
+    caps = torch.empty((n, 8), dtype=torch.int32, device="cuda")
+    gorp.extract_batch_device(data.data_ptr(), off.data_ptr(), n, mid.data_ptr(), caps.data_ptr())
+    size = gorp.results_to_jsonl_device(data.data_ptr(), off.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), None, 0, id_as="id")
+    assert size > 2 ** 31
+    out = torch.zeros(size, dtype=torch.uint8, device="cuda")
+    loff = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    assert gorp.results_to_jsonl_device(data.data_ptr(), off.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), out.data_ptr(), size,
+                                        line_offsets_ptr=loff.data_ptr(), id_as="id") == size
+    torch.cuda.synchronize()
+    lens = loff[1:] - loff[:-1]
+    assert int(loff[0]) == 0 and int(loff[-1]) == size and bool((lens >= 0).all())
+    assert bool(((lens == 0) == (mid < 0)).all())                    # text exactly for the matched lines
+    ends = loff[1:][mid >= 0] - 1
+    assert bool((out[ends] == 0x0A).all())                           # every object ends its line
+    assert bool((out[loff[:-1][mid >= 0]] == ord("{")).all())
+    assert int((out == 0x0A).sum()) == int((mid >= 0).sum())         # and there is no other newline
+    # samples from both ends and the middle against the oracle
+    xs = gorp.getExtractions()
+    idx = [0, 1, 2, n // 2, n // 2 + 1, n - 3, n - 2, n - 1] + list(range(5_000_000, 5_000_200))
+    d_host = data.view(n, W.LINE_BYTES)[idx].cpu().numpy()
+    m_host, c_host = mid[idx].cpu().numpy(), caps[idx].cpu().numpy()
+    lo_host = loff.cpu().numpy()
+    lines = [bytes(r) for r in d_host]
+    want, woff = O.results_to_jsonl(lines, m_host, c_host, [x.getName() for x in xs], [x._extractorNames for x in xs],
+                                    [x.getExtra() for x in xs], id_as="id")
+    for j, i in enumerate(idx):
+        got = out[int(lo_host[i]):int(lo_host[i + 1])].cpu().numpy().tobytes()
+        assert got == want[int(woff[j]):int(woff[j + 1])]
