@@ -28,6 +28,7 @@ SYMBOLS = [
     "gx_create_from_definition", "gx_definition_to_json",
     "gx_extraction_name", "gx_extractor_name", "gx_extraction_append_json",
     "gx_split_lines", "gx_results_to_jsonl", "gx_set_extraction_meta",
+    "gx_extraction_append_count", "gx_extraction_append_key", "gx_extraction_append_value_json",
 ]
 
 
@@ -141,6 +142,11 @@ def lib():
     L.gx_results_to_jsonl.restype = C.c_int
     L.gx_set_extraction_meta.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.POINTER(C.c_char_p), C.c_int32, C.c_char_p]
     L.gx_set_extraction_meta.restype = C.c_int
+    L.gx_extraction_append_count.argtypes = [C.c_void_p, C.c_int32]
+    L.gx_extraction_append_count.restype = C.c_int32
+    for f in ("gx_extraction_append_key", "gx_extraction_append_value_json"):
+        getattr(L, f).argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        getattr(L, f).restype = C.c_char_p
     _lib = L
     return L
 

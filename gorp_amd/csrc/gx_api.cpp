@@ -65,6 +65,7 @@ struct gx_handle {
     void* d_l2_image = nullptr;
     int num_cus = 256;
     std::vector<dsl::Extraction> meta;  // names / extractor names / append (from definition text or gx_set_extraction_meta)
+    std::vector<std::vector<std::pair<std::string, std::string>>> append_entries;  // per extraction: (key, value JSON), lazily
     struct JsonlImage { void* d = nullptr; GxJsonl dev{}; };
     std::map<std::string, JsonlImage> jsonl;  // device templates per id_as ("0" = none, "1" + id_as)
     std::mutex mu;  // serialises host-pointer batches that share nothing else
@@ -630,6 +631,7 @@ int gx_set_extraction_meta(gx_handle* h, int32_t k, const char* name, const char
         x.append_json = append_json ? dsl::canonical_json_object(append_json) : std::string();
         for (auto& e : h->jsonl) if (e.second.d) (void)hipFree(e.second.d);
         h->jsonl.clear();
+        h->append_entries.clear();
         return GX_OK;
     } catch (GxError& e) { return fail(e.code, e.what()); }
     catch (std::exception& e) { return fail(GX_E_ARG, e.what()); }
@@ -803,6 +805,30 @@ const char* gx_extractor_name(const gx_handle* h, int32_t k, int32_t g) {
 const char* gx_extraction_append_json(const gx_handle* h, int32_t k) {
     if (!h || k < 0 || k >= static_cast<int32_t>(h->meta.size()) || h->meta[k].append_json.empty()) return nullptr;
     return h->meta[k].append_json.c_str();
+}
+
+static const std::vector<std::pair<std::string, std::string>>* append_entries_of(const gx_handle* hc, int32_t k) {
+    gx_handle* h = const_cast<gx_handle*>(hc);
+    if (!h || k < 0 || k >= static_cast<int32_t>(h->meta.size())) return nullptr;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (h->append_entries.size() != h->meta.size()) {
+        h->append_entries.assign(h->meta.size(), {});
+        for (size_t x = 0; x < h->meta.size(); ++x)
+            if (!h->meta[x].append_json.empty()) h->append_entries[x] = dsl::json_object_entries(h->meta[x].append_json);
+    }
+    return &h->append_entries[k];
+}
+int32_t gx_extraction_append_count(const gx_handle* h, int32_t k) {
+    auto* e = append_entries_of(h, k);
+    return e ? static_cast<int32_t>(e->size()) : 0;
+}
+const char* gx_extraction_append_key(const gx_handle* h, int32_t k, int32_t j) {
+    auto* e = append_entries_of(h, k);
+    return (e && j >= 0 && j < static_cast<int32_t>(e->size())) ? (*e)[j].first.c_str() : nullptr;
+}
+const char* gx_extraction_append_value_json(const gx_handle* h, int32_t k, int32_t j) {
+    auto* e = append_entries_of(h, k);
+    return (e && j >= 0 && j < static_cast<int32_t>(e->size())) ? (*e)[j].second.c_str() : nullptr;
 }
 
 int gx_definition_to_json(const char* definition_text, const char* source_ref, const char* stage, char* out, size_t cap,

@@ -9,7 +9,8 @@
 //   gorp::DefinitionParseException               core/DefinitionParseException.java
 //   gorp::RegexHelper                            core/util/RegexHelper.java
 //
-// plus the batch entry point the GPU needs (Gorp::extractBatch over a CSR byte buffer).  All matching runs in the
+// plus the batch entry points the GPU needs (Gorp::extractBatch over a CSR byte buffer, splitLines before it,
+// Gorp::resultsToJsonl after it).  All matching runs in the
 // HIP kernels; nothing here computes a match on the CPU.  Link: -lgorp_hip -lamdhip64.
 #pragma once
 #include <cstdint>
@@ -45,7 +46,16 @@ struct CookedExtraction {
     std::string name;
     std::vector<std::string> extractorNames;
     std::string appendJson;  // getExtra() as JSON object text; empty when there is none
+    std::vector<std::pair<std::string, std::string>> extra;  // getExtra() entry by entry: key, value as JSON text
     const std::string& getName() const { return name; }
+};
+
+// A value of ExtractionResult.asMap(): the captured text, null (Matcher.group() == null), or -- for `append`
+// entries, whose values are typed -- JSON text.
+struct MapValue {
+    enum Kind { Null, String, Json } kind;
+    std::string text;
+    bool operator==(const char* s) const { return kind == String && text == s; }
 };
 
 // core/ExtractionResult.java.  Values are (present, text) because Matcher.group may return null.
@@ -56,13 +66,18 @@ public:
     const std::string& getId() const { return x_->name; }
     const std::string& getInput() const { return input_; }
     const CookedExtraction& getMatchedExtraction() const { return *x_; }
-    // id (optional) first, captures in group order; `append` extras are exposed separately as JSON
-    // (getMatchedExtraction().appendJson) because their values are typed (core/ExtractionResult.java:65-88)
-    std::vector<std::pair<std::string, std::string>> asMap(const char* idAs = nullptr) const {
-        std::vector<std::pair<std::string, std::string>> m;
-        if (idAs) m.emplace_back(idAs, x_->name);
+    // core/ExtractionResult.java:65-88 on a LinkedHashMap: the id (optional) first, every extractor name -> its text
+    // or null in group order, then the `append` entries; a key put again keeps its position and takes the new value
+    std::vector<std::pair<std::string, MapValue>> asMap(const char* idAs = nullptr) const {
+        std::vector<std::pair<std::string, MapValue>> m;
+        auto put = [&m](const std::string& key, MapValue v) {
+            for (auto& e : m) if (e.first == key) { e.second = std::move(v); return; }
+            m.emplace_back(key, std::move(v));
+        };
+        if (idAs) put(idAs, MapValue{MapValue::String, x_->name});
         for (size_t i = 0; i < values_.size(); ++i)
-            if (values_[i].first) m.emplace_back(x_->extractorNames[i], values_[i].second);
+            put(x_->extractorNames[i], values_[i].first ? MapValue{MapValue::String, values_[i].second} : MapValue{MapValue::Null, ""});
+        for (auto& kv : x_->extra) put(kv.first, MapValue{MapValue::Json, kv.second});
         return m;
     }
     bool has(size_t group) const { return group < values_.size() && values_[group].first; }
@@ -119,6 +134,17 @@ public:
                       const gx_batch_opts* opts = nullptr) const {
         int rc = gx_extract_batch(h_, bytes, offsets, n, match_id, caps, opts);
         if (rc != GX_OK) throw GorpError(rc, gx_last_error());
+    }
+    // Result materialisation for a finished batch: asMap(idAs) of every matched line as JSON Lines (gx_results_to_jsonl)
+    std::string resultsToJsonl(const uint8_t* bytes, const uint32_t* offsets, uint64_t n, const int32_t* match_id, const int32_t* caps,
+                               const char* idAs = nullptr, const gx_batch_opts* opts = nullptr) const {
+        uint64_t size = 0;
+        int rc = gx_results_to_jsonl(h_, bytes, offsets, n, match_id, caps, idAs, nullptr, 0, &size, nullptr, opts);
+        if (rc != GX_OK) throw GorpError(rc, gx_last_error());
+        std::string out(static_cast<size_t>(size), '\0');
+        rc = gx_results_to_jsonl(h_, bytes, offsets, n, match_id, caps, idAs, reinterpret_cast<uint8_t*>(&out[0]), size, &size, nullptr, opts);
+        if (rc != GX_OK) throw GorpError(rc, gx_last_error());
+        return out;
     }
     int maxGroups() const { return gx_max_groups(h_); }
     gx_handle* handle() const { return h_; }
@@ -183,6 +209,17 @@ private:
     }
 };
 
+// Line ingestion (gx_split_lines): BufferedReader.readLine() boundaries of a raw text buffer as CSR offsets; the lines
+// keep their terminators, so pass gx_batch_opts.strip_eol = 1 to extractBatch.
+inline std::vector<uint32_t> splitLines(const uint8_t* bytes, uint64_t size) {
+    std::vector<uint32_t> offsets(static_cast<size_t>(size) + 2);
+    uint64_t n = 0;
+    int rc = gx_split_lines(bytes, size, offsets.data(), size + 1, &n, nullptr, nullptr);
+    if (rc != GX_OK) throw GorpError(rc, gx_last_error());
+    offsets.resize(static_cast<size_t>(n) + 1);
+    return offsets;
+}
+
 // core/DefinitionReader.java
 class DefinitionReader {
 public:
@@ -202,6 +239,8 @@ public:
             x.name = gx_extraction_name(h, k);
             for (int32_t g = 0; gx_extractor_name(h, k, g); ++g) x.extractorNames.push_back(gx_extractor_name(h, k, g));
             if (const char* a = gx_extraction_append_json(h, k)) x.appendJson = a;
+            for (int32_t j = 0; j < gx_extraction_append_count(h, k); ++j)
+                x.extra.emplace_back(gx_extraction_append_key(h, k, j), gx_extraction_append_value_json(h, k, j));
             xs.push_back(std::move(x));
         }
         return std::unique_ptr<Gorp>(new Gorp(h, std::move(xs)));

@@ -175,12 +175,17 @@ int gx_massage_regexp_for_jdk(const char* pattern, char* out, size_t cap, size_t
 int gx_create_from_definition(const char* definition_text, const char* source_ref, uint32_t flags, gx_handle** out);
 int gx_definition_to_json(const char* definition_text, const char* source_ref, const char* stage,
                           char* out, size_t cap, size_t* out_len);
-/* Metadata of a handle built by gx_create_from_definition (NULL otherwise / out of range); strings live as long
- * as the handle.  CookedExtraction.getName() (core/model/CookedExtraction.java:36), the extractor names in
+/* Metadata of a handle built by gx_create_from_definition or completed with gx_set_extraction_meta (NULL otherwise /
+ * out of range); strings live as long as the handle (or until the next gx_set_extraction_meta).  CookedExtraction.getName() (core/model/CookedExtraction.java:36), the extractor names in
  * capture-group order (FlattenedExtraction.getExtractorNames()), and getExtra() as JSON object text. */
 const char* gx_extraction_name(const gx_handle* h, int32_t k);
 const char* gx_extractor_name(const gx_handle* h, int32_t k, int32_t g);
 const char* gx_extraction_append_json(const gx_handle* h, int32_t k);
+/* getExtra() entry by entry, in order: the key (decoded, UTF-8) and the value as JSON text (a string value keeps
+ * its quotes and escapes); count = 0 when the extraction appends nothing. */
+int32_t gx_extraction_append_count(const gx_handle* h, int32_t k);
+const char* gx_extraction_append_key(const gx_handle* h, int32_t k, int32_t j);
+const char* gx_extraction_append_value_json(const gx_handle* h, int32_t k, int32_t j);
 
 /* Thread-local message for the last failing call on this thread. */
 const char* gx_last_error(void);

@@ -51,7 +51,9 @@ int main(int argc, char** argv) {
     CHECK(result);
     CHECK(result->getId() == "single");
     auto stuff = result->asMap("id");
-    CHECK(stuff.size() == 2 && stuff[0].first == "id" && stuff[0].second == "single" && stuff[1].first == "value" && stuff[1].second == "foobar");
+    // (this DEF adds `append "marker":"EXTRACTED"` to the reference test's second extraction: one more entry, typed)
+    CHECK(stuff.size() == 3 && stuff[0].first == "id" && stuff[0].second == "single" && stuff[1].first == "value" && stuff[1].second == "foobar");
+    CHECK(stuff[2].first == "marker" && stuff[2].second.kind == MapValue::Json && stuff[2].second.text == "\"EXTRACTED\"");
     result = def->extract("prefix value=a value2=b");
     CHECK(result && result->getId() == "double");
     stuff = result->asMap("id");
@@ -70,6 +72,18 @@ int main(int argc, char** argv) {
     def->extractBatch(reinterpret_cast<const uint8_t*>(lines), off, 3, mid, caps);
     CHECK(mid[0] == 1 && mid[1] == 0 && mid[2] == -1);
     CHECK(caps[0] == 6 && caps[1] == 7 && caps[4] == 13 && caps[5] == 14 && caps[6] == 22 && caps[7] == 23);
+    // the steps either side: raw text -> lines -> extract (terminators ignored) -> JSON Lines
+    const std::string text = "value=x\r\nprefix value=a value2=b\nnope\rvalue=q\"uote";
+    auto offs = splitLines(reinterpret_cast<const uint8_t*>(text.data()), text.size());
+    CHECK(offs.size() == 5 && offs[1] == 9 && offs[2] == 33 && offs[3] == 38 && offs[4] == text.size());
+    gx_batch_opts bo{};
+    bo.struct_size = sizeof bo;
+    bo.strip_eol = 1;
+    std::vector<int32_t> m2(4), c2(4 * 4);
+    def->extractBatch(reinterpret_cast<const uint8_t*>(text.data()), offs.data(), 4, m2.data(), c2.data(), &bo);
+    CHECK(m2[0] == 1 && m2[1] == 0 && m2[2] == -1 && m2[3] == -1);   // value=q"uote: %word is letters only
+    const std::string jl = def->resultsToJsonl(reinterpret_cast<const uint8_t*>(text.data()), offs.data(), 4, m2.data(), c2.data(), "id");
+    CHECK(jl == "{\"id\":\"single\",\"value\":\"x\",\"marker\":\"EXTRACTED\"}\n{\"id\":\"double\",\"value\":\"a\",\"value2\":\"b\"}\n");
     printf("host_api_test: GPU checks ok\n");
     return 0;
 }
