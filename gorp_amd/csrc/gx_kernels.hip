@@ -575,8 +575,9 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 uint8_t* out = reinterpret_cast<uint8_t*>(caps + (cur.i - lane) * static_cast<uint64_t>(slots));
+                if (L.debug_ablate != 5)  // (timing ablation 5: no capture stores)
                 for (uint32_t c = lane; c < 4u * row_b; c += 64u)  // 64 * row_b / 16 chunks
-                    *reinterpret_cast<u32x4*>(out + (c << 4)) = *reinterpret_cast<const u32x4*>(stage + (c << 4));
+                    *reinterpret_cast<u32x4*>(out + (c << 4)) = *reinterpret_cast<const u32x4*>(stage + (c << 4));  // (nontemporal: measured slower)
                 if (lane < 16u)
                     *reinterpret_cast<u32x4*>(match_id + (cur.i - lane) + 4u * lane) = *reinterpret_cast<const u32x4*>(ids + 4u * lane);
             } else if (valid) {
