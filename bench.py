@@ -156,6 +156,7 @@ def main():
 
     # ---- final gather of results to rank 0 over xGMI (reported, not in `value`) ----
     gather_ms = None
+    gather_compact_ms = None
     if distributed and not args.no_gather:
         torch.cuda.synchronize()
         dist.barrier()
@@ -165,7 +166,16 @@ def main():
         gather_ms = (time.perf_counter() - tg) * 1e3
         if rank == 0:
             assert gm.shape[0] == n * world and torch.equal(gm[:n], mid) and torch.equal(gc[:n], caps)
-        del gm, gc
+        # the same with compact transport rows (int16 id + uint16 offsets, HIP pack/unpack kernels)
+        torch.cuda.synchronize()
+        dist.barrier()
+        tg = time.perf_counter()
+        cm, cc = gdist.gather_results_compact(mid, caps, dst=0)
+        torch.cuda.synchronize()
+        gather_compact_ms = (time.perf_counter() - tg) * 1e3
+        if rank == 0:
+            assert torch.equal(cm, gm) and torch.equal(cc, gc)
+        del gm, gc, cm, cc
 
     if rank == 0:
         steps = args.steps
@@ -217,6 +227,7 @@ def main():
             "setup_s": setup_s,
             "table_bcast_ms": bcast_ms,
             "gather_ms": gather_ms,
+            "gather_compact_ms": gather_compact_ms,
         }
         if not args.no_cpu_baseline and world == 1:
             sample = min(n, 10_000_000)

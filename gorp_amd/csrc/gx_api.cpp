@@ -617,6 +617,36 @@ int gx_results_to_jsonl(gx_handle* h, const uint8_t* bytes, const void* offsets,
     catch (std::exception& e) { return fail(GX_E_ARG, e.what()); }
 }
 
+int gx_pack_results(const int32_t* match_id, const int32_t* caps, uint64_t n, int32_t slots, uint16_t* packed, uint64_t* n_overflow,
+                    const gx_batch_opts* opts) {
+    if (slots < 0 || !n_overflow || (n && (!match_id || !packed || (slots && !caps)))) return fail(GX_E_ARG, "gx_pack_results: bad argument");
+    gx_batch_opts o{};
+    if (!read_opts(opts, &o)) return fail(GX_E_ARG, "gx_batch_opts.struct_size mismatch");
+    try {
+        hipStream_t stream = static_cast<hipStream_t>(o.stream);
+        DevBuf cnt;
+        cnt.alloc(8);
+        GX_HIP(launch_pack_results(match_id, caps, n, slots, packed, static_cast<unsigned long long*>(cnt.p), stream));
+        unsigned long long over = 0;
+        GX_HIP(hipMemcpyAsync(&over, cnt.p, 8, hipMemcpyDeviceToHost, stream));
+        GX_HIP(hipStreamSynchronize(stream));
+        *n_overflow = over;
+        return GX_OK;
+    } catch (GxError& e) { return fail(e.code, e.what()); }
+}
+
+int gx_unpack_results(const uint16_t* packed, uint64_t n, int32_t slots, int32_t* match_id, int32_t* caps, const gx_batch_opts* opts) {
+    if (slots < 0 || (n && (!match_id || !packed || (slots && !caps)))) return fail(GX_E_ARG, "gx_unpack_results: bad argument");
+    gx_batch_opts o{};
+    if (!read_opts(opts, &o)) return fail(GX_E_ARG, "gx_batch_opts.struct_size mismatch");
+    try {
+        hipStream_t stream = static_cast<hipStream_t>(o.stream);
+        GX_HIP(launch_unpack_results(packed, n, slots, match_id, caps, stream));
+        if (!o.no_sync) GX_HIP(hipStreamSynchronize(stream));
+        return GX_OK;
+    } catch (GxError& e) { return fail(e.code, e.what()); }
+}
+
 int gx_set_extraction_meta(gx_handle* h, int32_t k, const char* name, const char* const* extractor_names, int32_t n_names,
                            const char* append_json) {
     if (!h || !name || k < 0 || k >= h->T.n_rules || n_names < 0 || (n_names && !extractor_names))

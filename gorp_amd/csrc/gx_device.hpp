@@ -119,6 +119,9 @@ struct GxJsonl {
 size_t jsonl_workspace_bytes(uint64_t n);
 hipError_t launch_jsonl_sizes(const GxJsonl& tm, const GxBatch& b, int slots, int passthrough, uint64_t* line_out_off, void* workspace,
                               hipStream_t stream);
+hipError_t launch_pack_results(const int32_t* match_id, const int32_t* caps, uint64_t n, int slots, uint16_t* packed,
+                               unsigned long long* d_overflow, hipStream_t stream);
+hipError_t launch_unpack_results(const uint16_t* packed, uint64_t n, int slots, int32_t* match_id, int32_t* caps, hipStream_t stream);
 hipError_t launch_jsonl_write(const GxJsonl& tm, const GxBatch& b, int slots, int passthrough, const uint64_t* line_out_off, uint8_t* out,
                               hipStream_t stream);
 

@@ -355,6 +355,61 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_write(const uint32_t* __r
 
 }  // namespace
 
+// ---- compact result rows for transport (the gather payload) ----
+// row = [match id as int16][2 * Gmax offsets as uint16, 0xFFFF = unset]: 2 + 4 * Gmax bytes per line instead of
+// 4 + 8 * Gmax.  Offsets above 65534 do not fit: such lines are counted and the caller sends the batch wide.
+namespace {
+__global__ void __launch_bounds__(256) k_pack_results(const int32_t* __restrict__ match_id, const int32_t* __restrict__ caps, uint64_t n, int slots,
+                                                     uint16_t* __restrict__ packed, unsigned long long* __restrict__ n_overflow) {
+    const uint64_t width = static_cast<uint64_t>(slots) + 1;
+    const uint64_t total = n * width;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    uint32_t over = 0;
+    for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const uint64_t line = t / width;
+        const uint32_t col = static_cast<uint32_t>(t - line * width);
+        int32_t v;
+        if (col == 0) v = match_id[line];
+        else {
+            v = caps[line * static_cast<uint64_t>(slots) + (col - 1)];
+            if (v > 65534) { over = 1; v = 65534; }
+        }
+        packed[t] = static_cast<uint16_t>(v);  // -1 -> 0xFFFF; match ids are >= -32768 (at most 32767 extractions)
+    }
+    if (over) atomicAdd(n_overflow, 1ull);
+}
+__global__ void __launch_bounds__(256) k_unpack_results(const uint16_t* __restrict__ packed, uint64_t n, int slots, int32_t* __restrict__ match_id,
+                                                       int32_t* __restrict__ caps) {
+    const uint64_t width = static_cast<uint64_t>(slots) + 1;
+    const uint64_t total = n * width;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const uint64_t line = t / width;
+        const uint32_t col = static_cast<uint32_t>(t - line * width);
+        const uint16_t v = packed[t];
+        if (col == 0) match_id[line] = static_cast<int16_t>(v);
+        else caps[line * static_cast<uint64_t>(slots) + (col - 1)] = v == 0xFFFFu ? -1 : static_cast<int32_t>(v);
+    }
+}
+}  // namespace
+
+hipError_t launch_pack_results(const int32_t* match_id, const int32_t* caps, uint64_t n, int slots, uint16_t* packed,
+                               unsigned long long* d_overflow, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(d_overflow, 0, 8, stream);
+    if (e != hipSuccess || n == 0) return e;
+    uint64_t blocks = (n * (static_cast<uint64_t>(slots) + 1) + 255) / 256;
+    if (blocks > 256u * 64u) blocks = 256u * 64u;
+    hipLaunchKernelGGL(k_pack_results, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, match_id, caps, n, slots, packed, d_overflow);
+    return hipGetLastError();
+}
+hipError_t launch_unpack_results(const uint16_t* packed, uint64_t n, int slots, int32_t* match_id, int32_t* caps, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n * (static_cast<uint64_t>(slots) + 1) + 255) / 256;
+    if (blocks > 256u * 64u) blocks = 256u * 64u;
+    hipLaunchKernelGGL(k_unpack_results, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, packed, n, slots, match_id, caps);
+    return hipGetLastError();
+}
+
 size_t jsonl_workspace_bytes(uint64_t n) {
     const uint64_t nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     return static_cast<size_t>(n * 4 + (nblocks + 2) * 8 + 64);

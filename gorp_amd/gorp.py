@@ -437,6 +437,25 @@ def split_lines(data, cap_lines=None, offsets_dtype=np.uint32, want_flags=False)
     return offsets[:n.value + 1], (flags[:n.value] if want_flags else None)
 
 
+def pack_results_device(match_id_ptr, caps_ptr, n, slots, packed_ptr, stream=None):
+    """gx_pack_results: int32 rows -> [int16 id, uint16 offsets] rows on the device; returns the overflow count."""
+    o = N.gx_batch_opts()
+    o.struct_size = C.sizeof(N.gx_batch_opts)
+    o.device_pointers = 1
+    o.stream = stream
+    over = C.c_uint64(0)
+    _check(N.lib().gx_pack_results(match_id_ptr, caps_ptr, n, slots, packed_ptr, C.byref(over), C.byref(o)))
+    return over.value
+
+
+def unpack_results_device(packed_ptr, n, slots, match_id_ptr, caps_ptr, stream=None):
+    o = N.gx_batch_opts()
+    o.struct_size = C.sizeof(N.gx_batch_opts)
+    o.device_pointers = 1
+    o.stream = stream
+    _check(N.lib().gx_unpack_results(packed_ptr, n, slots, match_id_ptr, caps_ptr, C.byref(o)))
+
+
 def split_lines_device(data_ptr, size, offsets_ptr, cap_lines, flags_ptr=None, offsets64=False, stream=None):
     """gx_split_lines on device buffers (ints, e.g. torch data_ptr()); returns the number of lines."""
     o = N.gx_batch_opts()

@@ -136,6 +136,16 @@ int gx_results_to_jsonl(gx_handle* h, const uint8_t* bytes, const void* offsets,
                         const int32_t* caps, const char* id_as, uint8_t* out, uint64_t out_cap, uint64_t* out_size,
                         uint64_t* line_out_offsets, const gx_batch_opts* opts);
 
+/* Compact result rows for transport between GPUs (the gather of SURVEY.md section 8(e)): per line one int16 match id
+ * followed by `slots` (= 2 * gx_max_groups) uint16 offsets, 0xFFFF = unset: 2 + 2*slots bytes instead of 4 + 4*slots.
+ * Device buffers only.  *n_overflow (host) receives the number of offsets above 65534, which do not fit (they are
+ * stored saturated): when it is not 0 the caller sends that batch in the wide format.  gx_unpack_results is the
+ * inverse.  Both run on the stream in opts (NULL = the null stream); pack synchronises it to read the counter. */
+int gx_pack_results(const int32_t* match_id, const int32_t* caps, uint64_t n, int32_t slots, uint16_t* packed,
+                    uint64_t* n_overflow, const gx_batch_opts* opts);
+int gx_unpack_results(const uint16_t* packed, uint64_t n, int32_t slots, int32_t* match_id, int32_t* caps,
+                      const gx_batch_opts* opts);
+
 /* Names for a handle built from regex strings (the caller did DefinitionReader's work itself and holds the
  * CookedExtraction data, core/model/CookedExtraction.java:18-66): extraction name, extractor names in group
  * order (n_names == gx_num_groups(h, k)), and the `append` object as JSON text (NULL = none). */

@@ -399,3 +399,51 @@ def test_mixed_lengths_take_several_rounds_per_group(tier, monkeypatch):
     assert len(set(mid.tolist())) == 4
     m2, _ = gorp.extract_batch(*lines_to_csr(lines), match_only=True)
     assert np.array_equal(m2, mid)
+
+
+def test_compact_result_rows_roundtrip_and_gather():
+    """gx_pack_results / gx_unpack_results (the gather payload) and dist.gather_results_compact on a 1-rank RCCL group."""
+    import torch
+    from gorp_amd.gorp import pack_results_device, unpack_results_device
+    rng = np.random.default_rng(3)
+    n, slots = 100_003, 8
+    mid = rng.integers(-40, 300, size=n).astype(np.int32)
+    mid[:4] = [-32768, 32767, -1, -2]
+    caps = rng.integers(-1, 65535, size=(n, slots)).astype(np.int32)   # -1 .. 65534
+    m, c = torch.from_numpy(mid).cuda(), torch.from_numpy(caps).cuda()
+    packed = torch.empty((n, slots + 1), dtype=torch.int16, device="cuda")
+    assert pack_results_device(m.data_ptr(), c.data_ptr(), n, slots, packed.data_ptr()) == 0
+    m2 = torch.empty_like(m); c2 = torch.empty_like(c)
+    unpack_results_device(packed.data_ptr(), n, slots, m2.data_ptr(), c2.data_ptr())
+    assert torch.equal(m, m2) and torch.equal(c, c2)
+    c[5, 3] = 65535
+    c[77, 0] = 1 << 20
+    assert pack_results_device(m.data_ptr(), c.data_ptr(), n, slots, packed.data_ptr()) > 0   # does not fit: caller goes wide
+    # the gather itself, one rank over RCCL
+    import torch.distributed as dist
+    from gorp_amd import dist as gdist
+    import os
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        c[5, 3] = 7; c[77, 0] = 9
+        gm, gc = gdist.gather_results_compact(m, c, dst=0)
+        assert torch.equal(gm, m) and torch.equal(gc, c)
+        c[77, 0] = 1 << 20   # overflow: falls back to the wide rows
+        gm, gc = gdist.gather_results_compact(m, c, dst=0)
+        assert torch.equal(gm, m) and torch.equal(gc, c)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_gpu():
+    """The N > 1 plumbing on device tensors (see tests/dist_gpu_worker.py)."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "tests", "dist_gpu_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "dist_gpu_worker ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
