@@ -44,6 +44,8 @@ class gx_batch_opts(C.Structure):
         ("line_bytes_hint", C.c_uint32),
         ("strip_eol", C.c_uint32),
         ("utf8_passthrough", C.c_uint32),
+        ("utf16", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 

@@ -443,12 +443,12 @@ int64_t gx_stat(const gx_handle* h, int32_t which) {
     }
 }
 
-// Accepts the current gx_batch_opts and the shorter first version of it (struct_size says which).
+// Accepts the current gx_batch_opts and every earlier, shorter layout of it (struct_size says which).
 static bool read_opts(const gx_batch_opts* opts, gx_batch_opts* o) {
     *o = gx_batch_opts{};
     if (!opts) return true;
-    const size_t v1 = offsetof(gx_batch_opts, strip_eol);
-    if (opts->struct_size != sizeof(gx_batch_opts) && opts->struct_size != v1) return false;
+    const size_t v1 = offsetof(gx_batch_opts, strip_eol);  // the first layout; later ones only appended fields
+    if (opts->struct_size < v1 || opts->struct_size > sizeof(gx_batch_opts) || (opts->struct_size & 3u)) return false;
     memcpy(o, opts, opts->struct_size);
     return true;
 }
@@ -680,7 +680,8 @@ int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, ui
         hipStream_t stream = static_cast<hipStream_t>(o.stream);
         GxBatch b{};
         b.n = n;
-        b.wide = 0;
+        b.wide = o.utf16 ? 1 : 0;
+        const size_t unit = o.utf16 ? 2 : 1;  // bytes per code unit
         b.offsets64 = o.offsets64 ? 1 : 0;
         b.match_only = match_only ? 1 : 0;
         b.strip_eol = o.strip_eol ? 1 : 0;
@@ -713,9 +714,9 @@ int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, ui
         uint32_t hint = o.line_bytes_hint;
         if (hint == 0 && n) hint = static_cast<uint32_t>((total + n - 1) / n);
         DevBuf d_bytes, d_off, d_mid, d_caps;
-        d_bytes.alloc(total); d_off.alloc((n + 1) * off_w); d_mid.alloc(n * 4);
+        d_bytes.alloc(total * unit); d_off.alloc((n + 1) * off_w); d_mid.alloc(n * 4);
         if (!match_only) d_caps.alloc(n * slots * 4);
-        if (total) GX_HIP(hipMemcpyAsync(d_bytes.p, bytes, total, hipMemcpyHostToDevice, stream));
+        if (total) GX_HIP(hipMemcpyAsync(d_bytes.p, bytes, total * unit, hipMemcpyHostToDevice, stream));
         GX_HIP(hipMemcpyAsync(d_off.p, offsets, (n + 1) * off_w, hipMemcpyHostToDevice, stream));
         b.data = d_bytes.p; b.offsets = d_off.p; b.match_id = static_cast<int32_t*>(d_mid.p);
         b.caps = match_only ? nullptr : static_cast<int32_t*>(d_caps.p);

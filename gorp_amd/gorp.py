@@ -377,9 +377,11 @@ class Gorp:
 
     # -- batch API -----------------------------------------------------------
     def extract_batch(self, data, offsets, match_only=False, strip_eol=False):
-        """Host buffers: data uint8[total], offsets uint32|uint64[n+1].
+        """Host buffers: data uint8[total] (Latin-1 code units) or uint16[total] (UTF-16 code units),
+        offsets uint32|uint64[n+1] in code units.
         Returns (match_id int32[n], caps int32[n, 2*max_groups])."""
-        data = np.ascontiguousarray(data, dtype=np.uint8)
+        utf16 = getattr(data, "dtype", None) == np.uint16
+        data = np.ascontiguousarray(data, dtype=np.uint16 if utf16 else np.uint8)
         offsets = np.ascontiguousarray(offsets)
         if offsets.dtype not in (np.uint32, np.uint64):
             raise TypeError("offsets must be uint32 or uint64")
@@ -391,6 +393,7 @@ class Gorp:
         o.offsets64 = 1 if offsets.dtype == np.uint64 else 0
         o.match_only = 1 if match_only else 0
         o.strip_eol = 1 if strip_eol else 0
+        o.utf16 = 1 if utf16 else 0
         _check(N.lib().gx_extract_batch(self._h.ptr, data.ctypes.data if data.size else None, offsets.ctypes.data, n,
                                         mid.ctypes.data, caps.ctypes.data if caps.size else None, C.byref(o)))
         return mid, caps

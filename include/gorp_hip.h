@@ -98,6 +98,12 @@ typedef struct gx_batch_opts {
     uint32_t utf8_passthrough; /* gx_results_to_jsonl only.  0: line bytes are Latin-1 code units (the batch path's input
                                   model) and bytes >= 0x80 leave as two-byte UTF-8; 1: copy them unchanged (the
                                   input was UTF-8 all along and the patterns only look at its ASCII structure) */
+    uint32_t utf16;            /* gx_extract_batch only.  1: `bytes` holds UTF-16 code units (uint16_t, host byte order), exactly
+                                  the chars of the Java Strings, and offsets count code units.  For the lines that
+                                  gx_split_lines flags as non-ASCII once the caller has decoded them.  Runs on the
+                                  per-line kernel (no LDS staging). */
+    uint32_t reserved;         /* 0.  (New fields are only ever appended: a caller compiled against an older, shorter
+                                  layout passes its own struct_size and keeps working.) */
 } gx_batch_opts;
 
 /* Replaces the per-line loop "for each line: Gorp.extract(line)"

@@ -447,3 +447,23 @@ def test_two_ranks_share_one_gpu():
            "--master-port", "29533", os.path.join(root, "tests", "dist_gpu_worker.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0 and "dist_gpu_worker ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_utf16_batch_input():
+    """gx_batch_opts.utf16: the batch entry point over UTF-16 code units (what the Java Strings hold)."""
+    definition = [FlattenedExtraction("kv", [["text", "k="], ["extractor", "v", [["pattern", "[^ ]+"]]], ["pattern", "( .*)?"]]),
+                  FlattenedExtraction("cjk", [["extractor", "w", [["pattern", "[一-鿿]+"]]], ["text", "!"]])]
+    gorp, orc = Gorp.construct(definition), oracle_for(definition)
+    lines = ["k=中文é rest", "中文!", "k=plain", "", "k=\U0001F600x", "nope", "k=" + "é" * 300, "中" * 70 + "!"]
+    units = [np.frombuffer(s.encode("utf-16-le"), dtype=np.uint16) for s in lines]
+    data = np.concatenate(units) if units else np.zeros(0, np.uint16)
+    offsets = np.zeros(len(lines) + 1, np.uint32)
+    offsets[1:] = np.cumsum([len(u) for u in units])
+    mid, caps = gorp.extract_batch(data, offsets)
+    assert mid.tolist() == [0, 1, 0, -1, 0, -1, 0, 1]
+    for i, s in enumerate(lines):
+        om, oc = orc.extract(s)
+        flat = [v for g in oc for v in (g if g is not None else (-1, -1))]
+        assert mid[i] == om and caps[i].tolist()[:len(flat)] == flat, (s, mid[i], om, caps[i], oc)
+    m2, _ = gorp.extract_batch(data, offsets, match_only=True)
+    assert m2.tolist() == mid.tolist()
