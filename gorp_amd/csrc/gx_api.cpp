@@ -559,6 +559,9 @@ static const GxJsonl& jsonl_templates(gx_handle* h, const char* id_as) {
     ji.dev.group = reinterpret_cast<const int32_t*>(base + o_g);
     ji.dev.fixed_len = reinterpret_cast<const uint32_t*>(base + o_f);
     ji.dev.lits = base + o_l;
+    ji.dev.lits_bytes = static_cast<uint32_t>(lits.size());
+    ji.dev.n_rules = static_cast<uint32_t>(T.n_rules);
+    ji.dev.n_segs = static_cast<uint32_t>(group.size());
     return h->jsonl.emplace(key, ji).first->second.dev;
 }
 
@@ -598,7 +601,20 @@ int gx_results_to_jsonl(gx_handle* h, const uint8_t* bytes, const void* offsets,
             b.data = d_bytes.p; b.offsets = d_off.p; b.match_id = static_cast<int32_t*>(d_mid.p); b.caps = static_cast<int32_t*>(d_caps.p);
             loff = static_cast<uint64_t*>(d_loff.p);
         }
-        GX_HIP(launch_jsonl_sizes(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, loff, ws.p, stream));
+        // mean line length, for the LDS staging of the kernels (device pointers: from the two ends of the offsets array)
+        uint64_t first_off = 0, last_off = 0;
+        if (n) {
+            if (o.device_pointers) {
+                GX_HIP(hipMemcpyAsync(&first_off, offsets, off_w, hipMemcpyDeviceToHost, stream));
+                GX_HIP(hipMemcpyAsync(&last_off, static_cast<const uint8_t*>(offsets) + n * off_w, off_w, hipMemcpyDeviceToHost, stream));
+                GX_HIP(hipStreamSynchronize(stream));
+            } else {
+                first_off = o.offsets64 ? static_cast<const uint64_t*>(offsets)[0] : static_cast<const uint32_t*>(offsets)[0];
+                last_off = o.offsets64 ? static_cast<const uint64_t*>(offsets)[n] : static_cast<const uint32_t*>(offsets)[n];
+            }
+        }
+        const uint32_t mean_in = n ? static_cast<uint32_t>(std::min<uint64_t>((last_off - first_off + n - 1) / n, 1u << 20)) : 1u;
+        GX_HIP(launch_jsonl_sizes(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, mean_in, loff, ws.p, stream));
         uint64_t total = 0;
         GX_HIP(hipMemcpyAsync(&total, loff + n, 8, hipMemcpyDeviceToHost, stream));
         GX_HIP(hipStreamSynchronize(stream));
@@ -608,7 +624,8 @@ int gx_results_to_jsonl(gx_handle* h, const uint8_t* bytes, const void* offsets,
         if (total > out_cap) return fail(GX_E_LIMIT, "gx_results_to_jsonl: out_cap is smaller than the text (see *out_size)");
         uint8_t* dst = out;
         if (!o.device_pointers) { d_out.alloc(total); dst = static_cast<uint8_t*>(d_out.p); }
-        GX_HIP(launch_jsonl_write(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, loff, dst, stream));
+        const uint32_t mean_out = n ? static_cast<uint32_t>(std::min<uint64_t>((total + n - 1) / n, 1u << 20)) : 1u;
+        GX_HIP(launch_jsonl_write(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, mean_in, mean_out, loff, dst, stream));
         if (!o.device_pointers && total) GX_HIP(hipMemcpyAsync(out, dst, total, hipMemcpyDeviceToHost, stream));
         GX_HIP(hipStreamSynchronize(stream));
         return GX_OK;

@@ -115,14 +115,16 @@ struct GxJsonl {
     const int32_t* group;       // [n_segs]
     const uint32_t* fixed_len;  // [n_rules] sum of the template's literal lengths
     const uint8_t* lits;
+    uint32_t lits_bytes, n_rules, n_segs;
 };
 size_t jsonl_workspace_bytes(uint64_t n);
-hipError_t launch_jsonl_sizes(const GxJsonl& tm, const GxBatch& b, int slots, int passthrough, uint64_t* line_out_off, void* workspace,
-                              hipStream_t stream);
+// mean_in / mean_out: mean bytes per line of input and of output text; they size the LDS staging of the tile kernels
+hipError_t launch_jsonl_sizes(const GxJsonl& tm, const GxBatch& b, int slots, int passthrough, uint32_t mean_in, uint64_t* line_out_off,
+                              void* workspace, hipStream_t stream);
 hipError_t launch_pack_results(const int32_t* match_id, const int32_t* caps, uint64_t n, int slots, uint16_t* packed,
                                unsigned long long* d_overflow, hipStream_t stream);
 hipError_t launch_unpack_results(const uint16_t* packed, uint64_t n, int slots, int32_t* match_id, int32_t* caps, hipStream_t stream);
-hipError_t launch_jsonl_write(const GxJsonl& tm, const GxBatch& b, int slots, int passthrough, const uint64_t* line_out_off, uint8_t* out,
-                              hipStream_t stream);
+hipError_t launch_jsonl_write(const GxJsonl& tm, const GxBatch& b, int slots, int passthrough, uint32_t mean_in, uint32_t mean_out,
+                              const uint64_t* line_out_off, uint8_t* out, hipStream_t stream);
 
 }  // namespace gx

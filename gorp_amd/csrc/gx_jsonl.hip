@@ -10,6 +10,7 @@
 // One wave per line, one lane per byte: pass 1 sums the escaped lengths, an exclusive scan turns the sizes into
 // output offsets, pass 2 writes.  Bytes are Latin-1 code units
 // (the batch path's input model) and leave as UTF-8; with utf8_passthrough the bytes >= 0x80 are copied as they are (input that was UTF-8 all along).
+#include <algorithm>
 #include <cstdint>
 #include <hip/hip_runtime.h>
 
@@ -132,139 +133,360 @@ __device__ __forceinline__ LineSegs load_line_segs(const JsonlTemplates& tm, con
     return L;
 }
 
-// One wave per line.  Pass 1: sizes[i] = bytes of line i's JSON text (0 for lines without a match).  One sweep
-// over the line: byte p contributes esc_len(p) once per template group that covers it (nested extractors repeat
-// their bytes).
-template <typename OFF>
-__global__ void __launch_bounds__(256) k_jsonl_sizes(JsonlTemplates tm, const uint8_t* __restrict__ data, const OFF* __restrict__ off, uint64_t n,
-                                                    const int32_t* __restrict__ match_id, const int32_t* __restrict__ caps, int slots,
-                                                    int passthrough, uint32_t* __restrict__ sizes) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t wave = static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + uni(threadIdx.x >> 6);
-    const uint64_t nwaves = static_cast<uint64_t>(gridDim.x) * (blockDim.x >> 6);
-    const bool pt = passthrough != 0;
-    for (uint64_t i = wave; i < n; i += nwaves) {
-        const uint64_t line_off = static_cast<uint64_t>(off[i]);  // issued with round 1
-        const LineSegs L = load_line_segs(tm, match_id, caps, slots, i, lane);
-        if (L.k < 0) {
-            if (lane == 0) sizes[i] = 0;
-            continue;
+// One line, the whole wave (the fallback of the tile kernels for a line that does not fit their LDS staging, and
+// the path for templates with more than 64 segments).  Returns the bytes of line i's JSON text (0: no match); one
+// sweep over the line: byte p contributes esc_len(p) once per template group that covers it (nested extractors
+// repeat their bytes).
+__device__ uint32_t line_size_wave(const JsonlTemplates& tm, const uint8_t* __restrict__ data, uint64_t line_off, uint64_t i,
+                                   const int32_t* __restrict__ match_id, const int32_t* __restrict__ caps, int slots, bool pt, uint32_t lane) {
+    const LineSegs L = load_line_segs(tm, match_id, caps, slots, i, lane);
+    if (L.k < 0) return 0u;
+    const uint8_t* line = data + line_off;
+    uint32_t mine = 0;
+    if (L.nseg <= 64u) {
+        // quotes / "null", and the span of the line that any group touches
+        mine = L.g < 0 ? 0u : (L.b < 0 ? 4u : 2u);
+        int32_t lo = 0x7FFFFFFF, hi = 0;
+        for (uint32_t s = 0; s < L.nseg; ++s) {
+            const int32_t b = lane_of(L.b, s), e = lane_of(L.e, s);
+            if (b >= 0) { lo = min(lo, b); hi = max(hi, e); }
         }
-        const uint8_t* line = data + uni(line_off);
-        uint32_t mine = 0;
-        if (L.nseg <= 64u) {
-            // quotes / "null", and the span of the line that any group touches
-            mine = L.g < 0 ? 0u : (L.b < 0 ? 4u : 2u);
-            int32_t lo = 0x7FFFFFFF, hi = 0;
-            for (uint32_t s = 0; s < L.nseg; ++s) {
-                const int32_t b = lane_of(L.b, s), e = lane_of(L.e, s);
-                if (b >= 0) { lo = min(lo, b); hi = max(hi, e); }
-            }
-            for (int32_t c0 = lo; c0 < hi; c0 += 64) {
-                const int32_t p = c0 + static_cast<int32_t>(lane);
-                const uint32_t el = p < hi ? esc_len(line[p], pt) : 0u;
-                uint32_t cover = 0;
-                for (uint32_t s = 0; s < L.nseg; ++s) cover += (p >= lane_of(L.b, s) && p < lane_of(L.e, s)) ? 1u : 0u;  // b < 0: e < 0 too
-                mine += el * cover;
-            }
-        } else {
-            // (templates with more than 64 segments: the plain loop, one segment after the other)
-            const int32_t* cp = caps + i * static_cast<uint64_t>(slots);
-            const uint32_t s0 = uni(tm.seg_off[L.k]);
-            for (uint32_t s = s0; s < s0 + L.nseg; ++s) {
-                const int32_t g = uni(tm.group[s]);
-                if (g < 0) continue;
-                const int32_t b = uni(cp[2 * g]), e = uni(cp[2 * g + 1]);
-                if (b < 0) { if (lane == 0) mine += 4u; continue; }
-                if (lane == 0) mine += 2u;
-                for (int32_t p = b + static_cast<int32_t>(lane); p < e; p += 64) mine += esc_len(line[p], pt);
-            }
+        for (int32_t c0 = lo; c0 < hi; c0 += 64) {
+            const int32_t p = c0 + static_cast<int32_t>(lane);
+            const uint32_t el = p < hi ? esc_len(line[p], pt) : 0u;
+            uint32_t cover = 0;
+            for (uint32_t s = 0; s < L.nseg; ++s) cover += (p >= lane_of(L.b, s) && p < lane_of(L.e, s)) ? 1u : 0u;  // b < 0: e < 0 too
+            mine += el * cover;
         }
-        const uint32_t total = L.fixed + wave_sum(mine);
-        if (lane == 0) sizes[i] = total;
-    }
-}
-
-// Pass 2: the text goes to out + out_off[i].  The line's output is a flat sequence of items -- literal bytes,
-// quotes, the letters of null, capture bytes -- in output order; the wave takes 64 items at a time: each lane
-// finds its item's segment, loads its one source byte (all 64 loads are independent), and a running wave scan
-// of the escaped lengths gives every item its place.
-template <typename OFF>
-__global__ void __launch_bounds__(256) k_jsonl_write(JsonlTemplates tm, const uint8_t* __restrict__ data, const OFF* __restrict__ off, uint64_t n,
-                                                    const int32_t* __restrict__ match_id, const int32_t* __restrict__ caps, int slots,
-                                                    int passthrough, const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t wave = static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + uni(threadIdx.x >> 6);
-    const uint64_t nwaves = static_cast<uint64_t>(gridDim.x) * (blockDim.x >> 6);
-    const bool pt = passthrough != 0;
-    for (uint64_t i = wave; i < n; i += nwaves) {
-        const uint64_t line_off = static_cast<uint64_t>(off[i]);  // issued with round 1
-        const uint64_t o0v = out_off[i];
-        const LineSegs L = load_line_segs(tm, match_id, caps, slots, i, lane);
-        if (L.k < 0) continue;
-        const uint8_t* line = data + uni(line_off);
-        uint8_t* dst = out + uni(o0v);
-        if (L.nseg <= 64u) {
-            const uint32_t cnt = L.ll + (L.g < 0 ? 0u : (L.b < 0 ? 4u : static_cast<uint32_t>(L.e - L.b) + 2u));
-            const uint32_t item_end = wave_inclusive(cnt, lane);
-            const uint32_t item_start = item_end - cnt;
-            const uint32_t items = uni(static_cast<uint32_t>(__shfl(static_cast<int>(item_end), 63)));
-            uint32_t running = 0;
-            for (uint32_t c0 = 0; c0 < items; c0 += 64u) {
-                const uint32_t t = c0 + lane;
-                const bool valid = t < items;
-                uint32_t seg = 0;
-                for (uint32_t s = 0; s + 1 < L.nseg; ++s) seg += t >= static_cast<uint32_t>(lane_of(static_cast<int32_t>(item_end), s)) ? 1u : 0u;
-                const uint32_t u = t - static_cast<uint32_t>(__shfl(static_cast<int>(item_start), static_cast<int>(seg)));
-                const uint32_t sll = static_cast<uint32_t>(__shfl(static_cast<int>(L.ll), static_cast<int>(seg)));
-                const uint32_t slo = static_cast<uint32_t>(__shfl(static_cast<int>(L.lo), static_cast<int>(seg)));
-                const int32_t sb = __shfl(L.b, static_cast<int>(seg)), se = __shfl(L.e, static_cast<int>(seg));
-                const bool is_lit = u < sll;
-                const uint32_t u2 = u - sll;  // position inside the capture's text: quote, bytes, quote -- or n,u,l,l
-                const bool is_byte = !is_lit && sb >= 0 && u2 != 0u && u2 != static_cast<uint32_t>(se - sb) + 1u;
-                const uint8_t* src = is_byte ? line + (sb + static_cast<int32_t>(u2) - 1) : tm.lits + (is_lit ? slo + u : 0u);
-                uint32_t v = valid ? *src : 0u;
-                if (!is_lit && !is_byte) v = sb < 0 ? static_cast<uint32_t>("null"[u2 & 3u]) : 0x22u;
-                const uint32_t el = !valid ? 0u : (is_byte ? esc_len(v, pt) : 1u);
-                const uint32_t inc = wave_inclusive(el, lane);
-                uint8_t* at = dst + (running + inc - el);
-                if (valid) {
-                    if (is_byte) esc_write(at, v, pt);
-                    else at[0] = static_cast<uint8_t>(v);
-                }
-                running += uni(static_cast<uint32_t>(__shfl(static_cast<int>(inc), 63)));
-            }
-            continue;
-        }
+    } else {
         // (templates with more than 64 segments: the plain loop, one segment after the other)
         const int32_t* cp = caps + i * static_cast<uint64_t>(slots);
         const uint32_t s0 = uni(tm.seg_off[L.k]);
         for (uint32_t s = s0; s < s0 + L.nseg; ++s) {
-            const uint8_t* lit = tm.lits + uni(tm.lit_off[s]);
-            const uint32_t ll = uni(tm.lit_len[s]);
-            for (uint32_t q = lane; q < ll; q += 64u) dst[q] = lit[q];
-            dst += ll;
             const int32_t g = uni(tm.group[s]);
             if (g < 0) continue;
             const int32_t b = uni(cp[2 * g]), e = uni(cp[2 * g + 1]);
-            if (b < 0) {
-                if (lane < 4u) dst[lane] = "null"[lane];
-                dst += 4;
+            if (b < 0) { if (lane == 0) mine += 4u; continue; }
+            if (lane == 0) mine += 2u;
+            for (int32_t p = b + static_cast<int32_t>(lane); p < e; p += 64) mine += esc_len(line[p], pt);
+        }
+    }
+    return L.fixed + wave_sum(mine);
+}
+
+// Pass 2 for one line, the whole wave: the text goes to dst.  The line's output is a flat sequence of items --
+// literal bytes, quotes, the letters of null, capture bytes -- in output order; the wave takes 64 items at a
+// time: each lane finds its item's segment, loads its one source byte (all 64 loads are independent), and a
+// running wave scan of the escaped lengths gives every item its place.
+__device__ void line_write_wave(const JsonlTemplates& tm, const uint8_t* __restrict__ data, uint64_t line_off, uint64_t i,
+                                const int32_t* __restrict__ match_id, const int32_t* __restrict__ caps, int slots, bool pt, uint32_t lane,
+                                uint8_t* dst) {
+    const LineSegs L = load_line_segs(tm, match_id, caps, slots, i, lane);
+    if (L.k < 0) return;
+    const uint8_t* line = data + line_off;
+    if (L.nseg <= 64u) {
+        const uint32_t cnt = L.ll + (L.g < 0 ? 0u : (L.b < 0 ? 4u : static_cast<uint32_t>(L.e - L.b) + 2u));
+        const uint32_t item_end = wave_inclusive(cnt, lane);
+        const uint32_t item_start = item_end - cnt;
+        const uint32_t items = uni(static_cast<uint32_t>(__shfl(static_cast<int>(item_end), 63)));
+        uint32_t running = 0;
+        for (uint32_t c0 = 0; c0 < items; c0 += 64u) {
+            const uint32_t t = c0 + lane;
+            const bool valid = t < items;
+            uint32_t seg = 0;
+            for (uint32_t s = 0; s + 1 < L.nseg; ++s) seg += t >= static_cast<uint32_t>(lane_of(static_cast<int32_t>(item_end), s)) ? 1u : 0u;
+            const uint32_t u = t - static_cast<uint32_t>(__shfl(static_cast<int>(item_start), static_cast<int>(seg)));
+            const uint32_t sll = static_cast<uint32_t>(__shfl(static_cast<int>(L.ll), static_cast<int>(seg)));
+            const uint32_t slo = static_cast<uint32_t>(__shfl(static_cast<int>(L.lo), static_cast<int>(seg)));
+            const int32_t sb = __shfl(L.b, static_cast<int>(seg)), se = __shfl(L.e, static_cast<int>(seg));
+            const bool is_lit = u < sll;
+            const uint32_t u2 = u - sll;  // position inside the capture's text: quote, bytes, quote -- or n,u,l,l
+            const bool is_byte = !is_lit && sb >= 0 && u2 != 0u && u2 != static_cast<uint32_t>(se - sb) + 1u;
+            const uint8_t* src = is_byte ? line + (sb + static_cast<int32_t>(u2) - 1) : tm.lits + (is_lit ? slo + u : 0u);
+            uint32_t v = valid ? *src : 0u;
+            if (!is_lit && !is_byte) v = sb < 0 ? static_cast<uint32_t>("null"[u2 & 3u]) : 0x22u;
+            const uint32_t el = !valid ? 0u : (is_byte ? esc_len(v, pt) : 1u);
+            const uint32_t inc = wave_inclusive(el, lane);
+            uint8_t* at = dst + (running + inc - el);
+            if (valid) {
+                if (is_byte) esc_write(at, v, pt);
+                else at[0] = static_cast<uint8_t>(v);
+            }
+            running += uni(static_cast<uint32_t>(__shfl(static_cast<int>(inc), 63)));
+        }
+        return;
+    }
+    // (templates with more than 64 segments: the plain loop, one segment after the other)
+    const int32_t* cp = caps + i * static_cast<uint64_t>(slots);
+    const uint32_t s0 = uni(tm.seg_off[L.k]);
+    for (uint32_t s = s0; s < s0 + L.nseg; ++s) {
+        const uint8_t* lit = tm.lits + uni(tm.lit_off[s]);
+        const uint32_t ll = uni(tm.lit_len[s]);
+        for (uint32_t q = lane; q < ll; q += 64u) dst[q] = lit[q];
+        dst += ll;
+        const int32_t g = uni(tm.group[s]);
+        if (g < 0) continue;
+        const int32_t b = uni(cp[2 * g]), e = uni(cp[2 * g + 1]);
+        if (b < 0) {
+            if (lane < 4u) dst[lane] = "null"[lane];
+            dst += 4;
+            continue;
+        }
+        if (lane == 0) dst[0] = '"';
+        ++dst;
+        for (int32_t c0 = b; c0 < e; c0 += 64) {
+            const int32_t p = c0 + static_cast<int32_t>(lane);
+            const bool in = p < e;
+            const uint32_t v = in ? line[p] : 0u;
+            const uint32_t el = in ? esc_len(v, pt) : 0u;
+            const uint32_t inc = wave_inclusive(el, lane);
+            if (in) esc_write(dst + (inc - el), v, pt);
+            dst += uni(static_cast<uint32_t>(__shfl(static_cast<int>(inc), 63)));
+        }
+        if (lane == 0) dst[0] = '"';
+        ++dst;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Tile kernels: one wave per 64 consecutive lines, one lane per line
+// ---------------------------------------------------------------------------
+// With one line per wave nearly all of the ~300-500 vector instructions per line are wave-uniform bookkeeping.
+// Here, as in the extraction kernel, a wave stages the contiguous bytes of 64 lines in LDS with coalesced
+// 16-byte loads and every lane then works through its own line (template, capture offsets, escapes).  The write
+// pass assembles the tile's output -- also one contiguous span -- in LDS and flushes it with 16-byte stores.
+// A group of lines that does not fit the staging areas is taken in several rounds of consecutive lanes; a
+// single line that does not fit goes through line_size_wave / line_write_wave.
+extern __shared__ __attribute__((aligned(16))) uint8_t jx_smem[];
+
+struct JsonlTileCfg {
+    uint32_t lits_lds;    // LDS offset of a copy of tm.lits, or 0xFFFFFFFF: read them from global memory
+    uint32_t lits_bytes;
+    uint32_t waves;       // per workgroup
+    uint32_t in_bytes;    // per-wave staging of line bytes (multiple of 16)
+    uint32_t out_bytes;   // per-wave staging of output text (multiple of 16; 0 in the sizes pass)
+    uint32_t stage0;      // LDS offset of wave 0's areas
+    uint32_t tm_lds;      // LDS offset of a copy of the template arrays (seg_off | fixed_len | lit_off | lit_len | group),
+                          // or 0xFFFFFFFF: read them from global memory
+    uint32_t n_rules, n_segs;
+    uint32_t caps_bytes;  // per-wave staging of the tile's capture rows (64 * slots * 4), 0: read them from global memory
+};
+
+// some byte of w is a control character (< 0x20) or >= 0x80
+__device__ __forceinline__ bool ctrl_or_high4(uint32_t w) {
+    const uint32_t t = (w & 0x7F7F7F7Fu) + 0x60606060u;  // bit 7 of a byte set iff its low 7 bits >= 0x20
+    return ((~t | w) & 0x80808080u) != 0u;
+}
+
+// global -> LDS copy of the span [lo, hi) of `data`, 16 bytes per lane, skewed so that LDS and global addresses
+// agree modulo 16; chunks that stick out of [data, data_end) are read byte by byte.
+__device__ __forceinline__ void stage_in(const uint8_t* __restrict__ data, const uint8_t* data_end, uint64_t lo, uint64_t hi, uint8_t* stage,
+                                         uint32_t lane) {
+    const uint8_t* g_lo = data + lo;
+    const uint32_t skew = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(g_lo) & 15u);
+    const uint8_t* g_al = g_lo - skew;
+    const uint32_t nch = static_cast<uint32_t>(((hi - lo) + skew + 15u) >> 4);
+    for (uint32_t c = lane; c < nch; c += 64u) {
+        const uint8_t* src = g_al + (static_cast<uint64_t>(c) << 4);
+        uint4 v;
+        if (src >= data && src + 16 <= data_end) v = *reinterpret_cast<const uint4*>(src);
+        else {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (int q = 0; q < 16; ++q)
+                if (src + q >= data && src + q < data_end) w[q >> 2] |= static_cast<uint32_t>(src[q]) << ((q & 3) * 8);
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        *reinterpret_cast<uint4*>(stage + (c << 4)) = v;
+    }
+}
+
+template <typename OFF, bool WRITE>
+__global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTileCfg cfg, const uint8_t* __restrict__ data, const OFF* __restrict__ off,
+                                                   uint64_t n, const int32_t* __restrict__ match_id, const int32_t* __restrict__ caps, int slots,
+                                                   int passthrough, uint32_t* __restrict__ sizes, const uint64_t* __restrict__ out_off,
+                                                   uint8_t* __restrict__ out) {
+    const bool pt = passthrough != 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    // LDS copies of the template arrays, when they are small enough (plan_jsonl_tile)
+    uint32_t* tl_seg_off = reinterpret_cast<uint32_t*>(jx_smem + (cfg.tm_lds == 0xFFFFFFFFu ? 0u : cfg.tm_lds));
+    uint32_t* tl_fixed = tl_seg_off + (cfg.n_rules + 1u);
+    uint32_t* tl_lit_off = tl_fixed + cfg.n_rules;
+    uint32_t* tl_lit_len = tl_lit_off + cfg.n_segs;
+    int32_t* tl_group = reinterpret_cast<int32_t*>(tl_lit_len + cfg.n_segs);
+    if (cfg.lits_lds != 0xFFFFFFFFu)
+        for (uint32_t q = threadIdx.x; q < cfg.lits_bytes; q += blockDim.x) jx_smem[cfg.lits_lds + q] = tm.lits[q];
+    if (cfg.tm_lds != 0xFFFFFFFFu) {
+        for (uint32_t q = threadIdx.x; q <= cfg.n_rules; q += blockDim.x) tl_seg_off[q] = tm.seg_off[q];
+        for (uint32_t q = threadIdx.x; q < cfg.n_rules; q += blockDim.x) tl_fixed[q] = tm.fixed_len[q];
+        for (uint32_t q = threadIdx.x; q < cfg.n_segs; q += blockDim.x) {
+            tl_lit_off[q] = tm.lit_off[q];
+            tl_lit_len[q] = tm.lit_len[q];
+            tl_group[q] = tm.group[q];
+        }
+    }
+    __syncthreads();
+    const uint32_t per_wave = cfg.in_bytes + cfg.out_bytes + cfg.caps_bytes;
+    uint8_t* in_stage = jx_smem + cfg.stage0 + wave * per_wave;
+    uint8_t* out_stage = in_stage + cfg.in_bytes;
+    uint8_t* caps_stage = out_stage + cfg.out_bytes;
+    const uint8_t* data_end = data + static_cast<uint64_t>(off[n]);
+    const uint64_t tiles = (n + 63) >> 6;
+    const uint64_t wstride = static_cast<uint64_t>(gridDim.x) * cfg.waves;
+    for (uint64_t tile = static_cast<uint64_t>(blockIdx.x) * cfg.waves + wave; tile < tiles; tile += wstride) {
+        const uint64_t i = (tile << 6) + lane;
+        const bool valid = i < n;
+        const uint64_t o0 = off[valid ? i : n], o1 = off[valid ? i + 1 : n];
+        const int32_t k = valid ? match_id[i] : -1;
+        uint64_t oo0 = 0, oo1 = 0;
+        if (WRITE) { oo0 = out_off[valid ? i : n]; oo1 = out_off[valid ? i + 1 : n]; }
+        const uint32_t group_lines = static_cast<uint32_t>(min(static_cast<uint64_t>(64), n - (tile << 6)));
+        uint32_t a = 0;
+        while (a < group_lines) {
+            // ---- the round: lanes [a, b) whose input (and output) fit the staging areas ----
+            const uint64_t lo = uni(static_cast<uint64_t>(__shfl(static_cast<unsigned long long>(o0), static_cast<int>(a))));
+            const uint32_t skew = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(data + lo) & 15u);
+            bool fits = lane >= a && valid && (o1 - lo) + skew <= cfg.in_bytes;
+            uint64_t olo = 0;
+            uint32_t oskew = 0;
+            if (WRITE) {
+                olo = uni(static_cast<uint64_t>(__shfl(static_cast<unsigned long long>(oo0), static_cast<int>(a))));
+                oskew = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(out + olo) & 15u);
+                fits = fits && (oo1 - olo) + oskew <= cfg.out_bytes;
+            }
+            const uint32_t cnt = static_cast<uint32_t>(__popcll(__ballot(fits)));
+            if (cnt == 0) {
+                // line a alone does not fit: the whole wave takes it
+                const uint64_t ia = (tile << 6) + a;
+                if (WRITE) line_write_wave(tm, data, lo, ia, match_id, caps, slots, pt, lane, out + olo);
+                else {
+                    const uint32_t t = line_size_wave(tm, data, lo, ia, match_id, caps, slots, pt, lane);
+                    if (lane == 0) sizes[ia] = t;
+                }
+                a += 1;
                 continue;
             }
-            if (lane == 0) dst[0] = '"';
-            ++dst;
-            for (int32_t c0 = b; c0 < e; c0 += 64) {
-                const int32_t p = c0 + static_cast<int32_t>(lane);
-                const bool in = p < e;
-                const uint32_t v = in ? line[p] : 0u;
-                const uint32_t el = in ? esc_len(v, pt) : 0u;
-                const uint32_t inc = wave_inclusive(el, lane);
-                if (in) esc_write(dst + (inc - el), v, pt);
-                dst += uni(static_cast<uint32_t>(__shfl(static_cast<int>(inc), 63)));
+            const uint32_t b = a + cnt;
+            const uint64_t hi = uni(static_cast<uint64_t>(__shfl(static_cast<unsigned long long>(o1), static_cast<int>(b - 1u))));
+            stage_in(data, data_end, lo, hi, in_stage, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const bool active = lane >= a && lane < b;
+            if (cfg.caps_bytes) {
+                // the round's capture rows are contiguous: stage them with coalesced 16-byte loads
+                const uint64_t row0 = ((tile << 6) + a) * static_cast<uint64_t>(slots);     // in int32 units
+                const uint32_t words = (b - a) * static_cast<uint32_t>(slots);
+                const int32_t* src = caps + row0;
+                int32_t* cst = reinterpret_cast<int32_t*>(caps_stage);
+                for (uint32_t q = lane; q < words; q += 64u) cst[q] = src[q];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            if (lane == 0) dst[0] = '"';
-            ++dst;
+            // ---- lane = line ----
+            if (active) {
+                const uint8_t* line = in_stage + skew + static_cast<uint32_t>(o0 - lo);
+                uint32_t total = 0;
+                uint8_t* dst = WRITE ? out_stage + oskew + static_cast<uint32_t>(oo0 - olo) : nullptr;
+                if (k >= 0) {
+                    const int32_t* cp_g = caps + i * static_cast<uint64_t>(slots);
+                    const int32_t* cp_l = reinterpret_cast<const int32_t*>(caps_stage) + (lane - a) * static_cast<uint32_t>(slots);
+                    auto cap = [&](int idx) { return cfg.caps_bytes ? cp_l[idx] : cp_g[idx]; };
+                    auto t_seg_off = [&](uint32_t x) { return cfg.tm_lds != 0xFFFFFFFFu ? tl_seg_off[x] : tm.seg_off[x]; };
+                    auto t_fixed = [&](uint32_t x) { return cfg.tm_lds != 0xFFFFFFFFu ? tl_fixed[x] : tm.fixed_len[x]; };
+                    auto t_lit_off = [&](uint32_t x) { return cfg.tm_lds != 0xFFFFFFFFu ? tl_lit_off[x] : tm.lit_off[x]; };
+                    auto t_lit_len = [&](uint32_t x) { return cfg.tm_lds != 0xFFFFFFFFu ? tl_lit_len[x] : tm.lit_len[x]; };
+                    auto t_group = [&](uint32_t x) { return cfg.tm_lds != 0xFFFFFFFFu ? tl_group[x] : tm.group[x]; };
+                    const uint32_t s1 = t_seg_off(k + 1);
+                    if (!WRITE) total = t_fixed(k);
+                    for (uint32_t s = t_seg_off(k); s < s1; ++s) {
+                        if (WRITE) {
+                            const uint32_t ll = t_lit_len(s), lo_l = t_lit_off(s);
+                            if (cfg.lits_lds != 0xFFFFFFFFu) {
+                                const uint8_t* lit = jx_smem + cfg.lits_lds + lo_l;
+                                uint32_t q = 0;
+                                for (; q + 4u <= ll; q += 4u) {  // reads first, then writes: four LDS round trips overlap
+                                    const uint8_t v0 = lit[q], v1 = lit[q + 1], v2 = lit[q + 2], v3 = lit[q + 3];
+                                    dst[q] = v0; dst[q + 1] = v1; dst[q + 2] = v2; dst[q + 3] = v3;
+                                }
+                                for (; q < ll; ++q) dst[q] = lit[q];
+                            } else {
+                                const uint8_t* lit = tm.lits + lo_l;
+                                for (uint32_t q = 0; q < ll; ++q) dst[q] = lit[q];
+                            }
+                            dst += ll;
+                        }
+                        const int32_t g = t_group(s);
+                        if (g < 0) continue;
+                        const int32_t cb = cap(2 * g), ce = cap(2 * g + 1);
+                        if (cb < 0) {
+                            if (WRITE) { dst[0] = 'n'; dst[1] = 'u'; dst[2] = 'l'; dst[3] = 'l'; dst += 4; }
+                            else total += 4u;
+                            continue;
+                        }
+                        if (WRITE) {
+                            *dst++ = '"';
+                            // Lanes run in lock step, so whatever one lane needs every lane pays for: the common
+                            // characters -- plain ones and the two that only take a backslash -- go through one
+                            // branch-free sequence (two byte stores, the second overwriting the first for a plain
+                            // character); only control characters and bytes >= 0x80 take the branchy path.
+                            int32_t p = cb;
+                            for (; p + 4 <= ce; p += 4) {
+                                const uint32_t v0 = line[p], v1 = line[p + 1], v2 = line[p + 2], v3 = line[p + 3];
+                                const uint32_t w = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
+                                if (!ctrl_or_high4(w)) {
+                                    const uint32_t q0 = (v0 == 0x22u || v0 == 0x5Cu) ? 1u : 0u, q1 = (v1 == 0x22u || v1 == 0x5Cu) ? 1u : 0u;
+                                    const uint32_t q2 = (v2 == 0x22u || v2 == 0x5Cu) ? 1u : 0u, q3 = (v3 == 0x22u || v3 == 0x5Cu) ? 1u : 0u;
+                                    dst[0] = static_cast<uint8_t>(q0 ? 0x5Cu : v0); dst[q0] = static_cast<uint8_t>(v0); dst += 1u + q0;
+                                    dst[0] = static_cast<uint8_t>(q1 ? 0x5Cu : v1); dst[q1] = static_cast<uint8_t>(v1); dst += 1u + q1;
+                                    dst[0] = static_cast<uint8_t>(q2 ? 0x5Cu : v2); dst[q2] = static_cast<uint8_t>(v2); dst += 1u + q2;
+                                    dst[0] = static_cast<uint8_t>(q3 ? 0x5Cu : v3); dst[q3] = static_cast<uint8_t>(v3); dst += 1u + q3;
+                                } else {
+                                    esc_write(dst, v0, pt); dst += esc_len(v0, pt);
+                                    esc_write(dst, v1, pt); dst += esc_len(v1, pt);
+                                    esc_write(dst, v2, pt); dst += esc_len(v2, pt);
+                                    esc_write(dst, v3, pt); dst += esc_len(v3, pt);
+                                }
+                            }
+                            for (; p < ce; ++p) {
+                                const uint32_t v = line[p];
+                                esc_write(dst, v, pt);
+                                dst += esc_len(v, pt);
+                            }
+                            *dst++ = '"';
+                        } else {
+                            uint32_t t = 2u;
+#pragma unroll 4
+                            for (int32_t p = cb; p < ce; ++p) t += esc_len(line[p], pt);
+                            total += t;
+                        }
+                    }
+                }
+                if (!WRITE) sizes[i] = total;
+            }
+            if (WRITE) {
+                // ---- flush: the round's text is the contiguous span [olo, ohi) of the output ----
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint64_t ohi = uni(static_cast<uint64_t>(__shfl(static_cast<unsigned long long>(oo1), static_cast<int>(b - 1u))));
+                const uint32_t span = static_cast<uint32_t>(ohi - olo);
+                uint8_t* g_al = out + olo - oskew;  // 16-byte aligned
+                const uint32_t nch = (span + oskew + 15u) >> 4;
+                for (uint32_t c = lane; c < nch; c += 64u) {
+                    const uint32_t first = c << 4;
+                    if (first >= oskew && first + 16u <= oskew + span)
+                        *reinterpret_cast<uint4*>(g_al + first) = *reinterpret_cast<const uint4*>(out_stage + first);
+                    else
+                        for (uint32_t q = first; q < first + 16u; ++q)
+                            if (q >= oskew && q < oskew + span) g_al[q] = out_stage[q];
+                }
+            }
+            // the staging areas are reused by the next round
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            a = b;
         }
     }
 }
@@ -415,23 +637,63 @@ size_t jsonl_workspace_bytes(uint64_t n) {
     return static_cast<size_t>(n * 4 + (nblocks + 2) * 8 + 64);
 }
 
+namespace {
+// LDS plan of the tile kernels for lines of mean_in bytes producing mean_out bytes of text (0: sizes pass).
+bool plan_jsonl_tile(const GxJsonl& tm, int slots, uint32_t mean_in, uint32_t mean_out, JsonlTileCfg* cfg) {
+    const uint32_t LDS = 163840;
+    JsonlTileCfg c{};
+    uint32_t used = 0;
+    c.lits_bytes = tm.lits_bytes;
+    c.lits_lds = 0xFFFFFFFFu;
+    c.tm_lds = 0xFFFFFFFFu;
+    c.n_rules = tm.n_rules;
+    c.n_segs = tm.n_segs;
+    if (tm.lits_bytes <= 24u * 1024u) { c.lits_lds = 0; used = (tm.lits_bytes + 15u) & ~15u; }
+    const uint32_t tm_bytes = (2u * tm.n_rules + 1u + 3u * tm.n_segs) * 4u;
+    if (tm_bytes <= 16u * 1024u) { c.tm_lds = used; used += (tm_bytes + 15u) & ~15u; }
+    c.caps_bytes = slots > 0 && slots <= 32 ? 64u * static_cast<uint32_t>(slots) * 4u : 0u;
+    c.in_bytes = std::min<uint32_t>((64u * std::max<uint32_t>(mean_in, 1u) + 64u + 15u) & ~15u, 16384u);
+    c.out_bytes = mean_out ? std::min<uint32_t>((64u * (mean_out + mean_out / 8u) + 64u + 15u) & ~15u, 49152u) : 0u;
+    c.stage0 = used;
+    const uint32_t per_wave = c.in_bytes + c.out_bytes + c.caps_bytes;
+    uint32_t w = (LDS - used) / per_wave;
+    if (w < 1) return false;
+    c.waves = std::min<uint32_t>(w, 12u);
+    *cfg = c;
+    return true;
+}
+}  // namespace
+
 // Pass 1 + scan: line_out_off[0..n] (device, u64) receives the output offset of every line's text and, in
 // [n], the total size.  workspace: jsonl_workspace_bytes(n).
-hipError_t launch_jsonl_sizes(const GxJsonl& tm, const GxBatch& b, int slots, int passthrough, uint64_t* line_out_off, void* workspace,
-                              hipStream_t stream) {
+hipError_t launch_jsonl_sizes(const GxJsonl& tm, const GxBatch& b, int slots, int passthrough, uint32_t mean_in, uint64_t* line_out_off,
+                              void* workspace, hipStream_t stream) {
     if (b.n == 0) return hipMemsetAsync(line_out_off, 0, 8, stream);
     const uint64_t nblocks = (b.n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     uint32_t* sizes = static_cast<uint32_t*>(workspace);
     uint64_t* block_sums = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(workspace) + ((b.n * 4 + 15) & ~static_cast<uint64_t>(15)));
     JsonlTemplates t{tm.seg_off, tm.lit_off, tm.lit_len, tm.group, tm.fixed_len, tm.lits};
-    uint64_t blocks = (b.n + 3) / 4;  // 4 waves (lines) per block
-    if (blocks > 256u * 32u) blocks = 256u * 32u;
-    if (b.offsets64)
-        hipLaunchKernelGGL(k_jsonl_sizes<uint64_t>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, t, static_cast<const uint8_t*>(b.data),
-                           static_cast<const uint64_t*>(b.offsets), b.n, b.match_id, b.caps, slots, passthrough, sizes);
-    else
-        hipLaunchKernelGGL(k_jsonl_sizes<uint32_t>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, t, static_cast<const uint8_t*>(b.data),
-                           static_cast<const uint32_t*>(b.offsets), b.n, b.match_id, b.caps, slots, passthrough, sizes);
+    JsonlTileCfg cfg;
+    if (!plan_jsonl_tile(tm, slots, mean_in, 0, &cfg)) return hipErrorInvalidValue;
+    {
+        const uint32_t lds = cfg.stage0 + cfg.waves * (cfg.in_bytes + cfg.out_bytes + cfg.caps_bytes);
+        const uint64_t tiles = (b.n + 63) >> 6;
+        uint64_t blocks = std::min<uint64_t>((tiles + cfg.waves - 1) / cfg.waves, 256u * 4u);
+        hipError_t e;
+        if (b.offsets64) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jsonl_tile<uint64_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_jsonl_tile<uint64_t, false>), dim3(static_cast<unsigned>(blocks)), dim3(cfg.waves * 64), lds, stream, t, cfg,
+                               static_cast<const uint8_t*>(b.data), static_cast<const uint64_t*>(b.offsets), b.n, b.match_id, b.caps, slots, passthrough,
+                               sizes, nullptr, nullptr);
+        } else {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jsonl_tile<uint32_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_jsonl_tile<uint32_t, false>), dim3(static_cast<unsigned>(blocks)), dim3(cfg.waves * 64), lds, stream, t, cfg,
+                               static_cast<const uint8_t*>(b.data), static_cast<const uint32_t*>(b.offsets), b.n, b.match_id, b.caps, slots, passthrough,
+                               sizes, nullptr, nullptr);
+        }
+    }
     if (nblocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_scan_block_sums, dim3(static_cast<unsigned>(nblocks)), dim3(SCAN_THREADS), 0, stream, sizes, b.n, block_sums);
     hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(1024), 0, stream, block_sums, nblocks);
@@ -440,18 +702,29 @@ hipError_t launch_jsonl_sizes(const GxJsonl& tm, const GxBatch& b, int slots, in
 }
 
 // Pass 2: write the text.
-hipError_t launch_jsonl_write(const GxJsonl& tm, const GxBatch& b, int slots, int passthrough, const uint64_t* line_out_off, uint8_t* out,
-                              hipStream_t stream) {
+hipError_t launch_jsonl_write(const GxJsonl& tm, const GxBatch& b, int slots, int passthrough, uint32_t mean_in, uint32_t mean_out,
+                              const uint64_t* line_out_off, uint8_t* out, hipStream_t stream) {
     if (b.n == 0) return hipSuccess;
     JsonlTemplates t{tm.seg_off, tm.lit_off, tm.lit_len, tm.group, tm.fixed_len, tm.lits};
-    uint64_t blocks = (b.n + 3) / 4;
-    if (blocks > 256u * 32u) blocks = 256u * 32u;
-    if (b.offsets64)
-        hipLaunchKernelGGL(k_jsonl_write<uint64_t>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, t, static_cast<const uint8_t*>(b.data),
-                           static_cast<const uint64_t*>(b.offsets), b.n, b.match_id, b.caps, slots, passthrough, line_out_off, out);
-    else
-        hipLaunchKernelGGL(k_jsonl_write<uint32_t>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, t, static_cast<const uint8_t*>(b.data),
-                           static_cast<const uint32_t*>(b.offsets), b.n, b.match_id, b.caps, slots, passthrough, line_out_off, out);
+    JsonlTileCfg cfg;
+    if (!plan_jsonl_tile(tm, slots, mean_in, std::max<uint32_t>(mean_out, 1u), &cfg)) return hipErrorInvalidValue;
+    const uint32_t lds = cfg.stage0 + cfg.waves * (cfg.in_bytes + cfg.out_bytes + cfg.caps_bytes);
+    const uint64_t tiles = (b.n + 63) >> 6;
+    uint64_t blocks = std::min<uint64_t>((tiles + cfg.waves - 1) / cfg.waves, 256u * 4u);
+    hipError_t e;
+    if (b.offsets64) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jsonl_tile<uint64_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_jsonl_tile<uint64_t, true>), dim3(static_cast<unsigned>(blocks)), dim3(cfg.waves * 64), lds, stream, t, cfg,
+                           static_cast<const uint8_t*>(b.data), static_cast<const uint64_t*>(b.offsets), b.n, b.match_id, b.caps, slots, passthrough,
+                           nullptr, line_out_off, out);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jsonl_tile<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_jsonl_tile<uint32_t, true>), dim3(static_cast<unsigned>(blocks)), dim3(cfg.waves * 64), lds, stream, t, cfg,
+                           static_cast<const uint8_t*>(b.data), static_cast<const uint32_t*>(b.offsets), b.n, b.match_id, b.caps, slots, passthrough,
+                           nullptr, line_out_off, out);
+    }
     return hipGetLastError();
 }
 
