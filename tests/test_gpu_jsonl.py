@@ -139,3 +139,38 @@ def test_output_beyond_2_gib_properties():
     for j, i in enumerate(idx):
         got = out[int(lo_host[i]):int(lo_host[i + 1])].cpu().numpy().tobytes()
         assert got == want[int(woff[j]):int(woff[j + 1])]
+
+
+def test_ragged_lines_rounds_and_whole_wave_fallback():
+    """Tile kernels: groups whose input or output does not fit the LDS staging go in several rounds; a single line
+    beyond the staging maximum is taken by the whole wave."""
+    gorp = Gorp.construct(W.readme3_definition())
+    rng = random.Random(123)
+    lines = []
+    for _ in range(3000):
+        r = rng.random()
+        body = "".join(rng.choice("abc/-_.=?&%09\"\\\t") for _ in range(int(3000 ** rng.random())))
+        if r < 0.05:
+            lines.append("")
+        elif r < 0.5:
+            lines.append("[%09d]: GET %dms /%s" % (rng.randrange(10 ** 9), rng.randrange(9999), body.replace("\t", "")))
+        elif r < 0.9:
+            lines.append("[%09d]: PUT %dms /%s" % (rng.randrange(10 ** 9), rng.randrange(9999), body.replace("\t", "")))
+        else:
+            lines.append(body)
+    lines[7] = "[1]: GET 5ms /" + "\"" * 20000          # 20 KB in, 40 KB out: beyond both staging areas
+    lines[8] = "[1]: GET 5ms /" + "z" * 17000
+    run(gorp, lines, id_as="id")
+    run(gorp, lines[:70])
+
+
+def test_many_extractions_templates_in_global_memory():
+    """512 syslog-like extractions: the template arrays and literals exceed the kernels' LDS budget for them."""
+    rules, meta = W.syslog_definition(512, seed=3)
+    gorp = Gorp.construct(rules)
+    data, offsets, cats = W.syslog_lines(meta, 3000, seed=5, min_len=50, max_len=900)
+    lines = [bytes(data[offsets[i]:offsets[i + 1]]) for i in range(len(offsets) - 1)]
+    raw, mid, caps, text = run(gorp, lines, id_as="rule")
+    assert (mid >= 0).sum() > 2500
+    for t in text.decode("utf-8").split("\n")[:50]:
+        json.loads(t)
