@@ -365,7 +365,7 @@ __device__ __forceinline__ void tile_issue_loads(const TileInfo& t, uint32_t lan
 #pragma unroll
         for (int k = 0; k < KCH; ++k) {
             const uint32_t c = min(lane + 64u * k, t.nch - 1u);
-            pre[k] = *reinterpret_cast<const u32x4*>(t.g_al + (static_cast<uint64_t>(c) << 4));
+            pre[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(t.g_al + (static_cast<uint64_t>(c) << 4)));
         }
     }
 }
