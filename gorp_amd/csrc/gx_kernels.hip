@@ -153,6 +153,10 @@ extern __shared__ __attribute__((aligned(16))) uint8_t gx_smem[];
 
 constexpr uint32_t HI_BITS = 0x80808080u;
 
+// native vector type: a plain 128-bit value the optimiser keeps in registers (HIP's uint4 struct is copied with
+// memcpy, which pins the prefetch array in scratch memory)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ uint32_t splat_byte0(uint32_t v) { return __builtin_amdgcn_perm(v, v, 0x00000000u); }
 __device__ __forceinline__ uint32_t splat_byte1(uint32_t v) { return __builtin_amdgcn_perm(v, v, 0x01010101u); }
 
@@ -271,6 +275,15 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
     return row;
 }
 
+// 16 bytes of a staged line at any byte address.  gfx950 reads LDS unaligned (ds_read_b128 at an arbitrary
+// address), which lets every line start its windows at its own first byte: no line has a partial first window,
+// whatever its alignment in the buffer, and only its last window can be partial.
+struct __attribute__((packed)) UnalignedWindow { u32x4 v; };
+__device__ __forceinline__ uint4 load_window(const uint8_t* p) {
+    const u32x4 v = reinterpret_cast<const UnalignedWindow*>(p)->v;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // Walk one automaton over the staged line [start, end), all lanes in lock step over 16-byte windows of their own
 // line.  In every window a lane either proves with one SWAR test that all its bytes stay inside the current
 // state's self-loop interval (state unchanged, 16 bytes skipped), or takes 16 exact steps (partial windows at
@@ -281,7 +294,7 @@ template <bool CAPTURE, bool GT>
 __device__ __forceinline__ uint32_t walk(const uint8_t* stage, const uint8_t* at, uint32_t row, uint32_t start, uint32_t end,
                                          bool on, uint32_t dead_row, uint16_t* regs, const GxLds& L) {
     const uint32_t acc_off = L.row_bytes - 8u; // self-loop interval column: lo | (0x7F - hi) << 8
-    uint32_t wb = start & ~15u;
+    uint32_t wb = start;  // windows are relative to the line, not to the staging area: see load_window
     const uint32_t len = end - start;
     const uint32_t full_lim = len >= 16u ? len - 15u : 0u;  // window at line offset rel is full iff rel < full_lim (unsigned)
     uint32_t acc = tab_read<GT>(at, row, acc_off, L.row_bytes);
@@ -289,7 +302,7 @@ __device__ __forceinline__ uint32_t walk(const uint8_t* stage, const uint8_t* at
     bool more = on && start < end;
     while (__any(more)) {
         // a finished lane keeps its last window: the address stays inside the staged tile
-        const uint4 w0 = *reinterpret_cast<const uint4*>(stage + wb);
+        const uint4 w0 = load_window(stage + wb);
         const uint32_t rel = wb - start;  // "negative" (huge) for the first window of a line that starts inside it
         const bool full0 = rel < full_lim;
         const uint32_t bx = outside_bits(w0.x, lo4, k4), by = outside_bits(w0.y, lo4, k4);
@@ -355,9 +368,6 @@ struct TileInfo {
 
 // Clamped, unconditional accesses on both sides: a lane beyond the span re-reads / rewrites the last chunk
 // with identical data.  (Per-lane conditions make the compiler spill the array and serialise the batch.)
-// native vector type: a plain 128-bit value the optimiser keeps in registers (HIP's uint4 struct is copied with
-// memcpy, which pins the prefetch array in scratch memory)
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int KCH>
 __device__ __forceinline__ void tile_issue_loads(const TileInfo& t, uint32_t lane, u32x4 (&pre)[KCH]) {
