@@ -369,14 +369,17 @@ struct TileInfo {
 // Clamped, unconditional accesses on both sides: a lane beyond the span re-reads / rewrites the last chunk
 // with identical data.  (Per-lane conditions make the compiler spill the array and serialise the batch.)
 
+// Unconditional as well: a round that is not prefetched (mode != 0, or no next round) loads one dummy chunk instead.
+// A branch around the loads would make the compiler lose count of them at the join and wait for all of them --
+// i.e. for the whole prefetch -- at the next vector-memory dependency, long before the walk.
 template <int KCH>
-__device__ __forceinline__ void tile_issue_loads(const TileInfo& t, uint32_t lane, u32x4 (&pre)[KCH]) {
-    if (t.mode == 0) {
+__device__ __forceinline__ void tile_issue_loads(const TileInfo& t, uint32_t lane, u32x4 (&pre)[KCH], const uint8_t* __restrict__ dummy) {
+    const uint8_t* src = t.mode == 0 ? t.g_al : dummy;
+    const uint32_t last = t.mode == 0 ? t.nch - 1u : 0u;
 #pragma unroll
-        for (int k = 0; k < KCH; ++k) {
-            const uint32_t c = min(lane + 64u * k, t.nch - 1u);
-            pre[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(t.g_al + (static_cast<uint64_t>(c) << 4)));
-        }
+    for (int k = 0; k < KCH; ++k) {
+        const uint32_t c = min(lane + 64u * k, last);
+        pre[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + (static_cast<uint64_t>(c) << 4)));
     }
 }
 template <int KCH>
@@ -484,8 +487,8 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
         load_offsets(tile, o0, o1);
         cur = make_round(tile, 0, o0, o1);
     }
-    if (match_only != 3) tile_issue_loads<KCH>(cur, lane, pre);
     load_offsets(min(tile + wstride, tiles - 1), no0, no1);
+    tile_issue_loads<KCH>(cur, lane, pre, lds_image);
 
     for (;;) {
         tile_commit<KCH>(cur, lane, pre, stage, data, data_end, match_only != 3);
@@ -494,16 +497,16 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
         const bool same_group = cur.b < group_lines;
         const uint64_t ntile = same_group ? tile : tile + wstride;
         const bool has_next = ntile < tiles;
-        TileInfo nxt = cur;
-        if (has_next) {
-            nxt = make_round(ntile, same_group ? cur.b : 0u, same_group ? cur.o0 : no0, same_group ? cur.o1 : no1);
-            if (match_only != 3) tile_issue_loads<KCH>(nxt, lane, pre);
-        }
-        // unconditional (index clamped; the same values again while the group is unchanged): a conditional load
-        // would need a register copy at the join, and that copy would wait for every load issued before it --
-        // including the prefetch above
+        // Offsets of the group after the next one first, then the prefetch, and nothing in between that depends on
+        // vector memory: both are unconditional (index clamped -- the same values again while the group is
+        // unchanged; a dummy chunk when there is no next round), because a conditional load needs a register copy
+        // at the join, and that copy would wait for every load issued before it.
         uint64_t nno0, nno1;
         load_offsets(min(ntile + wstride, tiles - 1), nno0, nno1);
+        TileInfo nxt = make_round(has_next ? ntile : tile, has_next ? (same_group ? cur.b : 0u) : cur.a,
+                                  has_next && !same_group ? no0 : cur.o0, has_next && !same_group ? no1 : cur.o1);
+        if (!has_next) nxt.mode = 3;  // nothing to fetch: the loop ends after this round
+        tile_issue_loads<KCH>(nxt, lane, pre, lds_image);
 
         const uint64_t i = cur.i;
         const bool valid = cur.active != 0u;
