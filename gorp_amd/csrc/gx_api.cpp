@@ -251,6 +251,27 @@ bool plan_tile_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out) 
     return true;
 }
 
+// Layout for the slice kernel: a 64 x 80-byte slice buffer per wave, up to 16 waves.
+bool plan_slice_launch(const gx_handle* h, GxLds* out) {
+    if (!h->tile_ok) return false;
+    if (h->T.has_capture && !h->T.union_ok) return false;  // the slice kernel walks the fused automaton
+    GxLds L = h->lds;
+    L.stage_bytes = 64u * 80u;
+    const uint32_t per_wave = L.stage_bytes + L.regs_wave_bytes;
+    if (L.table_bytes + per_wave > LDS_BYTES) return false;
+    uint32_t nw = (LDS_BYTES - L.table_bytes) / per_wave;
+    if (nw > 16) nw = 16;
+    static const int force_nw = getenv("GX_DEBUG_NWAVES") ? atoi(getenv("GX_DEBUG_NWAVES")) : 0;
+    if (force_nw > 0 && static_cast<uint32_t>(force_nw) < nw) nw = static_cast<uint32_t>(force_nw);
+    L.nwaves = nw;
+    L.regs = L.table_bytes;
+    L.stage = L.regs + nw * L.regs_wave_bytes;
+    L.total_bytes = L.stage + nw * L.stage_bytes;
+    L.debug_ablate = 0;
+    *out = L;
+    return true;
+}
+
 void upload(gx_handle* h) {
     const Tables& T = h->T;
     int count = 0;
@@ -343,6 +364,17 @@ void upload(gx_handle* h) {
 // One batch on the device: tile kernel (LDS tier when the tables fit LDS, else L2 tier), generic kernel otherwise.
 void launch_batch(gx_handle* h, const GxBatch& b, uint32_t line_bytes_hint, hipStream_t stream) {
     GxLds L;
+    // Lines whose 64-line groups do not fit the tile kernel's staging area (mean length above 255 bytes) go to the
+    // slice kernel, which stages 64 bytes of every line at a time: measured 2.4x faster on config 5 (512 extractions,
+    // 50-2000-byte lines), but 0.8x on 200-byte lines, where the tile kernel's one contiguous span per group wins.
+    // (GX_DEBUG_SLICES=1 forces it, =0 forbids it: tests and measurements.)
+    const int force = getenv("GX_DEBUG_SLICES") ? atoi(getenv("GX_DEBUG_SLICES")) : -1;
+    const bool slices = force == 1 || (force != 0 && line_bytes_hint > 255u);
+    if (!b.wide && !b.state_out && slices && plan_slice_launch(h, &L)) {
+        GX_HIP(launch_extract_slices(h->dev, L, static_cast<const uint8_t*>(h->d_lds_image),
+                                     h->tile_global ? static_cast<const uint8_t*>(h->d_l2_image) : nullptr, h->num_cus, b, stream));
+        return;
+    }
     if (!b.wide && !b.state_out && plan_tile_launch(h, line_bytes_hint, &L))
         GX_HIP(launch_extract_tile(h->dev, L, static_cast<const uint8_t*>(h->d_lds_image),
                                    h->tile_global ? static_cast<const uint8_t*>(h->d_l2_image) : nullptr, h->num_cus, b, stream));

@@ -98,6 +98,9 @@ hipError_t launch_extract_generic(const GxDev& dev, const GxBatch& b, hipStream_
 hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
                                const GxBatch& b, hipStream_t stream);
 hipError_t prepare_tile_kernels(uint32_t lds_bytes);
+// Slice kernel: the same tables, lines staged 64 bytes at a time (GxLds::stage_bytes = 64 * 80); fused automaton or match only.
+hipError_t launch_extract_slices(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
+                                 const GxBatch& b, hipStream_t stream);
 
 // Line ingestion (gx_ingest.hip): raw bytes -> CSR offsets of readLine()-style lines, terminators included.
 // `workspace` holds split_workspace_bytes(size) bytes; *d_n_lines receives the device address of the line count.

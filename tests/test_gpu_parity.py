@@ -467,3 +467,45 @@ def test_utf16_batch_input():
         assert mid[i] == om and caps[i].tolist()[:len(flat)] == flat, (s, mid[i], om, caps[i], oc)
     m2, _ = gorp.extract_batch(data, offsets, match_only=True)
     assert m2.tolist() == mid.tolist()
+
+
+@pytest.mark.parametrize("tier", [1, 2])
+def test_slice_kernel_agrees_with_oracle(tier, monkeypatch):
+    """The slice kernel (64 bytes of every line staged at a time; the default for batches with long lines) forced
+    on for short, ragged, terminated and very long lines, tables in LDS and in global memory."""
+    monkeypatch.setenv("GX_DEBUG_SLICES", "1")
+    if tier == 2:
+        monkeypatch.setenv("GX_DEBUG_TIER", "2")
+    definition = W.simple_grp_definition()
+    gorp, orc = Gorp.construct(definition), oracle_for(definition)
+    check_batch(gorp, orc, W.simple_grp_lines(3000, seed=31))
+    definition = W.readme3_definition()
+    gorp, orc = Gorp.construct(definition), oracle_for(definition)
+    data, offsets, cat = W.readme3_lines(40000, seed=32)
+    d, o = data.numpy(), offsets.numpy()
+    mid, caps = gorp.extract_batch(d, o)
+    omid, ocaps = orc.extract_batch(d, o, nthreads=8)
+    assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+    m2, _ = gorp.extract_batch(d, o, match_only=True)
+    assert np.array_equal(m2, omid)
+    rng = random.Random(5)
+    lines = []
+    for _ in range(2000):
+        body = "".join(rng.choice("abc/-_.=?&%09") for _ in range(int(5000 ** rng.random())))
+        lines.append(rng.choice(["", "[%09d]: GET %dms /%s" % (rng.randrange(10 ** 9), rng.randrange(9999), body),
+                                 "[%09d]: PUT %dms /%s" % (rng.randrange(10 ** 9), rng.randrange(9999), body), body, "[12]: HEAD 7ms /a " + body]))
+    lines[3] = "[1]: GET 5ms /" + "x" * 70000          # beyond 16-bit positions: per-lane path
+    lines[4] = "[1]: GET 5ms /" + "x" * 65000
+    mid, caps = check_batch(gorp, orc, lines)
+    d64, o64 = lines_to_csr(lines, offsets_dtype=np.uint64)
+    m64, c64 = gorp.extract_batch(d64, o64)
+    assert np.array_equal(m64, mid) and np.array_equal(c64, caps)
+    # terminated text
+    from gorp_amd.gorp import split_lines
+    raw = b"".join(ln.encode() + rng.choice([b"\n", b"\r\n", b"\r"]) for ln in lines[5:400])
+    off, _ = split_lines(raw)
+    _, want_lines, _ = O.read_lines(raw)
+    m3, c3 = gorp.extract_batch(np.frombuffer(raw, np.uint8), off, strip_eol=True)
+    cd, co = lines_to_csr(want_lines)
+    om3, oc3 = orc.extract_batch(cd, co, nthreads=8)
+    assert np.array_equal(m3, om3) and np.array_equal(c3, oc3)
