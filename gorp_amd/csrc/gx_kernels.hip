@@ -615,16 +615,18 @@ k_extract_tile(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const ui
 }
 
 // ---------------------------------------------------------------------------
-// Slice kernel: lines staged 64 bytes at a time
+// Slice kernel: lines staged 64 bytes at a time, lanes refilled as their lines end
 // ---------------------------------------------------------------------------
-// The tile kernel stages whole lines, so LDS holds 64 x line-length bytes per wave: long lines mean few waves, and a
-// group of long or uneven lines has to go in several rounds of a few lanes each.  Here a wave stages only the next
-// 64-byte slice of each of its 64 lines (a [64][80]-byte buffer, 5 KB per wave whatever the lengths): every lane
-// always has a line, more waves fit a CU, and a line may be as long as the 16-bit positions allow.  The price is
+// The tile kernel stages whole lines, so LDS holds 64 x line-length bytes per wave: long lines mean few waves, a
+// group of long or uneven lines has to go in several rounds of a few lanes each, and every lane waits for the
+// longest line of its round.  Here a wave owns a contiguous range of lines and stages only the next 64-byte slice
+// of the line each lane is on (a [64][80]-byte buffer, 5 KB per wave whatever the lengths).  A lane whose line
+// has ended (or whose automaton has died) writes its result and takes the next line of the range, so all lanes
+// stay busy however uneven the lines are, and a line may be as long as the 16-bit positions allow.  The price is
 // the load pattern -- four instructions per slice, each fetching 16-byte pieces of 16 different lines (unaligned
-// global loads) instead of one contiguous span.  Used for the L2 tier, where the walk waits on table gathers and
-// the number of lines in flight is what counts, and for batches whose lines do not fit the tile kernel's staging.
-// Walks the fused automaton (or the match automaton alone); needs Tables::union_ok for captures.
+// global loads), not prefetched -- and per-line result stores.  Used for batches whose lines do not fit the tile
+// kernel's staging (mean length above 255 bytes).  Walks the fused automaton (or the match automaton alone);
+// needs Tables::union_ok for captures.
 constexpr uint32_t SLICE_BYTES = 64, SLICE_ROW = 80;
 
 template <typename OFF, bool GT>
@@ -650,165 +652,149 @@ k_extract_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const 
     uint16_t* regs = reinterpret_cast<uint16_t*>(gx_smem + L.regs + wave * L.regs_wave_bytes) + 64 + lane;
     const int slots = 2 * T.max_groups;
     const bool want_caps = match_only == 0 && T.has_capture;
-    const bool caps_aligned = ((reinterpret_cast<uintptr_t>(caps) | reinterpret_cast<uintptr_t>(match_id)) & 15u) == 0u;
-    const uint64_t tiles = (n + 63) >> 6;
-    const uint64_t wstride = static_cast<uint64_t>(gridDim.x) * L.nwaves;
     const uint8_t* data_end = data + static_cast<uint64_t>(off[n]);
     const uint8_t* A = want_caps ? at_c : at;                       // the automaton this launch walks
     const uint32_t row0 = want_caps ? L.u_start : L.m_start, dead_row = want_caps ? L.u_dead : L.m_dead;
 
-    for (uint64_t tile = static_cast<uint64_t>(blockIdx.x) * L.nwaves + wave; tile < tiles; tile += wstride) {
-        const uint64_t i = (tile << 6) + lane;
-        const bool valid = i < n;
-        const uint64_t o0 = off[valid ? i : n], o1 = off[valid ? i + 1 : n];
-        int64_t len64 = static_cast<int64_t>(o1 - o0);
-        if (strip_eol && valid) len64 = trim_eol(data + o0, len64);
-        const bool too_long = len64 > 65535;  // positions are 16-bit in the register block: the per-lane path takes these
-        const uint32_t len = (valid && !too_long) ? static_cast<uint32_t>(len64) : 0u;
-        uint32_t maxlen = len;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) maxlen = max(maxlen, static_cast<uint32_t>(__shfl_xor(static_cast<int>(maxlen), d)));
-        const uint32_t nsl = (maxlen + SLICE_BYTES - 1u) / SLICE_BYTES;
+    // this wave's range of lines
+    const uint64_t nwaves = static_cast<uint64_t>(gridDim.x) * L.nwaves;
+    const uint64_t per_wave = (n + nwaves - 1) / nwaves;
+    const uint64_t wid = static_cast<uint64_t>(blockIdx.x) * L.nwaves + wave;
+    const uint64_t range_lo = min(n, wid * per_wave), range_hi = min(n, range_lo + per_wave);
+    uint64_t next = range_lo;   // first line of the range not yet handed to a lane (wave-uniform)
 
-        // slice s of the wave's 64 lines: lane l fetches chunk l & 3 of lines (l >> 2) + 16 r, r = 0..3
-        u32x4 pre[4];
-        auto issue_slice = [&](uint32_t s) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = static_cast<int>(lane >> 2) + 16 * r;
-                const uint64_t oq = __shfl(static_cast<unsigned long long>(o0), q);
-                const uint32_t lq = static_cast<uint32_t>(__shfl(static_cast<int>(len), q));
-                const uint32_t pos = s * SLICE_BYTES + (lane & 3u) * 16u;
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (pos < lq) {
-                    const uint8_t* src = data + oq + pos;
-                    if (src + 16 <= data_end) v = __builtin_nontemporal_load(&reinterpret_cast<const UnalignedWindow*>(src)->v);
-                    else {
-                        uint32_t w[4] = {0, 0, 0, 0};
-                        for (int b = 0; b < 16; ++b)
-                            if (src + b < data_end) w[b >> 2] |= static_cast<uint32_t>(src[b]) << ((b & 3) * 8);
-                        v = u32x4{w[0], w[1], w[2], w[3]};
-                    }
-                }
-                pre[r] = v;
-            }
-        };
-        auto commit_slice = [&]() {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t q = (lane >> 2) + 16u * r;
-                *reinterpret_cast<u32x4*>(slice + q * SLICE_ROW + (lane & 3u) * 16u) = pre[r];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        };
+    // the line this lane is on
+    bool has_line = false;
+    uint64_t i = 0, o0 = 0;
+    uint32_t len = 0, pos = 0, row = row0;
+    uint32_t lo4 = 0u, k4 = HI_BITS;
+    const uint8_t* my = slice + lane * SLICE_ROW;
 
-        uint32_t row = row0;
-        uint32_t acc = tab_read<GT>(A, row, acc_off, L.row_bytes);
-        uint32_t lo4 = splat_byte0(acc), k4 = splat_byte1(acc);
-        bool more = len > 0u;
-        const uint8_t* my = slice + lane * SLICE_ROW;
-        if (nsl) issue_slice(0);
-        for (uint32_t s = 0; s < nsl; ++s) {
-            commit_slice();
-            if (s + 1u < nsl) issue_slice(s + 1u);
-            for (uint32_t w = 0; w < SLICE_BYTES / 16u; ++w) {
-                const uint32_t rel = s * SLICE_BYTES + w * 16u;
-                const bool act = more && rel < len;
-                if (!__any(act)) break;
-                const uint4 w0 = *reinterpret_cast<const uint4*>(my + w * 16u);
-                const bool full0 = rel + 16u <= len;
-                const uint32_t bx = outside_bits(w0.x, lo4, k4), by = outside_bits(w0.y, lo4, k4);
-                const uint32_t bz = outside_bits(w0.z, lo4, k4), bw = outside_bits(w0.w, lo4, k4);
-                const bool ok0 = full0 & (((or3(bx, by, bz) | bw) & HI_BITS) == 0u);
-                bool step = act && !ok0;
-                uint32_t mask = 0xFFFFu;
-                if (step && !full0) {
-                    mask = window_mask(0u, len, rel);
-                    step = !partial_window_ok(bx, by, bz, bw, mask);
-                }
-                const bool masked = __any(step && !full0);
-                if (step) {
-                    if (want_caps) {
-                        if (L.simple_ops) {
-                            if (!masked) row = steps16<true, false, true, GT>(w0, mask, A, row, rel, regs, L);
-                            else row = steps16<true, true, true, GT>(w0, mask, A, row, rel, regs, L);
-                        } else {
-                            if (!masked) row = steps16<true, false, false, GT>(w0, mask, A, row, rel, regs, L);
-                            else row = steps16<true, true, false, GT>(w0, mask, A, row, rel, regs, L);
-                        }
-                    } else {
-                        if (!masked) row = steps16<false, false, false, GT>(w0, mask, A, row, rel, regs, L);
-                        else row = steps16<false, true, false, GT>(w0, mask, A, row, rel, regs, L);
-                    }
-                    acc = tab_read<GT>(A, row, acc_off, L.row_bytes);
-                    lo4 = splat_byte0(acc);
-                    k4 = splat_byte1(acc);
-                }
-                more = more && row != dead_row;
-            }
-            // the slice buffer is rewritten by the next commit
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-
-        // ---- results ----
-        if (!want_caps) {
+    for (;;) {
+        // ---- lanes whose line is finished write its result ----
+        const bool done = has_line && (pos >= len || row == dead_row);
+        if (done) {
             const int32_t info = static_cast<int32_t>(tab_read<GT>(A, row, info_off, L.row_bytes));
-            if (valid && !too_long) match_id[i] = info;
-        } else {
-            const int32_t info = static_cast<int32_t>(tab_read<GT>(A, row, info_off, L.row_bytes));
-            int32_t result = info, f = -1;
-            uint32_t ng = 0;
-            if (info >= 0) {
-                result = fin_tags[info];
-                ng = GT ? static_cast<uint32_t>(T.c_ngroups[result]) : c_rule[2 * result + 1];
-                f = info;
-            }
-            auto group_span = [&](int g, int32_t& pb, int32_t& pe) {
-                pb = -1; pe = -1;
-                if (f >= 0 && static_cast<uint32_t>(g) < ng) {
-                    const uint16_t vb = fin_tags[f + 1 + 2 * g], ve = fin_tags[f + 1 + 2 * g + 1];
-                    pb = (vb == SRC_POS) ? static_cast<int32_t>(len) : (vb == SRC_NIL ? -1 : static_cast<int32_t>(regs[vb * 64]));
-                    pe = (ve == SRC_POS) ? static_cast<int32_t>(len) : (ve == SRC_NIL ? -1 : static_cast<int32_t>(regs[ve * 64]));
-                    if (pb < 0 || pe < 0) { pb = -1; pe = -1; }
+            if (!want_caps) match_id[i] = info;
+            else {
+                int32_t result = info, f = -1;
+                uint32_t ng = 0;
+                if (info >= 0) {
+                    result = fin_tags[info];  // the record starts with the winning extraction
+                    ng = GT ? static_cast<uint32_t>(T.c_ngroups[result]) : c_rule[2 * result + 1];
+                    f = info;
                 }
-            };
-            const int G = T.max_groups;
-            const uint32_t row_b = static_cast<uint32_t>(slots) * 4u;
-            const bool whole = (tile << 6) + 64u <= n && !__any(too_long);
-            if (whole && caps_aligned && 64u * row_b + 256u <= L.stage_bytes) {
-                uint8_t* my_row = slice + lane * row_b;
-                for (int g = 0; g < G; ++g) {
-                    int32_t pb, pe;
-                    group_span(g, pb, pe);
-                    *reinterpret_cast<int2*>(my_row + g * 8) = make_int2(pb, pe);
-                }
-                int32_t* ids = reinterpret_cast<int32_t*>(slice + 64u * row_b);
-                ids[lane] = result;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                uint8_t* out = reinterpret_cast<uint8_t*>(caps + (i - lane) * static_cast<uint64_t>(slots));
-                for (uint32_t c = lane; c < 4u * row_b; c += 64u)
-                    *reinterpret_cast<u32x4*>(out + (c << 4)) = *reinterpret_cast<const u32x4*>(slice + (c << 4));
-                if (lane < 16u)
-                    *reinterpret_cast<u32x4*>(match_id + (i - lane) + 4u * lane) = *reinterpret_cast<const u32x4*>(ids + 4u * lane);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            } else if (valid && !too_long) {
                 int32_t* cp = caps + i * static_cast<uint64_t>(slots);
-                for (int g = 0; g < G; ++g) {
-                    int32_t pb, pe;
-                    group_span(g, pb, pe);
+                for (int g = 0; g < T.max_groups; ++g) {
+                    int32_t pb = -1, pe = -1;
+                    if (f >= 0 && static_cast<uint32_t>(g) < ng) {
+                        const uint16_t vb = fin_tags[f + 1 + 2 * g], ve = fin_tags[f + 1 + 2 * g + 1];
+                        pb = (vb == SRC_POS) ? static_cast<int32_t>(len) : (vb == SRC_NIL ? -1 : static_cast<int32_t>(regs[vb * 64]));
+                        pe = (ve == SRC_POS) ? static_cast<int32_t>(len) : (ve == SRC_NIL ? -1 : static_cast<int32_t>(regs[ve * 64]));
+                        if (pb < 0 || pe < 0) { pb = -1; pe = -1; }
+                    }
                     cp[2 * g] = pb;
                     cp[2 * g + 1] = pe;
                 }
                 match_id[i] = result;
             }
+            has_line = false;
         }
-        if (valid && too_long)
-            extract_line_global<uint8_t, uint16_t>(T, T.m_next16, data + o0, len64, i, match_id, caps, nullptr, match_only);
+        // ---- free lanes take the next lines of the range, in lane order ----
+        const uint64_t free_mask = __ballot(!has_line);
+        if (free_mask && next < range_hi) {
+            const uint32_t rank = static_cast<uint32_t>(__popcll(free_mask & ((1ull << lane) - 1ull)));
+            const uint64_t cand = next + rank;
+            if (!has_line && cand < range_hi) {
+                i = cand;
+                o0 = off[i];
+                int64_t len64 = static_cast<int64_t>(static_cast<uint64_t>(off[i + 1]) - o0);
+                if (strip_eol) len64 = trim_eol(data + o0, len64);
+                if (len64 > 65535) {
+                    // positions are 16-bit in the register block: such a line takes the per-lane path, whole
+                    extract_line_global<uint8_t, uint16_t>(T, T.m_next16, data + o0, len64, i, match_id, caps, nullptr, match_only);
+                } else {
+                    has_line = true;
+                    len = static_cast<uint32_t>(len64);
+                    pos = 0;
+                    row = row0;
+                    const uint32_t acc = tab_read<GT>(A, row, acc_off, L.row_bytes);
+                    lo4 = splat_byte0(acc);
+                    k4 = splat_byte1(acc);
+                }
+            }
+            next = min(range_hi, next + static_cast<uint64_t>(__popcll(free_mask)));
+        }
+        if (!__any(has_line)) {
+            if (next >= range_hi) break;
+            continue;  // (only lines for the per-lane path were handed out: hand out more)
+        }
+        // ---- stage the next slice of every lane's line: lane l fetches chunk l & 3 of the lines of lanes (l >> 2) + 16 r ----
+        const bool walking = has_line && pos < len && row != dead_row;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = static_cast<int>(lane >> 2) + 16 * r;
+            const uint64_t oq = __shfl(static_cast<unsigned long long>(o0), q);
+            const uint32_t pq = static_cast<uint32_t>(__shfl(static_cast<int>(pos), q));
+            const uint32_t lq = static_cast<uint32_t>(__shfl(static_cast<int>(walking ? len : 0u), q));
+            const uint32_t at_byte = pq + (lane & 3u) * 16u;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (at_byte < lq) {
+                const uint8_t* src = data + oq + at_byte;
+                if (src + 16 <= data_end) v = __builtin_nontemporal_load(&reinterpret_cast<const UnalignedWindow*>(src)->v);
+                else {
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    for (int b = 0; b < 16; ++b)
+                        if (src + b < data_end) w[b >> 2] |= static_cast<uint32_t>(src[b]) << ((b & 3) * 8);
+                    v = u32x4{w[0], w[1], w[2], w[3]};
+                }
+            }
+            *reinterpret_cast<u32x4*>(slice + static_cast<uint32_t>(q) * SLICE_ROW + (lane & 3u) * 16u) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- walk the slice: four 16-byte windows of every lane's own line ----
+        bool more = walking;
+        for (uint32_t w = 0; w < SLICE_BYTES / 16u; ++w) {
+            const uint32_t rel = pos + w * 16u;
+            const bool act = more && rel < len;
+            if (!__any(act)) break;
+            const uint4 w0 = *reinterpret_cast<const uint4*>(my + w * 16u);
+            const bool full0 = rel + 16u <= len;
+            const uint32_t bx = outside_bits(w0.x, lo4, k4), by = outside_bits(w0.y, lo4, k4);
+            const uint32_t bz = outside_bits(w0.z, lo4, k4), bw = outside_bits(w0.w, lo4, k4);
+            const bool ok0 = full0 & (((or3(bx, by, bz) | bw) & HI_BITS) == 0u);
+            bool step = act && !ok0;
+            uint32_t mask = 0xFFFFu;
+            if (step && !full0) {
+                mask = window_mask(0u, len, rel);
+                step = !partial_window_ok(bx, by, bz, bw, mask);
+            }
+            const bool masked = __any(step && !full0);
+            if (step) {
+                if (want_caps) {
+                    if (L.simple_ops) {
+                        if (!masked) row = steps16<true, false, true, GT>(w0, mask, A, row, rel, regs, L);
+                        else row = steps16<true, true, true, GT>(w0, mask, A, row, rel, regs, L);
+                    } else {
+                        if (!masked) row = steps16<true, false, false, GT>(w0, mask, A, row, rel, regs, L);
+                        else row = steps16<true, true, false, GT>(w0, mask, A, row, rel, regs, L);
+                    }
+                } else {
+                    if (!masked) row = steps16<false, false, false, GT>(w0, mask, A, row, rel, regs, L);
+                    else row = steps16<false, true, false, GT>(w0, mask, A, row, rel, regs, L);
+                }
+                const uint32_t acc = tab_read<GT>(A, row, acc_off, L.row_bytes);
+                lo4 = splat_byte0(acc);
+                k4 = splat_byte1(acc);
+            }
+            more = more && row != dead_row;
+        }
+        if (walking) pos += SLICE_BYTES;
+        // the slice buffer is rewritten by the next iteration
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -871,9 +857,9 @@ hipError_t launch_slices_t(const GxDev& dev, const GxLds& lds, const uint8_t* ld
 hipError_t launch_extract_slices(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
                                  const GxBatch& b, hipStream_t stream) {
     if (b.n == 0) return hipSuccess;
-    const uint64_t tiles = (b.n + 63) >> 6;
+    // every wave owns a contiguous range of lines; at least 256 lines per wave so that lanes can be refilled
     uint64_t blocks = static_cast<uint64_t>(num_cus);
-    const uint64_t need = (tiles + lds.nwaves - 1) / lds.nwaves;
+    const uint64_t need = (b.n + 256ull * lds.nwaves - 1) / (256ull * lds.nwaves);
     if (blocks > need) blocks = need;
     dim3 grid(static_cast<unsigned>(blocks)), block(lds.nwaves * 64);
     if (at_global) {
