@@ -202,3 +202,24 @@ def test_read_lines_is_buffered_reader_readline():
     assert O.read_lines(b"")[1] == [] and O.read_lines(b"\n")[1] == [b""]
     # a vertical tab / form feed / NEL are ordinary bytes of a line, as for readLine()
     assert O.read_lines(b"a\x0bb\x0cc\x85d")[1] == [b"a\x0bb\x0cc\x85d"]
+
+
+def test_results_to_jsonl_is_asmap_serialised():
+    """oracle.results_to_jsonl (the materialisation checker): ExtractionResult.asMap(idAs) as a LinkedHashMap -- id,
+    captures in group order (null for an unset group), append entries; a key put again keeps its place."""
+    import numpy as np
+    names = ["first", "second"]
+    extractor_names = [["a", "b"], ["v", "v"]]
+    appends = [{"b": 7, "extra": {"k": [1, None]}}, None]
+    lines = [b'x"y' + bytes([0x5C]) + b"z", b"plain", b"nothing"]
+    mid = np.array([0, 1, -1], np.int32)
+    caps = np.array([[0, 3, -1, -1], [0, 2, 2, 5], [-1, -1, -1, -1]], np.int32)
+    text, offs = O.results_to_jsonl(lines, mid, caps, names, extractor_names, appends, id_as="id")
+    bs = bytes([0x5C])  # one backslash
+    line0 = b'{"id":"first","a":"x' + bs + b'"y","b":7,"extra":{"k":[1,null]}}' + b"\n"
+    line1 = b'{"id":"second","v":"ain"}' + b"\n"
+    assert text == line0 + line1
+    assert offs.tolist() == [0, len(line0), len(line0) + len(line1), len(line0) + len(line1)]
+    t2, _ = O.results_to_jsonl([bytes([1, 9, 0xE9])], np.array([0], np.int32), np.array([[0, 3, -1, -1]], np.int32), names,
+                               extractor_names, [None, None])
+    assert t2 == b'{"a":"' + bs + b"u0001" + bs + b"t" + bytes([0xC3, 0xA9]) + b'","b":null}' + b"\n"
