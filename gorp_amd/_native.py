@@ -29,7 +29,7 @@ SYMBOLS = [
     "gx_extraction_name", "gx_extractor_name", "gx_extraction_append_json",
     "gx_split_lines", "gx_results_to_jsonl", "gx_set_extraction_meta",
     "gx_extraction_append_count", "gx_extraction_append_key", "gx_extraction_append_value_json",
-    "gx_pack_results", "gx_unpack_results",
+    "gx_pack_results", "gx_unpack_results", "gx_text_to_jsonl",
 ]
 
 
@@ -145,6 +145,9 @@ def lib():
     L.gx_results_to_jsonl.restype = C.c_int
     L.gx_set_extraction_meta.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.POINTER(C.c_char_p), C.c_int32, C.c_char_p]
     L.gx_set_extraction_meta.restype = C.c_int
+    L.gx_text_to_jsonl.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(gx_batch_opts)]
+    L.gx_text_to_jsonl.restype = C.c_int
     L.gx_pack_results.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(gx_batch_opts)]
     L.gx_pack_results.restype = C.c_int
     L.gx_unpack_results.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(gx_batch_opts)]

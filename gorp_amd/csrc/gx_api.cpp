@@ -666,6 +666,82 @@ int gx_results_to_jsonl(gx_handle* h, const uint8_t* bytes, const void* offsets,
     catch (std::exception& e) { return fail(GX_E_ARG, e.what()); }
 }
 
+int gx_text_to_jsonl(gx_handle* h, const uint8_t* text, uint64_t size, const char* id_as, uint8_t* out, uint64_t out_cap, uint64_t* out_size,
+                     uint64_t* n_lines, uint64_t* n_matched, uint64_t* n_exceptions, const gx_batch_opts* opts) {
+    if (!h || !out_size || (size && !text)) return fail(GX_E_ARG, "gx_text_to_jsonl: bad argument");
+    if (!h->on_device) return fail(GX_E_DEVICE, "handle was created host-only; no device tables (there is no CPU fallback)");
+    if (size > 0xFFFFFFFFull) return fail(GX_E_LIMIT, "gx_text_to_jsonl: split texts of 4 GiB and more at a line boundary");
+    gx_batch_opts o{};
+    if (!read_opts(opts, &o)) return fail(GX_E_ARG, "gx_batch_opts.struct_size mismatch");
+    const size_t slots = 2 * static_cast<size_t>(h->T.max_groups);
+    if (slots > 128) return fail(GX_E_LIMIT, "gx_text_to_jsonl: more than 64 capture groups per extraction");
+    try {
+        GX_HIP(hipSetDevice(h->device));
+        std::lock_guard<std::mutex> lock(h->mu);
+        const GxJsonl& tm = jsonl_templates(h, id_as);
+        hipStream_t stream = static_cast<hipStream_t>(o.stream);
+        DevBuf d_text, ws_split, d_off, d_mid, d_caps, ws_json, d_loff, d_counts, d_out;
+        const uint8_t* src = text;
+        if (!o.device_pointers) {
+            d_text.alloc(size);
+            if (size) GX_HIP(hipMemcpyAsync(d_text.p, text, size, hipMemcpyHostToDevice, stream));
+            src = static_cast<const uint8_t*>(d_text.p);
+        } else if (reinterpret_cast<uintptr_t>(text) & 15u) {
+            return fail(GX_E_ARG, "gx_text_to_jsonl: device text must be 16-byte aligned");
+        }
+        // 1. lines: count them, then write their offsets
+        ws_split.alloc(split_workspace_bytes(size));
+        d_off.alloc(16);
+        uint64_t* d_n = nullptr;
+        GX_HIP(launch_split_lines(src, size, d_off.p, 0, 0, nullptr, ws_split.p, &d_n, stream));
+        uint64_t n = 0;
+        GX_HIP(hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, stream));
+        GX_HIP(hipStreamSynchronize(stream));
+        DevBuf d_off2;
+        d_off2.alloc((n + 1) * 4);
+        GX_HIP(launch_split_lines(src, size, d_off2.p, 0, n, nullptr, ws_split.p, &d_n, stream));
+        // 2. the path
+        d_mid.alloc(n * 4);
+        d_caps.alloc(n * slots * 4);
+        GxBatch b{};
+        b.data = src; b.offsets = d_off2.p; b.n = n; b.match_id = static_cast<int32_t*>(d_mid.p);
+        b.caps = h->T.has_capture ? static_cast<int32_t*>(d_caps.p) : nullptr;
+        b.match_only = h->T.has_capture ? 0 : 1;
+        b.strip_eol = 1;
+        const uint32_t mean_in = n ? static_cast<uint32_t>(std::min<uint64_t>((size + n - 1) / n, 1u << 20)) : 1u;
+        launch_batch(h, b, mean_in, stream);
+        if (!h->T.has_capture && n && slots) GX_HIP(hipMemsetAsync(d_caps.p, 0xFF, n * slots * 4, stream));
+        b.caps = static_cast<int32_t*>(d_caps.p);
+        d_counts.alloc(16);
+        GX_HIP(launch_count_outcomes(b.match_id, n, static_cast<unsigned long long*>(d_counts.p), stream));
+        // 3. the text
+        ws_json.alloc(jsonl_workspace_bytes(n));
+        d_loff.alloc((n + 1) * 8);
+        uint64_t* loff = static_cast<uint64_t*>(d_loff.p);
+        GX_HIP(launch_jsonl_sizes(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, mean_in, loff, ws_json.p, stream));
+        uint64_t total = 0;
+        unsigned long long counts[2] = {0, 0};
+        GX_HIP(hipMemcpyAsync(&total, loff + n, 8, hipMemcpyDeviceToHost, stream));
+        GX_HIP(hipMemcpyAsync(counts, d_counts.p, 16, hipMemcpyDeviceToHost, stream));
+        GX_HIP(hipStreamSynchronize(stream));
+        *out_size = total;
+        if (n_lines) *n_lines = n;
+        if (n_matched) *n_matched = counts[0];
+        if (n_exceptions) *n_exceptions = counts[1];
+        if (!out) return GX_OK;
+        if (total > out_cap) return fail(GX_E_LIMIT, "gx_text_to_jsonl: out_cap is smaller than the text (see *out_size)");
+        uint8_t* dst = out;
+        if (!o.device_pointers) { d_out.alloc(total); dst = static_cast<uint8_t*>(d_out.p); }
+        const uint32_t mean_out = n ? static_cast<uint32_t>(std::min<uint64_t>((total + n - 1) / n, 1u << 20)) : 1u;
+        GX_HIP(launch_jsonl_write(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, mean_in, mean_out, loff, dst, stream));
+        if (!o.device_pointers && total) GX_HIP(hipMemcpyAsync(out, dst, total, hipMemcpyDeviceToHost, stream));
+        GX_HIP(hipStreamSynchronize(stream));
+        return GX_OK;
+    } catch (GxError& e) { return fail(e.code, e.what()); }
+    catch (std::bad_alloc&) { return fail(GX_E_NOMEM, "out of memory"); }
+    catch (std::exception& e) { return fail(GX_E_ARG, e.what()); }
+}
+
 int gx_pack_results(const int32_t* match_id, const int32_t* caps, uint64_t n, int32_t slots, uint16_t* packed, uint64_t* n_overflow,
                     const gx_batch_opts* opts) {
     if (slots < 0 || !n_overflow || (n && (!match_id || !packed || (slots && !caps)))) return fail(GX_E_ARG, "gx_pack_results: bad argument");

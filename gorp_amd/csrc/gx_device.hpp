@@ -124,6 +124,7 @@ size_t jsonl_workspace_bytes(uint64_t n);
 // mean_in / mean_out: mean bytes per line of input and of output text; they size the LDS staging of the tile kernels
 hipError_t launch_jsonl_sizes(const GxJsonl& tm, const GxBatch& b, int slots, int passthrough, uint32_t mean_in, uint64_t* line_out_off,
                               void* workspace, hipStream_t stream);
+hipError_t launch_count_outcomes(const int32_t* match_id, uint64_t n, unsigned long long* d_counts, hipStream_t stream);
 hipError_t launch_pack_results(const int32_t* match_id, const int32_t* caps, uint64_t n, int slots, uint16_t* packed,
                                unsigned long long* d_overflow, hipStream_t stream);
 hipError_t launch_unpack_results(const uint16_t* packed, uint64_t n, int slots, int32_t* match_id, int32_t* caps, hipStream_t stream);

@@ -632,6 +632,33 @@ hipError_t launch_unpack_results(const uint16_t* packed, uint64_t n, int slots, 
     return hipGetLastError();
 }
 
+// counts[0] = lines with match_id >= 0, counts[1] = lines with match_id <= -2 (capture regexp rejected the line)
+namespace {
+__global__ void __launch_bounds__(256) k_count_outcomes(const int32_t* __restrict__ match_id, uint64_t n, unsigned long long* __restrict__ counts) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    uint32_t matched = 0, rejected = 0;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int32_t k = match_id[i];
+        matched += k >= 0 ? 1u : 0u;
+        rejected += k <= -2 ? 1u : 0u;
+    }
+    matched = wave_sum(matched);
+    rejected = wave_sum(rejected);
+    if ((threadIdx.x & 63u) == 0) {
+        if (matched) atomicAdd(counts, static_cast<unsigned long long>(matched));
+        if (rejected) atomicAdd(counts + 1, static_cast<unsigned long long>(rejected));
+    }
+}
+}  // namespace
+
+hipError_t launch_count_outcomes(const int32_t* match_id, uint64_t n, unsigned long long* d_counts, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(d_counts, 0, 16, stream);
+    if (e != hipSuccess || n == 0) return e;
+    uint64_t blocks = std::min<uint64_t>((n + 255) / 256, 256u * 8u);
+    hipLaunchKernelGGL(k_count_outcomes, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, match_id, n, d_counts);
+    return hipGetLastError();
+}
+
 size_t jsonl_workspace_bytes(uint64_t n) {
     const uint64_t nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     return static_cast<size_t>(n * 4 + (nblocks + 2) * 8 + 64);

@@ -287,6 +287,23 @@ class Gorp:
         text = out[:size.value].tobytes()
         return (text, loff) if want_line_offsets else text
 
+    def text_to_jsonl(self, text, id_as=None, utf8_passthrough=False):
+        """gx_text_to_jsonl on a host buffer: raw log text -> JSON Lines of the matched lines.
+        Returns (jsonl bytes, n_lines, n_matched, n_exceptions)."""
+        self._send_meta()
+        raw = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else text, dtype=np.uint8)
+        o = N.gx_batch_opts()
+        o.struct_size = C.sizeof(N.gx_batch_opts)
+        o.utf8_passthrough = 1 if utf8_passthrough else 0
+        ida = id_as.encode("utf-8") if id_as is not None else None
+        size, nl, nm, nx = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        ptr = raw.ctypes.data if raw.size else None
+        _check(N.lib().gx_text_to_jsonl(self._h.ptr, ptr, raw.size, ida, None, 0, C.byref(size), C.byref(nl), C.byref(nm), C.byref(nx), C.byref(o)))
+        out = np.zeros(max(1, size.value), np.uint8)
+        _check(N.lib().gx_text_to_jsonl(self._h.ptr, ptr, raw.size, ida, out.ctypes.data, size.value, C.byref(size), C.byref(nl), C.byref(nm),
+                                        C.byref(nx), C.byref(o)))
+        return out[:size.value].tobytes(), nl.value, nm.value, nx.value
+
     def results_to_jsonl_device(self, data_ptr, offsets_ptr, n, match_id_ptr, caps_ptr, out_ptr, out_cap, line_offsets_ptr=None,
                                 id_as=None, offsets64=False, utf8_passthrough=False, stream=None):
         """Device pointers; returns the size of the text (out_ptr=None only asks for it)."""

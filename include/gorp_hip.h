@@ -142,6 +142,17 @@ int gx_results_to_jsonl(gx_handle* h, const uint8_t* bytes, const void* offsets,
                         const int32_t* caps, const char* id_as, uint8_t* out, uint64_t out_cap, uint64_t* out_size,
                         uint64_t* line_out_offsets, const gx_batch_opts* opts);
 
+/* The three steps in one call, for whole files: raw text -> lines (gx_split_lines semantics) -> the match-and-extract
+ * path (terminators ignored) -> JSON Lines (gx_results_to_jsonl semantics).  What the reference's caller writes as
+ *     while ((line = reader.readLine()) != null) { r = gorp.extract(line); if (r != null) write(json(r.asMap(idAs))); }
+ * (README.md:26,63-79), with extractSafe semantics for lines the capture regexp rejects (no text, counted in
+ * *n_exceptions).  Intermediate buffers live and die on the device.  *n_lines / *n_matched / *n_exceptions (each
+ * optional) receive the counts; *out_size the size of the text; out == NULL only asks for the size; GX_E_LIMIT when
+ * out_cap is too small.  opts: device_pointers (text and out on the device), stream, utf8_passthrough.  Text of 4 GiB
+ * and more must be split by the caller (at a line boundary). */
+int gx_text_to_jsonl(gx_handle* h, const uint8_t* text, uint64_t size, const char* id_as, uint8_t* out, uint64_t out_cap,
+                     uint64_t* out_size, uint64_t* n_lines, uint64_t* n_matched, uint64_t* n_exceptions, const gx_batch_opts* opts);
+
 /* Compact result rows for transport between GPUs (the gather of SURVEY.md section 8(e)): per line one int16 match id
  * followed by `slots` (= 2 * gx_max_groups) uint16 offsets, 0xFFFF = unset: 2 + 2*slots bytes instead of 4 + 4*slots.
  * Device buffers only.  *n_overflow (host) receives the number of offsets above 65534, which do not fit (they are

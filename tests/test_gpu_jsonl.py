@@ -174,3 +174,34 @@ def test_many_extractions_templates_in_global_memory():
     assert (mid >= 0).sum() > 2500
     for t in text.decode("utf-8").split("\n")[:50]:
         json.loads(t)
+
+
+def test_text_to_jsonl_one_call():
+    """gx_text_to_jsonl: raw text -> JSON Lines in one call == readLine() + oracle extract (safe) + asMap serialised."""
+    gorp = Gorp.construct(W.readme3_definition())
+    from test_gpu_parity import oracle_for
+    orc = oracle_for(W.readme3_definition())
+    data, offsets, cat = W.readme3_lines(30000, seed=41)
+    d, o = data.numpy(), offsets.numpy()
+    rng = random.Random(9)
+    lines = [bytes(d[o[i]:o[i + 1]]) for i in range(len(o) - 1)]
+    lines[10] = b""
+    lines[11] = b"[1]: GET 5ms /" + b"q" * 70000
+    raw = b"".join(ln + rng.choice([b"\n", b"\r\n", b"\r"]) for ln in lines[:-1]) + lines[-1]
+    text, n_lines, n_matched, n_exc = gorp.text_to_jsonl(raw, id_as="id")
+    _, want_lines, _ = O.read_lines(raw)
+    assert n_lines == len(want_lines) == len(lines)
+    cd, co = lines_to_csr(want_lines)
+    omid, ocaps = orc.extract_batch(cd, co, nthreads=8)
+    xs = gorp.getExtractions()
+    want, _ = O.results_to_jsonl(want_lines, omid, ocaps, [x.getName() for x in xs], [x._extractorNames for x in xs],
+                                 [x.getExtra() for x in xs], id_as="id")
+    assert text == want
+    assert n_matched == int((omid >= 0).sum()) and n_exc == int((omid <= -2).sum())
+    # empty text, text without a final terminator, a definition whose regexps disagree (exception -> no text, counted)
+    assert gorp.text_to_jsonl(b"")[:2] == (b"", 0)
+    dot = Gorp.construct([FlattenedExtraction("r", [["text", "a"], ["extractor", "x", [["pattern", ".*"]]], ["text", "b"]])])
+    t, nl, nm, nx = dot.text_to_jsonl(b"axb\na\x0bb\nzzz", id_as=None)
+    o2 = oracle_for([FlattenedExtraction("r", [["text", "a"], ["extractor", "x", [["pattern", ".*"]]], ["text", "b"]])])
+    m2, c2 = o2.extract_batch(*lines_to_csr([b"axb", b"a\x0bb", b"zzz"]))
+    assert nm == int((m2 >= 0).sum()) and nx == int((m2 <= -2).sum())
