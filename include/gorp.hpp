@@ -146,6 +146,18 @@ public:
         if (rc != GX_OK) throw GorpError(rc, gx_last_error());
         return out;
     }
+    // Whole files: raw text in, JSON Lines of the matched lines out (gx_text_to_jsonl); counts are optional
+    std::string textToJsonl(const std::string& text, const char* idAs = nullptr, uint64_t* nLines = nullptr, uint64_t* nMatched = nullptr,
+                            uint64_t* nExceptions = nullptr) const {
+        uint64_t size = 0;
+        const uint8_t* p = reinterpret_cast<const uint8_t*>(text.data());
+        int rc = gx_text_to_jsonl(h_, p, text.size(), idAs, nullptr, 0, &size, nLines, nMatched, nExceptions, nullptr);
+        if (rc != GX_OK) throw GorpError(rc, gx_last_error());
+        std::string out(static_cast<size_t>(size), '\0');
+        rc = gx_text_to_jsonl(h_, p, text.size(), idAs, reinterpret_cast<uint8_t*>(&out[0]), size, &size, nLines, nMatched, nExceptions, nullptr);
+        if (rc != GX_OK) throw GorpError(rc, gx_last_error());
+        return out;
+    }
     int maxGroups() const { return gx_max_groups(h_); }
     gx_handle* handle() const { return h_; }
 
