@@ -13,6 +13,13 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def oracle_for(definition):
     built = [e.build() for e in definition]
     return O.OracleGorp([b[0] for b in built], [b[1] for b in built])
@@ -423,8 +430,8 @@ def test_compact_result_rows_roundtrip_and_gather():
     import torch.distributed as dist
     from gorp_amd import dist as gdist
     import os
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29517")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         c[5, 3] = 7; c[77, 0] = 9
@@ -444,7 +451,7 @@ def test_two_ranks_share_one_gpu():
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "tests", "dist_gpu_worker.py")]
+           "--master-port", str(_free_port()), os.path.join(root, "tests", "dist_gpu_worker.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0 and "dist_gpu_worker ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
