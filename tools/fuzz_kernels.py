@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Developer tool: a longer differential run than the test-suite's -- random definitions through every kernel
+variant (LDS tier, L2 tier, slice kernel on both, generic) against the oracle.  Usage: fuzz_kernels.py [defs] [seed]"""
+import os, sys, random
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import numpy as np
+import test_compiler_vs_oracle as TC
+from blob_interp import Blob
+from gorp_amd.gorp import Gorp, FlattenedExtraction, lines_to_csr
+from oracle import oracle as O
+
+n_defs = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2024
+rng = random.Random(seed)
+variants = [{}, {"GX_DEBUG_TIER": "2"}, {"GX_DEBUG_SLICES": "1"}, {"GX_DEBUG_TIER": "2", "GX_DEBUG_SLICES": "1"}, {"GX_DEBUG_TIER": "3"}]
+done = bad = 0
+while done < n_defs:
+    exts = [FlattenedExtraction("e%d" % i, TC.gen_pieces(rng)) for i in range(rng.randint(1, 5))]
+    try:
+        built = [e.build() for e in exts]
+        orc = O.OracleGorp([b[0] for b in built], [b[1] for b in built])
+        env = variants[done % len(variants)]
+        for k in ("GX_DEBUG_TIER", "GX_DEBUG_SLICES"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        gorp = Gorp.construct(exts)
+    except Exception:
+        continue
+    b = Blob(gorp.blob())
+    lines = [TC.gen_line(rng) for _ in range(40)] + [TC.sample_from_match_automaton(b, rng) for _ in range(88)]
+    lines += [ln * rng.randint(2, 40) for ln in lines[:20]]  # longer lines: several windows / slices
+    raw = [ln.encode("latin-1") if isinstance(ln, str) else ln for ln in lines]
+    data, offsets = lines_to_csr(raw)
+    mid, caps = gorp.extract_batch(data, offsets)
+    omid, ocaps = orc.extract_batch(data, offsets, nthreads=4)
+    if not (np.array_equal(mid, omid) and np.array_equal(caps, ocaps)):
+        bad += 1
+        i = int(np.nonzero((mid != omid) | (caps != ocaps).any(axis=1))[0][0])
+        print("MISMATCH variant", env, "line", repr(raw[i]), "gpu", mid[i], caps[i].tolist(), "oracle", omid[i], ocaps[i].tolist())
+        print("  definition:", [(e.name, e.pieces) for e in exts])
+    m2, _ = gorp.extract_batch(data, offsets, match_only=True)
+    want_m = np.where(omid <= -2, -2 - omid, omid)  # match-only reports the matcher's choice
+    if not np.array_equal(m2, want_m):
+        bad += 1
+        print("MATCH-ONLY MISMATCH variant", env)
+    done += 1
+print("fuzz: %d definitions, %d mismatches" % (done, bad))
+sys.exit(1 if bad else 0)
