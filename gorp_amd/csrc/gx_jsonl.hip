@@ -272,6 +272,10 @@ struct JsonlTileCfg {
     uint32_t caps_bytes;  // per-wave staging of the tile's capture rows (64 * slots * 4), 0: read them from global memory
 };
 
+// four bytes of LDS at any alignment (gfx950 reads LDS unaligned)
+struct __attribute__((packed)) UnalignedU32 { uint32_t v; };
+__device__ __forceinline__ uint32_t load_u32(const uint8_t* p) { return reinterpret_cast<const UnalignedU32*>(p)->v; }
+
 // some byte of w is a control character (< 0x20) or >= 0x80
 __device__ __forceinline__ bool ctrl_or_high4(uint32_t w) {
     const uint32_t t = (w & 0x7F7F7F7Fu) + 0x60606060u;  // bit 7 of a byte set iff its low 7 bits >= 0x20
@@ -431,23 +435,31 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
                             // characters -- plain ones and the two that only take a backslash -- go through one
                             // branch-free sequence (two byte stores, the second overwriting the first for a plain
                             // character); only control characters and bytes >= 0x80 take the branchy path.
-                            int32_t p = cb;
-                            for (; p + 4 <= ce; p += 4) {
-                                const uint32_t v0 = line[p], v1 = line[p + 1], v2 = line[p + 2], v3 = line[p + 3];
-                                const uint32_t w = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
-                                if (!ctrl_or_high4(w)) {
-                                    const uint32_t q0 = (v0 == 0x22u || v0 == 0x5Cu) ? 1u : 0u, q1 = (v1 == 0x22u || v1 == 0x5Cu) ? 1u : 0u;
-                                    const uint32_t q2 = (v2 == 0x22u || v2 == 0x5Cu) ? 1u : 0u, q3 = (v3 == 0x22u || v3 == 0x5Cu) ? 1u : 0u;
-                                    dst[0] = static_cast<uint8_t>(q0 ? 0x5Cu : v0); dst[q0] = static_cast<uint8_t>(v0); dst += 1u + q0;
-                                    dst[0] = static_cast<uint8_t>(q1 ? 0x5Cu : v1); dst[q1] = static_cast<uint8_t>(v1); dst += 1u + q1;
-                                    dst[0] = static_cast<uint8_t>(q2 ? 0x5Cu : v2); dst[q2] = static_cast<uint8_t>(v2); dst += 1u + q2;
-                                    dst[0] = static_cast<uint8_t>(q3 ? 0x5Cu : v3); dst[q3] = static_cast<uint8_t>(v3); dst += 1u + q3;
-                                } else {
-                                    esc_write(dst, v0, pt); dst += esc_len(v0, pt);
-                                    esc_write(dst, v1, pt); dst += esc_len(v1, pt);
-                                    esc_write(dst, v2, pt); dst += esc_len(v2, pt);
-                                    esc_write(dst, v3, pt); dst += esc_len(v3, pt);
+                            auto put4 = [&](uint32_t w) {  // four plain-or-backslashed characters
+                                const uint32_t v0 = w & 0xFFu, v1 = (w >> 8) & 0xFFu, v2 = (w >> 16) & 0xFFu, v3 = w >> 24;
+                                const uint32_t q0 = (v0 == 0x22u || v0 == 0x5Cu) ? 1u : 0u, q1 = (v1 == 0x22u || v1 == 0x5Cu) ? 1u : 0u;
+                                const uint32_t q2 = (v2 == 0x22u || v2 == 0x5Cu) ? 1u : 0u, q3 = (v3 == 0x22u || v3 == 0x5Cu) ? 1u : 0u;
+                                dst[0] = static_cast<uint8_t>(q0 ? 0x5Cu : v0); dst[q0] = static_cast<uint8_t>(v0); dst += 1u + q0;
+                                dst[0] = static_cast<uint8_t>(q1 ? 0x5Cu : v1); dst[q1] = static_cast<uint8_t>(v1); dst += 1u + q1;
+                                dst[0] = static_cast<uint8_t>(q2 ? 0x5Cu : v2); dst[q2] = static_cast<uint8_t>(v2); dst += 1u + q2;
+                                dst[0] = static_cast<uint8_t>(q3 ? 0x5Cu : v3); dst[q3] = static_cast<uint8_t>(v3); dst += 1u + q3;
+                            };
+                            auto slow4 = [&](uint32_t w) {
+                                for (int q = 0; q < 4; ++q) {
+                                    const uint32_t v = (w >> (8 * q)) & 0xFFu;
+                                    esc_write(dst, v, pt);
+                                    dst += esc_len(v, pt);
                                 }
+                            };
+                            int32_t p = cb;
+                            for (; p + 8 <= ce; p += 8) {  // two words per round trip to LDS
+                                const uint32_t w0 = load_u32(line + p), w1 = load_u32(line + p + 4);
+                                if (!ctrl_or_high4(w0)) put4(w0); else slow4(w0);
+                                if (!ctrl_or_high4(w1)) put4(w1); else slow4(w1);
+                            }
+                            for (; p + 4 <= ce; p += 4) {
+                                const uint32_t w = load_u32(line + p);
+                                if (!ctrl_or_high4(w)) put4(w); else slow4(w);
                             }
                             for (; p < ce; ++p) {
                                 const uint32_t v = line[p];
@@ -456,9 +468,23 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
                             }
                             *dst++ = '"';
                         } else {
+                            // four characters at a time: 4 + one per quote / backslash (+ one per byte >= 0x80 that becomes
+                            // two bytes of UTF-8); a word with a control character is counted byte by byte
                             uint32_t t = 2u;
-#pragma unroll 4
-                            for (int32_t p = cb; p < ce; ++p) t += esc_len(line[p], pt);
+                            int32_t p = cb;
+                            for (; p + 4 <= ce; p += 4) {
+                                const uint32_t w = load_u32(line + p);
+                                const uint32_t tt = (w & 0x7F7F7F7Fu) + 0x60606060u;
+                                if ((~(tt | w)) & 0x80808080u) {  // some byte < 0x20
+                                    for (int q = 0; q < 4; ++q) t += esc_len((w >> (8 * q)) & 0xFFu, pt);
+                                } else {
+                                    const uint32_t x = w ^ 0x22222222u, y = w ^ 0x5C5C5C5Cu;
+                                    const uint32_t zq = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+                                    const uint32_t zb = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
+                                    t += 4u + __popc(zq | zb) + (pt ? 0u : __popc(w & 0x80808080u));
+                                }
+                            }
+                            for (; p < ce; ++p) t += esc_len(line[p], pt);
                             total += t;
                         }
                     }
