@@ -275,6 +275,7 @@ struct JsonlTileCfg {
 // four bytes of LDS at any alignment (gfx950 reads LDS unaligned)
 struct __attribute__((packed)) UnalignedU32 { uint32_t v; };
 __device__ __forceinline__ uint32_t load_u32(const uint8_t* p) { return reinterpret_cast<const UnalignedU32*>(p)->v; }
+__device__ __forceinline__ void store_u32(uint8_t* p, uint32_t v) { reinterpret_cast<UnalignedU32*>(p)->v = v; }
 
 // some byte of w is a control character (< 0x20) or >= 0x80
 __device__ __forceinline__ bool ctrl_or_high4(uint32_t w) {
@@ -410,10 +411,12 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
                             if (cfg.lits_lds != 0xFFFFFFFFu) {
                                 const uint8_t* lit = jx_smem + cfg.lits_lds + lo_l;
                                 uint32_t q = 0;
-                                for (; q + 4u <= ll; q += 4u) {  // reads first, then writes: four LDS round trips overlap
-                                    const uint8_t v0 = lit[q], v1 = lit[q + 1], v2 = lit[q + 2], v3 = lit[q + 3];
-                                    dst[q] = v0; dst[q + 1] = v1; dst[q + 2] = v2; dst[q + 3] = v3;
+                                for (; q + 8u <= ll; q += 8u) {  // two unaligned words per LDS round trip
+                                    const uint32_t a = load_u32(lit + q), b2 = load_u32(lit + q + 4u);
+                                    store_u32(dst + q, a);
+                                    store_u32(dst + q + 4u, b2);
                                 }
+                                for (; q + 4u <= ll; q += 4u) store_u32(dst + q, load_u32(lit + q));
                                 for (; q < ll; ++q) dst[q] = lit[q];
                             } else {
                                 const uint8_t* lit = tm.lits + lo_l;
