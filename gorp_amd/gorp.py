@@ -96,32 +96,48 @@ class FlattenedExtraction:
         self.pieces = pieces
         self.append = append
 
-    def build(self):
-        autom, jdk, names = [], [], []
+    def getExtractorNames(self):
+        """Extractor names in pre-order == capture group order (core/model/CookedDefinitions.java:444-451)."""
+        names = []
+
+        def walk(p):
+            if p[0] == "extractor":
+                names.append(p[1])
+                for c in p[2]:
+                    walk(c)
+
+        for p in self.pieces:
+            walk(p)
+        return names
+
+    def build(self, cooker=None):
+        """Gorp._buildExtractor (core/Gorp.java:94-129) over all pieces: the automaton regexp is always built the
+        reference's way; the capture-side regexp goes through the ExtractionCooker's append* methods.
+        Returns (automaton regexp, cooker regexp, extractor names)."""
+        cooker = cooker or HipExtractionCooker.instance()
+        autom, regexp = [], []
 
         def walk(p):
             kind = p[0]
-            if kind == "pattern":
+            if kind == "pattern":                       # LiteralPattern, Gorp.java:98-108
                 autom.append(RegexHelper.massageRegexpForAutomaton(p[1]))
-                jdk.append(RegexHelper.massageRegexpForJDK(p[1]))
-            elif kind == "text":
-                q = RegexHelper.quoteLiteralAsRegexp(p[1])
-                autom.append(q)
-                jdk.append(q)
-            elif kind == "extractor":
-                names.append(p[1])
+                cooker.appendPattern(p[1], regexp)
+            elif kind == "text":                        # LiteralText, :109-114
+                autom.append(RegexHelper.quoteLiteralAsRegexp(p[1]))
+                cooker.appendLiteral(p[1], regexp)
+            elif kind == "extractor":                   # ExtractorExpression, :115-127
                 autom.append("(")
-                jdk.append("(")
+                cooker.appendStartExpression(regexp)
                 for c in p[2]:
                     walk(c)
                 autom.append(")")
-                jdk.append(")")
+                cooker.appendFinishExpression(regexp)
             else:
                 raise DefinitionParseException(N.GX_E_ARG, "Unrecognized DefPiece in FlattenedExtraction: %r" % (kind,))
 
         for p in self.pieces:
             walk(p)
-        return "".join(autom), "".join(jdk), names
+        return "".join(autom), "".join(regexp), self.getExtractorNames()
 
 
 class CookedExtraction:
@@ -145,6 +161,58 @@ class CookedExtraction:
 
     def getRegexpDesc(self):
         return self._regexpSource
+
+
+class ExtractionCooker:
+    """core/ExtractionCooker.java:16-30 -- the reference's plugin API for the capture backend: a factory that turns a
+    FlattenedExtraction into a CookedExtraction and says how pieces are spelled in the backend's regexp dialect.
+    `buffer` is a list of string fragments (the StringBuilder)."""
+
+    def cook(self, index, regexpSource, extr):
+        raise NotImplementedError
+
+    def appendPattern(self, pattern, buffer):
+        raise NotImplementedError
+
+    def appendLiteral(self, literal, buffer):
+        raise NotImplementedError
+
+    def appendStartExpression(self, buffer):
+        raise NotImplementedError
+
+    def appendFinishExpression(self, buffer):
+        raise NotImplementedError
+
+
+class HipExtractionCooker(ExtractionCooker):
+    """The backend of this package, plugged in where the reference plugs JDKRegexpExtractionCooker
+    (core/jdkre/JDKRegexpExtractionCooker.java:20-42): same dialect (java.util.regex), so the append* methods are the
+    same string rewrites; cook() keeps the data of the CookedExtraction -- the capture regexps of all extractions are
+    compiled together, with the match automaton, into the device tables by Gorp.construct (gx_create_from_patterns),
+    because one line at a time through CookedExtraction.match would leave the GPU idle."""
+
+    _INSTANCE = None
+
+    @classmethod
+    def instance(cls):
+        if cls._INSTANCE is None:
+            cls._INSTANCE = cls()
+        return cls._INSTANCE
+
+    def cook(self, index, regexpSource, extr):
+        return CookedExtraction(index, extr.name, regexpSource, extr.getExtractorNames(), extr.append)
+
+    def appendPattern(self, pattern, buffer):
+        buffer.append(RegexHelper.massageRegexpForJDK(pattern))
+
+    def appendLiteral(self, literal, buffer):
+        buffer.append(RegexHelper.quoteLiteralAsRegexp(literal))
+
+    def appendStartExpression(self, buffer):
+        buffer.append("(")
+
+    def appendFinishExpression(self, buffer):
+        buffer.append(")")
 
 
 class ExtractionResult:
@@ -322,15 +390,17 @@ class Gorp:
 
     # -- construction ------------------------------------------------------
     @staticmethod
-    def construct(extractions, host_only=False):
-        """extractions: list of FlattenedExtraction (what CookedDefinitions.getExtractions() yields)."""
-        autom, jdk, cooked = [], [], []
+    def construct(extractions, cooker=None, host_only=False):
+        """Gorp.construct(defs, cooker) (core/Gorp.java:50-92).  extractions: list of FlattenedExtraction (what
+        CookedDefinitions.getExtractions() yields); cooker: an ExtractionCooker, default HipExtractionCooker."""
+        cooker = cooker or HipExtractionCooker.instance()
+        autom, regexps, cooked = [], [], []
         for i, ext in enumerate(extractions):
-            a, j, names = ext.build()
+            a, r, _ = ext.build(cooker)
             autom.append(a)
-            jdk.append(j)
-            cooked.append(CookedExtraction(i, ext.name, j, names, ext.append))
-        h = _create(autom, jdk, N.GX_CREATE_HOST_ONLY if host_only else 0)
+            regexps.append(r)
+            cooked.append(cooker.cook(len(cooked), r, ext))
+        h = _create(autom, regexps, N.GX_CREATE_HOST_ONLY if host_only else 0)
         return Gorp(h, cooked)
 
     @staticmethod

@@ -321,3 +321,44 @@ def test_gx_create_from_definition_matches_the_two_step_path():
     # an invalid regex inside a pattern surfaces like Gorp.construct's wrapper (core/Gorp.java:84-90)
     rc = L.gx_create_from_definition(b"extract a {\n template %{(a}\n}\n", None, N.GX_CREATE_HOST_ONLY, C.byref(h))
     assert rc == N.GX_E_REGEX_SYNTAX and "problem with PolyMatcher construction" in N.last_error()
+
+
+def test_extraction_cooker_plugin_api():
+    """core/ExtractionCooker.java:16-30 mirrored: Gorp.construct(defs, cooker) drives the cooker's append* methods
+    exactly as Gorp._buildExtractor does (core/Gorp.java:94-129) and keeps what cook() returns."""
+    from gorp_amd.gorp import ExtractionCooker, HipExtractionCooker, FlattenedExtraction, Gorp
+
+    calls = []
+
+    class Recording(HipExtractionCooker):
+        def appendPattern(self, pattern, buffer):
+            calls.append(("pattern", pattern))
+            super().appendPattern(pattern, buffer)
+
+        def appendLiteral(self, literal, buffer):
+            calls.append(("literal", literal))
+            super().appendLiteral(literal, buffer)
+
+        def appendStartExpression(self, buffer):
+            calls.append(("start",))
+            super().appendStartExpression(buffer)
+
+        def appendFinishExpression(self, buffer):
+            calls.append(("finish",))
+            super().appendFinishExpression(buffer)
+
+        def cook(self, index, regexpSource, extr):
+            calls.append(("cook", index, regexpSource))
+            return super().cook(index, regexpSource, extr)
+
+    digit = chr(92) + "d"                      # the pattern \\d, spelled without escapes in this file
+    ext = FlattenedExtraction("x", [["text", "k= "], ["extractor", "v", [["pattern", "(a|b)+"], ["extractor", "w", [["pattern", digit]]]]]], {"t": 1})
+    g = Gorp.construct([ext], Recording(), host_only=True)
+    want = "k=[ " + chr(9) + "]+((?:a|b)+(" + digit + "))"   # quoteLiteralAsRegexp: blank run -> [ TAB]+
+    assert calls == [("literal", "k= "), ("start",), ("pattern", "(a|b)+"), ("start",), ("pattern", digit), ("finish",), ("finish",),
+                     ("cook", 0, want)]
+    x = g.getExtractions()[0]
+    assert x.getName() == "x" and x._extractorNames == ["v", "w"] and x.getExtra() == {"t": 1}
+    assert x.getRegexpSource() == want
+    with pytest.raises(NotImplementedError):
+        ExtractionCooker().cook(0, "", ext)
