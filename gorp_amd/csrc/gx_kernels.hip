@@ -671,8 +671,13 @@ k_extract_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const 
     const uint8_t* my = slice + lane * SLICE_ROW;
 
     for (;;) {
-        // ---- lanes whose line is finished write its result ----
-        const bool done = has_line && (pos >= len || row == dead_row);
+        // ---- lanes whose line is finished write its result -- not every time one finishes: lanes run in lock step,
+        // so this block (and the refill below) costs every lane of the wave its full length whenever a single lane
+        // enters it.  Finished lanes wait until a quarter of the wave is idle (or nothing is left to walk). ----
+        const bool finished = has_line && (pos >= len || row == dead_row);
+        const uint32_t idle = static_cast<uint32_t>(__popcll(__ballot(finished || !has_line)));
+        const bool service = idle >= 16u || !__any(has_line && !finished);
+        const bool done = service && finished;
         if (done) {
             const int32_t info = static_cast<int32_t>(tab_read<GT>(A, row, info_off, L.row_bytes));
             if (!want_caps) match_id[i] = info;
@@ -702,7 +707,7 @@ k_extract_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const 
         }
         // ---- free lanes take the next lines of the range, in lane order ----
         const uint64_t free_mask = __ballot(!has_line);
-        if (free_mask && next < range_hi) {
+        if (service && free_mask && next < range_hi) {
             const uint32_t rank = static_cast<uint32_t>(__popcll(free_mask & ((1ull << lane) - 1ull)));
             const uint64_t cand = next + rank;
             if (!has_line && cand < range_hi) {
