@@ -854,7 +854,8 @@ int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, ui
     catch (std::bad_alloc&) { return fail(GX_E_NOMEM, "out of memory"); }
 }
 
-static int one_line(gx_handle* h, const uint16_t* s, int32_t len, int32_t* match_id, int32_t* caps, int32_t* state, bool match_only) {
+// mode: 0 = extract, 1 = match only, -(k + 1) = extraction k's capture regexp alone
+static int one_line(gx_handle* h, const uint16_t* s, int32_t len, int32_t* match_id, int32_t* caps, int32_t* state, int mode) {
     if (!h || len < 0 || (len && !s)) return fail(GX_E_ARG, "bad argument");
     if (!h->on_device) return fail(GX_E_DEVICE, "handle was created host-only; no device tables (there is no CPU fallback)");
     try {
@@ -870,28 +871,40 @@ static int one_line(gx_handle* h, const uint16_t* s, int32_t len, int32_t* match
         GX_HIP(hipMemcpy(d_off.p, offs, 8, hipMemcpyHostToDevice));
         GxBatch b{};
         b.data = d_s.p; b.offsets = d_off.p; b.n = 1; b.wide = 1; b.offsets64 = 0;
-        b.match_only = (match_only || !h->T.has_capture) ? 1 : 0;
+        b.match_only = mode < 0 ? mode : ((mode == 1 || !h->T.has_capture) ? 1 : 0);
         int32_t* out = static_cast<int32_t*>(d_out.p);
-        b.match_id = out; b.state_out = out + 1; b.caps = b.match_only ? nullptr : out + 2;
+        b.match_id = out; b.state_out = out + 1; b.caps = b.match_only == 1 ? nullptr : out + 2;
         GX_HIP(launch_extract_generic(h->dev, b, nullptr));
         std::vector<int32_t> host(2 + slots, -1);
-        GX_HIP(hipMemcpy(host.data(), d_out.p, (b.match_only ? 2 : 2 + slots) * 4, hipMemcpyDeviceToHost));
+        GX_HIP(hipMemcpy(host.data(), d_out.p, (b.match_only == 1 ? 2 : 2 + slots) * 4, hipMemcpyDeviceToHost));
         if (match_id) *match_id = host[0];
         if (state) *state = host[1];
-        if (caps) for (size_t t = 0; t < slots; ++t) caps[t] = b.match_only ? -1 : host[2 + t];
+        if (caps) for (size_t t = 0; t < slots; ++t) caps[t] = b.match_only == 1 ? -1 : host[2 + t];
         return GX_OK;
     } catch (GxError& e) { return fail(e.code, e.what()); }
     catch (std::bad_alloc&) { return fail(GX_E_NOMEM, "out of memory"); }
 }
 
+int gx_capture_one_utf16(gx_handle* h, int32_t k, const uint16_t* s, int32_t len, int32_t* matched, int32_t* caps) {
+    if (!h || k < 0 || k >= h->T.n_rules || !matched) return fail(GX_E_ARG, "gx_capture_one_utf16: bad argument");
+    if (!h->T.has_capture) {  // no extraction of this definition has groups: a plain regexp match (the generic kernel needs capture tables)
+        return fail(GX_E_ARG, "gx_capture_one_utf16: the definition has no capture groups");
+    }
+    int32_t mid = -1;
+    const int rc = one_line(h, s, len, &mid, caps, nullptr, -(k + 1));
+    if (rc != GX_OK) return rc;
+    *matched = mid == k ? 1 : 0;
+    return GX_OK;
+}
+
 int gx_extract_one_utf16(gx_handle* h, const uint16_t* s, int32_t len, int32_t* match_id, int32_t* caps) {
     if (!match_id) return fail(GX_E_ARG, "gx_extract_one_utf16: match_id is NULL");
-    return one_line(h, s, len, match_id, caps, nullptr, false);
+    return one_line(h, s, len, match_id, caps, nullptr, 0);
 }
 
 int gx_match_one_utf16(gx_handle* h, const uint16_t* s, int32_t len, int32_t* indexes, int32_t cap) {
     int32_t mid = -1, state = -1;
-    int rc = one_line(h, s, len, &mid, nullptr, &state, true);
+    int rc = one_line(h, s, len, &mid, nullptr, &state, 1);
     if (rc != GX_OK) return -rc;
     if (state < 0) return 0;
     const uint32_t b = h->T.m_accept_off[state], e = h->T.m_accept_off[state + 1];

@@ -38,16 +38,22 @@ __device__ void extract_line_global(const GxDev& T, const MS* __restrict__ m_nex
                                     int32_t* __restrict__ state_out, int match_only) {
     const int ncls = T.ncls;
     const int slots = 2 * T.max_groups;
-    // ---- hot loop #1: walk the match automaton ----
-    uint32_t st = 0;
-    const uint32_t dead = static_cast<uint32_t>(T.m_dead);
-    for (int64_t p = 0; p < len; ++p) {
-        st = m_next[static_cast<size_t>(st) * ncls + class_of(T, s[p])];
-        if (st == dead) break;  // the reference's early return on -1
+    // match_only < 0: CookedExtraction.match(String) alone (core/jdkre/JDKRegexpCookedExtraction.java:36-39) for
+    // extraction -match_only - 1 -- no matcher stage, and a regexp that does not match means null, not an exception
+    const bool capture_only = match_only < 0;
+    int32_t k = -match_only - 1;
+    if (!capture_only) {
+        // ---- hot loop #1: walk the match automaton ----
+        uint32_t st = 0;
+        const uint32_t dead = static_cast<uint32_t>(T.m_dead);
+        for (int64_t p = 0; p < len; ++p) {
+            st = m_next[static_cast<size_t>(st) * ncls + class_of(T, s[p])];
+            if (st == dead) break;  // the reference's early return on -1
+        }
+        k = T.m_accept_first[st];
+        if (state_out) state_out[i] = (st == dead) ? -1 : static_cast<int32_t>(st);
+        if (match_only || !T.has_capture) { match_id[i] = k; return; }
     }
-    const int32_t k = T.m_accept_first[st];
-    if (state_out) state_out[i] = (st == dead) ? -1 : static_cast<int32_t>(st);
-    if (match_only || !T.has_capture) { match_id[i] = k; return; }
 
     int32_t* cp = caps + i * static_cast<uint64_t>(slots);
     if (k < 0) {
@@ -71,8 +77,8 @@ __device__ void extract_line_global(const GxDev& T, const MS* __restrict__ m_nex
         }
     }
     const int32_t f = (T.c_fin + T.c_fin_off[k])[ts];
-    if (f < 0) {  // DFA said yes, capture regex says no -> ExtractionException
-        match_id[i] = -2 - k;
+    if (f < 0) {  // DFA said yes, capture regex says no -> ExtractionException (capture alone: just no match)
+        match_id[i] = capture_only ? -1 : -2 - k;
         for (int t = 0; t < slots; ++t) cp[t] = -1;
         return;
     }

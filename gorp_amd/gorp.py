@@ -149,6 +149,7 @@ class CookedExtraction:
         self._regexpSource = regexp_source
         self._extractorNames = list(extractor_names)
         self._append = append
+        self._gorp_handle = None  # set by Gorp: match() runs on the definition's device tables
 
     def getName(self):
         return self._name
@@ -161,6 +162,25 @@ class CookedExtraction:
 
     def getRegexpDesc(self):
         return self._regexpSource
+
+    def match(self, input):
+        """CookedExtraction.match(String) (core/model/CookedExtraction.java:61): this extraction's capture regexp
+        alone -- ExtractionResult or None.  Runs on the GPU (gx_capture_one_utf16); needs the handle that
+        Gorp.construct attached."""
+        if self._gorp_handle is None:
+            raise GorpError(N.GX_E_ARG, "CookedExtraction.match: not attached to a Gorp (use Gorp.construct)")
+        a = _utf16(input)
+        matched = C.c_int32(0)
+        caps = np.full(2 * max(1, N.lib().gx_max_groups(self._gorp_handle.ptr)), -1, np.int32)
+        _check(N.lib().gx_capture_one_utf16(self._gorp_handle.ptr, self._index, a.ctypes.data if len(a) else None, len(a),
+                                            C.byref(matched), caps.ctypes.data))
+        if not matched.value:
+            return None
+        values = []
+        for g in range(len(self._extractorNames)):
+            b, e = int(caps[2 * g]), int(caps[2 * g + 1])
+            values.append(None if b < 0 else a[b:e].tobytes().decode("utf-16-le", "surrogatepass"))
+        return ExtractionResult(self._name, input, self, self._extractorNames, values)
 
 
 class ExtractionCooker:
@@ -318,6 +338,8 @@ class Gorp:
         self._h = handle
         self._matcher = PolyMatcher(handle)
         self._extractions = extractions
+        for x in extractions:
+            x._gorp_handle = handle
         self._meta_sent = False
 
     def _send_meta(self):

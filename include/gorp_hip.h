@@ -174,6 +174,13 @@ int gx_set_extraction_meta(gx_handle* h, int32_t k, const char* name, const char
  * caps has 2*gx_max_groups(h) slots. */
 int gx_extract_one_utf16(gx_handle* h, const uint16_t* s, int32_t len, int32_t* match_id, int32_t* caps);
 
+/* Replaces CookedExtraction.match(String) (core/model/CookedExtraction.java:61; JDKRegexpCookedExtraction.match,
+ * core/jdkre/JDKRegexpCookedExtraction.java:36-39) -- the product of the reference's plugin seam, ExtractionCooker.cook
+ * (core/ExtractionCooker.java:22): extraction k's capture regexp alone against one String, no matcher stage.
+ * *matched = 1 and caps filled (2*gx_max_groups(h) slots) when the regexp matches the whole line, else 0 (the reference
+ * returns null). */
+int gx_capture_one_utf16(gx_handle* h, int32_t k, const uint16_t* s, int32_t len, int32_t* matched, int32_t* caps);
+
 /* Replaces PolyMatcher.match(CharSequence) -> int[] (core/autom/PolyMatcher.java:123-133):
  * all matching extraction indexes, ascending.  Returns the count (<= cap written), or <0 on error. */
 int gx_match_one_utf16(gx_handle* h, const uint16_t* s, int32_t len, int32_t* indexes, int32_t cap);

@@ -516,3 +516,39 @@ def test_slice_kernel_agrees_with_oracle(tier, monkeypatch):
     cd, co = lines_to_csr(want_lines)
     om3, oc3 = orc.extract_batch(cd, co, nthreads=8)
     assert np.array_equal(m3, om3) and np.array_equal(c3, oc3)
+
+
+def test_cooked_extraction_match_is_the_capture_regexp_alone(golden):
+    """CookedExtraction.match(String) (the product of the ExtractionCooker seam): extraction k's regexp alone, against
+    java.util.regex restated (oracle.jdk_matches) -- including lines the combined matcher would give to another
+    extraction or reject."""
+    import test_compiler_vs_oracle as TC
+    gorp = Gorp.construct(W.readme3_definition())
+    xs = gorp.getExtractions()
+    r = xs[2].match("[123456789]: GET 12ms /index.html")      # OtherRequest's regexp matches a GET line too
+    assert r is not None and r.getId() == xs[2].getName()
+    assert xs[0].match("[123456789]: GET 12ms /index.html") is None
+    assert xs[1].match("[1]: GET 5ms /x").asMap()["path"] == "/x"
+    rng = random.Random(99)
+    n_match = 0
+    for _ in range(40):
+        exts = [FlattenedExtraction("e%d" % i, TC.gen_pieces(rng)) for i in range(rng.randint(1, 3))]
+        try:
+            gorp = Gorp.construct(exts)
+        except Exception:
+            continue
+        if gorp.max_groups == 0:
+            continue
+        from blob_interp import Blob
+        b = Blob(gorp.blob())
+        lines = [TC.gen_line(rng) for _ in range(6)] + [TC.sample_from_match_automaton(b, rng) for _ in range(10)]
+        for x in gorp.getExtractions():
+            for ln in lines:
+                got = x.match(ln)
+                want = O.jdk_matches(x.getRegexpSource(), ln)
+                assert (got is None) == (want is None), (x.getRegexpSource(), ln)
+                if got is not None:
+                    n_match += 1
+                    vals = [None if g is None else ln[g[0]:g[1]] for g in want]
+                    assert got._extractedValues == vals, (x.getRegexpSource(), ln, got._extractedValues, vals)
+    assert n_match > 50
