@@ -129,6 +129,18 @@ public:
     }
     std::unique_ptr<ExtractionResult> extractSafe(const std::string& input) const { return extract(input, true); }
 
+    // CookedExtraction.match(String) (core/model/CookedExtraction.java:61) for extraction k: its capture regexp alone,
+    // no matcher stage; nullptr when the regexp does not match the whole line.
+    std::unique_ptr<ExtractionResult> matchExtraction(size_t k, const std::string& input) const {
+        std::u16string u = to_utf16(input);
+        int32_t matched = 0;
+        std::vector<int32_t> caps(2 * static_cast<size_t>(gx_max_groups(h_)) + 2, -1);
+        int rc = gx_capture_one_utf16(h_, static_cast<int32_t>(k), reinterpret_cast<const uint16_t*>(u.data()), static_cast<int32_t>(u.size()),
+                                      &matched, caps.data());
+        if (rc != GX_OK) throw GorpError(rc, gx_last_error());
+        return matched ? materialise(input, u, static_cast<int32_t>(k), caps.data(), false) : nullptr;
+    }
+
     // The batch path: lines as one Latin-1 byte buffer + offsets[n+1]; match_id[n], caps[n * 2*maxGroups()].
     void extractBatch(const uint8_t* bytes, const uint32_t* offsets, uint64_t n, int32_t* match_id, int32_t* caps,
                       const gx_batch_opts* opts = nullptr) const {

@@ -84,6 +84,10 @@ int main(int argc, char** argv) {
     CHECK(m2[0] == 1 && m2[1] == 0 && m2[2] == -1 && m2[3] == -1);   // value=q"uote: %word is letters only
     const std::string jl = def->resultsToJsonl(reinterpret_cast<const uint8_t*>(text.data()), offs.data(), 4, m2.data(), c2.data(), "id");
     CHECK(jl == "{\"id\":\"single\",\"value\":\"x\",\"marker\":\"EXTRACTED\"}\n{\"id\":\"double\",\"value\":\"a\",\"value2\":\"b\"}\n");
+    // the plugin seam's product: one extraction's regexp alone
+    auto one = def->matchExtraction(1, "value=foobar");
+    CHECK(one && one->getId() == "single" && one->value(0) == "foobar");
+    CHECK(!def->matchExtraction(0, "value=foobar"));
     uint64_t nl = 0, nm = 0, nx = 0;
     CHECK(def->textToJsonl(text, "id", &nl, &nm, &nx) == jl && nl == 4 && nm == 2 && nx == 0);
     printf("host_api_test: GPU checks ok\n");
