@@ -882,7 +882,7 @@ struct Reader {
         uint64_t n = pod<uint64_t>();
         if (n > left / sizeof(V)) throw GxError(GX_E_ARG, "truncated table blob");
         std::vector<V> v(n);
-        memcpy(v.data(), p, n * sizeof(V));
+        if (n) memcpy(v.data(), p, n * sizeof(V));
         size_t adv = n * sizeof(V);
         adv = (adv + 7) & ~size_t(7);
         if (adv > left) adv = left;
