@@ -87,12 +87,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if os.environ.get("GORP_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank = 0   # rehearsal: every rank on the one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        # RCCL ("nccl") always; GORP_BENCH_BACKEND=gloo only exists to rehearse the N > 1 path with two ranks on ONE GPU
+        # (RCCL refuses two ranks on one device), which is all a one-GPU box allows
+        backend = os.environ.get("GORP_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     # ---- tables: compile on rank 0, broadcast the blob (RCCL), build everywhere ----
     definition = W.readme3_definition()
