@@ -394,6 +394,20 @@ class Gorp:
                                         C.byref(nx), C.byref(o)))
         return out[:size.value].tobytes(), nl.value, nm.value, nx.value
 
+    def text_to_jsonl_device(self, text_ptr, size, out_ptr, out_cap, id_as=None, utf8_passthrough=False, stream=None):
+        """gx_text_to_jsonl on device buffers (ints); out_ptr=None only asks for the size.
+        Returns (text size, n_lines, n_matched, n_exceptions)."""
+        self._send_meta()
+        o = N.gx_batch_opts()
+        o.struct_size = C.sizeof(N.gx_batch_opts)
+        o.device_pointers = 1
+        o.utf8_passthrough = 1 if utf8_passthrough else 0
+        o.stream = stream
+        size_out, nl, nm, nx = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _check(N.lib().gx_text_to_jsonl(self._h.ptr, text_ptr, size, id_as.encode("utf-8") if id_as is not None else None, out_ptr, out_cap,
+                                        C.byref(size_out), C.byref(nl), C.byref(nm), C.byref(nx), C.byref(o)))
+        return size_out.value, nl.value, nm.value, nx.value
+
     def results_to_jsonl_device(self, data_ptr, offsets_ptr, n, match_id_ptr, caps_ptr, out_ptr, out_cap, line_offsets_ptr=None,
                                 id_as=None, offsets64=False, utf8_passthrough=False, stream=None):
         """Device pointers; returns the size of the text (out_ptr=None only asks for it)."""

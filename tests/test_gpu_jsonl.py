@@ -198,6 +198,14 @@ def test_text_to_jsonl_one_call():
                                  [x.getExtra() for x in xs], id_as="id")
     assert text == want
     assert n_matched == int((omid >= 0).sum()) and n_exc == int((omid <= -2).sum())
+    # the same with the text and the output on the device
+    import torch
+    d_text = torch.from_numpy(np.frombuffer(raw, np.uint8).copy()).cuda()
+    size, nl2, nm2, nx2 = gorp.text_to_jsonl_device(d_text.data_ptr(), d_text.numel(), None, 0, id_as="id")
+    assert (size, nl2, nm2, nx2) == (len(text), n_lines, n_matched, n_exc)
+    d_out = torch.empty(size, dtype=torch.uint8, device="cuda")
+    assert gorp.text_to_jsonl_device(d_text.data_ptr(), d_text.numel(), d_out.data_ptr(), size, id_as="id")[0] == size
+    assert d_out.cpu().numpy().tobytes() == text
     # empty text, text without a final terminator, a definition whose regexps disagree (exception -> no text, counted)
     assert gorp.text_to_jsonl(b"")[:2] == (b"", 0)
     dot = Gorp.construct([FlattenedExtraction("r", [["text", "a"], ["extractor", "x", [["pattern", ".*"]]], ["text", "b"]])])
