@@ -100,7 +100,8 @@ bool build_tile_image(gx_handle* h, bool global) {
     const uint32_t cols = static_cast<uint32_t>(T.ncls) + 3u;
     const uint32_t RS = cols * 4u;
     // with the fused automaton present the per-extraction capture rows are not needed on the device
-    const bool fused = T.union_ok;
+    // (GX_DEBUG_NO_FUSED: tests force the two-pass layout, which otherwise only very large definitions get)
+    const bool fused = T.union_ok && !getenv("GX_DEBUG_NO_FUSED");
     const size_t m_rows = static_cast<size_t>(T.m_states);
     size_t c_rows = 0;
     if (fused) c_rows = T.uni.n_states;
@@ -254,7 +255,7 @@ bool plan_tile_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out) 
 // Layout for the slice kernel: a 64 x 80-byte slice buffer per wave, up to 16 waves.
 bool plan_slice_launch(const gx_handle* h, GxLds* out) {
     if (!h->tile_ok) return false;
-    if (h->T.has_capture && !h->T.union_ok) return false;  // the slice kernel walks the fused automaton
+    if (h->T.has_capture && h->lds.u_start == 0xFFFFFFFFu) return false;  // the slice kernel walks the fused automaton
     GxLds L = h->lds;
     L.stage_bytes = 64u * 80u;
     const uint32_t per_wave = L.stage_bytes + L.regs_wave_bytes;

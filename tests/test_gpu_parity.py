@@ -552,3 +552,42 @@ def test_cooked_extraction_match_is_the_capture_regexp_alone(golden):
                     vals = [None if g is None else ln[g[0]:g[1]] for g in want]
                     assert got._extractedValues == vals, (x.getRegexpSource(), ln, got._extractedValues, vals)
     assert n_match > 50
+
+
+@pytest.mark.parametrize("tier", [1, 2])
+def test_two_pass_layout_without_the_fused_automaton(tier, monkeypatch):
+    """Definitions too large for the fused automaton walk the match automaton and then the winning extraction's
+    capture automaton; forced here (GX_DEBUG_NO_FUSED) on small definitions, tables in LDS and in global memory."""
+    monkeypatch.setenv("GX_DEBUG_NO_FUSED", "1")
+    if tier == 2:
+        monkeypatch.setenv("GX_DEBUG_TIER", "2")
+    import test_compiler_vs_oracle as TC
+    from blob_interp import Blob
+    definition = W.readme3_definition()
+    gorp, orc = Gorp.construct(definition), oracle_for(definition)
+    data, offsets, cat = W.readme3_lines(30000, seed=61)
+    d, o = data.numpy(), offsets.numpy()
+    mid, caps = gorp.extract_batch(d, o)
+    omid, ocaps = orc.extract_batch(d, o, nthreads=8)
+    assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+    check_batch(gorp, orc, ["", "[1]: GET 5ms /x", "[1]: GET 5ms /" + "x" * 70000, "a\rb", "[12]: HEAD 7777ms /a?b=c"])
+    dot = [FlattenedExtraction("r", [["text", "a"], ["extractor", "x", [["pattern", ".*"]]], ["text", "b"]])]
+    g2, o2 = Gorp.construct(dot), oracle_for(dot)
+    m, _ = check_batch(g2, o2, ["a--b", "a\rb", "zzz", "ab"])
+    assert m.tolist() == [0, -2, -1, 0]
+    rng = random.Random(1234 + tier)
+    n_defs = 0
+    while n_defs < 40:
+        exts = [{"name": "e%d" % i, "pieces": TC.gen_pieces(rng)} for i in range(rng.randint(1, 4))]
+        try:
+            definition = fl(exts)
+            gorp = Gorp.construct(definition)
+            orc = oracle_for(definition)
+        except AssertionError:
+            raise
+        except Exception:
+            continue
+        n_defs += 1
+        b = Blob(gorp.blob())
+        lines = [TC.gen_line(rng) for _ in range(20)] + [TC.sample_from_match_automaton(b, rng) for _ in range(44)]
+        check_batch(gorp, orc, lines)

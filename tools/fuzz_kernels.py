@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool: a longer differential run than the test-suite's -- random definitions through every kernel
-variant (LDS tier, L2 tier, slice kernel on both, generic) against the oracle.  Usage: fuzz_kernels.py [defs] [seed]"""
+variant (LDS tier, L2 tier, slice kernel on both, generic, two-pass layout on both tiers) against the oracle.  Usage: fuzz_kernels.py [defs] [seed]"""
 import os, sys, random
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
@@ -13,7 +13,8 @@ from oracle import oracle as O
 n_defs = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2024
 rng = random.Random(seed)
-variants = [{}, {"GX_DEBUG_TIER": "2"}, {"GX_DEBUG_SLICES": "1"}, {"GX_DEBUG_TIER": "2", "GX_DEBUG_SLICES": "1"}, {"GX_DEBUG_TIER": "3"}]
+variants = [{}, {"GX_DEBUG_TIER": "2"}, {"GX_DEBUG_SLICES": "1"}, {"GX_DEBUG_TIER": "2", "GX_DEBUG_SLICES": "1"}, {"GX_DEBUG_TIER": "3"},
+            {"GX_DEBUG_NO_FUSED": "1"}, {"GX_DEBUG_NO_FUSED": "1", "GX_DEBUG_TIER": "2"}]
 done = bad = 0
 while done < n_defs:
     exts = [FlattenedExtraction("e%d" % i, TC.gen_pieces(rng)) for i in range(rng.randint(1, 5))]
@@ -21,7 +22,7 @@ while done < n_defs:
         built = [e.build() for e in exts]
         orc = O.OracleGorp([b[0] for b in built], [b[1] for b in built])
         env = variants[done % len(variants)]
-        for k in ("GX_DEBUG_TIER", "GX_DEBUG_SLICES"):
+        for k in ("GX_DEBUG_TIER", "GX_DEBUG_SLICES", "GX_DEBUG_NO_FUSED"):
             os.environ.pop(k, None)
         os.environ.update(env)
         gorp = Gorp.construct(exts)
