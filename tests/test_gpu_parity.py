@@ -591,3 +591,38 @@ def test_two_pass_layout_without_the_fused_automaton(tier, monkeypatch):
         b = Blob(gorp.blob())
         lines = [TC.gen_line(rng) for _ in range(20)] + [TC.sample_from_match_automaton(b, rng) for _ in range(44)]
         check_batch(gorp, orc, lines)
+
+
+@pytest.mark.parametrize("variant", [{}, {"GX_DEBUG_TIER": "2"}, {"GX_DEBUG_SLICES": "1"}])
+def test_unaligned_device_buffers(variant, monkeypatch):
+    """Device pointers with no particular alignment (a view 3 bytes into a tensor; results 4 bytes into theirs): the
+    edge chunks of the first and last tile take the guarded copy, results the per-line stores."""
+    import torch
+    for k, v in variant.items():
+        monkeypatch.setenv(k, v)
+    definition = W.readme3_definition()
+    gorp, orc = Gorp.construct(definition), oracle_for(definition)
+    n = 5000
+    data, offsets, cat = W.readme3_lines(n, seed=71)
+    big = torch.zeros(data.numel() + 64, dtype=torch.uint8, device="cuda")
+    view = big[3:3 + data.numel()]
+    view.copy_(data.cuda())
+    off = offsets.cuda()
+    mid_store = torch.full((n + 8,), -7, dtype=torch.int32, device="cuda")
+    caps_store = torch.full((n * 8 + 8,), -7, dtype=torch.int32, device="cuda")
+    mid, caps = mid_store[1:1 + n], caps_store[1:1 + n * 8]
+    gorp.extract_batch_device(view.data_ptr(), off.data_ptr(), n, mid.data_ptr(), caps.data_ptr())
+    omid, ocaps = orc.extract_batch(data.numpy(), offsets.numpy(), nthreads=4)
+    assert np.array_equal(mid.cpu().numpy(), omid) and np.array_equal(caps.view(n, 8).cpu().numpy(), ocaps)
+    assert int(mid_store[0]) == -7 and int(mid_store[n + 1]) == -7 and int(caps_store[0]) == -7 and int(caps_store[n * 8 + 1]) == -7
+    # the whole buffer is the batch: first chunk starts before `view`, last chunk ends after it
+    size = gorp.results_to_jsonl_device(view.data_ptr(), off.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), None, 0, id_as="id")
+    out_store = torch.zeros(size + 16, dtype=torch.uint8, device="cuda")
+    out = out_store[5:5 + size]
+    gorp.results_to_jsonl_device(view.data_ptr(), off.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), out.data_ptr(), size, id_as="id")
+    xs = gorp.getExtractions()
+    d, o = data.numpy(), offsets.numpy()
+    lines = [bytes(d[o[i]:o[i + 1]]) for i in range(n)]
+    want, _ = O.results_to_jsonl(lines, omid, ocaps, [x.getName() for x in xs], [x._extractorNames for x in xs], [x.getExtra() for x in xs], id_as="id")
+    assert out.cpu().numpy().tobytes() == want
+    assert int(out_store[4]) == 0 and int(out_store[5 + size]) == 0
