@@ -65,6 +65,9 @@ struct gx_handle {
     void* d_l2_image = nullptr;
     int num_cus = 256;
     std::vector<dsl::Extraction> meta;  // names / extractor names / append (from definition text or gx_set_extraction_meta)
+    void* one_dev = nullptr;     // scratch of the one-String entry points (device) ...
+    void* one_host = nullptr;    // ... and its pinned host mirror
+    size_t one_cap = 0;
     std::vector<std::vector<std::pair<std::string, std::string>>> append_entries;  // per extraction: (key, value JSON), lazily
     struct JsonlImage { void* d = nullptr; GxJsonl dev{}; };
     std::map<std::string, JsonlImage> jsonl;  // device templates per id_as ("0" = none, "1" + id_as)
@@ -451,6 +454,8 @@ void gx_destroy(gx_handle* h) {
     if (h->d_lds_image) (void)hipFree(h->d_lds_image);
     if (h->d_l2_image) (void)hipFree(h->d_l2_image);
     for (auto& e : h->jsonl) if (e.second.d) (void)hipFree(e.second.d);
+    if (h->one_dev) (void)hipFree(h->one_dev);
+    if (h->one_host) (void)hipHostFree(h->one_host);
     delete h;
 }
 
@@ -855,7 +860,9 @@ int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, ui
     catch (std::bad_alloc&) { return fail(GX_E_NOMEM, "out of memory"); }
 }
 
-// mode: 0 = extract, 1 = match only, -(k + 1) = extraction k's capture regexp alone
+// mode: 0 = extract, 1 = match only, -(k + 1) = extraction k's capture regexp alone.
+// One String per call is latency, not throughput: the handle keeps a device scratch buffer and a pinned host mirror
+// of it ([offsets 8 B][code units][match id, state, captures]), so a call is one copy in, one launch, one copy out.
 static int one_line(gx_handle* h, const uint16_t* s, int32_t len, int32_t* match_id, int32_t* caps, int32_t* state, int mode) {
     if (!h || len < 0 || (len && !s)) return fail(GX_E_ARG, "bad argument");
     if (!h->on_device) return fail(GX_E_DEVICE, "handle was created host-only; no device tables (there is no CPU fallback)");
@@ -863,21 +870,35 @@ static int one_line(gx_handle* h, const uint16_t* s, int32_t len, int32_t* match
         GX_HIP(hipSetDevice(h->device));
         std::lock_guard<std::mutex> lock(h->mu);
         const size_t slots = 2 * static_cast<size_t>(h->T.max_groups);
-        DevBuf d_s, d_off, d_out;
-        d_s.alloc(static_cast<size_t>(len) * 2);
-        d_off.alloc(8);
-        d_out.alloc((2 + slots) * 4);
-        uint32_t offs[2] = {0, static_cast<uint32_t>(len)};
-        if (len) GX_HIP(hipMemcpy(d_s.p, s, static_cast<size_t>(len) * 2, hipMemcpyHostToDevice));
-        GX_HIP(hipMemcpy(d_off.p, offs, 8, hipMemcpyHostToDevice));
+        const size_t out_words = 2 + slots;
+        const size_t in_bytes = 8 + ((static_cast<size_t>(len) * 2 + 7) & ~size_t(7));  // offsets + code units: one copy in
+        const size_t need = in_bytes + out_words * 4 + 16;
+        if (need > h->one_cap) {
+            if (h->one_dev) (void)hipFree(h->one_dev);
+            if (h->one_host) (void)hipHostFree(h->one_host);
+            h->one_dev = nullptr; h->one_host = nullptr; h->one_cap = 0;
+            const size_t cap = std::max<size_t>(need * 2, 4096);
+            GX_HIP(hipMalloc(&h->one_dev, cap));
+            GX_HIP(hipHostMalloc(&h->one_host, cap, hipHostMallocDefault));
+            h->one_cap = cap;
+        }
+        uint8_t* hb = static_cast<uint8_t*>(h->one_host);
+        uint8_t* db = static_cast<uint8_t*>(h->one_dev);
+        uint32_t* offs = reinterpret_cast<uint32_t*>(hb);
+        offs[0] = 0; offs[1] = static_cast<uint32_t>(len);
+        if (len) memcpy(hb + 8, s, static_cast<size_t>(len) * 2);
+        // (the results area is not initialised: the kernel writes every word that is read back)
+        GX_HIP(hipMemcpyAsync(db, hb, in_bytes, hipMemcpyHostToDevice, nullptr));
         GxBatch b{};
-        b.data = d_s.p; b.offsets = d_off.p; b.n = 1; b.wide = 1; b.offsets64 = 0;
+        b.data = db + 8; b.offsets = db; b.n = 1; b.wide = 1; b.offsets64 = 0;
         b.match_only = mode < 0 ? mode : ((mode == 1 || !h->T.has_capture) ? 1 : 0);
-        int32_t* out = static_cast<int32_t*>(d_out.p);
+        int32_t* out = reinterpret_cast<int32_t*>(db + in_bytes);
         b.match_id = out; b.state_out = out + 1; b.caps = b.match_only == 1 ? nullptr : out + 2;
         GX_HIP(launch_extract_generic(h->dev, b, nullptr));
-        std::vector<int32_t> host(2 + slots, -1);
-        GX_HIP(hipMemcpy(host.data(), d_out.p, (b.match_only == 1 ? 2 : 2 + slots) * 4, hipMemcpyDeviceToHost));
+        const size_t back = (b.match_only == 1 ? 2 : out_words) * 4;
+        GX_HIP(hipMemcpyAsync(hb + in_bytes, db + in_bytes, back, hipMemcpyDeviceToHost, nullptr));
+        GX_HIP(hipStreamSynchronize(nullptr));
+        const int32_t* host = reinterpret_cast<const int32_t*>(hb + in_bytes);
         if (match_id) *match_id = host[0];
         if (state) *state = host[1];
         if (caps) for (size_t t = 0; t < slots; ++t) caps[t] = b.match_only == 1 ? -1 : host[2 + t];
