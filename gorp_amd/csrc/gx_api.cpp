@@ -686,7 +686,7 @@ int gx_text_to_jsonl(gx_handle* h, const uint8_t* text, uint64_t size, const cha
         std::lock_guard<std::mutex> lock(h->mu);
         const GxJsonl& tm = jsonl_templates(h, id_as);
         hipStream_t stream = static_cast<hipStream_t>(o.stream);
-        DevBuf d_text, ws_split, d_off, d_mid, d_caps, ws_json, d_loff, d_counts, d_out;
+        DevBuf d_text, ws_split, d_mid, d_caps, ws_json, d_loff, d_counts, d_out;
         const uint8_t* src = text;
         if (!o.device_pointers) {
             d_text.alloc(size);
@@ -695,17 +695,22 @@ int gx_text_to_jsonl(gx_handle* h, const uint8_t* text, uint64_t size, const cha
         } else if (reinterpret_cast<uintptr_t>(text) & 15u) {
             return fail(GX_E_ARG, "gx_text_to_jsonl: device text must be 16-byte aligned");
         }
-        // 1. lines: count them, then write their offsets
+        // 1. lines: offsets for the guess "64 bytes or more per line"; a text with shorter lines is split a second time
         ws_split.alloc(split_workspace_bytes(size));
-        d_off.alloc(16);
+        uint64_t cap = size / 64 + 4096;
+        DevBuf d_off2;
+        d_off2.alloc((cap + 1) * 4);
         uint64_t* d_n = nullptr;
-        GX_HIP(launch_split_lines(src, size, d_off.p, 0, 0, nullptr, ws_split.p, &d_n, stream));
+        GX_HIP(launch_split_lines(src, size, d_off2.p, 0, cap, nullptr, ws_split.p, &d_n, stream));
         uint64_t n = 0;
         GX_HIP(hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, stream));
         GX_HIP(hipStreamSynchronize(stream));
-        DevBuf d_off2;
-        d_off2.alloc((n + 1) * 4);
-        GX_HIP(launch_split_lines(src, size, d_off2.p, 0, n, nullptr, ws_split.p, &d_n, stream));
+        if (n > cap) {
+            (void)hipFree(d_off2.p);
+            d_off2.p = nullptr;
+            d_off2.alloc((n + 1) * 4);
+            GX_HIP(launch_split_lines(src, size, d_off2.p, 0, n, nullptr, ws_split.p, &d_n, stream));
+        }
         // 2. the path
         d_mid.alloc(n * 4);
         d_caps.alloc(n * slots * 4);

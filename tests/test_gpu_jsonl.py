@@ -213,3 +213,16 @@ def test_text_to_jsonl_one_call():
     o2 = oracle_for([FlattenedExtraction("r", [["text", "a"], ["extractor", "x", [["pattern", ".*"]]], ["text", "b"]])])
     m2, c2 = o2.extract_batch(*lines_to_csr([b"axb", b"a\x0bb", b"zzz"]))
     assert nm == int((m2 >= 0).sum()) and nx == int((m2 <= -2).sum())
+
+
+def test_text_to_jsonl_short_lines_need_a_second_split():
+    """Lines far shorter than 64 bytes overflow the first guess of the line count: gx_text_to_jsonl splits again."""
+    gorp = Gorp.construct([FlattenedExtraction("kv", [["extractor", "k", [["pattern", "[a-z]"]]], ["text", "="], ["extractor", "v", [["pattern", "[0-9]"]]]])])
+    rng = random.Random(4)
+    lines = [("%s=%d" % (rng.choice("abcxyz"), rng.randrange(10))).encode() if rng.random() < 0.8 else b"?" for _ in range(200000)]
+    raw = b"\n".join(lines) + b"\n"
+    text, n_lines, n_matched, n_exc = gorp.text_to_jsonl(raw)
+    assert n_lines == len(lines) and n_exc == 0 and n_matched == sum(1 for ln in lines if ln != b"?")
+    assert text.count(b"\n") == n_matched
+    first = next(ln for ln in lines if ln != b"?").decode()
+    assert text.split(b"\n")[0] == ('{"k":"%s","v":"%s"}' % (first[0], first[2])).encode()
