@@ -46,5 +46,7 @@ while done < n_defs:
         bad += 1
         print("MATCH-ONLY MISMATCH variant", env)
     done += 1
+    if done % 500 == 0:
+        print("fuzz: %d definitions so far, %d mismatches" % (done, bad), flush=True)
 print("fuzz: %d definitions, %d mismatches" % (done, bad))
 sys.exit(1 if bad else 0)
