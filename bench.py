@@ -61,9 +61,15 @@ def cpu_baseline(definition, data_cpu, offsets_cpu, budget_s=20.0):
     t0 = time.perf_counter()
     mid, caps = orc.extract_batch(data_cpu, offsets_cpu[:n + 1], nthreads=cores)
     dt = time.perf_counter() - t0
+    # the same on one thread (SURVEY 8d asks for T = 1 beside T = all cores): ~2 s
+    n1 = int(min(n, max(20000, 2.0 * (n / dt) / cores)))
+    t1 = time.perf_counter()
+    orc.extract_batch(data_cpu, offsets_cpu[:n1 + 1], nthreads=1)
+    dt1 = time.perf_counter() - t1
     return {"value": n / dt, "unit": "lines/s", "cores": cores, "kind": "port",
             "sample": "first %d lines of the rank-0 shard, %d threads, %.1f s; C++ restatement of "
-                      "PolyMatcher.match + java.util.regex capture (oracle/), not the JVM" % (n, cores, dt)}, mid, caps, n
+                      "PolyMatcher.match + java.util.regex capture (oracle/), not the JVM" % (n, cores, dt),
+            "single_thread_value": n1 / dt1, "single_thread_sample": "first %d lines, 1 thread, %.1f s" % (n1, dt1)}, mid, caps, n
 
 
 def main():
