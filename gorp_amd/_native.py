@@ -30,6 +30,7 @@ SYMBOLS = [
     "gx_split_lines", "gx_results_to_jsonl", "gx_set_extraction_meta",
     "gx_extraction_append_count", "gx_extraction_append_key", "gx_extraction_append_value_json",
     "gx_pack_results", "gx_unpack_results", "gx_text_to_jsonl", "gx_capture_one_utf16",
+    "gx_match_batch", "gx_state_accepts",
 ]
 
 
@@ -118,6 +119,10 @@ def lib():
     L.gx_extract_batch.restype = C.c_int
     L.gx_extract_one_utf16.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p]
     L.gx_extract_one_utf16.restype = C.c_int
+    L.gx_match_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(gx_batch_opts)]
+    L.gx_match_batch.restype = C.c_int
+    L.gx_state_accepts.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+    L.gx_state_accepts.restype = C.c_int
     L.gx_capture_one_utf16.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p]
     L.gx_capture_one_utf16.restype = C.c_int
     L.gx_match_one_utf16.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]

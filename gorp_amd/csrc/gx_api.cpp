@@ -803,13 +803,15 @@ int gx_set_extraction_meta(gx_handle* h, int32_t k, const char* name, const char
     catch (std::exception& e) { return fail(GX_E_ARG, e.what()); }
 }
 
-int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, uint64_t n, int32_t* match_id, int32_t* caps,
-                     const gx_batch_opts* opts) {
+// gx_extract_batch, and gx_match_batch when `states` is given (final product-DFA state per line, -1 = dead: the
+// per-line generic kernel then, which is the one that keeps it)
+static int extract_batch_impl(gx_handle* h, const uint8_t* bytes, const void* offsets, uint64_t n, int32_t* match_id, int32_t* caps,
+                              int32_t* states, const gx_batch_opts* opts) {
     if (!h || !offsets || !match_id || (n && !bytes && false)) return fail(GX_E_ARG, "gx_extract_batch: bad argument");
     if (!h->on_device) return fail(GX_E_DEVICE, "handle was created host-only; no device tables (there is no CPU fallback)");
     gx_batch_opts o{};
     if (!read_opts(opts, &o)) return fail(GX_E_ARG, "gx_batch_opts.struct_size mismatch");
-    const bool match_only = o.match_only || !h->T.has_capture;
+    const bool match_only = o.match_only || states || !h->T.has_capture;
     if (!match_only && !caps && n > 0 && h->T.max_groups > 0) return fail(GX_E_ARG, "gx_extract_batch: caps is NULL");
     try {
         GX_HIP(hipSetDevice(h->device));
@@ -828,6 +830,7 @@ int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, ui
             static const int ablate = getenv("GX_DEBUG_ABLATE") ? atoi(getenv("GX_DEBUG_ABLATE")) : 0;
             if (ablate > 1 && !match_only) b.match_only = ablate;
             b.data = bytes; b.offsets = offsets; b.match_id = match_id; b.caps = match_only ? nullptr : caps;
+            b.state_out = states;
             uint32_t hint = o.line_bytes_hint;
             if (hint == 0 && n && !o.no_sync) {
                 // no hint: the mean line length, from the two ends of the offsets array (a small synchronous read;
@@ -849,7 +852,9 @@ int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, ui
         if (n) total = o.offsets64 ? static_cast<const uint64_t*>(offsets)[n] : static_cast<const uint32_t*>(offsets)[n];
         uint32_t hint = o.line_bytes_hint;
         if (hint == 0 && n) hint = static_cast<uint32_t>((total + n - 1) / n);
-        DevBuf d_bytes, d_off, d_mid, d_caps;
+        DevBuf d_bytes, d_off, d_mid, d_caps, d_states;
+        if (states) d_states.alloc(n * 4);
+        b.state_out = states ? static_cast<int32_t*>(d_states.p) : nullptr;
         d_bytes.alloc(total * unit); d_off.alloc((n + 1) * off_w); d_mid.alloc(n * 4);
         if (!match_only) d_caps.alloc(n * slots * 4);
         if (total) GX_HIP(hipMemcpyAsync(d_bytes.p, bytes, total * unit, hipMemcpyHostToDevice, stream));
@@ -859,10 +864,30 @@ int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, ui
         launch_batch(h, b, hint, stream);
         if (n) GX_HIP(hipMemcpyAsync(match_id, d_mid.p, n * 4, hipMemcpyDeviceToHost, stream));
         if (!match_only && n && slots) GX_HIP(hipMemcpyAsync(caps, d_caps.p, n * slots * 4, hipMemcpyDeviceToHost, stream));
+        if (states && n) GX_HIP(hipMemcpyAsync(states, d_states.p, n * 4, hipMemcpyDeviceToHost, stream));
         GX_HIP(hipStreamSynchronize(stream));
         return GX_OK;
     } catch (GxError& e) { return fail(e.code, e.what()); }
     catch (std::bad_alloc&) { return fail(GX_E_NOMEM, "out of memory"); }
+}
+
+int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, uint64_t n, int32_t* match_id, int32_t* caps,
+                     const gx_batch_opts* opts) {
+    return extract_batch_impl(h, bytes, offsets, n, match_id, caps, nullptr, opts);
+}
+
+int gx_match_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, uint64_t n, int32_t* first_match, int32_t* states,
+                   const gx_batch_opts* opts) {
+    if (!states) return fail(GX_E_ARG, "gx_match_batch: states is NULL (gx_extract_batch with match_only gives the first match alone)");
+    return extract_batch_impl(h, bytes, offsets, n, first_match, nullptr, states, opts);
+}
+
+int gx_state_accepts(const gx_handle* h, int32_t state, int32_t* indexes, int32_t cap) {
+    if (!h || state >= h->T.m_states || (cap > 0 && !indexes)) return -GX_E_ARG;
+    if (state < 0) return 0;
+    const uint32_t b = h->T.m_accept_off[state], e = h->T.m_accept_off[state + 1];
+    for (uint32_t i = b; i < e && static_cast<int32_t>(i - b) < cap; ++i) indexes[i - b] = h->T.m_accept_list[i];
+    return static_cast<int>(e - b);
 }
 
 // mode: 0 = extract, 1 = match only, -(k + 1) = extraction k's capture regexp alone.

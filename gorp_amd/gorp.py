@@ -327,6 +327,29 @@ class PolyMatcher:
             raise GorpError(-c, N.last_error())
         return out[:c].tolist()
 
+    def match_batch(self, data, offsets):
+        """PolyMatcher.match for every line of a CSR batch: list of index lists (gx_match_batch + gx_state_accepts)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets)
+        n = len(offsets) - 1
+        first = np.zeros(n, np.int32)
+        states = np.zeros(n, np.int32)
+        o = N.gx_batch_opts()
+        o.struct_size = C.sizeof(N.gx_batch_opts)
+        o.offsets64 = 1 if offsets.dtype == np.uint64 else 0
+        _check(N.lib().gx_match_batch(self._h.ptr, data.ctypes.data if data.size else None, offsets.ctypes.data, n, first.ctypes.data,
+                                      states.ctypes.data, C.byref(o)))
+        cap = max(1, N.lib().gx_num_extractions(self._h.ptr))
+        buf = np.zeros(cap, np.int32)
+        cache = {}
+        out = []
+        for st in states.tolist():
+            if st not in cache:
+                c = N.lib().gx_state_accepts(self._h.ptr, st, buf.ctypes.data, cap)
+                cache[st] = buf[:c].tolist()
+            out.append(cache[st])
+        return out
+
     def stat(self, which):
         return N.lib().gx_stat(self._h.ptr, which)
 

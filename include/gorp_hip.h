@@ -174,6 +174,15 @@ int gx_set_extraction_meta(gx_handle* h, int32_t k, const char* name, const char
  * caps has 2*gx_max_groups(h) slots. */
 int gx_extract_one_utf16(gx_handle* h, const uint16_t* s, int32_t len, int32_t* match_id, int32_t* caps);
 
+/* PolyMatcher.match over a batch with the full answer: states[i] = the product-DFA state line i ends in (-1: the dead
+ * state, the reference's early return, core/autom/PolyMatcher.java:128-130); gx_state_accepts(h, state, ...) is
+ * Automata.accept(state) (core/autom/Automata.java:137-139): all extraction indexes accepting there, ascending
+ * (returns the count, <= cap written; 0 for -1).  first_match[i] = their first element or -1, as with
+ * gx_extract_batch + match_only.  Runs on the per-line kernel (the batch kernels keep only the first match). */
+int gx_match_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, uint64_t n, int32_t* first_match,
+                   int32_t* states, const gx_batch_opts* opts);
+int gx_state_accepts(const gx_handle* h, int32_t state, int32_t* indexes, int32_t cap);
+
 /* Replaces CookedExtraction.match(String) (core/model/CookedExtraction.java:61; JDKRegexpCookedExtraction.match,
  * core/jdkre/JDKRegexpCookedExtraction.java:36-39) -- the product of the reference's plugin seam, ExtractionCooker.cook
  * (core/ExtractionCooker.java:22): extraction k's capture regexp alone against one String, no matcher stage.

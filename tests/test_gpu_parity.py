@@ -626,3 +626,18 @@ def test_unaligned_device_buffers(variant, monkeypatch):
     want, _ = O.results_to_jsonl(lines, omid, ocaps, [x.getName() for x in xs], [x._extractorNames for x in xs], [x.getExtra() for x in xs], id_as="id")
     assert out.cpu().numpy().tobytes() == want
     assert int(out_store[4]) == 0 and int(out_store[5 + size]) == 0
+
+
+def test_match_batch_returns_all_accepting_indexes(golden):
+    """PolyMatcher.match over a batch (gx_match_batch + gx_state_accepts) == the single-line API == the oracle,
+    on the reference's MultiPatternTest vectors and on the README definition."""
+    t = golden("multipattern")
+    pm = PolyMatcher.create(*t["patterns"])
+    inputs = [c["input"] for c in t["cases"]]
+    got = pm.match_batch(*lines_to_csr(inputs))
+    assert got == [c["match"] for c in t["cases"]]
+    gorp = Gorp.construct(W.readme3_definition())
+    lines = ["[123456789]: GET 12ms /index.html", "[1]: PUT 5ms /x", "[1]: HEAD 5ms /x", "nope", ""]
+    got = gorp.getMatcher().match_batch(*lines_to_csr(lines))
+    assert got == [gorp.getMatcher().match(ln) for ln in lines]
+    assert got[0] == [1, 2] and got[1] == [0, 2] and got[2] == [2] and got[3] == [] and got[4] == []
