@@ -18,6 +18,10 @@ GX_E_NOMEM = 5
 GX_E_LIMIT = 6
 GX_E_DEFINITION = 7
 GX_CREATE_HOST_ONLY = 1
+GX_CREATE_TIER_L2 = 2
+GX_CREATE_NO_TILES = 4
+GX_CREATE_NO_FUSED = 8
+GX_KERNEL_AUTO, GX_KERNEL_TILES, GX_KERNEL_SLICES, GX_KERNEL_PER_LINE = 0, 1, 2, 3
 
 # every symbol include/gorp_hip.h declares
 SYMBOLS = [
@@ -46,7 +50,10 @@ class gx_batch_opts(C.Structure):
         ("strip_eol", C.c_uint32),
         ("utf8_passthrough", C.c_uint32),
         ("utf16", C.c_uint32),
+        ("kernel", C.c_uint32),
+        ("compact_results", C.c_uint32),
         ("reserved", C.c_uint32),
+        ("overflow", C.c_void_p),
     ]
 
 

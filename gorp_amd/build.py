@@ -1,19 +1,26 @@
 """Builds gorp_amd/libgorp_hip.so in-tree with hipcc for gfx950.
 
-    python -m gorp_amd.build [--force]
+    python -m gorp_amd.build [--force] [--dev]
 
 hipcc cross-compiles without a GPU present.  The .so is git-ignored but travels
 with the tree (it is not listed in .gpurunignore).
+
+--dev additionally builds libgorp_hip_dev.so (-DGX_DEV): the same library plus
+the tile kernel's per-phase cycle counters, for tools/phase_cycles.py.  The
+product library carries no developer hooks and reads no environment variables.
 """
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgorp_hip.so")
-SOURCES = ["gx_regex.cpp", "gx_compile.cpp", "gx_host.cpp", "gx_dsl.cpp", "gx_api.cpp", "gx_kernels.hip", "gx_ingest.hip", "gx_jsonl.hip"]
-HEADERS = ["gx_common.hpp", "gx_compile.hpp", "gx_device.hpp", "gx_dsl.hpp", os.path.join("..", "..", "include", "gorp_hip.h")]
+LIB_DEV = os.path.join(HERE, "libgorp_hip_dev.so")
+SOURCES = ["gx_regex.cpp", "gx_compile.cpp", "gx_host.cpp", "gx_dsl.cpp", "gx_api.cpp", "gx_tile.hip", "gx_kernels.hip", "gx_ingest.hip",
+           "gx_jsonl.hip"]
+HEADERS = ["gx_common.hpp", "gx_compile.hpp", "gx_device.hpp", "gx_dsl.hpp", "gx_walk.hpp", os.path.join("..", "..", "include", "gorp_hip.h")]
 
 
 def _hipcc():
@@ -23,40 +30,51 @@ def _hipcc():
     return "hipcc"
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def needs_build(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     for f in SOURCES + HEADERS:
         if os.path.getmtime(os.path.join(CSRC, f)) > t:
             return True
     return False
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return LIB
-    objs = []
+def build(force=False, verbose=False, dev=False):
+    lib = LIB_DEV if dev else LIB
+    if not force and not needs_build(lib):
+        return lib
     common = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-result"]
+    if dev:
+        common.append("-DGX_DEV")
+    jobs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(CSRC, ("dev_" if dev else "") + os.path.splitext(src)[0] + ".o")
         cmd = [_hipcc()] + common + ["-c", os.path.join(CSRC, src), "-o", obj]
-        if src.endswith(".cpp"):
-            cmd[1:1] = ["-x", "hip"] if src == "gx_api.cpp" else []
+        if src == "gx_api.cpp":
+            cmd[1:1] = ["-x", "hip"]
+        jobs.append((cmd, obj))
+
+    def run(job):
         if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        objs.append(obj)
+            print(" ".join(job[0]), flush=True)
+        subprocess.check_call(job[0])
+        return job[1]
+
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(run, jobs))
     # -no-hip-rt: do not record a NEEDED entry for a particular libamdhip64.  The process
     # must hold exactly ONE HIP runtime; PyTorch wheels bundle their own copy (different
     # SONAME from /opt/rocm's), so the loader (gorp_amd/_native.py, or the JNI shim)
     # loads the runtime that the rest of the process uses before loading this library.
-    cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-no-hip-rt", "-o", LIB] + objs
+    cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-no-hip-rt", "-o", lib] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--dev" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, dev=True))

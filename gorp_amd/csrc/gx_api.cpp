@@ -4,6 +4,7 @@
 // every extract/match entry point runs the HIP kernels or fails with GX_E_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <cstddef>
 #include <cstdlib>
 #include <map>
@@ -72,6 +73,19 @@ struct gx_handle {
     struct JsonlImage { void* d = nullptr; GxJsonl dev{}; };
     std::map<std::string, JsonlImage> jsonl;  // device templates per id_as ("0" = none, "1" + id_as)
     std::mutex mu;  // serialises host-pointer batches that share nothing else
+    uint32_t create_flags = 0;   // GX_CREATE_* given at creation (kernel choice)
+    // Tile-kernel launches that are in flight share nothing but these slots: one word each, into which a launch
+    // stores its sequence number when it meets a line it cannot stage (gx_device.hpp: GxBatch::oversize_flag).
+    // A slot is reused only after the follow-up kernel of its previous user has run (event).
+    static const int N_SLOTS = 32;
+    uint32_t* d_slots = nullptr;
+    hipEvent_t slot_event[N_SLOTS] = {};
+    bool slot_used[N_SLOTS] = {};
+    uint32_t next_seq = 1;
+    std::mutex slot_mu;
+#ifdef GX_DEV
+    unsigned long long* dev_stamps = nullptr;  // developer build: device buffer for the tile kernel's phase cycle counts
+#endif
 };
 
 namespace {
@@ -103,18 +117,18 @@ bool build_tile_image(gx_handle* h, bool global) {
     const uint32_t cols = static_cast<uint32_t>(T.ncls) + 3u;
     const uint32_t RS = cols * 4u;
     // with the fused automaton present the per-extraction capture rows are not needed on the device
-    // (GX_DEBUG_NO_FUSED: tests force the two-pass layout, which otherwise only very large definitions get)
-    const bool fused = T.union_ok && !getenv("GX_DEBUG_NO_FUSED");
+    // (GX_CREATE_NO_FUSED forces the two-pass layout, which otherwise only very large definitions get)
+    const bool fused = T.union_ok && !(h->create_flags & GX_CREATE_NO_FUSED);
     const size_t m_rows = static_cast<size_t>(T.m_states);
     size_t c_rows = 0;
     if (fused) c_rows = T.uni.n_states;
     else for (auto& r : T.rules) c_rows += r.n_states;
     const size_t rows = m_rows + c_rows;
-    if (T.ncls > 252) return false;  // classes (+ the identity column) are bytes in the LDS class map
-    const uint32_t AT = 272;         // LDS tier: the rows follow the class map (256 bytes + the identity entry, padded)
+    if (T.ncls > 252) return false;  // keeps the column offsets of a row (class * 4, + 3 extra columns) below 1024
+    const uint32_t AT = 544;         // LDS tier: the rows follow the class map (u16[256] + the identity entry, padded)
     if (!global) {
         if (AT + rows * RS > 65536u) return false;  // successors are 16-bit LDS addresses
-        if (rows * RS + T.ops_off.size() * 4 + T.ops.size() * 2 + T.fin_tags.size() * 2 + 1024 > LDS_TABLE_BUDGET) return false;
+        if (rows * RS + T.ops_off.size() * 4 + T.ops.size() * 2 + 1024 > LDS_TABLE_BUDGET) return false;  // (+ the final records, below)
     } else {
         if (m_rows > 65536u || c_rows > 65536u) return false;  // state indexes are 16-bit per automaton table
         if (T.n_rules * 8 + T.ops_off.size() * 4 + T.ops.size() * 2 + 1024 > LDS_TABLE_BUDGET) return false;
@@ -125,19 +139,25 @@ bool build_tile_image(gx_handle* h, bool global) {
 
     Image img;
     GxLds L{};
-    std::vector<uint8_t> cmap(T.cls256, T.cls256 + 256);
-    cmap.resize(272, static_cast<uint8_t>(T.ncls));  // entry 256: the identity column, for bytes outside the line
+    std::vector<uint16_t> cmap(272, static_cast<uint16_t>(T.ncls * 4));  // entry 256: the identity column, for bytes outside the line
+    for (int b = 0; b < 256; ++b) cmap[b] = static_cast<uint16_t>(T.cls256[b] * 4);  // byte offset of the class's column
     L.cmap = static_cast<uint32_t>(img.put(cmap));  // offset 0
     L.ncls = static_cast<uint32_t>(T.ncls);
     L.row_bytes = RS;
     std::vector<uint32_t> at(rows * cols, 0);
     const uint32_t IDC = T.ncls, ACC = T.ncls + 1, INFO = T.ncls + 2;
+    // per row: the ASCII bytes the state loops on (with no capture program), for the choice of the hot interval
+    std::vector<std::array<uint64_t, 2>> loop_set(rows, std::array<uint64_t, 2>{0, 0});
+    auto loop_interval = [&](size_t row_index, auto loops) {
+        for (int b = 0; b < 128; ++b) if (loops(b)) loop_set[row_index][b >> 6] |= 1ull << (b & 63);
+        return self_loop_interval(loops);
+    };
     // match automaton rows
     for (int s = 0; s < T.m_states; ++s) {
         uint32_t* row = &at[static_cast<size_t>(s) * cols];
         for (int c = 0; c < T.ncls; ++c) row[c] = ORG + T.m_next[static_cast<size_t>(s) * T.ncls + c] * UNIT;
         row[IDC] = ORG + static_cast<uint32_t>(s) * UNIT;
-        row[ACC] = self_loop_interval([&](int b) { return T.m_next[static_cast<size_t>(s) * T.ncls + T.cls256[b]] == static_cast<uint32_t>(s); });
+        row[ACC] = loop_interval(static_cast<size_t>(s), [&](int b) { return T.m_next[static_cast<size_t>(s) * T.ncls + T.cls256[b]] == static_cast<uint32_t>(s); });
         row[INFO] = static_cast<uint32_t>(T.m_accept_first[s]);
     }
     L.m_start = ORG;
@@ -159,6 +179,34 @@ bool build_tile_image(gx_handle* h, bool global) {
     if (fused) scan_simple(T.uni);
     else for (auto& r : T.rules) scan_simple(r);
     L.simple_ops = simple ? 1u : 0u;
+    // Final records, one per distinct (final tag list, extraction): u16 [extraction][begin tag, end tag] x max_groups
+    // with the tags as line_result (gx_walk.hpp) wants them: 0 = unset, 1 = the line length, else the byte offset of
+    // the register's column from the dummy column.  Record 0 = "no groups" for the lines that match nothing.  A row's
+    // info word is the byte offset of its record.
+    const size_t rec_len = 1 + 2 * static_cast<size_t>(T.max_groups);
+    std::vector<uint16_t> fin_rec(rec_len, 0);
+    fin_rec[0] = 0xFFFFu;
+    std::map<std::pair<int32_t, int32_t>, uint32_t> rec_of;
+    auto fin_record = [&](int32_t f, int32_t k_or_minus1) -> uint32_t {  // k < 0: the list starts with the extraction
+        auto it = rec_of.find({f, k_or_minus1});
+        if (it != rec_of.end()) return it->second;
+        const int32_t k = k_or_minus1 >= 0 ? k_or_minus1 : static_cast<int32_t>(T.fin_tags[f]);
+        const size_t t0 = k_or_minus1 >= 0 ? f : f + 1;
+        const uint32_t at_byte = static_cast<uint32_t>(fin_rec.size() * 2);
+        fin_rec.push_back(static_cast<uint16_t>(k));
+        for (int g = 0; g < T.max_groups; ++g)
+            for (int e = 0; e < 2; ++e) {
+                uint16_t code = 0;
+                if (g < T.rules[k].n_groups) {
+                    const uint16_t v = T.fin_tags[t0 + 2 * g + e];
+                    code = v == GX_SRC_NIL ? 0 : v == GX_SRC_POS ? 1 : static_cast<uint16_t>((v + 1u) * 128u);
+                }
+                fin_rec.push_back(code);
+            }
+        rec_of[{f, k_or_minus1}] = at_byte;
+        return at_byte;
+    };
+    int rule_being_emitted = -1;  // per-extraction capture automata: the rule; fused automaton: -1
     auto emit_rows = [&](const RuleTables& r) {
         // LDS tier: LDS addresses; L2 tier: state indexes within the capture rows
         const uint32_t base = ORG + static_cast<uint32_t>(global ? base_row - m_rows : base_row) * UNIT;
@@ -179,9 +227,9 @@ bool build_tile_image(gx_handle* h, bool global) {
                 row[c] = (base + (w & 0xFFFFu) * UNIT) | (op << 16);
             }
             row[IDC] = base + static_cast<uint32_t>(s) * UNIT;
-            row[ACC] = self_loop_interval(
+            row[ACC] = loop_interval(base_row + s,
                 [&](int b) { return r.trans[static_cast<size_t>(s) * T.ncls + T.cls256[b]] == static_cast<uint32_t>(s); });
-            row[INFO] = static_cast<uint32_t>(r.fin[s]);
+            row[INFO] = r.fin[s] >= 0 ? fin_record(r.fin[s], rule_being_emitted) : static_cast<uint32_t>(r.fin[s]);
         }
         base_row += r.n_states;
         return base;
@@ -195,16 +243,54 @@ bool build_tile_image(gx_handle* h, bool global) {
         for (auto& r : T.rules) { c_rule.push_back(0); c_rule.push_back(static_cast<uint32_t>(r.n_groups)); }
     } else {
         for (auto& r : T.rules) {
+            rule_being_emitted = static_cast<int>(&r - &T.rules[0]);
             const uint32_t base = emit_rows(r);
             c_rule.push_back(base);
             c_rule.push_back(static_cast<uint32_t>(r.n_groups));
         }
     }
     if (too_many_programs) return false;  // too many distinct general programs for the 15-bit program field
+    while (fin_rec.size() % 8) fin_rec.push_back(0);
+    for (int q = 0; q < 8; ++q) fin_rec.push_back(0);  // line_result reads four groups' tags at a time, past a record's end
+    if (fin_rec.size() * 2 > 0xFFFFFFu) return false;
+    if (!global && rows * RS + T.ops_off.size() * 4 + T.ops.size() * 2 + fin_rec.size() * 2 + 1024 > LDS_TABLE_BUDGET) return false;
+    // Hot interval: among the self-loop intervals of all rows, the one that promises the longest skips -- width
+    // squared (only runs of several 16-byte chunks pay off) times the number of states that loop on all of it.
+    // Those states get bit 16 of their interval column; the tile kernel marks the staged chunks that lie inside the
+    // interval and lets such a state jump over runs of them (gx_tile.hip).
+    {
+        auto covers = [&](size_t r, int lo, int hi) {
+            for (int b = lo; b <= hi; ++b) if (!(loop_set[r][b >> 6] >> (b & 63) & 1ull)) return false;
+            return true;
+        };
+        std::map<uint32_t, int> candidates;
+        for (size_t r = 0; r < rows; ++r) if (at[r * cols + ACC] != 0x8000u) candidates[at[r * cols + ACC]] = 0;
+        double best = 0;
+        int best_lo = 0, best_hi = -1;
+        for (auto& c : candidates) {
+            const int lo = static_cast<int>(c.first & 0xFFu), hi = 0x7F - static_cast<int>((c.first >> 8) & 0xFFu);
+            if (hi - lo + 1 < 16) continue;  // a run of such bytes seldom fills whole chunks
+            int states = 0;
+            for (size_t r = 0; r < rows; ++r) if (covers(r, lo, hi)) ++states;
+            const double score = static_cast<double>(hi - lo + 1) * (hi - lo + 1) * states;
+            if (score > best) { best = score; best_lo = lo; best_hi = hi; }
+        }
+        L.hot_lo4 = 0;
+        L.hot_k4 = 0x80808080u;
+        if (best_hi >= best_lo) {
+            L.hot_lo4 = static_cast<uint32_t>(best_lo) * 0x01010101u;
+            L.hot_k4 = static_cast<uint32_t>(0x7F - best_hi) * 0x01010101u;
+            for (size_t r = 0; r < rows; ++r) if (covers(r, best_lo, best_hi)) at[r * cols + ACC] |= 0x10000u;
+        }
+    }
     if (c_rule.empty()) { c_rule.push_back(0); c_rule.push_back(0); }
     if (global) {
         L.at = 0;
         h->l2_image.assign(reinterpret_cast<const uint8_t*>(at.data()), reinterpret_cast<const uint8_t*>(at.data() + at.size()));
+        while (h->l2_image.size() % 16) h->l2_image.push_back(0);
+        L.fin_tags = static_cast<uint32_t>(h->l2_image.size());  // L2 tier: the final records follow the rows in global memory
+        const uint8_t* fr = reinterpret_cast<const uint8_t*>(fin_rec.data());
+        h->l2_image.insert(h->l2_image.end(), fr, fr + fin_rec.size() * 2);
     } else {
         L.at = static_cast<uint32_t>(img.put(at));
         if (L.at != AT) throw GxError(GX_E_ARG, "internal: LDS table image layout");
@@ -214,9 +300,7 @@ bool build_tile_image(gx_handle* h, bool global) {
     std::vector<uint16_t> ops = T.ops;
     if (ops.empty()) ops.push_back(0);
     L.ops = static_cast<uint32_t>(img.put(ops));
-    std::vector<uint16_t> fin_tags = T.fin_tags;
-    if (fin_tags.empty()) fin_tags.push_back(0);
-    L.fin_tags = global ? 0u : static_cast<uint32_t>(img.put(fin_tags));  // L2 tier reads GxDev::fin_tags
+    if (!global) L.fin_tags = static_cast<uint32_t>(img.put(fin_rec));
     while (img.bytes.size() % 16) img.bytes.push_back(0);
     L.table_bytes = static_cast<uint32_t>(img.bytes.size());
     int max_regs = 0;
@@ -235,22 +319,29 @@ bool plan_tile_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out) 
     GxLds L = h->lds;
     if (line_bytes_hint == 0) line_bytes_hint = 200;
     if (line_bytes_hint > 2000) line_bytes_hint = 2000;
-    L.stage_bytes = (64u * line_bytes_hint + 64u + 15u) & ~15u;  // + slack: the walk reads two windows ahead
+    L.stage_bytes = (64u * line_bytes_hint + 64u + 15u) & ~15u;  // + slack: the walk reads ahead of the line
     if (L.stage_bytes > 16384u) L.stage_bytes = 16384u;  // the kernel prefetches a tile into <= 64 VGPRs per lane;
-                                                          // tiles that do not fit take the per-lane global path
-    const uint32_t per_wave = L.stage_bytes + L.regs_wave_bytes;
-    if (L.table_bytes + 4 * per_wave > LDS_BYTES) return false;
-    uint32_t nw = (LDS_BYTES - L.table_bytes) / per_wave;
+                                                          // longer lines go in several rounds or to the per-line kernel
+    const uint32_t fixed = L.regs_wave_bytes + GX_BITMAP_WAVE_BYTES;
+    if (L.table_bytes + 4 * (L.stage_bytes + fixed) > LDS_BYTES) return false;
+    uint32_t nw = (LDS_BYTES - L.table_bytes) / (L.stage_bytes + fixed);
     if (nw > 12) nw = 12;  // 768 threads: leaves 170 VGPRs per lane for the prefetch registers
     if (L.stage_bytes > 13u * 1024u && nw > 8) nw = 8;  // the 16 KB variant prefetches 64 VGPRs: 2 waves per SIMD
-    static const int force_nw = getenv("GX_DEBUG_NWAVES") ? atoi(getenv("GX_DEBUG_NWAVES")) : 0;  // developer sweep
-    if (force_nw > 0 && static_cast<uint32_t>(force_nw) < nw) nw = static_cast<uint32_t>(force_nw);
+    // Whatever LDS is left goes to the staging areas, up to what the kernel variant's prefetch registers hold: a hint
+    // that is a few bytes short (mean length, lines of 201 bytes announced as 200) then still stages whole groups.
+    {
+        const uint32_t kch = (L.stage_bytes + 1023u) / 1024u;
+        const uint32_t cap = (kch <= 4 ? 4u : kch <= 8 ? 8u : kch <= 13 ? 13u : 16u) * 1024u;
+        uint32_t room = ((LDS_BYTES - L.table_bytes) / nw - fixed) & ~15u;
+        if (room > cap) room = cap;
+        if (room > L.stage_bytes) L.stage_bytes = room;
+    }
     L.nwaves = nw;
     L.regs = L.table_bytes;
-    L.stage = L.regs + nw * L.regs_wave_bytes;
+    L.bitmap = L.regs + nw * L.regs_wave_bytes;
+    L.stage = (L.bitmap + nw * GX_BITMAP_WAVE_BYTES + 15u) & ~15u;
     L.total_bytes = L.stage + nw * L.stage_bytes;
-    static const int ablate = getenv("GX_DEBUG_ABLATE") ? atoi(getenv("GX_DEBUG_ABLATE")) : 0;
-    L.debug_ablate = ablate >= 4 ? static_cast<uint32_t>(ablate) : 0u;
+    if (L.total_bytes > LDS_BYTES) { L.stage_bytes -= 16u; L.total_bytes = L.stage + nw * L.stage_bytes; }
     *out = L;
     return true;
 }
@@ -265,13 +356,11 @@ bool plan_slice_launch(const gx_handle* h, GxLds* out) {
     if (L.table_bytes + per_wave > LDS_BYTES) return false;
     uint32_t nw = (LDS_BYTES - L.table_bytes) / per_wave;
     if (nw > 16) nw = 16;
-    static const int force_nw = getenv("GX_DEBUG_NWAVES") ? atoi(getenv("GX_DEBUG_NWAVES")) : 0;
-    if (force_nw > 0 && static_cast<uint32_t>(force_nw) < nw) nw = static_cast<uint32_t>(force_nw);
     L.nwaves = nw;
     L.regs = L.table_bytes;
+    L.bitmap = 0;
     L.stage = L.regs + nw * L.regs_wave_bytes;
     L.total_bytes = L.stage + nw * L.stage_bytes;
-    L.debug_ablate = 0;
     *out = L;
     return true;
 }
@@ -349,8 +438,9 @@ void upload(gx_handle* h) {
     d.max_regs = max_regs;
     d.has_capture = T.has_capture ? 1 : 0;
 
-    const int force_tier = getenv("GX_DEBUG_TIER") ? atoi(getenv("GX_DEBUG_TIER")) : 0;  // developer/tests: 2 = L2 tier, 3 = generic
-    if (force_tier == 3 || !((force_tier != 2 && build_tile_image(h, false)) || build_tile_image(h, true))) h->tile_ok = false;
+    // kernel choice: automaton rows in LDS when they fit, else in global memory (L2), else the per-line kernel alone
+    const bool no_tiles = (h->create_flags & GX_CREATE_NO_TILES) != 0, force_l2 = (h->create_flags & GX_CREATE_TIER_L2) != 0;
+    if (no_tiles || !((!force_l2 && build_tile_image(h, false)) || build_tile_image(h, true))) h->tile_ok = false;
     if (h->tile_ok) {
         GX_HIP(hipMalloc(&h->d_lds_image, h->lds_image.size()));
         GX_HIP(hipMemcpy(h->d_lds_image, h->lds_image.data(), h->lds_image.size(), hipMemcpyHostToDevice));
@@ -358,35 +448,54 @@ void upload(gx_handle* h) {
             GX_HIP(hipMalloc(&h->d_l2_image, h->l2_image.size()));
             GX_HIP(hipMemcpy(h->d_l2_image, h->l2_image.data(), h->l2_image.size(), hipMemcpyHostToDevice));
         }
-        GX_HIP(prepare_tile_kernels(LDS_BYTES));
+        GX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_slots), gx_handle::N_SLOTS * sizeof(uint32_t)));
+        GX_HIP(hipMemset(h->d_slots, 0, gx_handle::N_SLOTS * sizeof(uint32_t)));
+        for (int q = 0; q < gx_handle::N_SLOTS; ++q) GX_HIP(hipEventCreateWithFlags(&h->slot_event[q], hipEventDisableTiming));
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->num_cus = cus;
     }
     h->on_device = true;
 }
 
-// One batch on the device: tile kernel (LDS tier when the tables fit LDS, else L2 tier), generic kernel otherwise.
-void launch_batch(gx_handle* h, const GxBatch& b, uint32_t line_bytes_hint, hipStream_t stream) {
+// One batch on the device: tile kernel (LDS tier when the tables fit LDS, else L2 tier), slice kernel for long lines,
+// per-line kernel otherwise.  kernel: gx_batch_opts.kernel (0 = choose).
+void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t kernel, hipStream_t stream) {
     GxLds L;
+    const bool batchable = !b.wide && !b.state_out && b.match_only >= 0 && kernel != GX_KERNEL_PER_LINE;
     // Lines whose 64-line groups do not fit the tile kernel's staging area (mean length above 255 bytes) go to the
     // slice kernel, which stages 64 bytes of every line at a time: measured 2.4x faster on config 5 (512 extractions,
     // 50-2000-byte lines), but 0.8x on 200-byte lines, where the tile kernel's one contiguous span per group wins.
-    // (GX_DEBUG_SLICES=1 forces it, =0 forbids it: tests and measurements.)
-    const int force = getenv("GX_DEBUG_SLICES") ? atoi(getenv("GX_DEBUG_SLICES")) : -1;
-    const bool slices = force == 1 || (force != 0 && line_bytes_hint > 255u);
-    if (!b.wide && !b.state_out && slices && plan_slice_launch(h, &L)) {
+    const bool slices = kernel == GX_KERNEL_SLICES || (kernel == GX_KERNEL_AUTO && line_bytes_hint > 255u);
+    if (batchable && slices && plan_slice_launch(h, &L)) {
         GX_HIP(launch_extract_slices(h->dev, L, static_cast<const uint8_t*>(h->d_lds_image),
                                      h->tile_global ? static_cast<const uint8_t*>(h->d_l2_image) : nullptr, h->num_cus, b, stream));
         return;
     }
-    if (!b.wide && !b.state_out && plan_tile_launch(h, line_bytes_hint, &L))
+    if (batchable && plan_tile_launch(h, line_bytes_hint, &L)) {
+        // a slot for the "lines I could not stage" word of this launch, free again once its follow-up kernel has run
+        // (submission of tile launches is serialised per handle; the launches themselves are asynchronous)
+        std::lock_guard<std::mutex> lock(h->slot_mu);
+        b.seq = h->next_seq++;
+        if (h->next_seq == 0) h->next_seq = 1;
+        const int slot = static_cast<int>(b.seq % gx_handle::N_SLOTS);
+        if (h->slot_used[slot]) GX_HIP(hipStreamWaitEvent(stream, h->slot_event[slot], 0));
+        h->slot_used[slot] = true;
+        b.oversize_flag = h->d_slots + slot;
+        unsigned long long* stamps = nullptr;
+#ifdef GX_DEV
+        stamps = h->dev_stamps;
+#endif
         GX_HIP(launch_extract_tile(h->dev, L, static_cast<const uint8_t*>(h->d_lds_image),
-                                   h->tile_global ? static_cast<const uint8_t*>(h->d_l2_image) : nullptr, h->num_cus, b, stream));
-    else
+                                   h->tile_global ? static_cast<const uint8_t*>(h->d_l2_image) : nullptr, h->num_cus, b, stream, stamps));
+        GX_HIP(launch_extract_oversize(h->dev, b, L.stage_bytes, stream));
+        GX_HIP(hipEventRecord(h->slot_event[slot], stream));
+    } else {
         GX_HIP(launch_extract_generic(h->dev, b, stream));
+    }
 }
 
 int finish_create(std::unique_ptr<gx_handle>& h, uint32_t flags, gx_handle** out) {
+    h->create_flags = flags;
     h->blob = pack_blob(h->T);
     if (!(flags & GX_CREATE_HOST_ONLY)) upload(h.get());
     *out = h.release();
@@ -453,6 +562,10 @@ void gx_destroy(gx_handle* h) {
     if (h->dimage) (void)hipFree(h->dimage);
     if (h->d_lds_image) (void)hipFree(h->d_lds_image);
     if (h->d_l2_image) (void)hipFree(h->d_l2_image);
+    if (h->d_slots) {
+        (void)hipFree(h->d_slots);
+        for (int q = 0; q < gx_handle::N_SLOTS; ++q) if (h->slot_event[q]) (void)hipEventDestroy(h->slot_event[q]);
+    }
     for (auto& e : h->jsonl) if (e.second.d) (void)hipFree(e.second.d);
     if (h->one_dev) (void)hipFree(h->one_dev);
     if (h->one_host) (void)hipHostFree(h->one_host);
@@ -477,6 +590,7 @@ int64_t gx_stat(const gx_handle* h, int32_t which) {
     case 5: { GxLds L; return plan_tile_launch(h, 0, &L) ? static_cast<int64_t>(L.total_bytes) : 0; }
     case 6: { GxLds L; return plan_tile_launch(h, 0, &L) ? static_cast<int64_t>(L.nwaves) : 0; }
     case 7: return !h->tile_ok ? 0 : h->tile_global ? 2 : 1;
+    case 8: return h->T.has_capture ? 1 : 0;
     default: return -1;
     }
 }
@@ -720,7 +834,7 @@ int gx_text_to_jsonl(gx_handle* h, const uint8_t* text, uint64_t size, const cha
         b.match_only = h->T.has_capture ? 0 : 1;
         b.strip_eol = 1;
         const uint32_t mean_in = n ? static_cast<uint32_t>(std::min<uint64_t>((size + n - 1) / n, 1u << 20)) : 1u;
-        launch_batch(h, b, mean_in, stream);
+        launch_batch(h, b, mean_in, GX_KERNEL_AUTO, stream);
         if (!h->T.has_capture && n && slots) GX_HIP(hipMemsetAsync(d_caps.p, 0xFF, n * slots * 4, stream));
         b.caps = static_cast<int32_t*>(d_caps.p);
         d_counts.alloc(16);
@@ -807,12 +921,15 @@ int gx_set_extraction_meta(gx_handle* h, int32_t k, const char* name, const char
 // per-line generic kernel then, which is the one that keeps it)
 static int extract_batch_impl(gx_handle* h, const uint8_t* bytes, const void* offsets, uint64_t n, int32_t* match_id, int32_t* caps,
                               int32_t* states, const gx_batch_opts* opts) {
-    if (!h || !offsets || !match_id || (n && !bytes && false)) return fail(GX_E_ARG, "gx_extract_batch: bad argument");
+    if (!h || !offsets) return fail(GX_E_ARG, "gx_extract_batch: bad argument");
     if (!h->on_device) return fail(GX_E_DEVICE, "handle was created host-only; no device tables (there is no CPU fallback)");
     gx_batch_opts o{};
     if (!read_opts(opts, &o)) return fail(GX_E_ARG, "gx_batch_opts.struct_size mismatch");
+    if (o.kernel > GX_KERNEL_PER_LINE) return fail(GX_E_ARG, "gx_batch_opts.kernel: unknown kernel");
     const bool match_only = o.match_only || states || !h->T.has_capture;
-    if (!match_only && !caps && n > 0 && h->T.max_groups > 0) return fail(GX_E_ARG, "gx_extract_batch: caps is NULL");
+    const bool compact = o.compact_results && !match_only;  // rows of u16[1 + slots] through `caps`
+    if (!compact && !match_id) return fail(GX_E_ARG, "gx_extract_batch: match_id is NULL");
+    if (!match_only && !caps && n > 0 && (compact || h->T.max_groups > 0)) return fail(GX_E_ARG, "gx_extract_batch: caps is NULL");
     try {
         GX_HIP(hipSetDevice(h->device));
         hipStream_t stream = static_cast<hipStream_t>(o.stream);
@@ -826,11 +943,15 @@ static int extract_batch_impl(gx_handle* h, const uint8_t* bytes, const void* of
         const size_t off_w = o.offsets64 ? 8 : 4;
         const size_t slots = 2 * static_cast<size_t>(h->T.max_groups);
         if (o.device_pointers) {
-            // developer-only timing ablations of the tile kernel (results are NOT valid when set)
-            static const int ablate = getenv("GX_DEBUG_ABLATE") ? atoi(getenv("GX_DEBUG_ABLATE")) : 0;
-            if (ablate > 1 && !match_only) b.match_only = ablate;
-            b.data = bytes; b.offsets = offsets; b.match_id = match_id; b.caps = match_only ? nullptr : caps;
+            b.data = bytes; b.offsets = offsets;
             b.state_out = states;
+            if (compact) {
+                b.packed = reinterpret_cast<uint16_t*>(caps);
+                b.overflow = static_cast<unsigned long long*>(o.overflow);
+            } else {
+                b.match_id = match_id;
+                b.caps = match_only ? nullptr : caps;
+            }
             uint32_t hint = o.line_bytes_hint;
             if (hint == 0 && n && !o.no_sync) {
                 // no hint: the mean line length, from the two ends of the offsets array (a small synchronous read;
@@ -842,7 +963,7 @@ static int extract_batch_impl(gx_handle* h, const uint8_t* bytes, const void* of
                 hint = static_cast<uint32_t>(std::min<uint64_t>((last - first + n - 1) / n, 4096));
                 if (hint == 0) hint = 1;
             }
-            launch_batch(h, b, hint, stream);
+            launch_batch(h, b, hint, o.kernel, stream);
             if (!o.no_sync) GX_HIP(hipStreamSynchronize(stream));
             return GX_OK;
         }
@@ -852,20 +973,38 @@ static int extract_batch_impl(gx_handle* h, const uint8_t* bytes, const void* of
         if (n) total = o.offsets64 ? static_cast<const uint64_t*>(offsets)[n] : static_cast<const uint32_t*>(offsets)[n];
         uint32_t hint = o.line_bytes_hint;
         if (hint == 0 && n) hint = static_cast<uint32_t>((total + n - 1) / n);
-        DevBuf d_bytes, d_off, d_mid, d_caps, d_states;
+        DevBuf d_bytes, d_off, d_mid, d_caps, d_states, d_over;
         if (states) d_states.alloc(n * 4);
         b.state_out = states ? static_cast<int32_t*>(d_states.p) : nullptr;
-        d_bytes.alloc(total * unit); d_off.alloc((n + 1) * off_w); d_mid.alloc(n * 4);
-        if (!match_only) d_caps.alloc(n * slots * 4);
+        d_bytes.alloc(total * unit); d_off.alloc((n + 1) * off_w);
+        const size_t packed_bytes = n * (1 + slots) * 2;
+        if (compact) {
+            d_caps.alloc(packed_bytes);
+            d_over.alloc(8);
+            GX_HIP(hipMemsetAsync(d_over.p, 0, 8, stream));
+            b.packed = static_cast<uint16_t*>(d_caps.p);
+            b.overflow = static_cast<unsigned long long*>(d_over.p);
+        } else {
+            d_mid.alloc(n * 4);
+            if (!match_only) d_caps.alloc(n * slots * 4);
+            b.match_id = static_cast<int32_t*>(d_mid.p);
+            b.caps = match_only ? nullptr : static_cast<int32_t*>(d_caps.p);
+        }
         if (total) GX_HIP(hipMemcpyAsync(d_bytes.p, bytes, total * unit, hipMemcpyHostToDevice, stream));
         GX_HIP(hipMemcpyAsync(d_off.p, offsets, (n + 1) * off_w, hipMemcpyHostToDevice, stream));
-        b.data = d_bytes.p; b.offsets = d_off.p; b.match_id = static_cast<int32_t*>(d_mid.p);
-        b.caps = match_only ? nullptr : static_cast<int32_t*>(d_caps.p);
-        launch_batch(h, b, hint, stream);
-        if (n) GX_HIP(hipMemcpyAsync(match_id, d_mid.p, n * 4, hipMemcpyDeviceToHost, stream));
-        if (!match_only && n && slots) GX_HIP(hipMemcpyAsync(caps, d_caps.p, n * slots * 4, hipMemcpyDeviceToHost, stream));
+        b.data = d_bytes.p; b.offsets = d_off.p;
+        launch_batch(h, b, hint, o.kernel, stream);
+        unsigned long long over = 0;
+        if (compact) {
+            if (n) GX_HIP(hipMemcpyAsync(caps, d_caps.p, packed_bytes, hipMemcpyDeviceToHost, stream));
+            GX_HIP(hipMemcpyAsync(&over, d_over.p, 8, hipMemcpyDeviceToHost, stream));
+        } else {
+            if (n) GX_HIP(hipMemcpyAsync(match_id, d_mid.p, n * 4, hipMemcpyDeviceToHost, stream));
+            if (!match_only && n && slots) GX_HIP(hipMemcpyAsync(caps, d_caps.p, n * slots * 4, hipMemcpyDeviceToHost, stream));
+        }
         if (states && n) GX_HIP(hipMemcpyAsync(states, d_states.p, n * 4, hipMemcpyDeviceToHost, stream));
         GX_HIP(hipStreamSynchronize(stream));
+        if (compact && o.overflow) *static_cast<uint64_t*>(o.overflow) += over;
         return GX_OK;
     } catch (GxError& e) { return fail(e.code, e.what()); }
     catch (std::bad_alloc&) { return fail(GX_E_NOMEM, "out of memory"); }
@@ -1067,3 +1206,14 @@ int gx_definition_to_json(const char* definition_text, const char* source_ref, c
 }
 
 }  // extern "C"
+
+#ifdef GX_DEV
+// Developer build only (libgorp_hip_dev.so, `python -m gorp_amd.build --dev`): the tile kernel adds up the cycles
+// each wave spends in its four phases (stage, prefetch issue, walk, results) into this device buffer,
+// 4 x uint64 per wave of the grid (256 workgroups x 12 waves at most).  Not part of the product ABI.
+extern "C" int gx_dev_set_stamps(gx_handle* h, void* device_buffer) {
+    if (!h) return GX_E_ARG;
+    h->dev_stamps = static_cast<unsigned long long*>(device_buffer);
+    return GX_OK;
+}
+#endif

@@ -39,17 +39,18 @@ struct GxDev {
 // host, kept in HBM next to the other tables and copied into LDS by every
 // workgroup's prologue.
 struct GxLds {
-    uint32_t cmap;        // u8[272] byte -> class, entry 256 = the identity column; always at offset 0 (the kernel
-                          // indexes LDS by byte value)
+    uint32_t cmap;        // u16[272] byte -> class * 4 (the byte offset of the class's column in a row), entry 256 = the
+                          // identity column; always at offset 0 (the kernel indexes LDS by 2 * byte value)
     uint32_t ncls;        // number of classes = index of the identity column
     uint32_t at;          // automaton rows, u32[rows][ncls + 3]: one row per state of the match automaton and of
                           // the fused automaton (or of every extraction's capture automaton).  Columns
                           // 0..ncls-1: successor | capture program << 16, where the successor is the LDS byte
                           // address of its row (LDS tier; always < 65536) or its state index (L2 tier); column
                           // ncls: identity (self, no program); column ncls+1: self-loop byte interval as
-                          // lo | (0x7F - hi) << 8 (0x8000: none); column ncls+2: info (match automaton: first
-                          // accepting extraction or -1; capture automaton: offset of the state's final tag
-                          // record in fin_tags, or -1 / -2-k)
+                          // lo | (0x7F - hi) << 8 (0x8000: none), bit 16 set when the state also loops on every byte
+                          // of the hot interval (hot_lo4 / hot_k4 below); column ncls+2: info (match automaton: first
+                          // accepting extraction or -1; capture automaton: byte offset of the state's final
+                          // record, or -1 / -2-k)
     uint32_t row_bytes;   // (ncls + 3) * 4
     uint32_t c_base;      // L2 tier: byte offset of the capture rows inside the global row image (0 in the LDS tier)
     uint32_t m_start;     // row (LDS address / state index) of the match automaton's start state
@@ -59,7 +60,7 @@ struct GxLds {
     uint32_t u_dead;      // row of its dead state
     uint32_t ops_off;     // u32[n_oplists + 1]
     uint32_t ops;         // u16 pairs
-    uint32_t fin_tags;    // u16[]
+    uint32_t fin_tags;    // final records (gx_walk.hpp: line_result): LDS address, or byte offset in the global row image (L2 tier)
     uint32_t table_bytes; // size of the image, multiple of 16
     uint32_t simple_ops;  // 1: every capture program is one "register := position"; the program field is then
                           // (register + 1) * 128 = byte offset of the register's column in the wave's register
@@ -67,12 +68,17 @@ struct GxLds {
                           // 0: program field 0 = none, 0x8000 | register = single set, else op-list index
     uint32_t regs;        // u16[nwaves][1 + max_regs][64]; column 0 is a write-only dummy
     uint32_t regs_wave_bytes;
+    uint32_t bitmap;      // tile kernel: u64[nwaves][18], bit c of a wave's map = "all 16 bytes of staged chunk c lie in
+                          // the hot interval" (written when the tile is staged, read by the walk to jump over runs)
     uint32_t stage;       // u8[nwaves][stage_bytes]
     uint32_t stage_bytes; // multiple of 16
     uint32_t nwaves;
     uint32_t total_bytes; // dynamic LDS size to launch with
-    uint32_t debug_ablate; // developer timing ablations (GX_DEBUG_ABLATE >= 4); 0 in production
+    // Hot interval: the widest self-loop byte interval of the automata (typically \S+ or .*), in the form the SWAR
+    // range test consumes (lo and 0x7F - hi in every byte; hot_k4 = 0x80808080: none, no chunk ever qualifies).
+    uint32_t hot_lo4, hot_k4;
 };
+constexpr uint32_t GX_BITMAP_WAVE_BYTES = 144;  // 16 x u64 (1024 chunks = 16 KB of staging) + one word read ahead
 
 struct GxBatch {
     const void* data;      // uint8_t (Latin-1) or uint16_t (UTF-16) code units
@@ -85,19 +91,42 @@ struct GxBatch {
     int32_t offsets64;
     int32_t match_only;
     int32_t strip_eol;     // 1: every line carries its terminator ("\n", "\r\n" or "\r"), to be ignored
+    // compact result rows (gx_batch_opts.compact_results): per line u16[1 + 2 * max_groups] = int16 match id, then the
+    // capture offsets (0xFFFF = unset) -- written instead of match_id / caps when `packed` is set
+    uint16_t* packed;
+    unsigned long long* overflow;  // with `packed`: += number of offsets above 65534 (stored saturated)
+    // lines the tile kernel cannot stage (longer than its staging area) are left to a follow-up launch of the
+    // per-line kernel: the tile kernel stores `seq` into *oversize_flag when it meets one
+    uint32_t* oversize_flag;
+    uint32_t seq;
 };
+
+// More than 64 KiB of dynamic LDS needs the attribute, once per kernel (= per instantiation of this template) and
+// per device.
+template <typename K>
+inline hipError_t allow_full_lds(K kernel) {
+    static bool prepared[64] = {};  // (a benign race: setting the attribute twice is harmless)
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && prepared[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    if (e == hipSuccess && dev >= 0 && dev < 64) prepared[dev] = true;
+    return e;
+}
 
 // Generic kernel: any table size, any line length, bytes or UTF-16.
 hipError_t launch_extract_generic(const GxDev& dev, const GxBatch& b, hipStream_t stream);
 
-// Tile kernel (LDS tier): tables resident in LDS, 64-line tiles staged through
-// LDS with coalesced loads, self-loop runs skipped 16 bytes at a time.
-// Byte input only.  `lds_image` is the device copy of the table image.
+// Tile kernel (gx_tile.hip): 64-line tiles staged through LDS with coalesced loads, self-loop runs skipped by SWAR
+// tests and a per-chunk bitmap.  Byte input only.  `lds_image` is the device copy of the table image.
 // at_global != nullptr selects the L2 tier: automaton rows are read from that global-memory table (row =
-// state index, GxLds::row_bytes per row) instead of from LDS.
+// state index, GxLds::row_bytes per row) instead of from LDS.  A line longer than the staging area is not
+// processed: the kernel stores b.seq into *b.oversize_flag and launch_extract_oversize (same stream, right after)
+// takes those lines with the per-line kernel.  dev_stamps: developer builds (-DGX_DEV) only, else ignored.
 hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
-                               const GxBatch& b, hipStream_t stream);
-hipError_t prepare_tile_kernels(uint32_t lds_bytes);
+                               const GxBatch& b, hipStream_t stream, unsigned long long* dev_stamps);
+hipError_t launch_extract_oversize(const GxDev& dev, const GxBatch& b, uint32_t stage_bytes, hipStream_t stream);
 // Slice kernel: the same tables, lines staged 64 bytes at a time (GxLds::stage_bytes = 64 * 80); fused automaton or match only.
 hipError_t launch_extract_slices(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
                                  const GxBatch& b, hipStream_t stream);

@@ -289,8 +289,15 @@ class _Handle:
             pass
 
 
+# Kernel-choice defaults of this module (GX_CREATE_* bits OR-ed into every handle creation, GX_KERNEL_* for batches
+# that name none): the tests set them to run whole scenarios on one kernel.  Results never depend on them.
+DEFAULT_CREATE_FLAGS = 0
+DEFAULT_KERNEL = 0
+
+
 def _create(autom, jdk, flags):
     L = N.lib()
+    flags |= DEFAULT_CREATE_FLAGS
     n = len(autom)
     A = (C.c_char_p * n)(*[s.encode("utf-8") for s in autom])
     J = None
@@ -312,10 +319,10 @@ class PolyMatcher:
         self._h = handle
 
     @staticmethod
-    def create(*patterns, host_only=False):
+    def create(*patterns, host_only=False, flags=0):
         if len(patterns) == 1 and isinstance(patterns[0], (list, tuple)):
             patterns = list(patterns[0])
-        return PolyMatcher(_create(list(patterns), None, N.GX_CREATE_HOST_ONLY if host_only else 0))
+        return PolyMatcher(_create(list(patterns), None, flags | (N.GX_CREATE_HOST_ONLY if host_only else 0)))
 
     def match(self, s):
         """Indexes of all patterns that matched (ascending); [] when none."""
@@ -449,9 +456,10 @@ class Gorp:
 
     # -- construction ------------------------------------------------------
     @staticmethod
-    def construct(extractions, cooker=None, host_only=False):
+    def construct(extractions, cooker=None, host_only=False, flags=0):
         """Gorp.construct(defs, cooker) (core/Gorp.java:50-92).  extractions: list of FlattenedExtraction (what
-        CookedDefinitions.getExtractions() yields); cooker: an ExtractionCooker, default HipExtractionCooker."""
+        CookedDefinitions.getExtractions() yields); cooker: an ExtractionCooker, default HipExtractionCooker.
+        flags: GX_CREATE_* kernel-choice bits (measurements and tests; results never depend on them)."""
         cooker = cooker or HipExtractionCooker.instance()
         autom, regexps, cooked = [], [], []
         for i, ext in enumerate(extractions):
@@ -459,15 +467,15 @@ class Gorp:
             autom.append(a)
             regexps.append(r)
             cooked.append(cooker.cook(len(cooked), r, ext))
-        h = _create(autom, regexps, N.GX_CREATE_HOST_ONLY if host_only else 0)
+        h = _create(autom, regexps, flags | (N.GX_CREATE_HOST_ONLY if host_only else 0))
         return Gorp(h, cooked)
 
     @staticmethod
-    def from_blob(blob, extractions, host_only=False):
+    def from_blob(blob, extractions, host_only=False, flags=0):
         """Rebuild on another rank from the broadcast table blob (no recompilation)."""
         b = np.frombuffer(bytes(blob), dtype=np.uint8)
         h = C.c_void_p()
-        _check(N.lib().gx_create_from_blob(b.ctypes.data, len(b), N.GX_CREATE_HOST_ONLY if host_only else 0, C.byref(h)))
+        _check(N.lib().gx_create_from_blob(b.ctypes.data, len(b), flags | DEFAULT_CREATE_FLAGS | (N.GX_CREATE_HOST_ONLY if host_only else 0), C.byref(h)))
         return Gorp(_Handle(h), extractions)
 
     def blob(self):
@@ -499,12 +507,14 @@ class Gorp:
         caps = np.full(max(2 * self.max_groups, 1), -1, np.int32)
         _check(N.lib().gx_extract_one_utf16(self._h.ptr, a.ctypes.data if len(a) else None, len(a), C.byref(mid),
                                             caps.ctypes.data))
-        return self._materialise(input_line, mid.value, caps, allowFallbacks)
+        return self._materialise(input_line, mid.value, caps, allowFallbacks, units=a)
 
     def extractSafe(self, input_line):
         return self.extract(input_line, True)
 
-    def _materialise(self, line, match_id, caps, allowFallbacks=False):
+    def _materialise(self, line, match_id, caps, allowFallbacks=False, units=None):
+        """units: the line's UTF-16 code units when the capture offsets count those (one-String API: a character
+        outside the BMP is two units, so the offsets are not indexes into the Python str)."""
         if match_id == -1:
             return None
         if match_id <= -2:
@@ -518,14 +528,21 @@ class Gorp:
         values = []
         for g in range(self.num_groups(match_id)):
             b, e = int(caps[2 * g]), int(caps[2 * g + 1])
-            values.append(None if b < 0 else line[b:e])
+            if b < 0:
+                values.append(None)
+            elif units is not None:
+                values.append(units[b:e].tobytes().decode("utf-16-le", "surrogatepass"))
+            else:
+                values.append(line[b:e])
         return ExtractionResult(extr.getName(), line, extr, extr._extractorNames, values)
 
     # -- batch API -----------------------------------------------------------
-    def extract_batch(self, data, offsets, match_only=False, strip_eol=False):
+    def extract_batch(self, data, offsets, match_only=False, strip_eol=False, kernel=0, line_bytes_hint=0, compact=False):
         """Host buffers: data uint8[total] (Latin-1 code units) or uint16[total] (UTF-16 code units),
         offsets uint32|uint64[n+1] in code units.
-        Returns (match_id int32[n], caps int32[n, 2*max_groups])."""
+        Returns (match_id int32[n], caps int32[n, 2*max_groups]); with compact=True the compact rows
+        uint16[n, 1 + 2*max_groups] and the number of offsets that did not fit them (see unpack_rows).
+        kernel: GX_KERNEL_* (0 = the library chooses)."""
         utf16 = getattr(data, "dtype", None) == np.uint16
         data = np.ascontiguousarray(data, dtype=np.uint16 if utf16 else np.uint8)
         offsets = np.ascontiguousarray(offsets)
@@ -540,14 +557,27 @@ class Gorp:
         o.match_only = 1 if match_only else 0
         o.strip_eol = 1 if strip_eol else 0
         o.utf16 = 1 if utf16 else 0
+        o.kernel = int(kernel) or DEFAULT_KERNEL
+        o.line_bytes_hint = int(line_bytes_hint)
+        if compact and not match_only and self.stat(8):
+            rows = np.zeros((n, 1 + 2 * self.max_groups), np.uint16)
+            over = C.c_uint64(0)
+            o.compact_results = 1
+            o.overflow = C.cast(C.pointer(over), C.c_void_p)
+            _check(N.lib().gx_extract_batch(self._h.ptr, data.ctypes.data if data.size else None, offsets.ctypes.data, n,
+                                            None, rows.ctypes.data, C.byref(o)))
+            return rows, over.value
         _check(N.lib().gx_extract_batch(self._h.ptr, data.ctypes.data if data.size else None, offsets.ctypes.data, n,
                                         mid.ctypes.data, caps.ctypes.data if caps.size else None, C.byref(o)))
         return mid, caps
 
     def extract_batch_device(self, data_ptr, offsets_ptr, n, match_id_ptr, caps_ptr, offsets64=False, match_only=False,
-                             stream=None, no_sync=False, strip_eol=False, line_bytes_hint=0):
+                             stream=None, no_sync=False, strip_eol=False, line_bytes_hint=0, kernel=0, compact=False,
+                             overflow_ptr=None):
         """Device pointers (ints), e.g. torch tensors' data_ptr(); results stay in HBM.  line_bytes_hint sizes
-        the kernel's staging area (0: 200 bytes with no_sync, else the batch's mean line length)."""
+        the kernel's staging area (0: 200 bytes with no_sync, else the batch's mean line length).
+        compact=True: caps_ptr receives compact rows uint16[n, 1 + 2*max_groups] (match_id_ptr may be None),
+        overflow_ptr (device uint64, zeroed by the caller) counts the offsets that did not fit."""
         o = N.gx_batch_opts()
         o.struct_size = C.sizeof(N.gx_batch_opts)
         o.device_pointers = 1
@@ -557,6 +587,9 @@ class Gorp:
         o.no_sync = 1 if no_sync else 0
         o.strip_eol = 1 if strip_eol else 0
         o.line_bytes_hint = int(line_bytes_hint)
+        o.kernel = int(kernel) or DEFAULT_KERNEL
+        o.compact_results = 1 if compact else 0
+        o.overflow = overflow_ptr
         _check(N.lib().gx_extract_batch(self._h.ptr, data_ptr, offsets_ptr, n, match_id_ptr, caps_ptr, C.byref(o)))
 
     def results(self, data, offsets, match_id, caps, safe=False):
@@ -567,6 +600,15 @@ class Gorp:
             line = raw[int(offsets[i]):int(offsets[i + 1])].decode("latin-1")
             out.append(self._materialise(line, int(match_id[i]), caps[i], safe))
         return out
+
+
+def unpack_rows(rows):
+    """Compact rows uint16[n, 1 + slots] -> (match_id int32[n], caps int32[n, slots]) on the host (numpy)."""
+    rows = np.asarray(rows, dtype=np.uint16)
+    mid = rows[:, 0].astype(np.int16).astype(np.int32)
+    caps = rows[:, 1:].astype(np.int32)
+    caps[caps == 0xFFFF] = -1
+    return mid, caps
 
 
 def split_lines(data, cap_lines=None, offsets_dtype=np.uint32, want_flags=False):
@@ -680,7 +722,7 @@ class DefinitionReader:
         d = _definition_json(self._text, self._source_ref, "flattened")
         return [FlattenedExtraction(x["name"], x["pieces"], x["append"]) for x in d["extractions"]], d
 
-    def read(self, host_only=False):
+    def read(self, host_only=False, flags=0):
         """DefinitionReader.read() (core/DefinitionReader.java:74-84): the native front-end parses, resolves and
         compiles the definition in one call (gx_create_from_definition)."""
         fl, d = self.flatten()
@@ -688,7 +730,7 @@ class DefinitionReader:
                   for i, x in enumerate(d["extractions"])]
         hp = C.c_void_p()
         rc = N.lib().gx_create_from_definition(self._text.encode("utf-8"), self._source_ref.encode("utf-8"),
-                                               N.GX_CREATE_HOST_ONLY if host_only else 0, C.byref(hp))
+                                               flags | DEFAULT_CREATE_FLAGS | (N.GX_CREATE_HOST_ONLY if host_only else 0), C.byref(hp))
         if rc in (N.GX_E_DEFINITION, N.GX_E_REGEX_SYNTAX, N.GX_E_UNSUPPORTED_CONSTRUCT, N.GX_E_LIMIT):
             raise DefinitionParseException(rc, N.last_error())
         _check(rc)

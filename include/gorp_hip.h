@@ -50,6 +50,12 @@ enum {
 /* gx_create flags */
 #define GX_CREATE_HOST_ONLY 1u     /* compile tables only; do not touch the GPU (used to build the
                                       blob that is broadcast to other ranks, and by CPU-only checks) */
+/* Kernel choice, for measurements and tests; results never depend on it.  By default the automaton rows live in
+ * LDS when they fit, else in global memory (L2), and the capture automata are fused with the match automaton
+ * when that product stays within the size limits. */
+#define GX_CREATE_TIER_L2   2u     /* keep the automaton rows in global memory even when they would fit LDS */
+#define GX_CREATE_NO_TILES  4u     /* per-line kernel only */
+#define GX_CREATE_NO_FUSED  8u     /* two passes: match automaton, then the winning extraction's capture automaton */
 
 /* Replaces Gorp.construct's per-extraction back half (core/Gorp.java:58-92):
  * PolyMatcher.create(automatonInputs) (core/autom/PolyMatcher.java:64-84 ->
@@ -80,7 +86,7 @@ int32_t gx_max_groups(const gx_handle* h);
 /* table statistics: 0 = match-DFA states, 1 = char classes, 2 = capture-automaton states (sum),
  * 3 = capture registers (max over extractions), 4 = blob bytes, 5 = LDS bytes the batch kernel stages,
  * 6 = waves per workgroup of the batch kernel, 7 = table tier of the batch kernel (1 = automaton rows in LDS,
- * 2 = rows in global memory / L2, 0 = per-line generic kernel) */
+ * 2 = rows in global memory / L2, 0 = per-line generic kernel), 8 = 1 when the handle has capture regexps */
 int64_t gx_stat(const gx_handle* h, int32_t which);
 
 typedef struct gx_batch_opts {
@@ -102,9 +108,21 @@ typedef struct gx_batch_opts {
                                   the chars of the Java Strings, and offsets count code units.  For the lines that
                                   gx_split_lines flags as non-ASCII once the caller has decoded them.  Runs on the
                                   per-line kernel (no LDS staging). */
-    uint32_t reserved;         /* 0.  (New fields are only ever appended: a caller compiled against an older, shorter
-                                  layout passes its own struct_size and keeps working.) */
+    uint32_t kernel;           /* gx_extract_batch only: GX_KERNEL_AUTO (0) or one of the kernels below, for measurements and
+                                  tests; results never depend on it.  (New fields are only ever appended: a caller compiled
+                                  against an older, shorter layout passes its own struct_size and keeps working.) */
+    uint32_t compact_results;  /* gx_extract_batch only.  1: results leave as compact rows -- `caps` points to
+                                  uint16_t[n * (1 + 2*gx_max_groups(h))], per line the match id as int16 followed by the capture
+                                  offsets, 0xFFFF = unset (the layout of gx_pack_results); match_id may be NULL.  Half the
+                                  result bytes of the dense format; what the gather between GPUs sends.  An offset above
+                                  65534 does not fit: it is stored as 65534 and counted in *overflow (take such a batch again
+                                  in the dense format).  Ignored with match_only. */
+    uint32_t reserved;         /* 0 */
+    void*    overflow;         /* with compact_results: uint64_t counter that the call ADDS to (the caller zeroes it); a device
+                                  pointer with device_pointers, else a host pointer.  NULL: not counted. */
 } gx_batch_opts;
+
+enum { GX_KERNEL_AUTO = 0, GX_KERNEL_TILES = 1, GX_KERNEL_SLICES = 2, GX_KERNEL_PER_LINE = 3 };
 
 /* Replaces the per-line loop "for each line: Gorp.extract(line)"
  * (core/Gorp.java:145-186 -> PolyMatcher.match core/autom/PolyMatcher.java:123-133

@@ -8,6 +8,7 @@ import pytest
 from gorp_amd import workloads as W
 from gorp_amd.gorp import Gorp, GorpError, lines_to_csr, split_lines, split_lines_device
 from gorp_amd import _native as N
+from gorp_amd import gorp as G
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -78,7 +79,7 @@ def test_cap_lines_and_device_pointers():
 def test_extract_from_raw_text(tier, monkeypatch):
     """raw log text -> gx_split_lines -> gx_extract_batch(strip_eol) == oracle on readLine()'s lines."""
     if tier != 1:
-        monkeypatch.setenv("GX_DEBUG_TIER", str(tier))
+        monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", {2: N.GX_CREATE_TIER_L2, 3: N.GX_CREATE_NO_TILES}[tier])
     definition = W.readme3_definition()
     gorp = Gorp.construct(definition)
     assert gorp.stat(7) == {1: 1, 2: 2, 3: 0}[tier]

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from gorp_amd import _native as N
+from gorp_amd import gorp as G
 from gorp_amd import workloads as W
 from gorp_amd.gorp import (ExtractionException, FlattenedExtraction, Gorp, PolyMatcher, lines_to_csr)
 from oracle import oracle as O
@@ -35,6 +36,13 @@ def check_batch(gorp, orc, lines):
     omid, ocaps = orc.extract_batch(data, offsets)
     assert np.array_equal(mid, omid)
     assert np.array_equal(caps, ocaps)
+    if gorp.stat(8):
+        # the same batch as compact rows (int16 id + uint16 offsets, written by the kernels themselves)
+        rows, over = gorp.extract_batch(data, offsets, compact=True)
+        cm, cc = G.unpack_rows(rows)
+        big = ocaps > 65534
+        assert over == int(big.sum())
+        assert np.array_equal(cm, omid) and np.array_equal(cc, np.where(big, 65534, ocaps))
     m2, _ = gorp.extract_batch(data, offsets, match_only=True)
     assert np.array_equal(m2, orc.extract_batch(data, offsets, match_only=True)[0])
     return mid, caps
@@ -284,7 +292,7 @@ def test_syslog_16_rules():
 def test_table_tiers_agree_with_oracle(tier, monkeypatch):
     """The same definitions through the L2-tier tile kernel (automaton rows in global memory) and through the
     per-line generic kernel; the default for these small definitions is the LDS tier, covered everywhere else."""
-    monkeypatch.setenv("GX_DEBUG_TIER", str(tier))
+    monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", {2: N.GX_CREATE_TIER_L2, 3: N.GX_CREATE_NO_TILES}[tier])
     want = {2: 2, 3: 0}[tier]
     # config 1
     definition = W.simple_grp_definition()
@@ -382,7 +390,7 @@ def test_mixed_lengths_take_several_rounds_per_group(tier, monkeypatch):
     """Lines of 0-3000 bytes against a staging area sized for the mean: groups are walked in several rounds of
     consecutive lanes, a line longer than the staging area alone takes the per-lane path; all bit-exact."""
     if tier == 2:
-        monkeypatch.setenv("GX_DEBUG_TIER", "2")
+        monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", N.GX_CREATE_TIER_L2)
     definition = W.readme3_definition()
     gorp, orc = Gorp.construct(definition), oracle_for(definition)
     rng = random.Random(99)
@@ -406,6 +414,32 @@ def test_mixed_lengths_take_several_rounds_per_group(tier, monkeypatch):
     assert len(set(mid.tolist())) == 4
     m2, _ = gorp.extract_batch(*lines_to_csr(lines), match_only=True)
     assert np.array_equal(m2, mid)
+
+
+@pytest.mark.parametrize("variant", [{}, {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_TIER_L2}, {"DEFAULT_KERNEL": N.GX_KERNEL_SLICES},
+                                     {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_NO_TILES}, {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_NO_FUSED}])
+def test_compact_rows_from_the_kernels(variant, monkeypatch):
+    """gx_batch_opts.compact_results: every kernel writes the compact rows itself (full tiles through the LDS transpose,
+    ragged groups and the per-line follow-up lane by lane); device buffers, offsets beyond 65534 counted."""
+    import torch
+    for k, v in variant.items():
+        monkeypatch.setattr(G, k, v)
+    definition = W.readme3_definition()
+    gorp, orc = Gorp.construct(definition), oracle_for(definition)
+    n = 20000
+    data, offsets, cat = W.readme3_lines(n, seed=81)
+    d, o = data.numpy(), offsets.numpy()
+    omid, ocaps = orc.extract_batch(d, o, nthreads=8)
+    dd, oo = data.cuda(), offsets.cuda()
+    rows = torch.zeros((n, 1 + 2 * gorp.max_groups), dtype=torch.int16, device="cuda")
+    over = torch.zeros(1, dtype=torch.int64, device="cuda")
+    gorp.extract_batch_device(dd.data_ptr(), oo.data_ptr(), n, None, rows.data_ptr(), compact=True, overflow_ptr=over.data_ptr(),
+                              line_bytes_hint=200)
+    cm, cc = G.unpack_rows(rows.cpu().numpy().view(np.uint16))
+    assert int(over.item()) == 0 and np.array_equal(cm, omid) and np.array_equal(cc, ocaps)
+    # ragged, empty, longer than the staging area, longer than the 16-bit offsets
+    lines = ["", "[1]: GET 5ms /x", "[1]: GET 5ms /" + "x" * 70000, "[12]: PUT 7ms /" + "y" * 3000, "nothing", "[3]: HEAD 1ms /z"] * 7
+    check_batch(gorp, orc, lines)
 
 
 def test_compact_result_rows_roundtrip_and_gather():
@@ -480,9 +514,9 @@ def test_utf16_batch_input():
 def test_slice_kernel_agrees_with_oracle(tier, monkeypatch):
     """The slice kernel (64 bytes of every line staged at a time; the default for batches with long lines) forced
     on for short, ragged, terminated and very long lines, tables in LDS and in global memory."""
-    monkeypatch.setenv("GX_DEBUG_SLICES", "1")
+    monkeypatch.setattr(G, "DEFAULT_KERNEL", N.GX_KERNEL_SLICES)
     if tier == 2:
-        monkeypatch.setenv("GX_DEBUG_TIER", "2")
+        monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", N.GX_CREATE_TIER_L2)
     definition = W.simple_grp_definition()
     gorp, orc = Gorp.construct(definition), oracle_for(definition)
     check_batch(gorp, orc, W.simple_grp_lines(3000, seed=31))
@@ -557,10 +591,8 @@ def test_cooked_extraction_match_is_the_capture_regexp_alone(golden):
 @pytest.mark.parametrize("tier", [1, 2])
 def test_two_pass_layout_without_the_fused_automaton(tier, monkeypatch):
     """Definitions too large for the fused automaton walk the match automaton and then the winning extraction's
-    capture automaton; forced here (GX_DEBUG_NO_FUSED) on small definitions, tables in LDS and in global memory."""
-    monkeypatch.setenv("GX_DEBUG_NO_FUSED", "1")
-    if tier == 2:
-        monkeypatch.setenv("GX_DEBUG_TIER", "2")
+    capture automaton; forced here (GX_CREATE_NO_FUSED) on small definitions, tables in LDS and in global memory."""
+    monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", N.GX_CREATE_NO_FUSED | (N.GX_CREATE_TIER_L2 if tier == 2 else 0))
     import test_compiler_vs_oracle as TC
     from blob_interp import Blob
     definition = W.readme3_definition()
@@ -593,13 +625,13 @@ def test_two_pass_layout_without_the_fused_automaton(tier, monkeypatch):
         check_batch(gorp, orc, lines)
 
 
-@pytest.mark.parametrize("variant", [{}, {"GX_DEBUG_TIER": "2"}, {"GX_DEBUG_SLICES": "1"}])
+@pytest.mark.parametrize("variant", [{}, {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_TIER_L2}, {"DEFAULT_KERNEL": N.GX_KERNEL_SLICES}])
 def test_unaligned_device_buffers(variant, monkeypatch):
     """Device pointers with no particular alignment (a view 3 bytes into a tensor; results 4 bytes into theirs): the
     edge chunks of the first and last tile take the guarded copy, results the per-line stores."""
     import torch
     for k, v in variant.items():
-        monkeypatch.setenv(k, v)
+        monkeypatch.setattr(G, k, v)
     definition = W.readme3_definition()
     gorp, orc = Gorp.construct(definition), oracle_for(definition)
     n = 5000

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool: the README 3-extraction definition (tables in LDS) over lines of log-uniform length 50-2000
-bytes: tile kernel with rounds (GX_DEBUG_SLICES=0) against the slice kernel (the default above 255 bytes)."""
+bytes: tile kernel with rounds (argv[2] = 1) against the slice kernel (argv[2] = 2; the default above 255 bytes)."""
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,6 +8,7 @@ from gorp_amd import workloads as W
 from gorp_amd.gorp import Gorp, lines_to_csr
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+kernel = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 g = Gorp.construct(W.readme3_definition())
 rng = random.Random(7)
 base_n = 20_000
@@ -29,14 +30,14 @@ caps = torch.empty((n, 8), dtype=torch.int32, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 hint = int(total / base_n + 0.999)
 for _ in range(2):
-    g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=st, no_sync=True, line_bytes_hint=hint)
+    g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=st, no_sync=True, line_bytes_hint=hint, kernel=kernel)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(5):
-    g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=st, no_sync=True, line_bytes_hint=hint)
+    g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=st, no_sync=True, line_bytes_hint=hint, kernel=kernel)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
-print("GX_DEBUG_SLICES=%s mean %d B: %.3f ms for %d lines (%.2f GB) -> %.2f G lines/s, %.0f GB/s" %
-      (os.environ.get("GX_DEBUG_SLICES", "default"), hint, ms, n, total * reps / 1e9, n / ms / 1e6, total * reps / ms / 1e6))
+print("kernel=%s mean %d B: %.3f ms for %d lines (%.2f GB) -> %.2f G lines/s, %.0f GB/s" %
+      (["auto", "tiles", "slices", "per-line"][kernel], hint, ms, n, total * reps / 1e9, n / ms / 1e6, total * reps / ms / 1e6))
 assert int((mid >= 0).sum()) == n

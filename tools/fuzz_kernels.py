@@ -7,14 +7,17 @@ sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np
 import test_compiler_vs_oracle as TC
 from blob_interp import Blob
-from gorp_amd.gorp import Gorp, FlattenedExtraction, lines_to_csr
+from gorp_amd import _native as N
+from gorp_amd.gorp import Gorp, FlattenedExtraction, lines_to_csr, unpack_rows
 from oracle import oracle as O
 
 n_defs = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2024
 rng = random.Random(seed)
-variants = [{}, {"GX_DEBUG_TIER": "2"}, {"GX_DEBUG_SLICES": "1"}, {"GX_DEBUG_TIER": "2", "GX_DEBUG_SLICES": "1"}, {"GX_DEBUG_TIER": "3"},
-            {"GX_DEBUG_NO_FUSED": "1"}, {"GX_DEBUG_NO_FUSED": "1", "GX_DEBUG_TIER": "2"}]
+# (create flags, kernel, compact result rows)
+variants = [(0, 0, False), (N.GX_CREATE_TIER_L2, 0, False), (0, N.GX_KERNEL_SLICES, False), (N.GX_CREATE_TIER_L2, N.GX_KERNEL_SLICES, False),
+            (N.GX_CREATE_NO_TILES, 0, False), (N.GX_CREATE_NO_FUSED, 0, False), (N.GX_CREATE_NO_FUSED | N.GX_CREATE_TIER_L2, 0, False),
+            (0, 0, True), (N.GX_CREATE_TIER_L2, 0, True), (0, N.GX_KERNEL_SLICES, True), (N.GX_CREATE_NO_FUSED, 0, True)]
 done = bad = 0
 while done < n_defs:
     exts = [FlattenedExtraction("e%d" % i, TC.gen_pieces(rng)) for i in range(rng.randint(1, 5))]
@@ -22,10 +25,7 @@ while done < n_defs:
         built = [e.build() for e in exts]
         orc = O.OracleGorp([b[0] for b in built], [b[1] for b in built])
         env = variants[done % len(variants)]
-        for k in ("GX_DEBUG_TIER", "GX_DEBUG_SLICES", "GX_DEBUG_NO_FUSED"):
-            os.environ.pop(k, None)
-        os.environ.update(env)
-        gorp = Gorp.construct(exts)
+        gorp = Gorp.construct(exts, flags=env[0])
     except Exception:
         continue
     b = Blob(gorp.blob())
@@ -33,14 +33,19 @@ while done < n_defs:
     lines += [ln * rng.randint(2, 40) for ln in lines[:20]]  # longer lines: several windows / slices
     raw = [ln.encode("latin-1") if isinstance(ln, str) else ln for ln in lines]
     data, offsets = lines_to_csr(raw)
-    mid, caps = gorp.extract_batch(data, offsets)
+    if env[2] and gorp.max_groups > 0:
+        rows, over = gorp.extract_batch(data, offsets, kernel=env[1], compact=True)
+        mid, caps = unpack_rows(rows)
+        assert over == 0
+    else:
+        mid, caps = gorp.extract_batch(data, offsets, kernel=env[1])
     omid, ocaps = orc.extract_batch(data, offsets, nthreads=4)
     if not (np.array_equal(mid, omid) and np.array_equal(caps, ocaps)):
         bad += 1
         i = int(np.nonzero((mid != omid) | (caps != ocaps).any(axis=1))[0][0])
         print("MISMATCH variant", env, "line", repr(raw[i]), "gpu", mid[i], caps[i].tolist(), "oracle", omid[i], ocaps[i].tolist())
         print("  definition:", [(e.name, e.pieces) for e in exts])
-    m2, _ = gorp.extract_batch(data, offsets, match_only=True)
+    m2, _ = gorp.extract_batch(data, offsets, match_only=True, kernel=env[1])
     want_m = np.where(omid <= -2, -2 - omid, omid)  # match-only reports the matcher's choice
     if not np.array_equal(m2, want_m):
         bad += 1
