@@ -1,26 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- Gorp match-and-extract throughput on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config {2,3,4,5}] [--results {compact,dense}]
 
-A "step" is one pass of the hot path (gx_extract_batch: product-DFA match +
-capture scan) over one batch of synthetic log lines that is already resident in
-HBM.  Workload at every N: BASELINE.json configs[1] -- the README 3-extraction
-GET/PUT/Other definition over 10 M x 200-byte lines PER GPU (weak scaling,
-lines sharded by rank, no data-path collective inside a step).
+A "step" is one pass of the hot path (gx_extract_batch: product-DFA match + capture scan) over one batch of
+synthetic log lines that is already resident in HBM.  Workloads (BASELINE.json `configs`, 1-based as in BASELINE.md):
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU, RCCL): rank 0
-compiles the tables and broadcasts the packed blob; every rank builds its handle
-from the blob, generates its own shard, and runs the same steps.  After the
-timed region the per-line results are gathered to rank 0 once over xGMI and the
-gather time is reported separately (`gather_ms`); it is not part of `value`
-(Multi-GPU).
+  2  README 3-extraction GET/PUT/Other definition, 10 M x 200-byte lines            (default at N = 1: the metric's config)
+  3  64 syslog-like extractions, 10 M x 200-byte lines
+  4  config 3's definition, 10 M lines PER GPU, table blob broadcast + final gather  (default at N > 1)
+  5  512 extractions, lines of 50-2000 bytes, ~2 GB
+
+Results leave the kernel as compact rows (int16 match id + uint16 capture offsets per line: what the gather between
+GPUs sends, gx_batch_opts.compact_results) unless --results dense; the other format is timed beside it and reported
+in `other_format`.
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU, RCCL): rank 0 compiles the tables and broadcasts the
+packed blob; every rank builds its handle from the blob, generates its own shard (seeded by rank), and runs the same
+steps -- lines are independent, so there is no collective inside a step (weak scaling).  After the timed region the
+per-line results are gathered to rank 0 once over xGMI and the gather time is reported separately (`gather_ms`); it
+is not part of `value` (Multi-GPU).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import shutil
 import sys
 import time
 
@@ -43,10 +49,21 @@ def host_cores():
     return min(cores, 64)
 
 
+def reference_jvm_probe():
+    """the preferred CPU baseline is the reference itself on a JVM.  It needs `java` and a classpath
+    holding gorp-core, dk.brics.automaton 1.11-8 and jackson-jr 2.8.2 (GORP_REFERENCE_CLASSPATH).  Neither exists in
+    this image; say so instead of pretending."""
+    java = shutil.which("java")
+    cp = os.environ.get("GORP_REFERENCE_CLASSPATH")
+    if java and cp:
+        return "found (java at %s, classpath given) but no Java driver ships with this repo: not run" % java
+    missing = [w for w, ok in (("java on PATH", java), ("GORP_REFERENCE_CLASSPATH", cp)) if not ok]
+    return "unavailable (no %s)" % ", no ".join(missing)
+
+
 def cpu_baseline(definition, data_cpu, offsets_cpu, budget_s=20.0):
     """The oracle (a CPU port of the reference path, not the JVM) timed on a bounded
     sample of the same lines, all host cores."""
-    import numpy as np
     from oracle import oracle as O
     built = [e.build() for e in definition]
     orc = O.OracleGorp([b[0] for b in built], [b[1] for b in built])
@@ -69,7 +86,45 @@ def cpu_baseline(definition, data_cpu, offsets_cpu, budget_s=20.0):
     return {"value": n / dt, "unit": "lines/s", "cores": cores, "kind": "port",
             "sample": "first %d lines of the rank-0 shard, %d threads, %.1f s; C++ restatement of "
                       "PolyMatcher.match + java.util.regex capture (oracle/), not the JVM" % (n, cores, dt),
-            "single_thread_value": n1 / dt1, "single_thread_sample": "first %d lines, 1 thread, %.1f s" % (n1, dt1)}, mid, caps, n
+            "single_thread_value": n1 / dt1, "single_thread_sample": "first %d lines, 1 thread, %.1f s" % (n1, dt1),
+            "reference_jvm": reference_jvm_probe()}, mid, caps, n
+
+
+def build_workload(config, n, rank, dev):
+    """(definition, data u8[total] on dev, offsets u32[n+1] on dev, n, expected match ids or None, known mask or None,
+    line_bytes_hint, description)."""
+    import numpy as np
+    import torch
+    from gorp_amd import workloads as W
+    if config == 2:
+        definition = W.readme3_definition()
+        data, offsets, category = W.readme3_lines(n, seed=2 + rank, device=dev)
+        return definition, data, offsets, n, category.to(torch.int32), None, W.LINE_BYTES, \
+            "README 3-extraction GET/PUT/Other definition (BASELINE.json configs[1]), %d x %d B lines per GPU, seed 2+rank" % (n, W.LINE_BYTES)
+    if config in (3, 4):
+        rules, meta = W.syslog_definition(64, seed=3)
+        base_n = 100_000
+        dh, oh, cats = W.syslog_lines(meta, base_n, seed=3 + rank)
+        desc = "64 syslog-like extractions (BASELINE.json configs[%d]), %%d x 200 B lines per GPU (a %d-line sample tiled), seed 3+rank" % (config - 1, base_n)
+        hint = 200
+    else:
+        rules, meta = W.syslog_definition(512, seed=3)
+        base_n = 20_000
+        dh, oh, cats = W.syslog_lines(meta, base_n, seed=5 + rank, min_len=50, max_len=2000)
+        desc = "512 syslog-like extractions (BASELINE.json configs[4]), %%d lines of 50-2000 B per GPU (a %d-line sample tiled), seed 5+rank" % base_n
+        hint = int(int(oh[-1]) / base_n + 0.999)
+    total = int(oh[-1])
+    reps = max(1, n // base_n)
+    while total * reps >= 2 ** 32:
+        reps -= 1
+    data = torch.from_numpy(dh.copy()).to(dev).repeat(reps)
+    off = (torch.from_numpy(oh[:-1].astype(np.int64)).to(dev)[None, :] +
+           torch.arange(reps, device=dev, dtype=torch.int64)[:, None] * total).reshape(-1)
+    off = torch.cat([off, torch.tensor([total * reps], device=dev, dtype=torch.int64)]).to(torch.uint32)
+    n = base_n * reps
+    want = torch.from_numpy(cats).to(dev).repeat(reps)
+    known = torch.from_numpy(cats != -9).to(dev).repeat(reps)
+    return rules, data, off, n, want, known, hint, desc % n
 
 
 def main():
@@ -77,22 +132,26 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--lines", type=int, default=10_000_000, help="lines per GPU")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5], help="BASELINE.md config (0: 2 at one GPU, 4 at several)")
+    ap.add_argument("--lines", type=int, default=0, help="lines per GPU (0: the config's size)")
+    ap.add_argument("--results", default="compact", choices=["compact", "dense"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    from gorp_amd import workloads as W
-    from gorp_amd.gorp import Gorp
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 bench.py --gpus N ...` (one rank per GPU)" % (args.gpus, world))
+    config = args.config or (2 if world == 1 else 4)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from gorp_amd.gorp import Gorp, unpack_rows
+
     if os.environ.get("GORP_BENCH_BACKEND", "nccl") != "nccl":
         local_rank = 0   # rehearsal: every rank on the one GPU
     torch.cuda.set_device(local_rank)
@@ -108,8 +167,12 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
+    # ---- this rank's shard (generated on / copied to the device before anything is timed) ----
+    n_req = args.lines or (3_800_000 if config == 5 else 10_000_000)
+    definition, data, offsets, n, want, known, hint, desc = build_workload(config, n_req, rank, dev)
+    total_bytes = int(data.numel())
+
     # ---- tables: compile on rank 0, broadcast the blob (RCCL), build everywhere ----
-    definition = W.readme3_definition()
     t0 = time.perf_counter()
     bcast_ms = None
     if distributed:
@@ -123,45 +186,53 @@ def main():
         gorp = Gorp.construct(definition)
     setup_s = time.perf_counter() - t0
 
-    # ---- this rank's shard, generated on the device ----
-    n = args.lines
-    data, offsets, category = W.readme3_lines(n, seed=2 + rank, device=dev)
-    total_bytes = int(data.numel())
     G = gorp.max_groups
     mid = torch.empty(n, dtype=torch.int32, device=dev)
     caps = torch.empty((n, 2 * G), dtype=torch.int32, device=dev)
+    rows = torch.empty((n, 1 + 2 * G), dtype=torch.int16, device=dev)
+    overflow = torch.zeros(1, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
-        gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, mid.data_ptr(), caps.data_ptr(),
-                                  stream=stream, no_sync=True)
+    def step(fmt):
+        if fmt == "compact":
+            gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, None, rows.data_ptr(), stream=stream, no_sync=True,
+                                      line_bytes_hint=hint, compact=True, overflow_ptr=overflow.data_ptr())
+        else:
+            gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=stream, no_sync=True,
+                                      line_bytes_hint=hint)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t_start = time.perf_counter()
-    ev[0].record()
-    for i in range(args.steps):
-        step()
-        ev[i + 1].record()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_start
-    kernel_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+    def timed(fmt, steps, warmup):
+        """K steps bracketed by barrier + synchronize, max over ranks; per-launch times from events on the launch stream."""
+        for _ in range(warmup):
+            step(fmt)
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t_start = time.perf_counter()
+        ev[0].record()
+        for i in range(steps):
+            step(fmt)
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t_start
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if distributed:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if distributed:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    other = "dense" if args.results == "compact" else "compact"
+    other_elapsed, other_ms = timed(other, max(3, min(args.steps, 5)), 2)   # the other result format, a few steps, reported beside
+    elapsed, kernel_ms = timed(args.results, args.steps, args.warmup)        # THE timed region
 
-    # ---- correctness of what was timed: the generator knows every line's answer ----
-    ok = bool(torch.equal(mid, category.to(torch.int32)))
+    # ---- correctness of what was timed: the generator knows every (uncorrupted) line's answer ----
+    got = rows[:, 0].to(torch.int32) if args.results == "compact" else mid
+    ok = bool(torch.equal(got, want)) if known is None else bool(torch.equal(got[known], want[known]))
+    ok = ok and int(overflow.item()) == 0
     okt = torch.tensor([1 if ok else 0], device=dev)
     if distributed:
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
@@ -170,50 +241,51 @@ def main():
 
     # ---- final gather of results to rank 0 over xGMI (reported, not in `value`) ----
     gather_ms = None
-    gather_compact_ms = None
+    gather_dense_ms = None
     if distributed and not args.no_gather:
+        step("compact"); step("dense")
         torch.cuda.synchronize()
         dist.barrier()
         tg = time.perf_counter()
-        gm, gc = gdist.gather_results(mid, caps, dst=0)
+        gr = gdist.gather_rows(rows, dst=0)            # the compact rows as the kernel wrote them
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
-        if rank == 0:
-            assert gm.shape[0] == n * world and torch.equal(gm[:n], mid) and torch.equal(gc[:n], caps)
-        # the same with compact transport rows (int16 id + uint16 offsets, HIP pack/unpack kernels)
         torch.cuda.synchronize()
         dist.barrier()
         tg = time.perf_counter()
-        cm, cc = gdist.gather_results_compact(mid, caps, dst=0)
+        gm, gc = gdist.gather_results(mid, caps, dst=0)  # the same in the dense format
         torch.cuda.synchronize()
-        gather_compact_ms = (time.perf_counter() - tg) * 1e3
+        gather_dense_ms = (time.perf_counter() - tg) * 1e3
         if rank == 0:
-            assert torch.equal(cm, gm) and torch.equal(cc, gc)
-        del gm, gc, cm, cc
+            assert gr.shape[0] == gm.shape[0] and torch.equal(gr[:n], rows) and torch.equal(gm[:n], mid) and torch.equal(gc[:n], caps)
+            assert torch.equal(gr[:, 0].to(torch.int32), gm)
+        del gr, gm, gc
 
     if rank == 0:
         steps = args.steps
         ms_per_step = elapsed * 1e3 / steps
-        lines_total = n * world * steps
-        value = lines_total / elapsed
+        value = n * world * steps / elapsed
         k_avg = sum(kernel_ms) / len(kernel_ms)
         k_sorted = sorted(kernel_ms)
         algo_read = total_bytes + 4 * (n + 1)            # line bytes + u32 offsets
-        algo_write = n * (4 + 8 * G)                     # match id + dense captures
+        write_bytes = {"compact": n * (2 + 4 * G), "dense": n * (4 + 8 * G)}
         achieved = algo_read / (k_avg * 1e-3) / 1e9
-        # HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this kernel on this exact
-        # workload (tools/traffic_target.py + tools/summarize_traffic.py; FETCH_SIZE doubled per the gfx950
-        # correction, calibrated against a same-size copy kernel in the same run).  Counters cannot be read from
-        # inside this process, so the committed summary is reported when the workload matches, else null.
+        # HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this kernel on this exact workload
+        # (tools/collect_profiles.sh: FETCH_SIZE doubled per the gfx950 correction, calibrated against a same-size copy
+        # kernel in the same run).  Counters cannot be read from inside this process: the RECORDED figure of the committed
+        # summary is reported when its workload and result format match this run, else null.
         traffic, traffic_src = None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if tj["algorithmic_read_bytes"] == algo_read and tj["algorithmic_write_bytes"] == algo_write:
-                traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_traffic.json"
+            path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+            tj = json.load(open(path))
+            if tj["algorithmic_read_bytes"] == algo_read and tj["algorithmic_write_bytes"] == write_bytes[args.results]:
+                traffic = tj["traffic_bytes_per_launch"]
+                traffic_src = "recorded: profiles/r02_traffic.json (%s)" % time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(path)))
         except (OSError, ValueError, KeyError):
             pass
+        o_avg = sum(other_ms) / len(other_ms)
         out = {
-            "metric": "lines/sec (Gorp.extract: product-DFA match + capture offsets), 200-byte lines",
+            "metric": "lines/sec (Gorp.extract: product-DFA match + capture offsets)",
             "value": value,
             "unit": "lines/s",
             "n_gpus": world,
@@ -225,31 +297,41 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "README 3-extraction GET/PUT/Other definition (BASELINE.json configs[1]), "
-                                   "%d x %d B lines per GPU, seed 2+rank" % (n, W.LINE_BYTES),
-                       "lines_per_gpu": n, "line_bytes": W.LINE_BYTES, "offsets": "u32",
+            "config": {"workload": desc, "baseline_config": config,
+                       "lines_per_gpu": n, "mean_line_bytes": total_bytes / n, "offsets": "u32",
+                       "results": args.results + (" rows (int16 id + uint16 offsets, %d B/line)" % (2 + 4 * G) if args.results == "compact"
+                                                  else " (int32 id + int32 offsets, %d B/line)" % (4 + 8 * G)),
                        "match_dfa_states": int(gorp.stat(0)), "char_classes": int(gorp.stat(1)),
                        "capture_states": int(gorp.stat(2)), "table_blob_bytes": int(gorp.stat(4)),
-                       "parallelism": "lines sharded by rank (dp%d)" % world},
+                       "table_tier": {0: "per-line kernel", 1: "LDS", 2: "L2"}.get(int(gorp.stat(7)), str(gorp.stat(7))),
+                       "parallelism": "lines sharded by rank (dp%d), no collective in a step" % world},
             "gb_per_s_scanned": total_bytes * world * steps / elapsed / 1e9,
             "kernel_ms": {"avg": k_avg, "min": k_sorted[0], "median": k_sorted[len(k_sorted) // 2]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,
-                         "algorithmic_read_bytes": algo_read, "algorithmic_write_bytes": algo_write,
+                         "algorithmic_read_bytes": algo_read, "algorithmic_write_bytes": write_bytes[args.results],
                          "frac_of_measured_copy_ceiling": achieved / 6290.0},
+            "other_format": {"results": other, "kernel_ms_avg": o_avg, "lines_per_s": n * world * len(other_ms) / other_elapsed,
+                             "algorithmic_write_bytes": write_bytes[other], "read_gb_per_s": algo_read / (o_avg * 1e-3) / 1e9,
+                             "frac": algo_read / (o_avg * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "setup_s": setup_s,
             "table_bcast_ms": bcast_ms,
             "gather_ms": gather_ms,
-            "gather_compact_ms": gather_compact_ms,
+            "gather_dense_ms": gather_dense_ms,
         }
         if not args.no_cpu_baseline and world == 1:
-            sample = min(n, 10_000_000)
-            d_cpu = data[: sample * W.LINE_BYTES].cpu().numpy()
+            sample = min(n, 10_000_000 if config == 2 else 2_000_000)
+            end = int(offsets[sample].item())
+            d_cpu = data[:end].cpu().numpy()
             o_cpu = offsets[: sample + 1].cpu().numpy().astype(np.uint32)
             base, omid, ocaps, ns = cpu_baseline(definition, d_cpu, o_cpu)
-            # the baseline run doubles as a parity check of the timed GPU output
-            if not (np.array_equal(mid[:ns].cpu().numpy(), omid) and np.array_equal(caps[:ns].cpu().numpy(), ocaps)):
+            # the baseline run doubles as a parity check of the timed GPU output (both formats)
+            step("compact"); step("dense")
+            torch.cuda.synchronize()
+            cm, cc = unpack_rows(rows[:ns].cpu().numpy().view(np.uint16))
+            if not (np.array_equal(mid[:ns].cpu().numpy(), omid) and np.array_equal(caps[:ns].cpu().numpy(), ocaps) and
+                    np.array_equal(cm, omid) and np.array_equal(cc, ocaps)):
                 raise SystemExit("bench: GPU results differ from the oracle on the baseline sample")
             out["cpu_baseline"] = base
         print(json.dumps(out), flush=True)

@@ -179,32 +179,30 @@ bool build_tile_image(gx_handle* h, bool global) {
     if (fused) scan_simple(T.uni);
     else for (auto& r : T.rules) scan_simple(r);
     L.simple_ops = simple ? 1u : 0u;
-    // Final records, one per distinct (final tag list, extraction): u16 [extraction][begin tag, end tag] x max_groups
-    // with the tags as line_result (gx_walk.hpp) wants them: 0 = unset, 1 = the line length, else the byte offset of
-    // the register's column from the dummy column.  Record 0 = "no groups" for the lines that match nothing.  A row's
-    // info word is the byte offset of its record.
-    const size_t rec_len = 1 + 2 * static_cast<size_t>(T.max_groups);
+    // Final records, one per distinct (final tag list, extraction): u16 [begin tag, end tag] x max_groups padded to a
+    // multiple of four groups (16 bytes), then the extraction and padding to the next 16 bytes; the tags as
+    // line_result (gx_walk.hpp) wants them: 0 = unset, 1 = the line length, else the byte offset of the register's
+    // column from the dummy column.  Record 0 = "no groups" for the lines that match nothing.  A row's info word is
+    // the byte offset of its record.
+    const size_t tag_slots = 8 * static_cast<size_t>((T.max_groups + 3) / 4), rec_len = tag_slots + 8;
     std::vector<uint16_t> fin_rec(rec_len, 0);
-    fin_rec[0] = 0xFFFFu;
+    fin_rec[tag_slots] = 0xFFFFu;
     std::map<std::pair<int32_t, int32_t>, uint32_t> rec_of;
     auto fin_record = [&](int32_t f, int32_t k_or_minus1) -> uint32_t {  // k < 0: the list starts with the extraction
         auto it = rec_of.find({f, k_or_minus1});
         if (it != rec_of.end()) return it->second;
         const int32_t k = k_or_minus1 >= 0 ? k_or_minus1 : static_cast<int32_t>(T.fin_tags[f]);
         const size_t t0 = k_or_minus1 >= 0 ? f : f + 1;
-        const uint32_t at_byte = static_cast<uint32_t>(fin_rec.size() * 2);
-        fin_rec.push_back(static_cast<uint16_t>(k));
-        for (int g = 0; g < T.max_groups; ++g)
+        const size_t at = fin_rec.size();
+        fin_rec.resize(at + rec_len, 0);
+        for (int g = 0; g < T.rules[k].n_groups; ++g)
             for (int e = 0; e < 2; ++e) {
-                uint16_t code = 0;
-                if (g < T.rules[k].n_groups) {
-                    const uint16_t v = T.fin_tags[t0 + 2 * g + e];
-                    code = v == GX_SRC_NIL ? 0 : v == GX_SRC_POS ? 1 : static_cast<uint16_t>((v + 1u) * 128u);
-                }
-                fin_rec.push_back(code);
+                const uint16_t v = T.fin_tags[t0 + 2 * g + e];
+                fin_rec[at + 2 * g + e] = v == GX_SRC_NIL ? 0 : v == GX_SRC_POS ? 1 : static_cast<uint16_t>((v + 1u) * 128u);
             }
-        rec_of[{f, k_or_minus1}] = at_byte;
-        return at_byte;
+        fin_rec[at + tag_slots] = static_cast<uint16_t>(k);
+        rec_of[{f, k_or_minus1}] = static_cast<uint32_t>(at * 2);
+        return static_cast<uint32_t>(at * 2);
     };
     int rule_being_emitted = -1;  // per-extraction capture automata: the rule; fused automaton: -1
     auto emit_rows = [&](const RuleTables& r) {
@@ -250,8 +248,6 @@ bool build_tile_image(gx_handle* h, bool global) {
         }
     }
     if (too_many_programs) return false;  // too many distinct general programs for the 15-bit program field
-    while (fin_rec.size() % 8) fin_rec.push_back(0);
-    for (int q = 0; q < 8; ++q) fin_rec.push_back(0);  // line_result reads four groups' tags at a time, past a record's end
     if (fin_rec.size() * 2 > 0xFFFFFFu) return false;
     if (!global && rows * RS + T.ops_off.size() * 4 + T.ops.size() * 2 + fin_rec.size() * 2 + 1024 > LDS_TABLE_BUDGET) return false;
     // Hot interval: among the self-loop intervals of all rows, the one that promises the longest skips -- width

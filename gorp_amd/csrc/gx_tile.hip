@@ -24,6 +24,9 @@
 //  Exactness never depends on either: a set bit / passed test is a fact about bytes on which the state provably
 //  stays put; everything else takes the exact steps.
 #include "gx_walk.hpp"
+#ifdef GX_DEV
+#include <cstdlib>
+#endif
 
 namespace gx {
 
@@ -45,6 +48,7 @@ struct TileIO {
     int32_t strip_eol;
 #ifdef GX_DEV
     unsigned long long* stamps;  // developer build: per-phase cycle totals, [4] per wave
+    uint32_t dev_flags;          // developer build: experiments (bit 0: consecutive tiles per wave; bit 1: nontemporal result stores)
 #endif
 };
 
@@ -66,18 +70,22 @@ __device__ __forceinline__ uint32_t walk(const WalkTab& W, uint32_t stage, uint3
     bool more = on && start < end;
     while (__any(more)) {
         // a finished lane keeps its last window: the address stays inside the staged tile
-        const uint4 w0 = lds_window(stage + wb);
+        const uint4 w0 = lds_window_any(stage + wb);
         const uint32_t rel = wb - start;
         const bool full0 = rel < full_lim;
-        const uint32_t bx = outside_bits(w0.x, lo4, k4), by = outside_bits(w0.y, lo4, k4);
-        const uint32_t bz = outside_bits(w0.z, lo4, k4), bw = outside_bits(w0.w, lo4, k4);
-        const bool ok0 = full0 & (((or3(bx, by, bz) | bw) & HI_BITS) == 0u);
-        bool step = more && !ok0;
+        bool ok0 = false;
+        bool step = more;
         uint32_t mask = 0xFFFFu;
-        if (step && !full0) {
-            mask = window_mask(start, end, wb);
-            step = !partial_window_ok(bx, by, bz, bw, mask);
-        }
+        if (__any(more && k4 != HI_BITS)) {  // (no lane in a state with a self-loop interval: straight to the steps)
+            const uint32_t bx = outside_bits(w0.x, lo4, k4), by = outside_bits(w0.y, lo4, k4);
+            const uint32_t bz = outside_bits(w0.z, lo4, k4), bw = outside_bits(w0.w, lo4, k4);
+            ok0 = full0 & (((or3(bx, by, bz) | bw) & HI_BITS) == 0u);
+            step = more && !ok0;
+            if (step && !full0) {
+                mask = window_mask(start, end, wb);
+                step = !partial_window_ok(bx, by, bz, bw, mask);
+            }
+        } else if (!full0) mask = window_mask(start, end, wb);
         uint32_t nwb = wb + 16u;
         // The window just tested is verified and the state loops on the whole hot interval: the chunk that begins
         // inside the window, and every chunk after it, is skipped as long as its bit says "all bytes hot".
@@ -142,12 +150,18 @@ struct TileInfo {
 // i.e. for the whole prefetch -- at the next vector-memory dependency, long before the walk.
 template <int KCH>
 __device__ __forceinline__ void tile_issue_loads(const TileInfo& t, uint32_t lane, u32x4 (&pre)[KCH], const uint8_t* __restrict__ dummy) {
-    const uint8_t* src = t.mode == 0 ? t.g_al : dummy;
-    const uint32_t last = t.mode == 0 ? t.nch - 1u : 0u;
+    // wave-uniform: scalar base + 32-bit lane offset (readfirstlane keeps the selects on the scalar unit; folded into
+    // the per-lane offsets they cost two vector instructions per load)
+    const uint64_t src_u = reinterpret_cast<uint64_t>(t.mode == 0 ? t.g_al : dummy);
+    const uint32_t src_lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(src_u));  // (the builtin returns int: no sign extension)
+    const uint32_t src_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(src_u >> 32));
+    const uint64_t src = (static_cast<uint64_t>(src_hi) << 32) | src_lo;
+    const uint32_t last16 = __builtin_amdgcn_readfirstlane(t.mode == 0 ? (t.nch - 1u) << 4 : 0u);
+    const uint32_t lane16 = lane << 4;
 #pragma unroll
     for (int k = 0; k < KCH; ++k) {
-        const uint32_t c = min(lane + 64u * k, last);
-        pre[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + (static_cast<uint64_t>(c) << 4)));
+        const uint32_t o = min(lane16 + 1024u * k, last16);
+        pre[k] = __builtin_nontemporal_load((__attribute__((address_space(1))) const u32x4*)(src + o));  // a global_load, not a flat one
     }
 }
 // Registers -> staging area, and the hot-interval bit of every chunk -> the wave's bitmap (bit 64 k + lane of the
@@ -156,10 +170,10 @@ __device__ __forceinline__ void tile_issue_loads(const TileInfo& t, uint32_t lan
 template <int KCH, int MAP>  // MAP 0: no bitmap; 1: general hot interval; 2: hot interval ends at 0x7F
 __device__ __forceinline__ void commit_chunks(const TileInfo& t, uint32_t lane, const u32x4 (&pre)[KCH], uint32_t stage, uint32_t bitmap,
                                               uint32_t hot_lo4, uint32_t hot_k4) {
+    const uint32_t last = stage + ((t.nch - 1u) << 4), mine = stage + (lane << 4);
 #pragma unroll
     for (int k = 0; k < KCH; ++k) {
-        const uint32_t c = min(lane + 64u * k, t.nch - 1u);
-        lds_st<u32x4>(stage + (c << 4), pre[k]);
+        lds_st<u32x4>(min(mine + 1024u * k, last), pre[k]);
         if (MAP) {
             const unsigned long long m = __ballot(chunk_inside<MAP == 2>(pre[k], hot_lo4, hot_k4));
             if (lane == 0) lds_st<u32x2>(bitmap + 8u * k, u32x2{static_cast<uint32_t>(m), static_cast<uint32_t>(m >> 32)});
@@ -227,7 +241,9 @@ k_extract_tile(GxLds L, TileIO io) {
     const uint32_t info_off = L.row_bytes - 4u;  // per-state info column: accept / final-tags offset
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
+    // (the wave index through readfirstlane: everything derived from it -- tile numbers, LDS areas, the round's span --
+    // is then wave-uniform for the compiler too, i.e. scalar registers and scalar arithmetic)
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t stage = L.stage + wave * L.stage_bytes;
     const uint32_t bitmap = L.bitmap + wave * GX_BITMAP_WAVE_BYTES;
     const bool use_map = L.hot_k4 != HI_BITS;
@@ -236,8 +252,8 @@ k_extract_tile(GxLds L, TileIO io) {
 
     const int G = io.max_groups;
     const uint32_t slots = 2u * static_cast<uint32_t>(G);
-    const uint64_t tiles = (n + 63) >> 6;
-    const uint64_t wstride = static_cast<uint64_t>(gridDim.x) * L.nwaves;
+    uint64_t tiles = (n + 63) >> 6;
+    uint64_t wstride = static_cast<uint64_t>(gridDim.x) * L.nwaves;
     const uint8_t* data_end = data + static_cast<uint64_t>(off[n]);
 
     auto load_offsets = [&](uint64_t tile, uint64_t& o0, uint64_t& o1) {
@@ -245,6 +261,13 @@ k_extract_tile(GxLds L, TileIO io) {
         const bool valid = i < n;
         o0 = off[valid ? i : n];
         o1 = off[valid ? i + 1 : n];
+    };
+    // the value lane `src` (wave-uniform) holds, as a wave-uniform value
+    auto lane_value = [&](uint64_t v, uint32_t src) -> uint64_t {
+        const uint32_t l = __builtin_amdgcn_readfirstlane(src);
+        const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(v), l);
+        const uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(v >> 32), l);
+        return (static_cast<uint64_t>(hi) << 32) | lo;
     };
     // Round of group `tile` starting at lane a: as many consecutive lines as fit the staging area.
     auto make_round = [&](uint64_t tile, uint32_t a, uint64_t o0, uint64_t o1) {
@@ -254,7 +277,7 @@ k_extract_tile(GxLds L, TileIO io) {
         t.pad_ = 0;
         t.o0 = o0; t.o1 = o1;
         t.a = a;
-        const uint64_t lo = __shfl(static_cast<unsigned long long>(o0), static_cast<int>(a));  // lane a holds a valid line
+        const uint64_t lo = lane_value(o0, a);  // lane a holds a valid line
         const uint8_t* g_lo = data + lo;
         const uint32_t skew = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(g_lo) & 15u);
         t.g_al = g_lo - skew;  // 16-byte aligned; still a global-address-space pointer for the compiler
@@ -267,7 +290,7 @@ k_extract_tile(GxLds L, TileIO io) {
             t.nch = 1;
         } else {
             t.b = a + cnt;
-            const uint64_t hi = __shfl(static_cast<unsigned long long>(o1), static_cast<int>(t.b - 1u));
+            const uint64_t hi = lane_value(o1, t.b - 1u);
             const uint64_t span = (hi - lo) + skew;
             t.nch = max(static_cast<uint32_t>((span + 15) >> 4), 1u);
             t.mode = (t.g_al >= data && t.g_al + (static_cast<uint64_t>(t.nch) << 4) <= data_end) ? 0u : 1u;
@@ -279,6 +302,14 @@ k_extract_tile(GxLds L, TileIO io) {
     };
 
     uint64_t tile = static_cast<uint64_t>(blockIdx.x) * L.nwaves + wave;
+#ifdef GX_DEV
+    if (io.dev_flags & 1u) {  // experiment: every wave takes a run of consecutive tiles instead of every wstride-th one
+        const uint64_t per = (tiles + wstride - 1) / wstride;
+        tile *= per;
+        tiles = min(tiles, tile + per);
+        wstride = 1;
+    }
+#endif
     if (tile >= tiles) return;
 #ifdef GX_DEV
     unsigned long long phase_cycles[4] = {0, 0, 0, 0};
@@ -373,8 +404,12 @@ k_extract_tile(GxLds L, TileIO io) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     uint8_t* out = reinterpret_cast<uint8_t*>(out_rows);
-                    for (uint32_t c = lane; c < 4u * row_b; c += 64u)  // 64 * row_b / 16 chunks
+                    for (uint32_t c = lane; c < 4u * row_b; c += 64u) {  // 64 * row_b / 16 chunks
+#ifdef GX_DEV
+                        if (io.dev_flags & 2u) { __builtin_nontemporal_store(lds_ld<u32x4>(stage + (c << 4)), reinterpret_cast<u32x4*>(out + (c << 4))); continue; }
+#endif
                         *reinterpret_cast<u32x4*>(out + (c << 4)) = lds_ld<u32x4>(stage + (c << 4));
+                    }
                 } else if (valid) {
                     uint16_t* rp = io.packed + i * static_cast<uint64_t>(1u + slots);
                     const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
@@ -478,6 +513,7 @@ hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t
     io.strip_eol = b.strip_eol;
 #ifdef GX_DEV
     io.stamps = dev_stamps;
+    io.dev_flags = getenv("GX_DEV_FLAGS") ? static_cast<uint32_t>(atoi(getenv("GX_DEV_FLAGS"))) : 0u;
 #else
     (void)dev_stamps;
 #endif

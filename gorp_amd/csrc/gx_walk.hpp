@@ -38,6 +38,17 @@ __device__ __forceinline__ uint4 lds_window(uint32_t a) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// The same where the wave can tell the alignment: an unaligned ds_read_b128 stalls the LDS pipe for dozens of cycles
+// (SQ_LDS_UNALIGNED_STALL: ~48 per wave-instruction on gfx950), two 8-byte-aligned halves (ds_read2_b64) do not.
+// Lines of a multiple-of-8 length in an 8-aligned buffer -- fixed-width records -- keep every window 8-aligned.
+__device__ __forceinline__ uint4 lds_window_any(uint32_t a) {
+    if (!__any((a & 7u) != 0u)) {
+        const u32x2 lo = lds_ld<u32x2>(a), hi = lds_ld<u32x2>(a + 8u);
+        return make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+    return lds_window(a);
+}
+
 __device__ __forceinline__ uint32_t splat_byte0(uint32_t v) { return __builtin_amdgcn_perm(v, v, 0x00000000u); }
 __device__ __forceinline__ uint32_t splat_byte1(uint32_t v) { return __builtin_amdgcn_perm(v, v, 0x01010101u); }
 
@@ -170,7 +181,8 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
 
 // The result of one line, from the info word of the state its walk ended in.  info < 0: -1 (null) or -2-k
 // (ExtractionException), no groups.  info >= 0: byte offset of a final record in the record array (LDS address
-// fin_lds, or global pointer fin_g in the L2 tier): u16 [extraction id][begin tag, end tag] x max_groups, a tag being
+// fin_lds, or global pointer fin_g in the L2 tier; 16-byte aligned): u16 [begin tag, end tag] x max_groups, padded to a
+// multiple of four groups, then the extraction id; a tag being
 // 0 = unset, 1 = the line length, else the byte offset of a register column from the wave's dummy column.  Record 0
 // has every tag unset and serves the lines without a match, so the loads below are unconditional and independent:
 // all tags, then all registers, then the selects -- two LDS round trips per four groups instead of two per group.
@@ -180,15 +192,14 @@ __device__ __forceinline__ int32_t line_result(int32_t info, uint32_t fin_lds, c
                                                EMIT emit) {
     const uint32_t rec = info >= 0 ? static_cast<uint32_t>(info) : 0u;
     const uint32_t dummy_col = regs - 128u;
+    const uint32_t id_at = rec + 16u * static_cast<uint32_t>((G + 3) >> 2);
     uint32_t id;
-    if (TIER == TIER_L2) id = *reinterpret_cast<const uint16_t*>(fin_g + rec);
-    else id = lds_ld<uint16_t>(fin_lds + rec);
+    if (TIER == TIER_L2) id = *reinterpret_cast<const uint16_t*>(fin_g + id_at);
+    else id = lds_ld<uint16_t>(fin_lds + id_at);
     for (int g0 = 0; g0 < G; g0 += 4) {
-        uint4 t;
-        if (TIER == TIER_L2) {
-            const u32x4 v = reinterpret_cast<const UnalignedWindow*>(fin_g + rec + 2u + 4u * g0)->v;
-            t = make_uint4(v.x, v.y, v.z, v.w);
-        } else t = lds_window(fin_lds + rec + 2u + 4u * g0);
+        u32x4 t;
+        if (TIER == TIER_L2) t = *reinterpret_cast<const u32x4*>(fin_g + rec + 4u * g0);
+        else t = lds_ld<u32x4>(fin_lds + rec + 4u * g0);
         const uint32_t tw[4] = {t.x, t.y, t.z, t.w};  // one dword = (begin tag, end tag) of one group
         uint32_t vb[4], ve[4];
 #pragma unroll

@@ -92,6 +92,28 @@ def gather_results_compact(match_id, caps, dst=0):
     return mid, cp
 
 
+def gather_rows(rows, dst=0):
+    """Gather the compact result rows the kernels write themselves (gx_batch_opts.compact_results: int16 id + uint16
+    offsets per line, [n, 1 + slots] int16/uint16 tensors) on `dst` in rank order -- no pack step, half the bytes of
+    the dense rows on the xGMI links.  Shards may differ in length.  Returns the concatenated rows (or None)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = rows.device
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    padded = rows
+    if rows.shape[0] != max(sizes):
+        padded = torch.zeros((max(sizes), rows.shape[1]), dtype=rows.dtype, device=dev)
+        padded[:rows.shape[0]] = rows
+    wire = padded.contiguous().view(torch.uint8)  # (RCCL has no 16-bit integer type: the rows travel as bytes)
+    bufs = [torch.empty_like(wire) for _ in range(world)] if rank == dst else None
+    dist.gather(wire, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([b.view(rows.dtype)[:s] for b, s in zip(bufs, sizes)], dim=0).contiguous()
+
+
 def gather_results(match_id, caps, dst=0):
     """Gather per-line results of all ranks on `dst` in rank order.  Shards may differ in length:
     they are padded to the longest one for the collective and trimmed afterwards."""

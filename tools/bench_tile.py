@@ -4,6 +4,9 @@ checked against the generator's answers.  Usage: bench_tile.py [lines] [line_byt
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+if os.environ.get("GX_DEV_FLAGS") is not None:   # experiments of the developer build
+    from gorp_amd import _native as N
+    N.LIB_PATH = os.path.join(os.path.dirname(N.LIB_PATH), "libgorp_hip_dev.so")
 from gorp_amd import workloads as W
 from gorp_amd.gorp import Gorp
 
