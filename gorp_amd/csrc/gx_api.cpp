@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <array>
+#include <cstdio>
 #include <cstddef>
 #include <cstdlib>
 #include <map>
@@ -62,6 +63,12 @@ struct gx_handle {
     GxLds lds{};                 // table part of the layout; staging is sized per batch
     std::vector<uint8_t> lds_image;
     void* d_lds_image = nullptr;
+    // record tier with a fused automaton: the image above holds the fused automaton alone, this one the match
+    // automaton alone (PolyMatcher.match batches) -- the two together would not leave LDS for the waves
+    bool has_mo = false;
+    GxLds lds_mo{};
+    std::vector<uint8_t> lds_image_mo;
+    void* d_lds_image_mo = nullptr;
     std::vector<uint8_t> l2_image;
     void* d_l2_image = nullptr;
     int num_cus = 256;
@@ -105,28 +112,268 @@ template <typename F> uint16_t self_loop_interval(F loops) {
     return static_cast<uint16_t>(best_lo | ((0x7F - (best_lo + best_len - 1)) << 8));
 }
 
-// Build the table image of the tile kernel (layout: GxLds).  global == false: LDS tier, everything in one
-// LDS-resident image, rows addressed by byte offset.  global == true: L2 tier, the automaton rows go to a
-// separate global-memory image (h->l2_image: match rows at 0, capture rows at GxLds::c_base) and are addressed
-// by state index; LDS keeps only the byte->class map, the per-extraction start rows and the capture programs.
-bool build_tile_image(gx_handle* h, bool global) {
+// ---- record tier ------------------------------------------------------------------------------------------
+// A state's dense row, as a handful of class ranges.  Classes are renumbered first so that the sets the rows use
+// (the classes of one successor: "digits", "\w", "not a blank", single literals) become contiguous id ranges
+// wherever one ordering can serve them all (greedy partition refinement, heaviest sets first); a set that stays
+// split simply takes several ranges.  A state is then
+//     [header: 8 bytes, only when its info word is not -1]
+//     item 0:  self range (plain self-loop, no program) + one exit range with its successor and program
+//     items 1..: one more range each (exit slot only), the last one flagged
+// every class in no range leads to the automaton's dead state.  An item is two dwords:
+//     w0 = self_lo | self_span << 8 | exit_lo << 16 | exit_span << 24      (class c is inside iff c - lo <= span, unsigned;
+//                                                                           lo = 255, span = 0: empty)
+//     w1 = successor (item index, 16 bits) | program << 16 (8 bits) | flags << 24 (1: last item, 2: a header precedes)
+// A state's index is the index of its item 0; the self-loop byte interval (GxLds rows' ACC word) is looked up by the
+// self range's first class in a small table.  The builder checks its own output against the dense rows, class by
+// class, before it is used.
+constexpr uint32_t REC_LAST = 1u << 24, REC_HDR = 2u << 24, REC_IDC = 254u, REC_EMPTY = 255u;
+
+bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t rows, uint32_t cols, const std::vector<uint32_t>& dead_of_row,
+                        const std::vector<std::array<uint64_t, 2>>& loop_set, bool simple, Image& img, GxLds& L, std::vector<uint32_t>& c_rule) {
     const Tables& T = h->T;
-    h->tile_ok = false;
-    h->tile_global = global;
+    const int ncls = T.ncls;
+    const uint32_t ACC = ncls + 1, INFO = ncls + 2;
+    typedef std::array<uint64_t, 4> ClassSet;
+    auto has = [](const ClassSet& s, int c) { return (s[c >> 6] >> (c & 63)) & 1ull; };
+    // the groups of every row: successor entry -> classes (the dead default is not a group)
+    struct Group { uint32_t entry; ClassSet set; };
+    std::vector<std::vector<Group>> groups(rows);
+    std::map<ClassSet, uint64_t> weight;
+    for (size_t r = 0; r < rows; ++r) {
+        std::map<uint32_t, ClassSet> by_entry;
+        for (int c = 0; c < ncls; ++c) {
+            const uint32_t e = at[r * cols + c];
+            if (e == dead_of_row[r]) continue;
+            by_entry[e][c >> 6] |= 1ull << (c & 63);
+        }
+        for (auto& g : by_entry) {
+            // the plain self-loop first: it takes item 0's self slot
+            if (g.first == static_cast<uint32_t>(r)) groups[r].insert(groups[r].begin(), Group{g.first, g.second});
+            else groups[r].push_back(Group{g.first, g.second});
+            ++weight[g.second];
+        }
+    }
+    // class order: ordered partition, refined set by set
+    std::vector<std::vector<int>> blocks(1);
+    for (int c = 0; c < ncls; ++c) blocks[0].push_back(c);
+    std::vector<std::pair<uint64_t, ClassSet>> by_weight;
+    for (auto& w : weight) {
+        int size = 0;
+        for (int c = 0; c < ncls; ++c) size += has(w.first, c) ? 1 : 0;
+        if (size > 1 && size < ncls) by_weight.push_back({w.second * static_cast<uint64_t>(size), w.first});
+    }
+    std::sort(by_weight.begin(), by_weight.end(), [](const std::pair<uint64_t, ClassSet>& a, const std::pair<uint64_t, ClassSet>& b) {
+        return a.first != b.first ? a.first > b.first : a.second < b.second;
+    });
+    for (auto& ws : by_weight) {
+        const ClassSet& S = ws.second;
+        int first = -1, last = -1;
+        bool ok = true;
+        std::vector<int> inside(blocks.size());
+        for (size_t b = 0; b < blocks.size(); ++b) {
+            int in = 0;
+            for (int c : blocks[b]) in += has(S, c) ? 1 : 0;
+            inside[b] = in;
+            if (in) { if (first < 0) first = static_cast<int>(b); last = static_cast<int>(b); }
+        }
+        for (int b = first + 1; b < last && ok; ++b) if (inside[b] != static_cast<int>(blocks[b].size())) ok = false;  // a hole in the middle
+        if (!ok || first < 0) continue;
+        auto split = [&](int b, bool inside_last) {  // block b -> (outside, inside) or (inside, outside)
+            std::vector<int> in, out;
+            for (int c : blocks[b]) (has(S, c) ? in : out).push_back(c);
+            if (in.empty() || out.empty()) return 0;
+            blocks[b] = inside_last ? out : in;
+            blocks.insert(blocks.begin() + b + 1, inside_last ? in : out);
+            return 1;
+        };
+        if (first == last) split(first, false);
+        else {
+            split(last, false);          // the inside part first, next to the run
+            split(first, true);          // the inside part last
+        }
+    }
+    std::vector<int> new_id(ncls);
+    {
+        int id = 0;
+        for (auto& b : blocks) for (int c : b) new_id[c] = id++;
+    }
+    // ranges (in new ids) of a class set
+    auto ranges_of = [&](const ClassSet& S) {
+        std::vector<char> in(ncls, 0);
+        for (int c = 0; c < ncls; ++c) if (has(S, c)) in[new_id[c]] = 1;
+        std::vector<std::pair<int, int>> out;
+        for (int i = 0; i < ncls; ++i) if (in[i]) { int j = i; while (j + 1 < ncls && in[j + 1]) ++j; out.push_back({i, j}); i = j; }
+        return out;
+    };
+    // pass 1: items per row -> indexes
+    struct Slot { int lo, hi; uint32_t entry; };
+    std::vector<std::vector<Slot>> exits(rows);   // everything but the first range of the plain self-loop
+    std::vector<std::pair<int, int>> self0(rows, {-1, -1});
+    std::vector<uint32_t> index_of(rows);
+    size_t n_items = 0;
+    // which exit shares item 0 with the self range decides how often a lane needs a second record: the one that
+    // printable text takes most likely first (a field's blank before some control character's odd successor)
+    std::vector<int> printable(ncls, 0), bytes_of(ncls, 0);
+    for (int b = 0; b < 256; ++b) { ++bytes_of[T.cls256[b]]; if (b >= 0x20 && b < 0x7F) ++printable[T.cls256[b]]; }
+    auto likelihood = [&](const ClassSet& S) {
+        long p = 0, n = 0;
+        for (int c = 0; c < ncls; ++c) if (has(S, c)) { p += printable[c]; n += bytes_of[c]; }
+        return p * 1000 + n;
+    };
+    for (size_t r = 0; r < rows; ++r) {
+        std::stable_sort(groups[r].begin(), groups[r].end(), [&](const Group& a, const Group& b) {
+            const bool sa = a.entry == static_cast<uint32_t>(r), sb = b.entry == static_cast<uint32_t>(r);
+            if (sa != sb) return sa;  // the plain self-loop stays first
+            return likelihood(a.set) > likelihood(b.set);
+        });
+        for (auto& g : groups[r]) {
+            auto rs = ranges_of(g.set);
+            size_t from = 0;
+            if (g.entry == static_cast<uint32_t>(r) && self0[r].first < 0) { self0[r] = rs[0]; from = 1; }
+            for (size_t q = from; q < rs.size(); ++q) exits[r].push_back(Slot{rs[q].first, rs[q].second, g.entry});
+        }
+        const bool hdr = at[r * cols + INFO] != 0xFFFFFFFFu;
+        if (hdr) ++n_items;
+        index_of[r] = static_cast<uint32_t>(n_items);
+        n_items += std::max<size_t>(1, exits[r].size());
+    }
+    if (n_items > 65535u) return false;
+    if (getenv("GX_REC_STATS")) {
+        size_t multi = 0, self_split = 0, self_states = 0;
+        std::map<size_t, size_t> hist;
+        for (size_t r = 0; r < rows; ++r) {
+            ++hist[std::max<size_t>(1, exits[r].size())];
+            if (exits[r].size() > 1) ++multi;
+            if (self0[r].first >= 0) { ++self_states; for (auto& e : exits[r]) if (e.entry == static_cast<uint32_t>(r)) { ++self_split; break; } }
+        }
+        fprintf(stderr, "records: rows %zu items %zu multi-item states %zu self-loop states %zu of which split %zu; blocks %zu\n", rows, n_items, multi, self_states, self_split, blocks.size());
+        for (auto& hh : hist) fprintf(stderr, "  %zu items: %zu states\n", hh.first, hh.second);
+        std::string order;
+        for (auto& b : blocks) { order += "["; for (int c : b) { for (int by = 0; by < 256; ++by) if (T.cls256[by] == c) { order += (by > 32 && by < 127) ? static_cast<char>(by) : '.'; break; } } order += "]"; }
+        fprintf(stderr, "  class order: %s\n", order.c_str());
+    }
+    // pass 2: emit
+    std::vector<uint32_t> items(2 * n_items, 0);
+    for (size_t r = 0; r < rows; ++r) {
+        const uint32_t info = at[r * cols + INFO];
+        const bool hdr = info != 0xFFFFFFFFu;
+        if (hdr) { items[2 * (index_of[r] - 1)] = 0; items[2 * (index_of[r] - 1) + 1] = info; }
+        const size_t n = std::max<size_t>(1, exits[r].size());
+        for (size_t q = 0; q < n; ++q) {
+            uint32_t w0 = REC_EMPTY | (REC_EMPTY << 16), w1 = 0;
+            if (q == 0 && self0[r].first >= 0) w0 = (w0 & 0xFFFF0000u) | self0[r].first | (static_cast<uint32_t>(self0[r].second - self0[r].first) << 8);
+            if (q < exits[r].size()) {
+                const Slot& e = exits[r][q];
+                w0 = (w0 & 0xFFFFu) | (static_cast<uint32_t>(e.lo) << 16) | (static_cast<uint32_t>(e.hi - e.lo) << 24);
+                uint32_t op = e.entry >> 16;  // as the dense rows carry it
+                if (simple) op /= 128u;       // register + 1
+                else if (op & 0x8000u) { if ((op & 0x7FFFu) > 127u) return false; op = 0x80u | (op & 0x7Fu); }
+                else if (op > 127u) return false;
+                if (op > 255u) return false;
+                w1 = index_of[e.entry & 0xFFFFu] | (op << 16);
+            }
+            if (q + 1 == n) w1 |= REC_LAST;
+            if (q == 0 && hdr) w1 |= REC_HDR;
+            items[2 * (index_of[r] + q)] = w0;
+            items[2 * (index_of[r] + q) + 1] = w1;
+        }
+    }
+    // self-loop interval words by the first class of the self range; states that share it must agree (else the
+    // narrowest claim that is true for all of them: none)
+    std::vector<uint32_t> acc_tab(ncls + 1, 0x8000u);
+    {
+        std::vector<std::vector<size_t>> by_lo(ncls);
+        for (size_t r = 0; r < rows; ++r) if (self0[r].first >= 0) by_lo[self0[r].first].push_back(r);
+        auto covers = [&](size_t r, int lo, int hi) {
+            for (int b = lo; b <= hi; ++b) if (!(loop_set[r][b >> 6] >> (b & 63) & 1ull)) return false;
+            return true;
+        };
+        for (int lo_c = 0; lo_c < ncls; ++lo_c) {
+            uint32_t best = 0x8000u;
+            int best_w = 0;
+            for (size_t r : by_lo[lo_c]) {
+                const uint32_t a = at[r * cols + ACC];
+                if ((a & 0xFFFFu) == 0x8000u) continue;
+                const int lo = static_cast<int>(a & 0xFFu), hi = 0x7F - static_cast<int>((a >> 8) & 0xFFu);
+                bool all = true, hot = true;
+                for (size_t q : by_lo[lo_c]) { all = all && covers(q, lo, hi); hot = hot && (at[q * cols + ACC] & 0x10000u); }
+                if (all && hi - lo + 1 > best_w) { best_w = hi - lo + 1; best = (a & 0xFFFFu) | (hot ? 0x10000u : 0u); }
+            }
+            acc_tab[lo_c] = best;
+        }
+    }
+    // check: every (row, class) decodes to the dense entry
+    for (size_t r = 0; r < rows; ++r)
+        for (int c = 0; c < ncls; ++c) {
+            const uint32_t id = static_cast<uint32_t>(new_id[c]);
+            uint32_t next = index_of[dead_of_row[r] & 0xFFFFu], op = 0;
+            for (uint32_t q = index_of[r];; ++q) {
+                const uint32_t w0 = items[2 * q], w1 = items[2 * q + 1];
+                if (id - ((w0 >> 16) & 0xFFu) <= (w0 >> 24)) { next = w1 & 0xFFFFu; op = (w1 >> 16) & 0xFFu; break; }
+                if (id - (w0 & 0xFFu) <= ((w0 >> 8) & 0xFFu)) { next = index_of[r]; break; }
+                if (w1 & REC_LAST) break;
+            }
+            const uint32_t e = at[r * cols + c];
+            uint32_t want_op = e >> 16;
+            if (simple) want_op /= 128u; else if (want_op & 0x8000u) want_op = 0x80u | (want_op & 0x7Fu);
+            if (next != index_of[e & 0xFFFFu] || op != want_op) throw GxError(GX_E_ARG, "internal: record tier does not reproduce the dense rows");
+        }
+    // image: class map (new ids; entry 256 = the identity class of masked bytes), interval table, items
+    std::vector<uint16_t> cmap(272, static_cast<uint16_t>(REC_IDC));
+    for (int b = 0; b < 256; ++b) cmap[b] = static_cast<uint16_t>(new_id[T.cls256[b]]);
+    L.cmap = static_cast<uint32_t>(img.put(cmap));
+    L.acc_tab = static_cast<uint32_t>(img.put(acc_tab));
+    L.rec = static_cast<uint32_t>(img.put(items));
+    L.at = 0;
+    if (L.m_dead < rows) { L.m_start = index_of[L.m_start]; L.m_dead = index_of[L.m_dead]; }  // (absent from a capture-only image)
+    if (L.u_start != 0xFFFFFFFFu) { L.u_start = index_of[L.u_start]; L.u_dead = index_of[L.u_dead]; }
+    else for (size_t k = 0; k + 1 < c_rule.size(); k += 2) {
+        // per-extraction capture automata: (start state, the rule's own dead state)
+        c_rule[k + 1] = index_of[dead_of_row[c_rule[k]] & 0xFFFFu];
+        c_rule[k] = index_of[c_rule[k]];
+    }
+    return true;
+}
+
+// Build the table image of the tile kernel (layout: GxLds).
+// tier 0: LDS tier, everything in one LDS-resident image, dense rows addressed by byte offset.
+// tier 1: L2 tier, the dense rows go to a separate global-memory image (h->l2_image: match rows at 0, capture rows
+//         at GxLds::c_base) and are addressed by state index; LDS keeps only the byte->class map, the per-extraction
+//         start rows and the capture programs.
+// tier 2: record tier, for automata whose dense rows do not fit LDS but whose states are sparse (a literal chain
+//         link has one live class, a field state one self range and one exit): every state becomes a few 8-byte
+//         range records in LDS (records_from_dense below; ~8.5 bytes per state instead of 4 * classes).
+bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t rows, uint32_t cols, const std::vector<uint32_t>& dead_of_row,
+                        const std::vector<std::array<uint64_t, 2>>& loop_set, bool simple, Image& img, GxLds& L, std::vector<uint32_t>& c_rule);
+
+// part 0: match automaton + capture automata in one image; 1: capture side alone (fused automaton); 2: match alone.
+bool build_tile_image(gx_handle* h, int tier, int part = 0) {
+    const Tables& T = h->T;
+    const bool global = tier == 1;
+    if (part != 2) {
+        h->tile_ok = false;
+        h->tile_global = global;
+        h->has_mo = false;
+    }
     if (T.n_rules > 32767) return false;
     const uint32_t cols = static_cast<uint32_t>(T.ncls) + 3u;
     const uint32_t RS = cols * 4u;
     // with the fused automaton present the per-extraction capture rows are not needed on the device
     // (GX_CREATE_NO_FUSED forces the two-pass layout, which otherwise only very large definitions get)
     const bool fused = T.union_ok && !(h->create_flags & GX_CREATE_NO_FUSED);
-    const size_t m_rows = static_cast<size_t>(T.m_states);
+    if (part == 1 && !(fused && T.has_capture)) return false;  // the two-pass layout needs both sides
+    const size_t m_rows = part == 1 ? 0 : static_cast<size_t>(T.m_states);
     size_t c_rows = 0;
-    if (fused) c_rows = T.uni.n_states;
+    if (part == 2) c_rows = 0;
+    else if (fused) c_rows = T.uni.n_states;
     else for (auto& r : T.rules) c_rows += r.n_states;
     const size_t rows = m_rows + c_rows;
     if (T.ncls > 252) return false;  // keeps the column offsets of a row (class * 4, + 3 extra columns) below 1024
     const uint32_t AT = 544;         // LDS tier: the rows follow the class map (u16[256] + the identity entry, padded)
-    if (!global) {
+    if (tier == 2) {
+        if (rows > 60000u || T.ncls > 250) return false;  // 16-bit record indexes; class ids 254 / 255 are reserved
+    } else if (!global) {
         if (AT + rows * RS > 65536u) return false;  // successors are 16-bit LDS addresses
         if (rows * RS + T.ops_off.size() * 4 + T.ops.size() * 2 + 1024 > LDS_TABLE_BUDGET) return false;  // (+ the final records, below)
     } else {
@@ -134,8 +381,9 @@ bool build_tile_image(gx_handle* h, bool global) {
         if (T.n_rules * 8 + T.ops_off.size() * 4 + T.ops.size() * 2 + 1024 > LDS_TABLE_BUDGET) return false;
     }
     // a state's successor field: LDS tier = LDS address of the row, L2 tier = state index
-    const uint32_t UNIT = global ? 1u : RS;
-    const uint32_t ORG = global ? 0u : AT;
+    const uint32_t UNIT = tier ? 1u : RS;
+    const uint32_t ORG = tier ? 0u : AT;
+    std::vector<uint32_t> dead_of_row(rows, 0);  // tier 2: the row every unlisted class of a row leads to
 
     Image img;
     GxLds L{};
@@ -153,19 +401,20 @@ bool build_tile_image(gx_handle* h, bool global) {
         return self_loop_interval(loops);
     };
     // match automaton rows
-    for (int s = 0; s < T.m_states; ++s) {
+    for (int s = 0; s < static_cast<int>(m_rows); ++s) {
         uint32_t* row = &at[static_cast<size_t>(s) * cols];
         for (int c = 0; c < T.ncls; ++c) row[c] = ORG + T.m_next[static_cast<size_t>(s) * T.ncls + c] * UNIT;
         row[IDC] = ORG + static_cast<uint32_t>(s) * UNIT;
         row[ACC] = loop_interval(static_cast<size_t>(s), [&](int b) { return T.m_next[static_cast<size_t>(s) * T.ncls + T.cls256[b]] == static_cast<uint32_t>(s); });
         row[INFO] = static_cast<uint32_t>(T.m_accept_first[s]);
+        dead_of_row[s] = static_cast<uint32_t>(T.m_dead);
     }
     L.m_start = ORG;
     L.m_dead = ORG + static_cast<uint32_t>(T.m_dead) * UNIT;
     L.c_base = global ? static_cast<uint32_t>(m_rows * RS) : 0u;
     // capture automata rows: the fused automaton, or one automaton per extraction
     std::vector<uint32_t> c_rule;
-    size_t base_row = static_cast<size_t>(T.m_states);
+    size_t base_row = m_rows;
     bool too_many_programs = false;
     // are all capture programs of the tables we ship "one register := position"?
     auto is_single_set = [&](uint32_t op) {
@@ -176,7 +425,8 @@ bool build_tile_image(gx_handle* h, bool global) {
     auto scan_simple = [&](const RuleTables& r) {
         for (uint32_t w : r.trans) if ((w >> 16) && !is_single_set(w >> 16)) simple = false;
     };
-    if (fused) scan_simple(T.uni);
+    if (part == 2) simple = true;
+    else if (fused) scan_simple(T.uni);
     else for (auto& r : T.rules) scan_simple(r);
     L.simple_ops = simple ? 1u : 0u;
     // Final records, one per distinct (final tag list, extraction): u16 [begin tag, end tag] x max_groups padded to a
@@ -206,10 +456,11 @@ bool build_tile_image(gx_handle* h, bool global) {
     };
     int rule_being_emitted = -1;  // per-extraction capture automata: the rule; fused automaton: -1
     auto emit_rows = [&](const RuleTables& r) {
-        // LDS tier: LDS addresses; L2 tier: state indexes within the capture rows
+        // LDS tier: LDS addresses; L2 tier: state indexes within the capture rows; record tier: indexes over all rows
         const uint32_t base = ORG + static_cast<uint32_t>(global ? base_row - m_rows : base_row) * UNIT;
         for (int s = 0; s < r.n_states; ++s) {
             uint32_t* row = &at[(base_row + s) * cols];
+            dead_of_row[base_row + s] = base + static_cast<uint32_t>(r.dead);
             for (int c = 0; c < T.ncls; ++c) {
                 const uint32_t w = r.trans[static_cast<size_t>(s) * T.ncls + c];
                 uint32_t op = w >> 16;
@@ -234,7 +485,9 @@ bool build_tile_image(gx_handle* h, bool global) {
     };
     L.u_start = 0xFFFFFFFFu;
     L.u_dead = 0xFFFFFFFFu;
-    if (fused) {
+    if (part == 2) {
+        // match automaton alone
+    } else if (fused) {
         const uint32_t base = emit_rows(T.uni);
         L.u_start = base;
         L.u_dead = base + static_cast<uint32_t>(T.uni.dead) * UNIT;
@@ -249,7 +502,7 @@ bool build_tile_image(gx_handle* h, bool global) {
     }
     if (too_many_programs) return false;  // too many distinct general programs for the 15-bit program field
     if (fin_rec.size() * 2 > 0xFFFFFFu) return false;
-    if (!global && rows * RS + T.ops_off.size() * 4 + T.ops.size() * 2 + fin_rec.size() * 2 + 1024 > LDS_TABLE_BUDGET) return false;
+    if (tier == 0 && rows * RS + T.ops_off.size() * 4 + T.ops.size() * 2 + fin_rec.size() * 2 + 1024 > LDS_TABLE_BUDGET) return false;
     // Hot interval: among the self-loop intervals of all rows, the one that promises the longest skips -- width
     // squared (only runs of several 16-byte chunks pay off) times the number of states that loop on all of it.
     // Those states get bit 16 of their interval column; the tile kernel marks the staged chunks that lie inside the
@@ -280,7 +533,11 @@ bool build_tile_image(gx_handle* h, bool global) {
         }
     }
     if (c_rule.empty()) { c_rule.push_back(0); c_rule.push_back(0); }
-    if (global) {
+    if (tier == 2) {
+        img.bytes.clear();  // the record tier has its own class map (classes renumbered so that sets become ranges)
+        if (!records_from_dense(h, at, rows, cols, dead_of_row, loop_set, simple, img, L, c_rule)) return false;
+        if (img.bytes.size() + T.ops_off.size() * 4 + T.ops.size() * 2 + fin_rec.size() * 2 + 1024 > LDS_TABLE_BUDGET) return false;
+    } else if (global) {
         L.at = 0;
         h->l2_image.assign(reinterpret_cast<const uint8_t*>(at.data()), reinterpret_cast<const uint8_t*>(at.data() + at.size()));
         while (h->l2_image.size() % 16) h->l2_image.push_back(0);
@@ -297,12 +554,20 @@ bool build_tile_image(gx_handle* h, bool global) {
     if (ops.empty()) ops.push_back(0);
     L.ops = static_cast<uint32_t>(img.put(ops));
     if (!global) L.fin_tags = static_cast<uint32_t>(img.put(fin_rec));
+    L.tier = static_cast<uint32_t>(tier);
     while (img.bytes.size() % 16) img.bytes.push_back(0);
     L.table_bytes = static_cast<uint32_t>(img.bytes.size());
     int max_regs = 0;
     for (auto& r : T.rules) max_regs = std::max(max_regs, r.n_regs);
     if (fused) max_regs = T.uni.n_regs;
+    if (part == 2) max_regs = 0;
     L.regs_wave_bytes = static_cast<uint32_t>(((max_regs + 1) * 64 * 2 + 15) & ~15);  // + the dummy column
+    if (part == 2) {
+        h->lds_mo = L;
+        h->lds_image_mo.swap(img.bytes);
+        h->has_mo = true;
+        return true;
+    }
     h->lds = L;
     h->lds_image.swap(img.bytes);
     h->tile_ok = true;
@@ -310,9 +575,9 @@ bool build_tile_image(gx_handle* h, bool global) {
 }
 
 // Complete the layout for one batch: staging sized for 64 lines of the hinted length.
-bool plan_tile_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out) {
+bool plan_tile_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out, bool match_only = false) {
     if (!h->tile_ok) return false;
-    GxLds L = h->lds;
+    GxLds L = match_only && h->has_mo ? h->lds_mo : h->lds;
     if (line_bytes_hint == 0) line_bytes_hint = 200;
     if (line_bytes_hint > 2000) line_bytes_hint = 2000;
     L.stage_bytes = (64u * line_bytes_hint + 64u + 15u) & ~15u;  // + slack: the walk reads ahead of the line
@@ -343,10 +608,10 @@ bool plan_tile_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out) 
 }
 
 // Layout for the slice kernel: a 64 x 80-byte slice buffer per wave, up to 16 waves.
-bool plan_slice_launch(const gx_handle* h, GxLds* out) {
+bool plan_slice_launch(const gx_handle* h, GxLds* out, bool match_only = false) {
     if (!h->tile_ok) return false;
     if (h->T.has_capture && h->lds.u_start == 0xFFFFFFFFu) return false;  // the slice kernel walks the fused automaton
-    GxLds L = h->lds;
+    GxLds L = match_only && h->has_mo ? h->lds_mo : h->lds;
     L.stage_bytes = 64u * 80u;
     const uint32_t per_wave = L.stage_bytes + L.regs_wave_bytes;
     if (L.table_bytes + per_wave > LDS_BYTES) return false;
@@ -359,6 +624,21 @@ bool plan_slice_launch(const gx_handle* h, GxLds* out) {
     L.total_bytes = L.stage + nw * L.stage_bytes;
     *out = L;
     return true;
+}
+
+// kernel choice: automaton rows in LDS when they fit, else sparse range records in LDS, else dense rows in global
+// memory (L2), else the per-line kernel alone.  Host work only (also done for host-only handles, where it is a check
+// of the builders and feeds gx_stat).
+void choose_tile_image(gx_handle* h) {
+    const bool no_tiles = (h->create_flags & GX_CREATE_NO_TILES) != 0, force_l2 = (h->create_flags & GX_CREATE_TIER_L2) != 0;
+    const bool force_rec = (h->create_flags & GX_CREATE_TIER_RECORDS) != 0;
+    auto records = [&]() {
+        if (build_tile_image(h, 2)) return true;
+        // the fused automaton alone, and a second image with the match automaton alone for match-only batches
+        return build_tile_image(h, 2, 1) && build_tile_image(h, 2, 2);
+    };
+    if (no_tiles || !((!force_l2 && !force_rec && build_tile_image(h, 0)) || (!force_l2 && records()) || build_tile_image(h, 1)))
+        h->tile_ok = false;
 }
 
 void upload(gx_handle* h) {
@@ -434,12 +714,14 @@ void upload(gx_handle* h) {
     d.max_regs = max_regs;
     d.has_capture = T.has_capture ? 1 : 0;
 
-    // kernel choice: automaton rows in LDS when they fit, else in global memory (L2), else the per-line kernel alone
-    const bool no_tiles = (h->create_flags & GX_CREATE_NO_TILES) != 0, force_l2 = (h->create_flags & GX_CREATE_TIER_L2) != 0;
-    if (no_tiles || !((!force_l2 && build_tile_image(h, false)) || build_tile_image(h, true))) h->tile_ok = false;
+    choose_tile_image(h);
     if (h->tile_ok) {
         GX_HIP(hipMalloc(&h->d_lds_image, h->lds_image.size()));
         GX_HIP(hipMemcpy(h->d_lds_image, h->lds_image.data(), h->lds_image.size(), hipMemcpyHostToDevice));
+        if (h->has_mo) {
+            GX_HIP(hipMalloc(&h->d_lds_image_mo, h->lds_image_mo.size()));
+            GX_HIP(hipMemcpy(h->d_lds_image_mo, h->lds_image_mo.data(), h->lds_image_mo.size(), hipMemcpyHostToDevice));
+        }
         if (h->tile_global) {
             GX_HIP(hipMalloc(&h->d_l2_image, h->l2_image.size()));
             GX_HIP(hipMemcpy(h->d_l2_image, h->l2_image.data(), h->l2_image.size(), hipMemcpyHostToDevice));
@@ -462,12 +744,14 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
     // slice kernel, which stages 64 bytes of every line at a time: measured 2.4x faster on config 5 (512 extractions,
     // 50-2000-byte lines), but 0.8x on 200-byte lines, where the tile kernel's one contiguous span per group wins.
     const bool slices = kernel == GX_KERNEL_SLICES || (kernel == GX_KERNEL_AUTO && line_bytes_hint > 255u);
-    if (batchable && slices && plan_slice_launch(h, &L)) {
-        GX_HIP(launch_extract_slices(h->dev, L, static_cast<const uint8_t*>(h->d_lds_image),
+    const bool mo = b.match_only != 0 || !h->T.has_capture;
+    const uint8_t* image = static_cast<const uint8_t*>(mo && h->has_mo ? h->d_lds_image_mo : h->d_lds_image);
+    if (batchable && slices && plan_slice_launch(h, &L, mo)) {
+        GX_HIP(launch_extract_slices(h->dev, L, image,
                                      h->tile_global ? static_cast<const uint8_t*>(h->d_l2_image) : nullptr, h->num_cus, b, stream));
         return;
     }
-    if (batchable && plan_tile_launch(h, line_bytes_hint, &L)) {
+    if (batchable && plan_tile_launch(h, line_bytes_hint, &L, mo)) {
         // a slot for the "lines I could not stage" word of this launch, free again once its follow-up kernel has run
         // (submission of tile launches is serialised per handle; the launches themselves are asynchronous)
         std::lock_guard<std::mutex> lock(h->slot_mu);
@@ -481,7 +765,7 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
 #ifdef GX_DEV
         stamps = h->dev_stamps;
 #endif
-        GX_HIP(launch_extract_tile(h->dev, L, static_cast<const uint8_t*>(h->d_lds_image),
+        GX_HIP(launch_extract_tile(h->dev, L, image,
                                    h->tile_global ? static_cast<const uint8_t*>(h->d_l2_image) : nullptr, h->num_cus, b, stream, stamps));
         GX_HIP(launch_extract_oversize(h->dev, b, L.stage_bytes, stream));
         GX_HIP(hipEventRecord(h->slot_event[slot], stream));
@@ -494,6 +778,7 @@ int finish_create(std::unique_ptr<gx_handle>& h, uint32_t flags, gx_handle** out
     h->create_flags = flags;
     h->blob = pack_blob(h->T);
     if (!(flags & GX_CREATE_HOST_ONLY)) upload(h.get());
+    else choose_tile_image(h.get());
     *out = h.release();
     return GX_OK;
 }
@@ -557,6 +842,7 @@ void gx_destroy(gx_handle* h) {
     if (!h) return;
     if (h->dimage) (void)hipFree(h->dimage);
     if (h->d_lds_image) (void)hipFree(h->d_lds_image);
+    if (h->d_lds_image_mo) (void)hipFree(h->d_lds_image_mo);
     if (h->d_l2_image) (void)hipFree(h->d_l2_image);
     if (h->d_slots) {
         (void)hipFree(h->d_slots);
@@ -585,7 +871,7 @@ int64_t gx_stat(const gx_handle* h, int32_t which) {
     case 4: return static_cast<int64_t>(h->blob.size());
     case 5: { GxLds L; return plan_tile_launch(h, 0, &L) ? static_cast<int64_t>(L.total_bytes) : 0; }
     case 6: { GxLds L; return plan_tile_launch(h, 0, &L) ? static_cast<int64_t>(L.nwaves) : 0; }
-    case 7: return !h->tile_ok ? 0 : h->tile_global ? 2 : 1;
+    case 7: return !h->tile_ok ? 0 : h->tile_global ? 2 : h->lds.tier == 2 ? 3 : 1;
     case 8: return h->T.has_capture ? 1 : 0;
     default: return -1;
     }

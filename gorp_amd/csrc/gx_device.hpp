@@ -77,6 +77,11 @@ struct GxLds {
     // Hot interval: the widest self-loop byte interval of the automata (typically \S+ or .*), in the form the SWAR
     // range test consumes (lo and 0x7F - hi in every byte; hot_k4 = 0x80808080: none, no chunk ever qualifies).
     uint32_t hot_lo4, hot_k4;
+    // Record tier (tier == 2; gx_api.cpp: records_from_dense): states are 8-byte range records at LDS address rec,
+    // a state is the index of its first record, cmap holds class ids (renumbered), acc_tab[first class of the self
+    // range] is the state's self-loop interval word.
+    uint32_t tier;        // 0: dense rows in LDS, 1: dense rows in global memory, 2: records in LDS
+    uint32_t rec, acc_tab;
 };
 constexpr uint32_t GX_BITMAP_WAVE_BYTES = 144;  // 16 x u64 (1024 chunks = 16 KB of staging) + one word read ahead
 

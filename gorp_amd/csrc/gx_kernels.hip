@@ -222,8 +222,10 @@ k_extract_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const 
     W.row_bytes = L.row_bytes;
     W.ops_off = L.ops_off;
     W.ops = L.ops;
-    const uint32_t info_off = L.row_bytes - 4u;
-    const uint32_t acc_off = L.row_bytes - 8u;
+    W.rec = L.rec;
+    W.acc_tab = L.acc_tab;
+    W.dead = want_caps ? L.u_dead : L.m_dead;
+    W.ncls = L.ncls;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t slice = L.stage + wave * L.stage_bytes;
@@ -255,7 +257,7 @@ k_extract_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const 
         const bool service = idle >= 16u || !__any(has_line && !finished);
         const bool done = service && finished;
         if (done) {
-            const int32_t info = static_cast<int32_t>(tab_word<TIER>(W, row, info_off));
+            const int32_t info = state_info<TIER>(W, row);
             if (!want_caps) out.id(i, info);
             else out.id(i, line_result<TIER>(info, L.fin_tags, fin_g, regs, len, T.max_groups, [&](int g, int32_t pb, int32_t pe) {
                 out.cap(i, 2 * g, pb);
@@ -282,7 +284,7 @@ k_extract_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const 
                     len = static_cast<uint32_t>(len64);
                     pos = 0;
                     row = row0;
-                    const uint32_t acc = tab_word<TIER>(W, row, acc_off);
+                    const uint32_t acc = state_acc<TIER>(W, row);
                     lo4 = splat_byte0(acc);
                     k4 = splat_byte1(acc);
                 }
@@ -350,7 +352,7 @@ k_extract_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const 
                     if (!masked) row = steps16<TIER, false, false, false>(w0, mask, W, row, rel, regs);
                     else row = steps16<TIER, false, true, false>(w0, mask, W, row, rel, regs);
                 }
-                const uint32_t acc = tab_word<TIER>(W, row, acc_off);
+                const uint32_t acc = state_acc<TIER>(W, row);
                 lo4 = splat_byte0(acc);
                 k4 = splat_byte1(acc);
             }
@@ -407,6 +409,10 @@ hipError_t launch_extract_slices(const GxDev& dev, const GxLds& lds, const uint8
     if (at_global) {
         if (b.offsets64) return launch_slices_t<uint64_t, TIER_L2>(dev, lds, lds_image, at_global, grid, block, b, stream);
         return launch_slices_t<uint32_t, TIER_L2>(dev, lds, lds_image, at_global, grid, block, b, stream);
+    }
+    if (lds.tier == 2) {
+        if (b.offsets64) return launch_slices_t<uint64_t, TIER_REC>(dev, lds, lds_image, nullptr, grid, block, b, stream);
+        return launch_slices_t<uint32_t, TIER_REC>(dev, lds, lds_image, nullptr, grid, block, b, stream);
     }
     if (b.offsets64) return launch_slices_t<uint64_t, TIER_LDS>(dev, lds, lds_image, nullptr, grid, block, b, stream);
     return launch_slices_t<uint32_t, TIER_LDS>(dev, lds, lds_image, nullptr, grid, block, b, stream);

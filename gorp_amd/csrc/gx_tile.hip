@@ -61,11 +61,10 @@ struct TileIO {
 template <int TIER, bool CAPTURE, bool SIMPLE>
 __device__ __forceinline__ uint32_t walk(const WalkTab& W, uint32_t stage, uint32_t bitmap, bool use_map, uint32_t row, uint32_t start,
                                          uint32_t end, bool on, uint32_t dead_row, uint32_t regs) {
-    const uint32_t acc_off = W.row_bytes - 8u;  // self-loop interval column: lo | (0x7F - hi) << 8 | hot << 16
     uint32_t wb = start;  // windows are relative to the line, not to the staging area: see lds_window
     const uint32_t len = end - start;
     const uint32_t full_lim = len >= 16u ? len - 15u : 0u;  // window at line offset rel is full iff rel < full_lim
-    uint32_t acc = tab_word<TIER>(W, row, acc_off);
+    uint32_t acc = state_acc<TIER>(W, row);  // self-loop interval: lo | (0x7F - hi) << 8 | hot << 16
     uint32_t lo4 = splat_byte0(acc), k4 = splat_byte1(acc);
     bool more = on && start < end;
     while (__any(more)) {
@@ -104,7 +103,7 @@ __device__ __forceinline__ uint32_t walk(const WalkTab& W, uint32_t stage, uint3
         if (step) {
             if (!masked) row = steps16<TIER, CAPTURE, false, SIMPLE>(w0, mask, W, row, rel, regs);
             else row = steps16<TIER, CAPTURE, true, SIMPLE>(w0, mask, W, row, rel, regs);
-            acc = tab_word<TIER>(W, row, acc_off);
+            acc = state_acc<TIER>(W, row);
             lo4 = splat_byte0(acc);
             k4 = splat_byte1(acc);
         }
@@ -236,9 +235,13 @@ k_extract_tile(GxLds L, TileIO io) {
     Wm.row_bytes = L.row_bytes;
     Wm.ops_off = L.ops_off;
     Wm.ops = L.ops;
+    Wm.rec = L.rec;
+    Wm.acc_tab = L.acc_tab;
+    Wm.dead = L.m_dead;
+    Wm.ncls = L.ncls;
     Wc = Wm;
     if (GT) Wc.at = io.at_global + L.c_base;
-    const uint32_t info_off = L.row_bytes - 4u;  // per-state info column: accept / final-tags offset
+    Wc.dead = L.u_dead;  // (two-pass layout: set per lane below)
 
     const uint32_t lane = threadIdx.x & 63u;
     // (the wave index through readfirstlane: everything derived from it -- tile numbers, LDS areas, the round's span --
@@ -360,7 +363,7 @@ k_extract_tile(GxLds L, TileIO io) {
         } else if (MODE == 0) {
             // ---- hot loop #1 alone: PolyMatcher.match ----
             const uint32_t mrow = walk<TIER, false, false>(Wm, stage, bitmap, use_map, L.m_start, start, end, true, L.m_dead, regs);
-            if (valid) io.match_id[i] = static_cast<int32_t>(tab_word<TIER>(Wm, mrow, info_off));
+            if (valid) io.match_id[i] = state_info<TIER>(Wm, mrow);
             GX_STAMP(2);
         } else {
             int32_t info;  // of the state the line's walk ended in: -1 null, -2-k ExtractionException, else its final record
@@ -369,18 +372,19 @@ k_extract_tile(GxLds L, TileIO io) {
                 uint32_t urow;
                 if (MODE == 1 || L.simple_ops) urow = walk<TIER, true, true>(Wc, stage, bitmap, use_map, L.u_start, start, end, true, L.u_dead, regs);
                 else urow = walk<TIER, true, false>(Wc, stage, bitmap, use_map, L.u_start, start, end, true, L.u_dead, regs);
-                info = static_cast<int32_t>(tab_word<TIER>(Wc, urow, info_off));
+                info = state_info<TIER>(Wc, urow);
             } else {
                 // ---- hot loop #1, then hot loop #2 on extraction k's tagged automaton ----
                 const uint32_t mrow = walk<TIER, false, false>(Wm, stage, bitmap, use_map, L.m_start, start, end, true, L.m_dead, regs);
-                const int32_t k = static_cast<int32_t>(tab_word<TIER>(Wm, mrow, info_off));
+                const int32_t k = state_info<TIER>(Wm, mrow);
                 info = k;
                 uint32_t crow = GT ? 0u : L.m_dead;  // any valid row: the walk below is off for lanes without a match
                 if (k >= 0) crow = lds_ld<uint32_t>(L.c_rule + 8u * k);
+                if (TIER == TIER_REC) Wc.dead = k >= 0 ? lds_ld<uint32_t>(L.c_rule + 8u * k + 4u) : L.m_dead;  // the rule's own dead state
                 if (L.simple_ops) crow = walk<TIER, true, true>(Wc, stage, bitmap, use_map, crow, start, end, k >= 0, 0xFFFFFFFFu, regs);
                 else crow = walk<TIER, true, false>(Wc, stage, bitmap, use_map, crow, start, end, k >= 0, 0xFFFFFFFFu, regs);
                 if (k >= 0) {
-                    info = static_cast<int32_t>(tab_word<TIER>(Wc, crow, info_off));
+                    info = state_info<TIER>(Wc, crow);
                     if (info < 0) info = -2 - k;  // DFA said yes, capture regex says no -> ExtractionException
                 }
             }
@@ -522,6 +526,10 @@ hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t
     if (at_global) {
         if (b.offsets64) return launch_tile_m<uint64_t, TIER_L2>(mode, lds, io, grid, block, stream);
         return launch_tile_m<uint32_t, TIER_L2>(mode, lds, io, grid, block, stream);
+    }
+    if (lds.tier == 2) {
+        if (b.offsets64) return launch_tile_m<uint64_t, TIER_REC>(mode, lds, io, grid, block, stream);
+        return launch_tile_m<uint32_t, TIER_REC>(mode, lds, io, grid, block, stream);
     }
     if (b.offsets64) return launch_tile_m<uint64_t, TIER_LDS>(mode, lds, io, grid, block, stream);
     return launch_tile_m<uint32_t, TIER_LDS>(mode, lds, io, grid, block, stream);

@@ -98,20 +98,44 @@ __device__ __forceinline__ uint32_t window_mask(uint32_t start, uint32_t end, ui
 
 // Where the automaton rows live.  TIER_LDS: dense rows in LDS, a state is the LDS byte address of its row (the host
 // bakes the table's position into every successor field).  TIER_L2: dense rows in global memory (they stay resident
-// in the XCD's L2), a state is its index and the row address is index * row_bytes.
-enum { TIER_LDS = 0, TIER_L2 = 1 };
+// in the XCD's L2), a state is its index and the row address is index * row_bytes.  TIER_REC: sparse range records
+// in LDS (gx_api.cpp: records_from_dense), a state is the index of its first 8-byte record.
+enum { TIER_LDS = 0, TIER_L2 = 1, TIER_REC = 2 };
 
 // wave-uniform description of the automaton being walked
 struct WalkTab {
     const uint8_t* at;     // TIER_L2: base of the rows in global memory
     uint32_t row_bytes;    // dense row stride
     uint32_t ops_off, ops; // LDS addresses of the capture program lists
+    uint32_t rec, acc_tab; // TIER_REC: LDS addresses of the records and of the interval table
+    uint32_t dead;         // TIER_REC: the automaton's dead state (where every class in no range leads)
+    uint32_t ncls;         // TIER_REC
 };
+
+constexpr uint32_t REC_LAST = 1u << 24, REC_HDR = 2u << 24, REC_IDC = 254u;
 
 template <int TIER>
 __device__ __forceinline__ uint32_t tab_word(const WalkTab& W, uint32_t row, uint32_t off) {
     if (TIER == TIER_L2) return *reinterpret_cast<const uint32_t*>(W.at + (static_cast<uint64_t>(row) * W.row_bytes + off));
     return lds_ld<uint32_t>(row + off);
+}
+// a state's self-loop interval word (lo | (0x7F - hi) << 8 | hot << 16) and its info word
+template <int TIER>
+__device__ __forceinline__ uint32_t state_acc(const WalkTab& W, uint32_t row) {
+    if (TIER == TIER_REC) {
+        const uint32_t self_lo = lds_ld<uint32_t>(W.rec + (row << 3)) & 0xFFu;  // 255: no self range
+        return lds_ld<uint32_t>(W.acc_tab + 4u * min(self_lo, W.ncls));          // entry ncls: no interval
+    }
+    return tab_word<TIER>(W, row, W.row_bytes - 8u);
+}
+template <int TIER>
+__device__ __forceinline__ int32_t state_info(const WalkTab& W, uint32_t row) {
+    if (TIER == TIER_REC) {
+        const uint32_t a = W.rec + (row << 3);
+        const bool hdr = (lds_ld<uint32_t>(a + 4u) & REC_HDR) != 0u;
+        return hdr ? static_cast<int32_t>(lds_ld<uint32_t>(a - 4u)) : -1;  // (a - 4 is inside the records for every state)
+    }
+    return static_cast<int32_t>(tab_word<TIER>(W, row, W.row_bytes - 4u));
 }
 
 // General capture program (anything but a single "tag := position"): executed from the LDS copy of the op lists
@@ -152,6 +176,82 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
         c4[j] = lds_ld<uint16_t>(b << 1);
     }
     const uint32_t dummy_col = regs - 128u;
+    if (TIER == TIER_REC) {
+        // c4[] holds class ids here.  One record read per byte, two range tests (c - lo <= span, the byte fields picked
+        // by operand selectors), two selects.  The sixteen steps are straight-line code; a lane that meets a state
+        // with more ranges than one record holds and finds its class in none of the first record's goes to the dead
+        // state (and writes nothing but the dummy column from there on) and raises `more`: the window is then walked
+        // again with the general steps below, which follow a state's further records -- same start, same writes, so
+        // the second pass simply overwrites the first.
+        const uint32_t row0 = row;
+        bool more = false;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t c = c4[j];
+            const u32x2 it = lds_ld<u32x2>(W.rec + (row << 3));
+            const bool in_exit = (c - ((it.x >> 16) & 0xFFu)) <= (it.x >> 24);
+            const bool in_self = (c - (it.x & 0xFFu)) <= ((it.x >> 8) & 0xFFu);
+            uint32_t next = in_exit ? (it.y & 0xFFFFu) : (in_self ? row : W.dead);
+            uint32_t op = in_exit ? ((it.y >> 16) & 0xFFu) : 0u;
+            bool pending = !in_exit && !in_self && (it.y & REC_LAST) == 0u;
+            if (MASKED) {
+                const bool idc = c == REC_IDC;  // a byte outside the line: stay, no program
+                next = idc ? row : next;
+                op = idc ? 0u : op;
+                pending = pending && !idc;
+            }
+            more = more || pending;
+            row = next;
+            if (CAPTURE) {
+                const uint16_t pos = static_cast<uint16_t>(rel + j);
+                if (SIMPLE) {
+                    lds_st<uint16_t>(dummy_col + (op << 7), pos);
+                } else if (op) {
+                    if (op & 0x80u) lds_st<uint16_t>(regs + (op & 0x7Fu) * 128u, pos);
+                    else run_op_list(W, regs, op, pos);
+                }
+            }
+        }
+        if (!__any(more)) return row;
+        row = row0;
+        for (int j = 0; j < 16; ++j) {  // (a real loop: this path is rare and long; no register array indexed by j)
+            const uint32_t dw = j < 8 ? (j < 4 ? win.x : win.y) : (j < 12 ? win.z : win.w);
+            uint32_t b = (dw >> ((j & 3) * 8)) & 0xFFu;
+            if (MASKED && ((mask >> j) & 1u) == 0u) b = 256u;
+            const uint32_t c = lds_ld<uint16_t>(b << 1);
+            uint32_t a = W.rec + (row << 3);
+            u32x2 it = lds_ld<u32x2>(a);
+            bool in_exit = (c - ((it.x >> 16) & 0xFFu)) <= (it.x >> 24);
+            const bool in_self = (c - (it.x & 0xFFu)) <= ((it.x >> 8) & 0xFFu);
+            uint32_t next = in_exit ? (it.y & 0xFFFFu) : (in_self ? row : W.dead);
+            uint32_t op = in_exit ? ((it.y >> 16) & 0xFFu) : 0u;
+            bool pending = !in_exit && !in_self && (it.y & REC_LAST) == 0u;
+            if (MASKED) {
+                const bool idc = c == REC_IDC;
+                next = idc ? row : next;
+                op = idc ? 0u : op;
+                pending = pending && !idc;
+            }
+            while (__any(pending)) {
+                a += pending ? 8u : 0u;
+                it = lds_ld<u32x2>(a);
+                in_exit = (c - ((it.x >> 16) & 0xFFu)) <= (it.x >> 24);
+                if (pending && in_exit) { next = it.y & 0xFFFFu; op = (it.y >> 16) & 0xFFu; }
+                pending = pending && !in_exit && (it.y & REC_LAST) == 0u;
+            }
+            row = next;
+            if (CAPTURE) {
+                const uint16_t pos = static_cast<uint16_t>(rel + j);
+                if (SIMPLE) {
+                    lds_st<uint16_t>(dummy_col + (op << 7), pos);
+                } else if (op) {
+                    if (op & 0x80u) lds_st<uint16_t>(regs + (op & 0x7Fu) * 128u, pos);
+                    else run_op_list(W, regs, op, pos);
+                }
+            }
+        }
+        return row;
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         uint32_t op = 0;

@@ -288,12 +288,13 @@ def test_syslog_16_rules():
     assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
 
 
-@pytest.mark.parametrize("tier", [2, 3])
+@pytest.mark.parametrize("tier", [2, 3, 4])
 def test_table_tiers_agree_with_oracle(tier, monkeypatch):
-    """The same definitions through the L2-tier tile kernel (automaton rows in global memory) and through the
-    per-line generic kernel; the default for these small definitions is the LDS tier, covered everywhere else."""
-    monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", {2: N.GX_CREATE_TIER_L2, 3: N.GX_CREATE_NO_TILES}[tier])
-    want = {2: 2, 3: 0}[tier]
+    """The same definitions through the L2-tier tile kernel (automaton rows in global memory), through the per-line
+    generic kernel and through the record tier (sparse range records in LDS); the default for these small definitions
+    is the LDS tier with dense rows, covered everywhere else."""
+    monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", {2: N.GX_CREATE_TIER_L2, 3: N.GX_CREATE_NO_TILES, 4: N.GX_CREATE_TIER_RECORDS}[tier])
+    want = {2: 2, 3: 0, 4: 3}[tier]
     # config 1
     definition = W.simple_grp_definition()
     gorp, orc = Gorp.construct(definition), oracle_for(definition)
@@ -337,12 +338,14 @@ def test_table_tiers_agree_with_oracle(tier, monkeypatch):
         check_batch(gorp, orc, lines)
 
 
-def test_config3_64_rules_parity():
-    """BASELINE.json configs[2]: 64 extractions (tables beyond the LDS tier -> L2-tier tile kernel)."""
+@pytest.mark.parametrize("flags", [0, N.GX_CREATE_TIER_L2])
+def test_config3_64_rules_parity(flags):
+    """BASELINE.json configs[2]: 64 extractions.  The dense rows (2.3 MB) do not fit LDS; the states are sparse, so the
+    tables become range records in LDS (tier 3) -- and, forced, dense rows in global memory / L2 (tier 2)."""
     rules, meta = W.syslog_definition(64, seed=3)
-    gorp, orc = Gorp.construct(rules), oracle_for(rules)
+    gorp, orc = Gorp.construct(rules, flags=flags), oracle_for(rules)
     assert gorp.stat(0) > 1000  # match-automaton states
-    assert gorp.stat(7) == 2    # automaton rows in global memory
+    assert gorp.stat(7) == (2 if flags else 3)
     data, offsets, cats = W.syslog_lines(meta, 30000, seed=3)
     mid, caps = gorp.extract_batch(data, offsets)
     omid, ocaps = orc.extract_batch(data, offsets, nthreads=8)
@@ -350,6 +353,85 @@ def test_config3_64_rules_parity():
     known = cats != -9
     assert np.array_equal(mid[known], cats[known])
     assert len(set(mid[mid >= 0].tolist())) == 64  # every extraction wins somewhere
+    m2, _ = gorp.extract_batch(data, offsets, match_only=True)   # (record tier: the match automaton's own image)
+    assert np.array_equal(m2, orc.extract_batch(data, offsets, match_only=True, nthreads=8)[0])
+    rows, over = gorp.extract_batch(data, offsets, compact=True)
+    cm, cc = G.unpack_rows(rows)
+    assert over == 0 and np.array_equal(cm, omid) and np.array_equal(cc, ocaps)
+
+
+def _tiled_on_device(data, offsets, reps):
+    """A host CSR sample repeated `reps` times in HBM (offsets rebased per copy): how the benchmarks build configs 3-5."""
+    import torch
+    total = int(offsets[-1])
+    d = torch.from_numpy(data.copy()).cuda().repeat(reps)
+    o = (torch.from_numpy(offsets[:-1].astype(np.int64)).cuda()[None, :] +
+         torch.arange(reps, device="cuda", dtype=torch.int64)[:, None] * total).reshape(-1)
+    o = torch.cat([o, torch.tensor([total * reps], device="cuda", dtype=torch.int64)])
+    assert total * reps < 2 ** 32
+    return d, o.to(torch.uint32)
+
+
+def _full_size_properties(gorp, orc, data, offsets, cats, reps, hint):
+    """Size-independent checks of a tiled batch at its full benchmark size: the generator's answers, every copy of the
+    sample identical to the first, idempotence, both result formats agreeing, and an oracle-checked strided sample."""
+    import torch
+    base_n = len(offsets) - 1
+    d, o = _tiled_on_device(data, offsets, reps)
+    n = base_n * reps
+    G_ = gorp.max_groups
+    mid = torch.empty(n, dtype=torch.int32, device="cuda")
+    caps = torch.empty((n, 2 * G_), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    gorp.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=st, line_bytes_hint=hint)
+    torch.cuda.synchronize()
+    known = torch.from_numpy(cats != -9).cuda().repeat(reps)
+    want = torch.from_numpy(cats).cuda().repeat(reps)
+    assert torch.equal(mid[known], want[known])                       # the generator knows the uncorrupted lines' answers
+    assert torch.equal(mid.view(reps, base_n), mid[:base_n].expand(reps, base_n))   # every copy like the first ...
+    assert torch.equal(caps.view(reps, base_n, 2 * G_), caps[:base_n].expand(reps, base_n, 2 * G_))  # ... offsets included
+    mid2, caps2 = torch.empty_like(mid), torch.empty_like(caps)
+    gorp.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid2.data_ptr(), caps2.data_ptr(), stream=st, line_bytes_hint=hint)
+    torch.cuda.synchronize()
+    assert torch.equal(mid, mid2) and torch.equal(caps, caps2)        # idempotence
+    rows = torch.empty((n, 1 + 2 * G_), dtype=torch.int16, device="cuda")
+    over = torch.zeros(1, dtype=torch.int64, device="cuda")
+    gorp.extract_batch_device(d.data_ptr(), o.data_ptr(), n, None, rows.data_ptr(), stream=st, line_bytes_hint=hint, compact=True,
+                              overflow_ptr=over.data_ptr())
+    torch.cuda.synchronize()
+    assert int(over.item()) == 0 and torch.equal(rows[:, 0].to(torch.int32), mid)
+    assert torch.equal(rows[:, 1:].to(torch.int32), caps)             # (-1 stays -1 through int16; offsets < 32768 here)
+    ok = mid >= 0
+    assert bool((caps[~ok] == -1).all())
+    assert bool((caps[ok][:, 0] >= 0).all())                          # a matched line has its first group
+    # captured spans lie inside their lines, begin <= end
+    lens = (o[1:].to(torch.int64) - o[:-1].to(torch.int64))
+    cb, ce = caps[:, 0::2].to(torch.int64), caps[:, 1::2].to(torch.int64)
+    setg = cb >= 0
+    assert bool((cb[setg] <= ce[setg]).all()) and bool((ce[setg] <= lens[:, None].expand_as(ce)[setg]).all())
+    # a strided sample of the first copy against the oracle (the other copies equal it)
+    take = np.arange(0, base_n, max(1, base_n // 20000))
+    sd = [bytes(data[int(offsets[i]):int(offsets[i + 1])]) for i in take]
+    sdat, soff = lines_to_csr(sd)
+    omid, ocaps = orc.extract_batch(sdat, soff, nthreads=8)
+    assert np.array_equal(mid[:base_n].cpu().numpy()[take], omid) and np.array_equal(caps[:base_n].cpu().numpy()[take], ocaps)
+
+
+def test_config3_full_size_properties():
+    """BASELINE.json configs[2] at its full size: 64 extractions, 10 M x 200-byte lines (a 100 k-line sample tiled)."""
+    rules, meta = W.syslog_definition(64, seed=3)
+    gorp, orc = Gorp.construct(rules), oracle_for(rules)
+    data, offsets, cats = W.syslog_lines(meta, 100_000, seed=3)
+    _full_size_properties(gorp, orc, data, offsets, cats, 100, 200)
+
+
+def test_config5_full_size_properties():
+    """BASELINE.json configs[4] at its full size: 512 extractions, ~2 GB of 50-2000-byte lines (a 20 k-line sample tiled)."""
+    rules, meta = W.syslog_definition(512, seed=3)
+    gorp, orc = Gorp.construct(rules), oracle_for(rules)
+    data, offsets, cats = W.syslog_lines(meta, 20_000, seed=5, min_len=50, max_len=2000)
+    total = int(offsets[-1])
+    _full_size_properties(gorp, orc, data, offsets, cats, 2_000_000_000 // total, int(total / 20_000 + 0.999))
 
 
 def test_config5_512_rules_mixed_lengths_parity():
@@ -385,12 +467,12 @@ def test_config1_from_definition_text(tmp_path):
     assert r.getId() == "sampleMatch" and r.asMap()["authStatus"] == "Accepted"
 
 
-@pytest.mark.parametrize("tier", [1, 2])
+@pytest.mark.parametrize("tier", [1, 2, 3])
 def test_mixed_lengths_take_several_rounds_per_group(tier, monkeypatch):
     """Lines of 0-3000 bytes against a staging area sized for the mean: groups are walked in several rounds of
     consecutive lanes, a line longer than the staging area alone takes the per-lane path; all bit-exact."""
-    if tier == 2:
-        monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", N.GX_CREATE_TIER_L2)
+    if tier != 1:
+        monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", {2: N.GX_CREATE_TIER_L2, 3: N.GX_CREATE_TIER_RECORDS}[tier])
     definition = W.readme3_definition()
     gorp, orc = Gorp.construct(definition), oracle_for(definition)
     rng = random.Random(99)
@@ -417,7 +499,8 @@ def test_mixed_lengths_take_several_rounds_per_group(tier, monkeypatch):
 
 
 @pytest.mark.parametrize("variant", [{}, {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_TIER_L2}, {"DEFAULT_KERNEL": N.GX_KERNEL_SLICES},
-                                     {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_NO_TILES}, {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_NO_FUSED}])
+                                     {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_NO_TILES}, {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_NO_FUSED},
+                                     {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_TIER_RECORDS}])
 def test_compact_rows_from_the_kernels(variant, monkeypatch):
     """gx_batch_opts.compact_results: every kernel writes the compact rows itself (full tiles through the LDS transpose,
     ragged groups and the per-line follow-up lane by lane); device buffers, offsets beyond 65534 counted."""
@@ -510,13 +593,13 @@ def test_utf16_batch_input():
     assert m2.tolist() == mid.tolist()
 
 
-@pytest.mark.parametrize("tier", [1, 2])
+@pytest.mark.parametrize("tier", [1, 2, 3])
 def test_slice_kernel_agrees_with_oracle(tier, monkeypatch):
     """The slice kernel (64 bytes of every line staged at a time; the default for batches with long lines) forced
     on for short, ragged, terminated and very long lines, tables in LDS and in global memory."""
     monkeypatch.setattr(G, "DEFAULT_KERNEL", N.GX_KERNEL_SLICES)
-    if tier == 2:
-        monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", N.GX_CREATE_TIER_L2)
+    if tier != 1:
+        monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", {2: N.GX_CREATE_TIER_L2, 3: N.GX_CREATE_TIER_RECORDS}[tier])
     definition = W.simple_grp_definition()
     gorp, orc = Gorp.construct(definition), oracle_for(definition)
     check_batch(gorp, orc, W.simple_grp_lines(3000, seed=31))
@@ -588,11 +671,11 @@ def test_cooked_extraction_match_is_the_capture_regexp_alone(golden):
     assert n_match > 50
 
 
-@pytest.mark.parametrize("tier", [1, 2])
+@pytest.mark.parametrize("tier", [1, 2, 3])
 def test_two_pass_layout_without_the_fused_automaton(tier, monkeypatch):
     """Definitions too large for the fused automaton walk the match automaton and then the winning extraction's
     capture automaton; forced here (GX_CREATE_NO_FUSED) on small definitions, tables in LDS and in global memory."""
-    monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", N.GX_CREATE_NO_FUSED | (N.GX_CREATE_TIER_L2 if tier == 2 else 0))
+    monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", N.GX_CREATE_NO_FUSED | {1: 0, 2: N.GX_CREATE_TIER_L2, 3: N.GX_CREATE_TIER_RECORDS}[tier])
     import test_compiler_vs_oracle as TC
     from blob_interp import Blob
     definition = W.readme3_definition()
@@ -625,7 +708,8 @@ def test_two_pass_layout_without_the_fused_automaton(tier, monkeypatch):
         check_batch(gorp, orc, lines)
 
 
-@pytest.mark.parametrize("variant", [{}, {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_TIER_L2}, {"DEFAULT_KERNEL": N.GX_KERNEL_SLICES}])
+@pytest.mark.parametrize("variant", [{}, {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_TIER_L2}, {"DEFAULT_KERNEL": N.GX_KERNEL_SLICES},
+                                     {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_TIER_RECORDS}])
 def test_unaligned_device_buffers(variant, monkeypatch):
     """Device pointers with no particular alignment (a view 3 bytes into a tensor; results 4 bytes into theirs): the
     edge chunks of the first and last tile take the guarded copy, results the per-line stores."""
