@@ -130,7 +130,8 @@ template <typename F> uint16_t self_loop_interval(F loops) {
 constexpr uint32_t REC_LAST = 1u << 24, REC_HDR = 2u << 24, REC_IDC = 254u, REC_EMPTY = 255u;
 
 bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t rows, uint32_t cols, const std::vector<uint32_t>& dead_of_row,
-                        const std::vector<std::array<uint64_t, 2>>& loop_set, bool simple, Image& img, GxLds& L, std::vector<uint32_t>& c_rule) {
+                        const std::vector<std::array<uint64_t, 2>>& loop_set, bool simple, Image& img, GxLds& L, std::vector<uint32_t>& c_rule,
+                        std::vector<uint32_t>* items_global) {
     const Tables& T = h->T;
     const int ncls = T.ncls;
     const uint32_t ACC = ncls + 1, INFO = ncls + 2;
@@ -324,7 +325,8 @@ bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t ro
     for (int b = 0; b < 256; ++b) cmap[b] = static_cast<uint16_t>(new_id[T.cls256[b]]);
     L.cmap = static_cast<uint32_t>(img.put(cmap));
     L.acc_tab = static_cast<uint32_t>(img.put(acc_tab));
-    L.rec = static_cast<uint32_t>(img.put(items));
+    if (items_global) { L.rec = 0; items_global->swap(items); }  // records in global memory (tier 3)
+    else L.rec = static_cast<uint32_t>(img.put(items));
     L.at = 0;
     if (L.m_dead < rows) { L.m_start = index_of[L.m_start]; L.m_dead = index_of[L.m_dead]; }  // (absent from a capture-only image)
     if (L.u_start != 0xFFFFFFFFu) { L.u_start = index_of[L.u_start]; L.u_dead = index_of[L.u_dead]; }
@@ -344,16 +346,20 @@ bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t ro
 // tier 2: record tier, for automata whose dense rows do not fit LDS but whose states are sparse (a literal chain
 //         link has one live class, a field state one self range and one exit): every state becomes a few 8-byte
 //         range records in LDS (records_from_dense below; ~8.5 bytes per state instead of 4 * classes).
+// tier 3: the same records in global memory (h->l2_image), where 64-512 KB of them live in the vector L1 / L2 caches.
 bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t rows, uint32_t cols, const std::vector<uint32_t>& dead_of_row,
-                        const std::vector<std::array<uint64_t, 2>>& loop_set, bool simple, Image& img, GxLds& L, std::vector<uint32_t>& c_rule);
+                        const std::vector<std::array<uint64_t, 2>>& loop_set, bool simple, Image& img, GxLds& L, std::vector<uint32_t>& c_rule,
+                        std::vector<uint32_t>* items_global);
 
 // part 0: match automaton + capture automata in one image; 1: capture side alone (fused automaton); 2: match alone.
 bool build_tile_image(gx_handle* h, int tier, int part = 0) {
     const Tables& T = h->T;
     const bool global = tier == 1;
+    const bool in_global = tier == 1 || tier == 3;  // automaton tables and final records in h->l2_image
+    if (part != 2 && tier == 3) h->l2_image.clear();
     if (part != 2) {
         h->tile_ok = false;
-        h->tile_global = global;
+        h->tile_global = in_global;
         h->has_mo = false;
     }
     if (T.n_rules > 32767) return false;
@@ -371,8 +377,8 @@ bool build_tile_image(gx_handle* h, int tier, int part = 0) {
     const size_t rows = m_rows + c_rows;
     if (T.ncls > 252) return false;  // keeps the column offsets of a row (class * 4, + 3 extra columns) below 1024
     const uint32_t AT = 544;         // LDS tier: the rows follow the class map (u16[256] + the identity entry, padded)
-    if (tier == 2) {
-        if (rows > 60000u || T.ncls > 250) return false;  // 16-bit record indexes; class ids 254 / 255 are reserved
+    if (tier >= 2) {
+        if (rows > 65000u || T.ncls > 250) return false;  // 16-bit record indexes; class ids 254 / 255 are reserved
     } else if (!global) {
         if (AT + rows * RS > 65536u) return false;  // successors are 16-bit LDS addresses
         if (rows * RS + T.ops_off.size() * 4 + T.ops.size() * 2 + 1024 > LDS_TABLE_BUDGET) return false;  // (+ the final records, below)
@@ -533,10 +539,24 @@ bool build_tile_image(gx_handle* h, int tier, int part = 0) {
         }
     }
     if (c_rule.empty()) { c_rule.push_back(0); c_rule.push_back(0); }
-    if (tier == 2) {
-        img.bytes.clear();  // the record tier has its own class map (classes renumbered so that sets become ranges)
-        if (!records_from_dense(h, at, rows, cols, dead_of_row, loop_set, simple, img, L, c_rule)) return false;
-        if (img.bytes.size() + T.ops_off.size() * 4 + T.ops.size() * 2 + fin_rec.size() * 2 + 1024 > LDS_TABLE_BUDGET) return false;
+    // tier 3: one global image per handle: [capture-side records + final records][match-only records]; GxLds::rec_g /
+    // fin_tags are byte offsets into it
+    const size_t g_base = h->l2_image.size();
+    if (tier >= 2) {
+        img.bytes.clear();  // the record tiers have their own class map (classes renumbered so that sets become ranges)
+        std::vector<uint32_t> items_g;
+        if (!records_from_dense(h, at, rows, cols, dead_of_row, loop_set, simple, img, L, c_rule, tier == 3 ? &items_g : nullptr)) return false;
+        if (tier == 2 && img.bytes.size() + T.ops_off.size() * 4 + T.ops.size() * 2 + fin_rec.size() * 2 + 1024 > LDS_TABLE_BUDGET) return false;
+        if (tier == 3) {
+            L.c_base = static_cast<uint32_t>(g_base);  // (byte offset of this image's records in the global image)
+            const uint8_t* ib = reinterpret_cast<const uint8_t*>(items_g.data());
+            h->l2_image.insert(h->l2_image.end(), ib, ib + items_g.size() * 4);
+            while (h->l2_image.size() % 16) h->l2_image.push_back(0);
+            L.fin_tags = static_cast<uint32_t>(h->l2_image.size());
+            const uint8_t* fr = reinterpret_cast<const uint8_t*>(fin_rec.data());
+            h->l2_image.insert(h->l2_image.end(), fr, fr + fin_rec.size() * 2);
+            while (h->l2_image.size() % 16) h->l2_image.push_back(0);
+        }
     } else if (global) {
         L.at = 0;
         h->l2_image.assign(reinterpret_cast<const uint8_t*>(at.data()), reinterpret_cast<const uint8_t*>(at.data() + at.size()));
@@ -553,7 +573,7 @@ bool build_tile_image(gx_handle* h, int tier, int part = 0) {
     std::vector<uint16_t> ops = T.ops;
     if (ops.empty()) ops.push_back(0);
     L.ops = static_cast<uint32_t>(img.put(ops));
-    if (!global) L.fin_tags = static_cast<uint32_t>(img.put(fin_rec));
+    if (!in_global) L.fin_tags = static_cast<uint32_t>(img.put(fin_rec));
     L.tier = static_cast<uint32_t>(tier);
     while (img.bytes.size() % 16) img.bytes.push_back(0);
     L.table_bytes = static_cast<uint32_t>(img.bytes.size());
@@ -632,13 +652,30 @@ bool plan_slice_launch(const gx_handle* h, GxLds* out, bool match_only = false) 
 void choose_tile_image(gx_handle* h) {
     const bool no_tiles = (h->create_flags & GX_CREATE_NO_TILES) != 0, force_l2 = (h->create_flags & GX_CREATE_TIER_L2) != 0;
     const bool force_rec = (h->create_flags & GX_CREATE_TIER_RECORDS) != 0;
-    auto records = [&]() {
-        if (build_tile_image(h, 2)) return true;
+    auto records = [&](int tier) {
+        if (build_tile_image(h, tier)) return true;
         // the fused automaton alone, and a second image with the match automaton alone for match-only batches
-        return build_tile_image(h, 2, 1) && build_tile_image(h, 2, 2);
+        return build_tile_image(h, tier, 1) && build_tile_image(h, tier, 2);
     };
-    if (no_tiles || !((!force_l2 && !force_rec && build_tile_image(h, 0)) || (!force_l2 && records()) || build_tile_image(h, 1)))
-        h->tile_ok = false;
+    const bool force_recg = (h->create_flags & GX_CREATE_TIER_RECORDS_GLOBAL) != 0;
+    bool ok = false;
+    if (!no_tiles) {
+        if (force_l2) ok = build_tile_image(h, 1);
+        else if (force_recg) ok = records(3) || build_tile_image(h, 1);
+        else if (force_rec) ok = records(2) || records(3) || build_tile_image(h, 1);
+        else {
+            // Measured on the 64-extraction definition of BASELINE configs[2] (10 M x 200-byte lines): captures -- dense
+            // rows in L2 3.0 ms, records in LDS 3.9 ms (6 waves and a longer decode per byte), records in global memory
+            // 4.0 ms; match only -- records in LDS 2.2 ms against 3.0 ms.  Hence: dense rows in LDS when they fit, else
+            // dense rows in global memory for the capture side and, when they fit, LDS records for match-only batches.
+            ok = build_tile_image(h, 0);
+            if (!ok) {
+                ok = build_tile_image(h, 1);
+                if (ok) (void)build_tile_image(h, 2, 2);
+            }
+        }
+    }
+    if (!ok) h->tile_ok = false;
 }
 
 void upload(gx_handle* h) {
@@ -746,9 +783,10 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
     const bool slices = kernel == GX_KERNEL_SLICES || (kernel == GX_KERNEL_AUTO && line_bytes_hint > 255u);
     const bool mo = b.match_only != 0 || !h->T.has_capture;
     const uint8_t* image = static_cast<const uint8_t*>(mo && h->has_mo ? h->d_lds_image_mo : h->d_lds_image);
+    const uint32_t image_tier = mo && h->has_mo ? h->lds_mo.tier : h->lds.tier;
+    const uint8_t* at_global = image_tier == 1 || image_tier == 3 ? static_cast<const uint8_t*>(h->d_l2_image) : nullptr;
     if (batchable && slices && plan_slice_launch(h, &L, mo)) {
-        GX_HIP(launch_extract_slices(h->dev, L, image,
-                                     h->tile_global ? static_cast<const uint8_t*>(h->d_l2_image) : nullptr, h->num_cus, b, stream));
+        GX_HIP(launch_extract_slices(h->dev, L, image, at_global, h->num_cus, b, stream));
         return;
     }
     if (batchable && plan_tile_launch(h, line_bytes_hint, &L, mo)) {
@@ -765,8 +803,7 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
 #ifdef GX_DEV
         stamps = h->dev_stamps;
 #endif
-        GX_HIP(launch_extract_tile(h->dev, L, image,
-                                   h->tile_global ? static_cast<const uint8_t*>(h->d_l2_image) : nullptr, h->num_cus, b, stream, stamps));
+        GX_HIP(launch_extract_tile(h->dev, L, image, at_global, h->num_cus, b, stream, stamps));
         GX_HIP(launch_extract_oversize(h->dev, b, L.stage_bytes, stream));
         GX_HIP(hipEventRecord(h->slot_event[slot], stream));
     } else {
@@ -871,8 +908,9 @@ int64_t gx_stat(const gx_handle* h, int32_t which) {
     case 4: return static_cast<int64_t>(h->blob.size());
     case 5: { GxLds L; return plan_tile_launch(h, 0, &L) ? static_cast<int64_t>(L.total_bytes) : 0; }
     case 6: { GxLds L; return plan_tile_launch(h, 0, &L) ? static_cast<int64_t>(L.nwaves) : 0; }
-    case 7: return !h->tile_ok ? 0 : h->tile_global ? 2 : h->lds.tier == 2 ? 3 : 1;
+    case 7: return !h->tile_ok ? 0 : h->lds.tier == 3 ? 4 : h->tile_global ? 2 : h->lds.tier == 2 ? 3 : 1;
     case 8: return h->T.has_capture ? 1 : 0;
+    case 9: return !h->tile_ok ? 0 : !h->has_mo ? gx_stat(h, 7) : h->lds_mo.tier == 3 ? 4 : h->lds_mo.tier == 2 ? 3 : h->lds_mo.tier == 1 ? 2 : 1;
     default: return -1;
     }
 }

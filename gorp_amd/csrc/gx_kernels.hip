@@ -215,10 +215,10 @@ k_extract_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const 
         for (uint32_t c = threadIdx.x; c < L.table_bytes / 16; c += blockDim.x) dst[c] = src[c];
     }
     __syncthreads();
-    constexpr bool GT = TIER == TIER_L2;
+    constexpr bool GT = TIER == TIER_L2 || TIER == TIER_RECG;
     const bool want_caps = match_only == 0 && T.has_capture;
     WalkTab W;  // the automaton this launch walks
-    W.at = GT ? (want_caps ? at_global + L.c_base : at_global) : nullptr;
+    W.at = GT ? (want_caps || TIER == TIER_RECG ? at_global + L.c_base : at_global) : nullptr;
     W.row_bytes = L.row_bytes;
     W.ops_off = L.ops_off;
     W.ops = L.ops;
@@ -406,6 +406,10 @@ hipError_t launch_extract_slices(const GxDev& dev, const GxLds& lds, const uint8
     const uint64_t need = (b.n + 256ull * lds.nwaves - 1) / (256ull * lds.nwaves);
     if (blocks > need) blocks = need;
     dim3 grid(static_cast<unsigned>(blocks)), block(lds.nwaves * 64);
+    if (at_global && lds.tier == 3) {
+        if (b.offsets64) return launch_slices_t<uint64_t, TIER_RECG>(dev, lds, lds_image, at_global, grid, block, b, stream);
+        return launch_slices_t<uint32_t, TIER_RECG>(dev, lds, lds_image, at_global, grid, block, b, stream);
+    }
     if (at_global) {
         if (b.offsets64) return launch_slices_t<uint64_t, TIER_L2>(dev, lds, lds_image, at_global, grid, block, b, stream);
         return launch_slices_t<uint32_t, TIER_L2>(dev, lds, lds_image, at_global, grid, block, b, stream);

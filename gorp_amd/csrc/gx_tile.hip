@@ -225,13 +225,13 @@ k_extract_tile(GxLds L, TileIO io) {
     }
     __syncthreads();
 
-    constexpr bool GT = TIER == TIER_L2;
+    constexpr bool GT = TIER == TIER_L2 || TIER == TIER_RECG;  // automaton tables and final records in global memory
     const uint8_t* __restrict__ data = io.data;
     const OFF* __restrict__ off = static_cast<const OFF*>(io.off);
     const uint64_t n = io.n;
     // match automaton / fused (or per-extraction capture) automaton
     WalkTab Wm, Wc;
-    Wm.at = GT ? io.at_global : nullptr;
+    Wm.at = GT ? io.at_global + (TIER == TIER_RECG ? L.c_base : 0u) : nullptr;  // (records: one index space per image)
     Wm.row_bytes = L.row_bytes;
     Wm.ops_off = L.ops_off;
     Wm.ops = L.ops;
@@ -380,7 +380,7 @@ k_extract_tile(GxLds L, TileIO io) {
                 info = k;
                 uint32_t crow = GT ? 0u : L.m_dead;  // any valid row: the walk below is off for lanes without a match
                 if (k >= 0) crow = lds_ld<uint32_t>(L.c_rule + 8u * k);
-                if (TIER == TIER_REC) Wc.dead = k >= 0 ? lds_ld<uint32_t>(L.c_rule + 8u * k + 4u) : L.m_dead;  // the rule's own dead state
+                if (TierTraits<TIER>::records) Wc.dead = k >= 0 ? lds_ld<uint32_t>(L.c_rule + 8u * k + 4u) : L.m_dead;  // the rule's own dead state
                 if (L.simple_ops) crow = walk<TIER, true, true>(Wc, stage, bitmap, use_map, crow, start, end, k >= 0, 0xFFFFFFFFu, regs);
                 else crow = walk<TIER, true, false>(Wc, stage, bitmap, use_map, crow, start, end, k >= 0, 0xFFFFFFFFu, regs);
                 if (k >= 0) {
@@ -523,6 +523,10 @@ hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t
 #endif
     const bool want_caps = b.match_only == 0 && dev.has_capture;
     const int mode = !want_caps ? 0 : (lds.u_start != 0xFFFFFFFFu && lds.simple_ops) ? 1 : 2;
+    if (at_global && lds.tier == 3) {
+        if (b.offsets64) return launch_tile_m<uint64_t, TIER_RECG>(mode, lds, io, grid, block, stream);
+        return launch_tile_m<uint32_t, TIER_RECG>(mode, lds, io, grid, block, stream);
+    }
     if (at_global) {
         if (b.offsets64) return launch_tile_m<uint64_t, TIER_L2>(mode, lds, io, grid, block, stream);
         return launch_tile_m<uint32_t, TIER_L2>(mode, lds, io, grid, block, stream);

@@ -100,11 +100,14 @@ __device__ __forceinline__ uint32_t window_mask(uint32_t start, uint32_t end, ui
 // bakes the table's position into every successor field).  TIER_L2: dense rows in global memory (they stay resident
 // in the XCD's L2), a state is its index and the row address is index * row_bytes.  TIER_REC: sparse range records
 // in LDS (gx_api.cpp: records_from_dense), a state is the index of its first 8-byte record.
-enum { TIER_LDS = 0, TIER_L2 = 1, TIER_REC = 2 };
+// TIER_RECG: the same records in global memory (64 KB - 512 KB: they live in the CUs' vector L1 and the XCD's L2, and
+// LDS is left to the waves' staging areas).
+enum { TIER_LDS = 0, TIER_L2 = 1, TIER_REC = 2, TIER_RECG = 3 };
+template <int TIER> struct TierTraits { static constexpr bool records = TIER == TIER_REC || TIER == TIER_RECG; };
 
 // wave-uniform description of the automaton being walked
 struct WalkTab {
-    const uint8_t* at;     // TIER_L2: base of the rows in global memory
+    const uint8_t* at;     // TIER_L2: base of the rows in global memory; TIER_RECG: base of the records
     uint32_t row_bytes;    // dense row stride
     uint32_t ops_off, ops; // LDS addresses of the capture program lists
     uint32_t rec, acc_tab; // TIER_REC: LDS addresses of the records and of the interval table
@@ -119,21 +122,26 @@ __device__ __forceinline__ uint32_t tab_word(const WalkTab& W, uint32_t row, uin
     if (TIER == TIER_L2) return *reinterpret_cast<const uint32_t*>(W.at + (static_cast<uint64_t>(row) * W.row_bytes + off));
     return lds_ld<uint32_t>(row + off);
 }
+// one record (two dwords) of state / record index `idx`
+template <int TIER>
+__device__ __forceinline__ u32x2 rec_ld(const WalkTab& W, uint32_t idx) {
+    if (TIER == TIER_RECG) return *reinterpret_cast<const u32x2*>(W.at + (static_cast<uint64_t>(idx) << 3));
+    return lds_ld<u32x2>(W.rec + (idx << 3));
+}
 // a state's self-loop interval word (lo | (0x7F - hi) << 8 | hot << 16) and its info word
 template <int TIER>
 __device__ __forceinline__ uint32_t state_acc(const WalkTab& W, uint32_t row) {
-    if (TIER == TIER_REC) {
-        const uint32_t self_lo = lds_ld<uint32_t>(W.rec + (row << 3)) & 0xFFu;  // 255: no self range
-        return lds_ld<uint32_t>(W.acc_tab + 4u * min(self_lo, W.ncls));          // entry ncls: no interval
+    if (TierTraits<TIER>::records) {
+        const uint32_t self_lo = rec_ld<TIER>(W, row).x & 0xFFu;            // 255: no self range
+        return lds_ld<uint32_t>(W.acc_tab + 4u * min(self_lo, W.ncls));      // entry ncls: no interval
     }
     return tab_word<TIER>(W, row, W.row_bytes - 8u);
 }
 template <int TIER>
 __device__ __forceinline__ int32_t state_info(const WalkTab& W, uint32_t row) {
-    if (TIER == TIER_REC) {
-        const uint32_t a = W.rec + (row << 3);
-        const bool hdr = (lds_ld<uint32_t>(a + 4u) & REC_HDR) != 0u;
-        return hdr ? static_cast<int32_t>(lds_ld<uint32_t>(a - 4u)) : -1;  // (a - 4 is inside the records for every state)
+    if (TierTraits<TIER>::records) {
+        const bool hdr = (rec_ld<TIER>(W, row).y & REC_HDR) != 0u;
+        return hdr ? static_cast<int32_t>(rec_ld<TIER>(W, row - (hdr ? 1u : 0u)).y) : -1;  // the header record precedes the state's first
     }
     return static_cast<int32_t>(tab_word<TIER>(W, row, W.row_bytes - 4u));
 }
@@ -176,7 +184,7 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
         c4[j] = lds_ld<uint16_t>(b << 1);
     }
     const uint32_t dummy_col = regs - 128u;
-    if (TIER == TIER_REC) {
+    if (TierTraits<TIER>::records) {
         // c4[] holds class ids here.  One record read per byte, two range tests (c - lo <= span, the byte fields picked
         // by operand selectors), two selects.  The sixteen steps are straight-line code; a lane that meets a state
         // with more ranges than one record holds and finds its class in none of the first record's goes to the dead
@@ -188,7 +196,7 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const uint32_t c = c4[j];
-            const u32x2 it = lds_ld<u32x2>(W.rec + (row << 3));
+            const u32x2 it = rec_ld<TIER>(W, row);
             const bool in_exit = (c - ((it.x >> 16) & 0xFFu)) <= (it.x >> 24);
             const bool in_self = (c - (it.x & 0xFFu)) <= ((it.x >> 8) & 0xFFu);
             uint32_t next = in_exit ? (it.y & 0xFFFFu) : (in_self ? row : W.dead);
@@ -219,8 +227,8 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
             uint32_t b = (dw >> ((j & 3) * 8)) & 0xFFu;
             if (MASKED && ((mask >> j) & 1u) == 0u) b = 256u;
             const uint32_t c = lds_ld<uint16_t>(b << 1);
-            uint32_t a = W.rec + (row << 3);
-            u32x2 it = lds_ld<u32x2>(a);
+            uint32_t a = row;
+            u32x2 it = rec_ld<TIER>(W, a);
             bool in_exit = (c - ((it.x >> 16) & 0xFFu)) <= (it.x >> 24);
             const bool in_self = (c - (it.x & 0xFFu)) <= ((it.x >> 8) & 0xFFu);
             uint32_t next = in_exit ? (it.y & 0xFFFFu) : (in_self ? row : W.dead);
@@ -233,8 +241,8 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
                 pending = pending && !idc;
             }
             while (__any(pending)) {
-                a += pending ? 8u : 0u;
-                it = lds_ld<u32x2>(a);
+                a += pending ? 1u : 0u;
+                it = rec_ld<TIER>(W, a);
                 in_exit = (c - ((it.x >> 16) & 0xFFu)) <= (it.x >> 24);
                 if (pending && in_exit) { next = it.y & 0xFFFFu; op = (it.y >> 16) & 0xFFu; }
                 pending = pending && !in_exit && (it.y & REC_LAST) == 0u;
@@ -294,11 +302,11 @@ __device__ __forceinline__ int32_t line_result(int32_t info, uint32_t fin_lds, c
     const uint32_t dummy_col = regs - 128u;
     const uint32_t id_at = rec + 16u * static_cast<uint32_t>((G + 3) >> 2);
     uint32_t id;
-    if (TIER == TIER_L2) id = *reinterpret_cast<const uint16_t*>(fin_g + id_at);
+    if (TIER == TIER_L2 || TIER == TIER_RECG) id = *reinterpret_cast<const uint16_t*>(fin_g + id_at);
     else id = lds_ld<uint16_t>(fin_lds + id_at);
     for (int g0 = 0; g0 < G; g0 += 4) {
         u32x4 t;
-        if (TIER == TIER_L2) t = *reinterpret_cast<const u32x4*>(fin_g + rec + 4u * g0);
+        if (TIER == TIER_L2 || TIER == TIER_RECG) t = *reinterpret_cast<const u32x4*>(fin_g + rec + 4u * g0);
         else t = lds_ld<u32x4>(fin_lds + rec + 4u * g0);
         const uint32_t tw[4] = {t.x, t.y, t.z, t.w};  // one dword = (begin tag, end tag) of one group
         uint32_t vb[4], ve[4];

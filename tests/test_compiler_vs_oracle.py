@@ -19,7 +19,7 @@ def product_blob(autom, jdk):
     # the table-image builders run for host-only handles too; forcing the record tier (fused and two-pass) runs its
     # self-check -- every (state, class) of the range records against the dense rows -- on this definition as well
     for flags in (N.GX_CREATE_TIER_RECORDS, N.GX_CREATE_TIER_RECORDS | N.GX_CREATE_NO_FUSED):
-        assert N.lib().gx_stat(_create(autom, jdk, N.GX_CREATE_HOST_ONLY | flags).ptr, 7) in (2, 3)
+        assert N.lib().gx_stat(_create(autom, jdk, N.GX_CREATE_HOST_ONLY | flags).ptr, 7) in (2, 3, 4)
     n = N.lib().gx_blob_size(h.ptr)
     out = np.zeros(n, np.uint8)
     assert N.lib().gx_blob_copy(h.ptr, out.ctypes.data, n) == 0
@@ -318,16 +318,16 @@ def test_dialect_disagreement_yields_exception_code():
 def test_tile_image_tiers_by_definition_size():
     """Host-only handles run the table-image builders too (their self-check compares the record tier with the dense
     rows state by state): small definitions keep dense rows in LDS, the 64-extraction definition of BASELINE configs[2]
-    becomes range records in LDS, the 512-extraction one stays in global memory."""
+    keeps them in global memory with range records in LDS for match-only batches."""
     from gorp_amd import _native as N
     from gorp_amd import workloads as W
     g = Gorp.construct(W.readme3_definition(), host_only=True)
     assert g.stat(7) == 1 and g.stat(6) >= 10
     for flags, tier in ((N.GX_CREATE_TIER_RECORDS, 3), (N.GX_CREATE_TIER_L2, 2), (N.GX_CREATE_NO_TILES, 0),
-                        (N.GX_CREATE_TIER_RECORDS | N.GX_CREATE_NO_FUSED, 3)):
+                        (N.GX_CREATE_TIER_RECORDS | N.GX_CREATE_NO_FUSED, 3), (N.GX_CREATE_TIER_RECORDS_GLOBAL, 4)):
         assert Gorp.construct(W.readme3_definition(), host_only=True, flags=flags).stat(7) == tier
     rules, _ = W.syslog_definition(64, seed=3)
     g = Gorp.construct(rules, host_only=True)
+    assert g.stat(7) == 2 and g.stat(9) == 3       # dense rows in global memory for captures, LDS records for match-only
+    g = Gorp.construct(rules, host_only=True, flags=N.GX_CREATE_TIER_RECORDS)
     assert g.stat(7) == 3 and g.stat(6) >= 5       # records in LDS, at least 5 waves of staging left
-    rules, _ = W.syslog_definition(160, seed=3)
-    assert Gorp.construct(rules, host_only=True).stat(7) == 2

@@ -288,13 +288,14 @@ def test_syslog_16_rules():
     assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
 
 
-@pytest.mark.parametrize("tier", [2, 3, 4])
+@pytest.mark.parametrize("tier", [2, 3, 4, 5])
 def test_table_tiers_agree_with_oracle(tier, monkeypatch):
     """The same definitions through the L2-tier tile kernel (automaton rows in global memory), through the per-line
     generic kernel and through the record tier (sparse range records in LDS); the default for these small definitions
     is the LDS tier with dense rows, covered everywhere else."""
-    monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", {2: N.GX_CREATE_TIER_L2, 3: N.GX_CREATE_NO_TILES, 4: N.GX_CREATE_TIER_RECORDS}[tier])
-    want = {2: 2, 3: 0, 4: 3}[tier]
+    monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", {2: N.GX_CREATE_TIER_L2, 3: N.GX_CREATE_NO_TILES, 4: N.GX_CREATE_TIER_RECORDS,
+                                                    5: N.GX_CREATE_TIER_RECORDS_GLOBAL}[tier])
+    want = {2: 2, 3: 0, 4: 3, 5: 4}[tier]
     # config 1
     definition = W.simple_grp_definition()
     gorp, orc = Gorp.construct(definition), oracle_for(definition)
@@ -338,14 +339,16 @@ def test_table_tiers_agree_with_oracle(tier, monkeypatch):
         check_batch(gorp, orc, lines)
 
 
-@pytest.mark.parametrize("flags", [0, N.GX_CREATE_TIER_L2])
+@pytest.mark.parametrize("flags", [0, N.GX_CREATE_TIER_L2, N.GX_CREATE_TIER_RECORDS])
 def test_config3_64_rules_parity(flags):
-    """BASELINE.json configs[2]: 64 extractions.  The dense rows (2.3 MB) do not fit LDS; the states are sparse, so the
-    tables become range records in LDS (tier 3) -- and, forced, dense rows in global memory / L2 (tier 2)."""
+    """BASELINE.json configs[2]: 64 extractions.  The dense rows (2.3 MB) do not fit LDS: by default the capture side keeps
+    them in global memory / L2 and match-only batches walk range records in LDS; forced: dense rows for both, records
+    in LDS for both."""
     rules, meta = W.syslog_definition(64, seed=3)
     gorp, orc = Gorp.construct(rules, flags=flags), oracle_for(rules)
     assert gorp.stat(0) > 1000  # match-automaton states
-    assert gorp.stat(7) == (2 if flags else 3)
+    assert gorp.stat(7) == {0: 2, N.GX_CREATE_TIER_L2: 2, N.GX_CREATE_TIER_RECORDS: 3}[flags]
+    assert gorp.stat(9) == {0: 3, N.GX_CREATE_TIER_L2: 2, N.GX_CREATE_TIER_RECORDS: 3}[flags]
     data, offsets, cats = W.syslog_lines(meta, 30000, seed=3)
     mid, caps = gorp.extract_batch(data, offsets)
     omid, ocaps = orc.extract_batch(data, offsets, nthreads=8)
@@ -438,7 +441,7 @@ def test_config5_512_rules_mixed_lengths_parity():
     """BASELINE.json configs[4]: 512 extractions, lines of 50-2000 bytes."""
     rules, meta = W.syslog_definition(512, seed=3)
     gorp, orc = Gorp.construct(rules), oracle_for(rules)
-    assert gorp.stat(7) == 2
+    assert gorp.stat(7) in (2, 4)
     data, offsets, cats = W.syslog_lines(meta, 6000, seed=5, min_len=50, max_len=2000)
     mid, caps = gorp.extract_batch(data, offsets)
     omid, ocaps = orc.extract_batch(data, offsets, nthreads=8)
@@ -467,12 +470,12 @@ def test_config1_from_definition_text(tmp_path):
     assert r.getId() == "sampleMatch" and r.asMap()["authStatus"] == "Accepted"
 
 
-@pytest.mark.parametrize("tier", [1, 2, 3])
+@pytest.mark.parametrize("tier", [1, 2, 3, 4])
 def test_mixed_lengths_take_several_rounds_per_group(tier, monkeypatch):
     """Lines of 0-3000 bytes against a staging area sized for the mean: groups are walked in several rounds of
     consecutive lanes, a line longer than the staging area alone takes the per-lane path; all bit-exact."""
     if tier != 1:
-        monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", {2: N.GX_CREATE_TIER_L2, 3: N.GX_CREATE_TIER_RECORDS}[tier])
+        monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", {2: N.GX_CREATE_TIER_L2, 3: N.GX_CREATE_TIER_RECORDS, 4: N.GX_CREATE_TIER_RECORDS_GLOBAL}[tier])
     definition = W.readme3_definition()
     gorp, orc = Gorp.construct(definition), oracle_for(definition)
     rng = random.Random(99)
@@ -500,7 +503,7 @@ def test_mixed_lengths_take_several_rounds_per_group(tier, monkeypatch):
 
 @pytest.mark.parametrize("variant", [{}, {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_TIER_L2}, {"DEFAULT_KERNEL": N.GX_KERNEL_SLICES},
                                      {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_NO_TILES}, {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_NO_FUSED},
-                                     {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_TIER_RECORDS}])
+                                     {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_TIER_RECORDS}, {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_TIER_RECORDS_GLOBAL}])
 def test_compact_rows_from_the_kernels(variant, monkeypatch):
     """gx_batch_opts.compact_results: every kernel writes the compact rows itself (full tiles through the LDS transpose,
     ragged groups and the per-line follow-up lane by lane); device buffers, offsets beyond 65534 counted."""
@@ -593,13 +596,13 @@ def test_utf16_batch_input():
     assert m2.tolist() == mid.tolist()
 
 
-@pytest.mark.parametrize("tier", [1, 2, 3])
+@pytest.mark.parametrize("tier", [1, 2, 3, 4])
 def test_slice_kernel_agrees_with_oracle(tier, monkeypatch):
     """The slice kernel (64 bytes of every line staged at a time; the default for batches with long lines) forced
     on for short, ragged, terminated and very long lines, tables in LDS and in global memory."""
     monkeypatch.setattr(G, "DEFAULT_KERNEL", N.GX_KERNEL_SLICES)
     if tier != 1:
-        monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", {2: N.GX_CREATE_TIER_L2, 3: N.GX_CREATE_TIER_RECORDS}[tier])
+        monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", {2: N.GX_CREATE_TIER_L2, 3: N.GX_CREATE_TIER_RECORDS, 4: N.GX_CREATE_TIER_RECORDS_GLOBAL}[tier])
     definition = W.simple_grp_definition()
     gorp, orc = Gorp.construct(definition), oracle_for(definition)
     check_batch(gorp, orc, W.simple_grp_lines(3000, seed=31))
@@ -671,11 +674,12 @@ def test_cooked_extraction_match_is_the_capture_regexp_alone(golden):
     assert n_match > 50
 
 
-@pytest.mark.parametrize("tier", [1, 2, 3])
+@pytest.mark.parametrize("tier", [1, 2, 3, 4])
 def test_two_pass_layout_without_the_fused_automaton(tier, monkeypatch):
     """Definitions too large for the fused automaton walk the match automaton and then the winning extraction's
     capture automaton; forced here (GX_CREATE_NO_FUSED) on small definitions, tables in LDS and in global memory."""
-    monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", N.GX_CREATE_NO_FUSED | {1: 0, 2: N.GX_CREATE_TIER_L2, 3: N.GX_CREATE_TIER_RECORDS}[tier])
+    monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", N.GX_CREATE_NO_FUSED | {1: 0, 2: N.GX_CREATE_TIER_L2, 3: N.GX_CREATE_TIER_RECORDS,
+                                                                           4: N.GX_CREATE_TIER_RECORDS_GLOBAL}[tier])
     import test_compiler_vs_oracle as TC
     from blob_interp import Blob
     definition = W.readme3_definition()
@@ -709,7 +713,7 @@ def test_two_pass_layout_without_the_fused_automaton(tier, monkeypatch):
 
 
 @pytest.mark.parametrize("variant", [{}, {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_TIER_L2}, {"DEFAULT_KERNEL": N.GX_KERNEL_SLICES},
-                                     {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_TIER_RECORDS}])
+                                     {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_TIER_RECORDS}, {"DEFAULT_CREATE_FLAGS": N.GX_CREATE_TIER_RECORDS_GLOBAL}])
 def test_unaligned_device_buffers(variant, monkeypatch):
     """Device pointers with no particular alignment (a view 3 bytes into a tensor; results 4 bytes into theirs): the
     edge chunks of the first and last tile take the guarded copy, results the per-line stores."""

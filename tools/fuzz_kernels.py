@@ -19,7 +19,9 @@ variants = [(0, 0, False), (N.GX_CREATE_TIER_L2, 0, False), (0, N.GX_KERNEL_SLIC
             (N.GX_CREATE_NO_TILES, 0, False), (N.GX_CREATE_NO_FUSED, 0, False), (N.GX_CREATE_NO_FUSED | N.GX_CREATE_TIER_L2, 0, False),
             (0, 0, True), (N.GX_CREATE_TIER_L2, 0, True), (0, N.GX_KERNEL_SLICES, True), (N.GX_CREATE_NO_FUSED, 0, True),
             (N.GX_CREATE_TIER_RECORDS, 0, False), (N.GX_CREATE_TIER_RECORDS, N.GX_KERNEL_SLICES, False),
-            (N.GX_CREATE_TIER_RECORDS | N.GX_CREATE_NO_FUSED, 0, False), (N.GX_CREATE_TIER_RECORDS, 0, True)]
+            (N.GX_CREATE_TIER_RECORDS | N.GX_CREATE_NO_FUSED, 0, False), (N.GX_CREATE_TIER_RECORDS, 0, True),
+            (N.GX_CREATE_TIER_RECORDS_GLOBAL, 0, False), (N.GX_CREATE_TIER_RECORDS_GLOBAL, N.GX_KERNEL_SLICES, False),
+            (N.GX_CREATE_TIER_RECORDS_GLOBAL | N.GX_CREATE_NO_FUSED, 0, True)]
 done = bad = 0
 while done < n_defs:
     exts = [FlattenedExtraction("e%d" % i, TC.gen_pieces(rng)) for i in range(rng.randint(1, 5))]
