@@ -81,6 +81,15 @@ struct gx_handle {
     std::map<std::string, JsonlImage> jsonl;  // device templates per id_as ("0" = none, "1" + id_as)
     std::mutex mu;  // serialises host-pointer batches that share nothing else
     uint32_t create_flags = 0;   // GX_CREATE_* given at creation (kernel choice)
+    // Asynchronous batches that give no line_bytes_hint: the mean line length of the previous such batch, read back
+    // without a synchronisation (two offsets copied to pinned memory, picked up by the next call once its event is done).
+    uint32_t learned_hint = 0;
+    uint64_t* hint_probe = nullptr;   // pinned: offsets[0], offsets[n] of the batch being probed
+    hipEvent_t hint_event = nullptr;
+    bool hint_pending = false;
+    uint64_t hint_n = 0;
+    bool hint_off64 = false;
+    std::mutex hint_mu;
     // Tile-kernel launches that are in flight share nothing but these slots: one word each, into which a launch
     // stores its sequence number when it meets a line it cannot stage (gx_device.hpp: GxBatch::oversize_flag).
     // A slot is reused only after the follow-up kernel of its previous user has run (event).
@@ -881,6 +890,7 @@ void gx_destroy(gx_handle* h) {
     if (h->d_lds_image) (void)hipFree(h->d_lds_image);
     if (h->d_lds_image_mo) (void)hipFree(h->d_lds_image_mo);
     if (h->d_l2_image) (void)hipFree(h->d_l2_image);
+    if (h->hint_probe) { (void)hipHostFree(h->hint_probe); (void)hipEventDestroy(h->hint_event); }
     if (h->d_slots) {
         (void)hipFree(h->d_slots);
         for (int q = 0; q < gx_handle::N_SLOTS; ++q) if (h->slot_event[q]) (void)hipEventDestroy(h->slot_event[q]);
@@ -1273,6 +1283,32 @@ static int extract_batch_impl(gx_handle* h, const uint8_t* bytes, const void* of
                 b.caps = match_only ? nullptr : caps;
             }
             uint32_t hint = o.line_bytes_hint;
+            if (hint == 0 && n && o.no_sync) {
+                // no hint and no synchronisation allowed: what the previous such batch measured (200 until one has), and
+                // a probe of this batch for the next call
+                std::lock_guard<std::mutex> lock(h->hint_mu);
+                if (!h->hint_probe) {
+                    GX_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->hint_probe), 16, hipHostMallocDefault));
+                    GX_HIP(hipEventCreateWithFlags(&h->hint_event, hipEventDisableTiming));
+                }
+                if (h->hint_pending && hipEventQuery(h->hint_event) == hipSuccess) {
+                    const uint64_t first = h->hint_off64 ? h->hint_probe[0] : (h->hint_probe[0] & 0xFFFFFFFFull);
+                    const uint64_t last = h->hint_off64 ? h->hint_probe[1] : (h->hint_probe[1] & 0xFFFFFFFFull);
+                    if (h->hint_n && last >= first)
+                        h->learned_hint = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>((last - first + h->hint_n - 1) / h->hint_n, 4096)));
+                    h->hint_pending = false;
+                }
+                hint = h->learned_hint;
+                if (!h->hint_pending) {
+                    h->hint_probe[0] = h->hint_probe[1] = 0;
+                    GX_HIP(hipMemcpyAsync(&h->hint_probe[0], offsets, off_w, hipMemcpyDeviceToHost, stream));
+                    GX_HIP(hipMemcpyAsync(&h->hint_probe[1], static_cast<const uint8_t*>(offsets) + n * off_w, off_w, hipMemcpyDeviceToHost, stream));
+                    GX_HIP(hipEventRecord(h->hint_event, stream));
+                    h->hint_pending = true;
+                    h->hint_n = n;
+                    h->hint_off64 = o.offsets64 != 0;
+                }
+            }
             if (hint == 0 && n && !o.no_sync) {
                 // no hint: the mean line length, from the two ends of the offsets array (a small synchronous read;
                 // asynchronous callers pass line_bytes_hint themselves)

@@ -948,6 +948,55 @@ Tables unpack_blob(const void* data, size_t size) {
     }
     if (t.m_next.size() != static_cast<size_t>(t.m_states) * t.ncls || t.hi_lo.size() != t.hi_cls.size() || t.hi_lo.empty())
         throw GxError(GX_E_ARG, "corrupt table blob");
+    // Everything the host walkers (gx_state_accepts, gx_match_one_utf16) and the kernels index with values read from
+    // the blob is range-checked once here: a truncated or version-skewed blob is refused, never walked.
+    auto bad = [](const char* what) { return GxError(GX_E_ARG, std::string("corrupt table blob: ") + what); };
+    if (t.n_rules < 0 || t.ncls <= 0 || t.ncls > 65535 || t.max_groups < 0 || t.m_states <= 0) throw bad("header counts");
+    if (t.m_dead < 0 || t.m_dead >= t.m_states) throw bad("dead state of the match automaton");
+    for (int b = 0; b < 256; ++b) if (t.cls256[b] >= t.ncls) throw bad("class map");
+    for (uint16_t c : t.hi_cls) if (c >= t.ncls) throw bad("class map above 255");
+    for (uint32_t v : t.m_next) if (v >= static_cast<uint32_t>(t.m_states)) throw bad("successor of the match automaton");
+    if (t.m_accept_first.size() != static_cast<size_t>(t.m_states) || t.m_accept_off.size() != static_cast<size_t>(t.m_states) + 1)
+        throw bad("accept arrays");
+    for (size_t s = 0; s < static_cast<size_t>(t.m_states); ++s) {
+        if (t.m_accept_off[s] > t.m_accept_off[s + 1] || t.m_accept_off[s + 1] > t.m_accept_list.size()) throw bad("accept offsets");
+        if (t.m_accept_first[s] < -1 || t.m_accept_first[s] >= t.n_rules) throw bad("first accepting extraction");
+    }
+    for (int32_t k : t.m_accept_list) if (k < 0 || k >= t.n_rules) throw bad("accept list");
+    if (t.has_capture && t.rules.size() != static_cast<size_t>(t.n_rules)) throw bad("capture automata missing");
+    if (!t.has_capture && (!t.rules.empty() || t.union_ok)) throw bad("capture automata without capture flag");
+    if (t.ops_off.empty() || t.ops.size() % 2) throw bad("capture programs");
+    for (size_t i = 0; i + 1 < t.ops_off.size(); ++i)
+        if (t.ops_off[i] > t.ops_off[i + 1] || t.ops_off[i + 1] > t.ops.size() / 2) throw bad("capture program offsets");
+    const size_t n_lists = t.ops_off.size() - 1;
+    auto check_rule = [&](const RuleTables& rt, bool fused) {
+        if (rt.n_states <= 0 || rt.n_groups < 0 || rt.n_regs < 0 || rt.dead < 0 || rt.dead >= rt.n_states) throw bad("capture automaton header");
+        if (rt.n_groups > t.max_groups && !fused) throw bad("group count");
+        for (uint32_t w : rt.trans) {
+            if ((w & 0xFFFFu) >= static_cast<uint32_t>(rt.n_states)) throw bad("successor of a capture automaton");
+            if ((w >> 16) >= n_lists) throw bad("capture program index");
+        }
+        for (int32_t f : rt.fin) {
+            if (f < -1 && (!fused || -2 - f >= t.n_rules)) throw bad("final marker");
+            if (f < 0) continue;
+            size_t need = static_cast<size_t>(f);
+            if (fused) {  // the list starts with the extraction
+                if (need >= t.fin_tags.size() || t.fin_tags[need] >= t.rules.size()) throw bad("final record");
+                need += 1 + 2 * static_cast<size_t>(t.rules[t.fin_tags[need]].n_groups);
+            } else need += 2 * static_cast<size_t>(rt.n_groups);
+            if (need > t.fin_tags.size()) throw bad("final record");
+        }
+    };
+    for (auto& rt : t.rules) check_rule(rt, false);
+    if (t.union_ok) check_rule(t.uni, true);
+    int max_regs = 0;
+    for (auto& rt : t.rules) max_regs = std::max(max_regs, rt.n_regs);
+    if (t.union_ok) max_regs = std::max(max_regs, t.uni.n_regs);
+    for (size_t i = 0; i < t.ops.size(); i += 2) {
+        if (t.ops[i] >= max_regs) throw bad("capture program destination");
+        if (t.ops[i + 1] != GX_SRC_POS && t.ops[i + 1] >= max_regs) throw bad("capture program source");
+    }
+    for (uint16_t v : t.fin_tags) if (v != GX_SRC_POS && v != GX_SRC_NIL && v >= std::max(max_regs, t.n_rules)) throw bad("final tag");
     return t;
 }
 

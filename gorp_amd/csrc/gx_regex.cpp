@@ -284,10 +284,38 @@ private:
         return static_cast<int>(v);
     }
 
+    // Can the sub-expression match the empty string / does it hold a capturing group?
+    static bool nullable(const Ast& n) {
+        switch (n.kind) {
+        case Ast::EMPTY: return true;
+        case Ast::FAIL: case Ast::SET: return false;
+        case Ast::CAT: for (auto& k : n.kids) if (!nullable(*k)) return false; return true;
+        case Ast::ALT: for (auto& k : n.kids) if (nullable(*k)) return true; return false;
+        case Ast::REP: return n.min == 0 || nullable(*n.kids[0]);
+        case Ast::GROUP: return nullable(*n.kids[0]);
+        }
+        return false;
+    }
+    static bool captures(const Ast& n) {
+        if (n.kind == Ast::GROUP && n.cap > 0) return true;
+        for (auto& k : n.kids) if (captures(*k)) return true;
+        return false;
+    }
+
+    // One quantifier per atom, as java.util.regex has it: Pattern.sequence() meets a second '*', '+' or '?' as a
+    // "Dangling meta character" (PatternSyntaxException), and a second '{' would quantify an empty literal -- refused
+    // rather than imitated.  A loop around a capturing body that can match the empty string is refused too: there
+    // java.util.regex lets an empty last iteration move the group (Loop / GroupTail: "(a*)*" on "aaa" leaves group 1
+    // at (3,3)), a rule the tagged automaton does not implement; Gorp's own extractor groups are never quantified.
     AstP quantified(AstP a) {
-        for (;;) {
+        for (int count = 0;; ++count) {
             int mn, mx;
             int c = cur();
+            if (count == 1) {
+                if (c == '?' || c == '*' || c == '+') syntax(std::string("Dangling meta character '") + static_cast<char>(c) + "'");
+                if (c == '{') unsupported("a quantifier applied to a quantifier");
+                return a;
+            }
             if (c == '?') { ++at_; mn = 0; mx = 1; }
             else if (c == '*') { ++at_; mn = 0; mx = -1; }
             else if (c == '+') { ++at_; mn = 1; mx = -1; }
@@ -306,6 +334,8 @@ private:
             bool greedy = true;
             if (cur() == '?') { ++at_; greedy = false; }
             else if (cur() == '+') unsupported("possessive quantifier");
+            if (mx != 1 && mx != 0 && captures(*a) && nullable(*a))
+                unsupported("a repeated capturing group that can match the empty string");
             a = rep_node(std::move(a), mn, mx, greedy);
         }
     }

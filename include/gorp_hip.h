@@ -101,8 +101,10 @@ typedef struct gx_batch_opts {
     uint32_t match_only;       /* 1: PolyMatcher.match only; caps may be NULL */
     void*    stream;           /* hipStream_t to launch on (NULL = the null stream) */
     uint32_t no_sync;          /* 1 (device pointers only): return after enqueueing */
-    uint32_t line_bytes_hint;  /* typical line length in bytes (0 = 200); sizes the per-wave LDS staging
-                                  area of the batch kernel.  A wrong hint costs speed, never correctness. */
+    uint32_t line_bytes_hint;  /* typical line length in bytes; sizes the per-wave LDS staging area of the batch kernel.
+                                  A wrong hint costs speed, never correctness.  0: the batch's mean line length -- read
+                                  from the offsets (a small synchronous copy), or with no_sync the mean of the previous
+                                  no_sync batch of this handle (200 until one has completed) */
     uint32_t strip_eol;        /* 1: every line carries its terminator ("\n", "\r\n" or "\r", as produced by
                                   gx_split_lines); it is not part of the String the reference would see, so
                                   it is ignored and capture offsets stay relative to the start of the line */

@@ -821,10 +821,36 @@ struct JdkParser {
         }
         return cat;
     }
+    // java.util.regex takes ONE quantifier per atom: Pattern.sequence() throws "Dangling meta character" on a second
+    // '*', '+' or '?' (a second '{' would quantify an empty literal: refused here, not imitated).  A loop around a
+    // capturing body that can match the empty string is refused as well: java.util.regex's Loop / GroupTail let an
+    // empty last iteration move the group ("(a*)*" on "aaa": group 1 = (3,3)), which this restatement does not
+    // model; Gorp's extractor groups are never quantified (core/Gorp.java:94-129).
+    static bool nullable(const JNode& n) {
+        switch (n.kind) {
+        case N_EMPTY: case N_BOL: case N_EOL: return true;
+        case N_SET: return false;
+        case N_CAT: for (auto& k : n.kids) if (!nullable(*k)) return false; return true;
+        case N_ALT: for (auto& k : n.kids) if (nullable(*k)) return true; return false;
+        case N_REP: return n.min == 0 || nullable(*n.kids[0]);
+        case N_GROUP: return nullable(*n.kids[0]);
+        }
+        return false;
+    }
+    static bool captures(const JNode& n) {
+        if (n.kind == N_GROUP && n.cap > 0) return true;
+        for (auto& k : n.kids) if (captures(*k)) return true;
+        return false;
+    }
     JP closure(JP a) {
-        for (;;) {
+        for (int count = 0;; ++count) {
             int c = peekc();
             int mn, mx;
+            if (count == 1) {
+                if (c == u'?' || c == u'*' || c == u'+') syntax(std::string("Dangling meta character '") + (char)c + "'");
+                if (c == u'{') unsupported("a quantifier applied to a quantifier");
+                return a;
+            }
             if (c == u'?') { pos++; mn = 0; mx = 1; }
             else if (c == u'*') { pos++; mn = 0; mx = -1; }
             else if (c == u'+') { pos++; mn = 1; mx = -1; }
@@ -852,6 +878,7 @@ struct JdkParser {
             bool lazy = false;
             if (peekc() == u'?') { pos++; lazy = true; }
             else if (peekc() == u'+') unsupported("possessive quantifier");
+            if (mx != 1 && mx != 0 && captures(*a) && nullable(*a)) unsupported("a repeated capturing group that can match the empty string");
             JP r = mk(N_REP);
             r->min = mn; r->max = mx; r->lazy = lazy;
             r->kids.push_back(std::move(a));

@@ -69,6 +69,12 @@ def test_random_regexes_against_python_re():
             re.compile(rx, re.ASCII)
         except re.error:
             continue
+        try:
+            O.jdk_matches(rx, "")
+        except O.OracleError as e:
+            # the one thing CPython accepts that the restatement refuses: a loop around a capturing body that can be empty
+            assert "repeated capturing group" in str(e), (rx, str(e))
+            continue
         for _ in range(12):
             s = "".join(rng.choice(ALPHA) for _ in range(rng.randint(0, 10)))
             exp = py_groups(rx, s)
@@ -105,3 +111,22 @@ def test_anchors_and_line_terminators():
     assert O.jdk_matches("a.", "a\t") == []
     assert O.jdk_matches("a\\s", "a\x0b") == []
     assert O.jdk_matches("a\\s", "a\x08") is None
+
+
+def test_one_quantifier_per_atom_and_no_nullable_capturing_loops():
+    """java.util.regex rejects a second quantifier ("Dangling meta character", Pattern.sequence) and moves a group on
+    an empty last iteration of a loop ("(a*)*" on "aaa": group 1 = (3,3), as CPython's re does) -- the oracle and the
+    product both refuse these instead of answering differently from the JVM."""
+    import re
+    from gorp_amd import _native as N
+    from gorp_amd.gorp import DefinitionParseException, _create
+    assert re.fullmatch("(a*)*", "aaa").span(1) == (3, 3)
+    for rx in ("a**", "a?*", "a+?+x", "a{2}{3}", "(a*)*", "(a*)+", "(a|b*)*x", "((a?)b*)+", "(a*){2,}"):
+        with pytest.raises(O.OracleError):
+            O.jdk_matches(rx, "aaa")
+        with pytest.raises(DefinitionParseException):
+            _create(["a*"], [rx], N.GX_CREATE_HOST_ONLY)
+    # still fine: bodies that cannot be empty, optional groups, non-capturing loops
+    for rx, s, want in (("(a+)*", "aaa", [(0, 3)]), ("(a*)?", "aaa", [(0, 3)]), ("(?:a*)*", "aaa", []), ("(a|b)*c", "abc", [(1, 2)])):
+        assert O.jdk_matches(rx, s) == want
+        _create(["[abc]*"], [rx], N.GX_CREATE_HOST_ONLY)
