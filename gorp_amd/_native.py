@@ -36,7 +36,8 @@ SYMBOLS = [
     "gx_split_lines", "gx_results_to_jsonl", "gx_set_extraction_meta",
     "gx_extraction_append_count", "gx_extraction_append_key", "gx_extraction_append_value_json",
     "gx_pack_results", "gx_unpack_results", "gx_text_to_jsonl", "gx_capture_one_utf16",
-    "gx_match_batch", "gx_state_accepts",
+    "gx_match_batch", "gx_state_accepts", "gx_set_device", "gx_handle_device", "gx_extract_batch_multi",
+    "gx_host_register", "gx_host_unregister",
 ]
 
 
@@ -140,6 +141,17 @@ def lib():
     L.gx_last_error.restype = C.c_char_p
     L.gx_device_count.argtypes = []
     L.gx_device_count.restype = C.c_int
+    L.gx_set_device.argtypes = [C.c_int]
+    L.gx_set_device.restype = C.c_int
+    L.gx_handle_device.argtypes = [C.c_void_p]
+    L.gx_handle_device.restype = C.c_int
+    L.gx_extract_batch_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                         C.POINTER(gx_batch_opts)]
+    L.gx_extract_batch_multi.restype = C.c_int
+    L.gx_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    L.gx_host_register.restype = C.c_int
+    L.gx_host_unregister.argtypes = [C.c_void_p]
+    L.gx_host_unregister.restype = C.c_int
     for f in ("gx_quote_literal_as_regexp", "gx_massage_regexp_for_automaton", "gx_massage_regexp_for_jdk"):
         getattr(L, f).argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
         getattr(L, f).restype = C.c_int

@@ -12,6 +12,8 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
+#include <atomic>
 
 #include "gx_compile.hpp"
 #include "gx_device.hpp"
@@ -80,6 +82,20 @@ struct gx_handle {
     struct JsonlImage { void* d = nullptr; GxJsonl dev{}; };
     std::map<std::string, JsonlImage> jsonl;  // device templates per id_as ("0" = none, "1" + id_as)
     std::mutex mu;  // serialises host-pointer batches that share nothing else
+    // Host-pointer batches (what a JNI caller hands over) go through a small pipeline: the batch is cut into chunks of
+    // whole lines, and HOST_WORKERS threads, each with its own stream and persistent device buffers, take alternate
+    // chunks -- copy in, kernels, copy out -- so that one chunk's copy-in overlaps another's kernels and copy-out on
+    // the bus' two directions.  (Threads, not just streams: a copy from pageable memory holds its host thread.)
+    static const int HOST_WORKERS = 4;
+    struct HostSlot {
+        hipStream_t stream = nullptr;
+        void* d_bytes = nullptr; size_t cap_bytes = 0;
+        void* d_off = nullptr; size_t cap_off = 0;
+        void* d_res = nullptr; size_t cap_res = 0;      // match ids, or compact rows
+        void* d_caps = nullptr; size_t cap_caps = 0;
+        void* d_states = nullptr; size_t cap_states = 0;
+        unsigned long long* d_over = nullptr;
+    } host_slot[HOST_WORKERS];
     uint32_t create_flags = 0;   // GX_CREATE_* given at creation (kernel choice)
     // Asynchronous batches that give no line_bytes_hint: the mean line length of the previous such batch, read back
     // without a synchronisation (two offsets copied to pinned memory, picked up by the next call once its event is done).
@@ -891,6 +907,10 @@ void gx_destroy(gx_handle* h) {
     if (h->d_lds_image_mo) (void)hipFree(h->d_lds_image_mo);
     if (h->d_l2_image) (void)hipFree(h->d_l2_image);
     if (h->hint_probe) { (void)hipHostFree(h->hint_probe); (void)hipEventDestroy(h->hint_event); }
+    for (auto& sl : h->host_slot) {
+        for (void* p : {sl.d_bytes, sl.d_off, sl.d_res, sl.d_caps, sl.d_states, static_cast<void*>(sl.d_over)}) if (p) (void)hipFree(p);
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
+    }
     if (h->d_slots) {
         (void)hipFree(h->d_slots);
         for (int q = 0; q < gx_handle::N_SLOTS; ++q) if (h->slot_event[q]) (void)hipEventDestroy(h->slot_event[q]);
@@ -1247,6 +1267,105 @@ int gx_set_extraction_meta(gx_handle* h, int32_t k, const char* name, const char
     catch (std::exception& e) { return fail(GX_E_ARG, e.what()); }
 }
 
+// One host-pointer batch through the workers of gx_handle::host_slot.  `proto` carries the batch's modes (wide,
+// offsets64, match_only, strip_eol); lines [0, n) are cut into chunks of whole lines of about chunk_bytes, chunk c goes
+// to worker c % HOST_WORKERS.  A chunk's lines keep their offsets: the kernels get a data pointer moved back by the
+// chunk's first offset instead of rebased offsets.
+static void host_pipeline(gx_handle* h, const GxBatch& proto, const uint8_t* bytes, const void* offsets, uint64_t n, uint64_t total,
+                          int32_t* match_id, int32_t* caps, int32_t* states, bool compact, bool match_only, uint32_t hint, uint32_t kernel,
+                          uint64_t* over_total) {
+    if (n == 0) return;
+    const size_t unit = proto.wide ? 2 : 1, off_w = proto.offsets64 ? 8 : 4;
+    const size_t slots = 2 * static_cast<size_t>(h->T.max_groups);
+    auto off_at = [&](uint64_t i) -> uint64_t {
+        return proto.offsets64 ? static_cast<const uint64_t*>(offsets)[i] : static_cast<const uint32_t*>(offsets)[i];
+    };
+    // chunks: large enough to amortise a launch, small enough that the pipeline has several in flight
+    const uint64_t total_bytes = total * unit;
+    uint64_t chunk_bytes = std::max<uint64_t>(total_bytes / (4 * gx_handle::HOST_WORKERS), 8ull << 20);
+    chunk_bytes = std::min<uint64_t>(chunk_bytes, 128ull << 20);
+    std::vector<uint64_t> cuts(1, 0);
+    while (cuts.back() < n) {
+        const uint64_t a = cuts.back(), want = off_at(a) * unit + chunk_bytes;
+        uint64_t lo = a + 1, hi = n;  // first line index whose start lies at or beyond `want` (at least one line per chunk)
+        while (lo < hi) { const uint64_t mid = (lo + hi) / 2; if (off_at(mid) * unit >= want) hi = mid; else lo = mid + 1; }
+        uint64_t b_ = lo;
+        if (b_ - a > 0x7FFFFFF0ull) b_ = a + 0x7FFFFFF0ull;
+        cuts.push_back(std::min<uint64_t>(b_, n));
+    }
+    const size_t n_chunks = cuts.size() - 1;
+    const int workers = static_cast<int>(std::min<size_t>(gx_handle::HOST_WORKERS, n_chunks));
+    std::atomic<uint64_t> over_sum{0};
+    std::mutex err_mu;
+    int err_code = GX_OK;
+    std::string err_msg;
+    auto work = [&](int w) {
+        try {
+            GX_HIP(hipSetDevice(h->device));
+            gx_handle::HostSlot& sl = h->host_slot[w];
+            if (!sl.stream) GX_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+            auto grow = [&](void*& p, size_t& cap, size_t need) {
+                if (need <= cap) return;
+                if (p) GX_HIP(hipFree(p));
+                p = nullptr; cap = 0;
+                GX_HIP(hipMalloc(&p, need + need / 8 + 256));
+                cap = need + need / 8 + 256;
+            };
+            if (compact && !sl.d_over) GX_HIP(hipMalloc(reinterpret_cast<void**>(&sl.d_over), 8));
+            for (size_t c = static_cast<size_t>(w); c < n_chunks; c += static_cast<size_t>(workers)) {
+                const uint64_t a = cuts[c], e = cuts[c + 1], m = e - a;
+                const uint64_t b0 = off_at(a) * unit, nbytes = off_at(e) * unit - b0;
+                grow(sl.d_bytes, sl.cap_bytes, nbytes + 64);
+                grow(sl.d_off, sl.cap_off, (m + 1) * off_w);
+                GxBatch b = proto;
+                b.n = m;
+                uint8_t* place = static_cast<uint8_t*>(sl.d_bytes) + 16;  // (a 16-byte aligned first line, room for the aligned span before it)
+                b.data = place - b0;
+                b.offsets = sl.d_off;
+                if (nbytes) GX_HIP(hipMemcpyAsync(place, bytes + b0, nbytes, hipMemcpyHostToDevice, sl.stream));
+                GX_HIP(hipMemcpyAsync(sl.d_off, static_cast<const uint8_t*>(offsets) + a * off_w, (m + 1) * off_w, hipMemcpyHostToDevice, sl.stream));
+                if (states) { grow(sl.d_states, sl.cap_states, m * 4); b.state_out = static_cast<int32_t*>(sl.d_states); }
+                if (compact) {
+                    grow(sl.d_res, sl.cap_res, m * (1 + slots) * 2);
+                    GX_HIP(hipMemsetAsync(sl.d_over, 0, 8, sl.stream));
+                    b.packed = static_cast<uint16_t*>(sl.d_res);
+                    b.overflow = sl.d_over;
+                } else {
+                    grow(sl.d_res, sl.cap_res, m * 4);
+                    b.match_id = static_cast<int32_t*>(sl.d_res);
+                    if (!match_only) { grow(sl.d_caps, sl.cap_caps, m * slots * 4 + 16); b.caps = static_cast<int32_t*>(sl.d_caps); }
+                }
+                launch_batch(h, b, hint, kernel, sl.stream);
+                unsigned long long over = 0;
+                if (compact) {
+                    GX_HIP(hipMemcpyAsync(reinterpret_cast<uint16_t*>(caps) + a * (1 + slots), sl.d_res, m * (1 + slots) * 2, hipMemcpyDeviceToHost, sl.stream));
+                    GX_HIP(hipMemcpyAsync(&over, sl.d_over, 8, hipMemcpyDeviceToHost, sl.stream));
+                } else {
+                    GX_HIP(hipMemcpyAsync(match_id + a, sl.d_res, m * 4, hipMemcpyDeviceToHost, sl.stream));
+                    if (!match_only && slots) GX_HIP(hipMemcpyAsync(caps + a * slots, sl.d_caps, m * slots * 4, hipMemcpyDeviceToHost, sl.stream));
+                }
+                if (states) GX_HIP(hipMemcpyAsync(states + a, sl.d_states, m * 4, hipMemcpyDeviceToHost, sl.stream));
+                GX_HIP(hipStreamSynchronize(sl.stream));  // this worker's buffers are free again; the other workers keep the bus busy
+                over_sum += over;
+            }
+        } catch (GxError& e) {
+            std::lock_guard<std::mutex> g(err_mu);
+            if (err_code == GX_OK) { err_code = e.code; err_msg = e.what(); }
+        } catch (std::bad_alloc&) {
+            std::lock_guard<std::mutex> g(err_mu);
+            if (err_code == GX_OK) { err_code = GX_E_NOMEM; err_msg = "out of memory"; }
+        }
+    };
+    if (workers == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int w = 0; w < workers; ++w) pool.emplace_back(work, w);
+        for (auto& t : pool) t.join();
+    }
+    if (err_code != GX_OK) throw GxError(err_code, err_msg);
+    *over_total = over_sum.load();
+}
+
 // gx_extract_batch, and gx_match_batch when `states` is given (final product-DFA state per line, -1 = dead: the
 // per-line generic kernel then, which is the one that keeps it)
 static int extract_batch_impl(gx_handle* h, const uint8_t* bytes, const void* offsets, uint64_t n, int32_t* match_id, int32_t* caps,
@@ -1323,44 +1442,16 @@ static int extract_batch_impl(gx_handle* h, const uint8_t* bytes, const void* of
             if (!o.no_sync) GX_HIP(hipStreamSynchronize(stream));
             return GX_OK;
         }
-        // host pointers: stage through device buffers
+        // host pointers: the chunked pipeline (gx_handle::host_slot)
         std::lock_guard<std::mutex> lock(h->mu);
-        uint64_t total = 0;
-        if (n) total = o.offsets64 ? static_cast<const uint64_t*>(offsets)[n] : static_cast<const uint32_t*>(offsets)[n];
+        uint64_t total = 0;  // code units in the batch (offsets need not start at 0: a shard of a larger CSR buffer)
+        if (n) total = o.offsets64 ? static_cast<const uint64_t*>(offsets)[n] - static_cast<const uint64_t*>(offsets)[0]
+                                   : static_cast<const uint32_t*>(offsets)[n] - static_cast<const uint32_t*>(offsets)[0];
         uint32_t hint = o.line_bytes_hint;
-        if (hint == 0 && n) hint = static_cast<uint32_t>((total + n - 1) / n);
-        DevBuf d_bytes, d_off, d_mid, d_caps, d_states, d_over;
-        if (states) d_states.alloc(n * 4);
-        b.state_out = states ? static_cast<int32_t*>(d_states.p) : nullptr;
-        d_bytes.alloc(total * unit); d_off.alloc((n + 1) * off_w);
-        const size_t packed_bytes = n * (1 + slots) * 2;
-        if (compact) {
-            d_caps.alloc(packed_bytes);
-            d_over.alloc(8);
-            GX_HIP(hipMemsetAsync(d_over.p, 0, 8, stream));
-            b.packed = static_cast<uint16_t*>(d_caps.p);
-            b.overflow = static_cast<unsigned long long*>(d_over.p);
-        } else {
-            d_mid.alloc(n * 4);
-            if (!match_only) d_caps.alloc(n * slots * 4);
-            b.match_id = static_cast<int32_t*>(d_mid.p);
-            b.caps = match_only ? nullptr : static_cast<int32_t*>(d_caps.p);
-        }
-        if (total) GX_HIP(hipMemcpyAsync(d_bytes.p, bytes, total * unit, hipMemcpyHostToDevice, stream));
-        GX_HIP(hipMemcpyAsync(d_off.p, offsets, (n + 1) * off_w, hipMemcpyHostToDevice, stream));
-        b.data = d_bytes.p; b.offsets = d_off.p;
-        launch_batch(h, b, hint, o.kernel, stream);
-        unsigned long long over = 0;
-        if (compact) {
-            if (n) GX_HIP(hipMemcpyAsync(caps, d_caps.p, packed_bytes, hipMemcpyDeviceToHost, stream));
-            GX_HIP(hipMemcpyAsync(&over, d_over.p, 8, hipMemcpyDeviceToHost, stream));
-        } else {
-            if (n) GX_HIP(hipMemcpyAsync(match_id, d_mid.p, n * 4, hipMemcpyDeviceToHost, stream));
-            if (!match_only && n && slots) GX_HIP(hipMemcpyAsync(caps, d_caps.p, n * slots * 4, hipMemcpyDeviceToHost, stream));
-        }
-        if (states && n) GX_HIP(hipMemcpyAsync(states, d_states.p, n * 4, hipMemcpyDeviceToHost, stream));
-        GX_HIP(hipStreamSynchronize(stream));
-        if (compact && o.overflow) *static_cast<uint64_t*>(o.overflow) += over;
+        if (hint == 0 && n) hint = static_cast<uint32_t>(std::min<uint64_t>((total + n - 1) / n, 1u << 20));
+        uint64_t over_total = 0;
+        host_pipeline(h, b, bytes, offsets, n, total, match_id, caps, states, compact, match_only, hint, o.kernel, &over_total);
+        if (compact && o.overflow) *static_cast<uint64_t*>(o.overflow) += over_total;
         return GX_OK;
     } catch (GxError& e) { return fail(e.code, e.what()); }
     catch (std::bad_alloc&) { return fail(GX_E_NOMEM, "out of memory"); }
@@ -1375,6 +1466,82 @@ int gx_match_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, uint
                    const gx_batch_opts* opts) {
     if (!states) return fail(GX_E_ARG, "gx_match_batch: states is NULL (gx_extract_batch with match_only gives the first match alone)");
     return extract_batch_impl(h, bytes, offsets, n, first_match, nullptr, states, opts);
+}
+
+int gx_set_device(int device) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return fail(GX_E_DEVICE, "gx_set_device: no such device");
+    if (hipSetDevice(device) != hipSuccess) return fail(GX_E_DEVICE, "gx_set_device: hipSetDevice failed");
+    return GX_OK;
+}
+
+int gx_handle_device(const gx_handle* h) { return h && h->on_device ? h->device : -1; }
+
+int gx_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) return fail(GX_E_ARG, "gx_host_register: bad argument");
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) return fail(GX_E_DEVICE, std::string("hipHostRegister: ") + hipGetErrorString(e));
+    return GX_OK;
+}
+int gx_host_unregister(void* p) {
+    if (!p) return fail(GX_E_ARG, "gx_host_unregister: bad argument");
+    const hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) return fail(GX_E_DEVICE, std::string("hipHostUnregister: ") + hipGetErrorString(e));
+    return GX_OK;
+}
+
+// One CSR batch in host memory over several devices: lines are independent (core/Gorp.java:159-186 keeps no cross-line
+// state), so the batch is cut into contiguous shards of about equal BYTES, one per handle (each on its own GPU, built
+// from the same definition or blob), and every shard runs through its handle's host pipeline on its own thread.
+int gx_extract_batch_multi(gx_handle* const* handles, int32_t n_handles, const uint8_t* bytes, const void* offsets, uint64_t n,
+                           int32_t* match_id, int32_t* caps, const gx_batch_opts* opts) {
+    if (!handles || n_handles <= 0 || !offsets) return fail(GX_E_ARG, "gx_extract_batch_multi: bad argument");
+    gx_batch_opts o{};
+    if (!read_opts(opts, &o)) return fail(GX_E_ARG, "gx_batch_opts.struct_size mismatch");
+    if (o.device_pointers) return fail(GX_E_ARG, "gx_extract_batch_multi: host buffers only (device buffers belong to one device: use gx_extract_batch per handle)");
+    for (int32_t k = 0; k < n_handles; ++k) {
+        if (!handles[k] || !handles[k]->on_device) return fail(GX_E_ARG, "gx_extract_batch_multi: NULL or host-only handle");
+        if (handles[k]->T.max_groups != handles[0]->T.max_groups || handles[k]->T.n_rules != handles[0]->T.n_rules)
+            return fail(GX_E_ARG, "gx_extract_batch_multi: the handles were not built from the same definition");
+    }
+    const size_t off_w = o.offsets64 ? 8 : 4;
+    auto off_at = [&](uint64_t i) -> uint64_t {
+        return o.offsets64 ? static_cast<const uint64_t*>(offsets)[i] : static_cast<const uint32_t*>(offsets)[i];
+    };
+    // shard boundaries by bytes
+    std::vector<uint64_t> cuts(static_cast<size_t>(n_handles) + 1, n);
+    cuts[0] = 0;
+    const uint64_t base = n ? off_at(0) : 0, total = n ? off_at(n) - base : 0;
+    for (int32_t k = 1; k < n_handles; ++k) {
+        const uint64_t want = base + total / static_cast<uint64_t>(n_handles) * static_cast<uint64_t>(k);
+        uint64_t lo = cuts[k - 1], hi = n;
+        while (lo < hi) { const uint64_t mid = (lo + hi) / 2; if (off_at(mid) >= want) hi = mid; else lo = mid + 1; }
+        cuts[k] = lo;
+    }
+    const bool compact = o.compact_results && !(o.match_only || !handles[0]->T.has_capture);
+    const size_t slots = 2 * static_cast<size_t>(handles[0]->T.max_groups);
+    std::vector<int> rc(static_cast<size_t>(n_handles), GX_OK);
+    std::vector<std::string> msg(static_cast<size_t>(n_handles));
+    std::vector<uint64_t> over(static_cast<size_t>(n_handles), 0);
+    std::vector<std::thread> pool;
+    for (int32_t k = 0; k < n_handles; ++k) {
+        pool.emplace_back([&, k]() {
+            const uint64_t a = cuts[k], m = cuts[k + 1] - cuts[k];
+            if (m == 0) return;
+            gx_batch_opts ok = o;
+            ok.struct_size = sizeof(gx_batch_opts);
+            ok.stream = nullptr;
+            ok.overflow = compact ? &over[k] : nullptr;
+            int32_t* mid_k = match_id ? match_id + a : nullptr;
+            int32_t* caps_k = !caps ? nullptr : compact ? reinterpret_cast<int32_t*>(reinterpret_cast<uint16_t*>(caps) + a * (1 + slots)) : caps + a * slots;
+            rc[k] = gx_extract_batch(handles[k], bytes, static_cast<const uint8_t*>(offsets) + a * off_w, m, mid_k, caps_k, &ok);
+            if (rc[k] != GX_OK) msg[k] = gx_last_error();
+        });
+    }
+    for (auto& t : pool) t.join();
+    for (int32_t k = 0; k < n_handles; ++k) if (rc[k] != GX_OK) return fail(rc[k], msg[k]);
+    if (compact && o.overflow) for (uint64_t v : over) *static_cast<uint64_t*>(o.overflow) += v;
+    return GX_OK;
 }
 
 int gx_state_accepts(const gx_handle* h, int32_t state, int32_t* indexes, int32_t cap) {

@@ -602,6 +602,34 @@ class Gorp:
         return out
 
 
+def extract_batch_multi(gorps, data, offsets, match_only=False, strip_eol=False, compact=False):
+    """gx_extract_batch_multi: one host CSR batch sharded by bytes over several Gorp objects (one per device, built
+    from the same definition).  Returns what Gorp.extract_batch returns."""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets)
+    n = len(offsets) - 1
+    G = gorps[0].max_groups
+    o = N.gx_batch_opts()
+    o.struct_size = C.sizeof(N.gx_batch_opts)
+    o.offsets64 = 1 if offsets.dtype == np.uint64 else 0
+    o.match_only = 1 if match_only else 0
+    o.strip_eol = 1 if strip_eol else 0
+    hs = (C.c_void_p * len(gorps))(*[g._h.ptr for g in gorps])
+    if compact and not match_only:
+        rows = np.zeros((n, 1 + 2 * G), np.uint16)
+        over = C.c_uint64(0)
+        o.compact_results = 1
+        o.overflow = C.cast(C.pointer(over), C.c_void_p)
+        _check(N.lib().gx_extract_batch_multi(hs, len(gorps), data.ctypes.data if data.size else None, offsets.ctypes.data, n, None,
+                                              rows.ctypes.data, C.byref(o)))
+        return rows, over.value
+    mid = np.zeros(n, np.int32)
+    caps = np.full((n, 2 * G), -1, np.int32)
+    _check(N.lib().gx_extract_batch_multi(hs, len(gorps), data.ctypes.data if data.size else None, offsets.ctypes.data, n, mid.ctypes.data,
+                                          caps.ctypes.data if caps.size else None, C.byref(o)))
+    return mid, caps
+
+
 def unpack_rows(rows):
     """Compact rows uint16[n, 1 + slots] -> (match_id int32[n], caps int32[n, slots]) on the host (numpy)."""
     rows = np.asarray(rows, dtype=np.uint16)

@@ -258,8 +258,27 @@ const char* gx_extraction_append_value_json(const gx_handle* h, int32_t k, int32
 /* Thread-local message for the last failing call on this thread. */
 const char* gx_last_error(void);
 
-/* Device selection for subsequently created handles (default: current HIP device). */
+/* Devices.  A handle lives on the device that is current for the calling thread when it is created (HIP's per-thread
+ * current device; device 0 unless gx_set_device was called on that thread) and every call on the handle runs there,
+ * whichever thread makes it.  One process drives several GPUs with one handle per device -- built from the same
+ * definition, or from one blob (gx_create_from_blob) -- and either its own threads, each calling gx_extract_batch on
+ * its handle (Gorp "may be used concurrently", core/Gorp.java:22), or gx_extract_batch_multi below. */
 int gx_device_count(void);
+int gx_set_device(int device);
+int gx_handle_device(const gx_handle* h);   /* -1 for a host-only handle */
+
+/* One CSR batch in HOST memory over several devices: the lines are cut into n_handles contiguous shards of about
+ * equal bytes (lines are independent: no exchange between the shards), shard k runs on handles[k]'s device through that
+ * handle's host pipeline, all shards concurrently, and the results land in the caller's arrays in line order.  The
+ * handles must come from the same definition.  opts as for gx_extract_batch (host pointers only; stream is ignored). */
+int gx_extract_batch_multi(gx_handle* const* handles, int32_t n_handles, const uint8_t* bytes, const void* offsets, uint64_t n,
+                           int32_t* match_id, int32_t* caps, const gx_batch_opts* opts);
+
+/* Host buffers that are handed to gx_extract_batch again and again (a JNI caller's direct ByteBuffers) can be pinned
+ * once: copies from and to pinned memory run at the bus' rate without a staging copy by the CPU (hipHostRegister /
+ * hipHostUnregister). */
+int gx_host_register(void* p, size_t bytes);
+int gx_host_unregister(void* p);
 
 #ifdef __cplusplus
 }

@@ -761,3 +761,55 @@ def test_match_batch_returns_all_accepting_indexes(golden):
     got = gorp.getMatcher().match_batch(*lines_to_csr(lines))
     assert got == [gorp.getMatcher().match(ln) for ln in lines]
     assert got[0] == [1, 2] and got[1] == [0, 2] and got[2] == [2] and got[3] == [] and got[4] == []
+
+
+def test_host_pipeline_chunks_and_multi_device_shards():
+    """Host buffers go through the chunked pipeline (several chunks on four worker streams), and gx_extract_batch_multi
+    shards one batch by bytes over several handles -- here two handles on the one GPU of the box, each driven by its own
+    thread: ragged lines, compact rows, match-only with final states, pinned (registered) buffers."""
+    from gorp_amd.gorp import extract_batch_multi
+    definition = W.readme3_definition()
+    orc = oracle_for(definition)
+    g1, g2 = Gorp.construct(definition), Gorp.construct(definition)
+    assert N.lib().gx_handle_device(g1._h.ptr) == 0 and N.lib().gx_set_device(0) == 0 and N.lib().gx_set_device(99) != 0
+    n = 250_000   # 50 MB: six chunks of 8 MB and a tail
+    data, offsets, cat = W.readme3_lines(n, seed=91)
+    d, o = data.numpy().copy(), offsets.numpy().copy()
+    omid, ocaps = orc.extract_batch(d, o, nthreads=8)
+    mid, caps = g1.extract_batch(d, o)
+    assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+    rows, over = g1.extract_batch(d, o, compact=True)
+    cm, cc = G.unpack_rows(rows)
+    assert over == 0 and np.array_equal(cm, omid) and np.array_equal(cc, ocaps)
+    # pinned in place: the same answers (and the copies skip the staging copy)
+    assert N.lib().gx_host_register(d.ctypes.data, d.nbytes) == 0
+    try:
+        mid, caps = g1.extract_batch(d, o)
+        assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+    finally:
+        assert N.lib().gx_host_unregister(d.ctypes.data) == 0
+    # two handles, two threads, one batch
+    mid, caps = extract_batch_multi([g1, g2], d, o)
+    assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+    rows, over = extract_batch_multi([g1, g2], d, o, compact=True)
+    cm, cc = G.unpack_rows(rows)
+    assert over == 0 and np.array_equal(cm, omid) and np.array_equal(cc, ocaps)
+    m2, _ = extract_batch_multi([g1, g2], d, o, match_only=True)
+    assert np.array_equal(m2, orc.extract_batch(d, o, match_only=True, nthreads=8)[0])
+    # ragged lines incl. empty and very long ones, more handles than it takes, 64-bit offsets
+    rng = random.Random(5)
+    lines = []
+    for k in range(3000):
+        r = rng.random()
+        body = "".join(rng.choice("abc/-_.=?&%09") for _ in range(int(40000 ** rng.random())))
+        lines.append("" if r < 0.05 else ("[%09d]: GET %dms /%s" % (rng.randrange(10 ** 9), rng.randrange(9999), body)) if r < 0.7 else body)
+    dd, oo = lines_to_csr(lines, offsets_dtype=np.uint64)
+    wm, wc = orc.extract_batch(dd, oo, nthreads=8)
+    g3 = Gorp.construct(definition)
+    mid, caps = extract_batch_multi([g1, g2, g3], dd, oo)
+    assert np.array_equal(mid, wm) and np.array_equal(caps, wc)
+    # PolyMatcher.match over a batch (final states) through the pipeline
+    pm = PolyMatcher.create(*[e.build()[0] for e in definition])
+    got = pm.match_batch(d[: 200 * 40000], o[:40001])
+    want = [orc.match(bytes(d[o[i]:o[i + 1]]).decode("latin-1")) for i in range(0, 40000, 997)]
+    assert [got[i] for i in range(0, 40000, 997)] == want
