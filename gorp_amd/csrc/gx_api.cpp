@@ -633,19 +633,23 @@ bool plan_tile_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out, 
     uint32_t nw = (LDS_BYTES - L.table_bytes) / (L.stage_bytes + fixed);
     if (nw > 12) nw = 12;  // 768 threads: leaves 170 VGPRs per lane for the prefetch registers
     if (L.stage_bytes > 13u * 1024u && nw > 8) nw = 8;  // the 16 KB variant prefetches 64 VGPRs: 2 waves per SIMD
+#ifdef GX_DEV
+    if (getenv("GX_DEV_NWAVES") && static_cast<uint32_t>(atoi(getenv("GX_DEV_NWAVES"))) < nw) nw = static_cast<uint32_t>(atoi(getenv("GX_DEV_NWAVES")));
+#endif
     // Whatever LDS is left goes to the staging areas, up to what the kernel variant's prefetch registers hold: a hint
     // that is a few bytes short (mean length, lines of 201 bytes announced as 200) then still stages whole groups.
     {
         const uint32_t kch = (L.stage_bytes + 1023u) / 1024u;
         const uint32_t cap = (kch <= 4 ? 4u : kch <= 8 ? 8u : kch <= 13 ? 13u : 16u) * 1024u;
-        uint32_t room = ((LDS_BYTES - L.table_bytes) / nw - fixed) & ~15u;
+        uint32_t room = ((LDS_BYTES - L.table_bytes - 32u) / nw - fixed) & ~15u;
         if (room > cap) room = cap;
         if (room > L.stage_bytes) L.stage_bytes = room;
     }
     L.nwaves = nw;
     L.regs = L.table_bytes;
     L.bitmap = L.regs + nw * L.regs_wave_bytes;
-    L.stage = (L.bitmap + nw * GX_BITMAP_WAVE_BYTES + 15u) & ~15u;
+    L.counter = L.bitmap + nw * GX_BITMAP_WAVE_BYTES;
+    L.stage = (L.counter + 16u + 15u) & ~15u;
     L.total_bytes = L.stage + nw * L.stage_bytes;
     if (L.total_bytes > LDS_BYTES) { L.stage_bytes -= 16u; L.total_bytes = L.stage + nw * L.stage_bytes; }
     *out = L;

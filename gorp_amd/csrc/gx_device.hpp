@@ -70,6 +70,7 @@ struct GxLds {
     uint32_t regs_wave_bytes;
     uint32_t bitmap;      // tile kernel: u64[nwaves][18], bit c of a wave's map = "all 16 bytes of staged chunk c lie in
                           // the hot interval" (written when the tile is staged, read by the walk to jump over runs)
+    uint32_t counter;     // tile kernel: u32, the workgroup's next tile (gx_tile.hip)
     uint32_t stage;       // u8[nwaves][stage_bytes]
     uint32_t stage_bytes; // multiple of 16
     uint32_t nwaves;

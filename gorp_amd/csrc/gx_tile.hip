@@ -48,7 +48,8 @@ struct TileIO {
     int32_t strip_eol;
 #ifdef GX_DEV
     unsigned long long* stamps;  // developer build: per-phase cycle totals, [4] per wave
-    uint32_t dev_flags;          // developer build: experiments (bit 0: consecutive tiles per wave; bit 1: nontemporal result stores)
+    uint32_t dev_flags;          // developer build: experiments (bit 1: nontemporal result stores;
+                                 // bit 2: no result stores)
 #endif
 };
 
@@ -222,6 +223,7 @@ k_extract_tile(GxLds L, TileIO io) {
         const uint4* src = reinterpret_cast<const uint4*>(io.image);
         uint4* dst = reinterpret_cast<uint4*>(gx_smem);
         for (uint32_t c = threadIdx.x; c < L.table_bytes / 16; c += blockDim.x) dst[c] = src[c];
+        if (threadIdx.x == 0) lds_st<uint32_t>(L.counter, 2u * L.nwaves);  // the workgroup's tile counter (below)
     }
     __syncthreads();
 
@@ -255,8 +257,7 @@ k_extract_tile(GxLds L, TileIO io) {
 
     const int G = io.max_groups;
     const uint32_t slots = 2u * static_cast<uint32_t>(G);
-    uint64_t tiles = (n + 63) >> 6;
-    uint64_t wstride = static_cast<uint64_t>(gridDim.x) * L.nwaves;
+    const uint64_t tiles = (n + 63) >> 6;
     const uint8_t* data_end = data + static_cast<uint64_t>(off[n]);
 
     auto load_offsets = [&](uint64_t tile, uint64_t& o0, uint64_t& o1) {
@@ -304,15 +305,22 @@ k_extract_tile(GxLds L, TileIO io) {
         return t;
     };
 
-    uint64_t tile = static_cast<uint64_t>(blockIdx.x) * L.nwaves + wave;
-#ifdef GX_DEV
-    if (io.dev_flags & 1u) {  // experiment: every wave takes a run of consecutive tiles instead of every wstride-th one
-        const uint64_t per = (tiles + wstride - 1) / wstride;
-        tile *= per;
-        tiles = min(tiles, tile + per);
-        wstride = 1;
-    }
-#endif
+    // Tiles are handed out inside the workgroup on demand: workgroup b owns tiles b, b + grid, b + 2 grid, ... (so the
+    // tiles being read at any moment are one dense window of the buffer), and a wave that has finished a tile takes
+    // the workgroup's next one from a counter in LDS.  A static split would leave every wave the same number of tiles,
+    // but the waves of a workgroup do not run at the same speed -- 11 waves sit 3, 3, 3 and 2 to a SIMD -- and the
+    // kernel would end with the slowest.  Each wave looks three tiles ahead (walking / bytes in flight / offsets in
+    // flight), so the counter's answer is never waited for.
+    const uint64_t grid = gridDim.x;
+    auto tile_of = [&](uint32_t j) -> uint64_t { return min(static_cast<uint64_t>(blockIdx.x) + static_cast<uint64_t>(j) * grid, tiles); };
+    auto grab = [&]() -> uint32_t {  // (lane 0's value counts; read with readfirstlane where it is used)
+        uint32_t j = 0;
+        if (lane == 0) j = __hip_atomic_fetch_add((GX_LDS uint32_t*)(uintptr_t)L.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return j;
+    };
+    uint64_t tile = tile_of(wave);
+    uint64_t t1 = tile_of(L.nwaves + wave);   // the group after `tile`: its offsets are loaded one iteration ahead
+    uint32_t j2 = grab();                     // and the one after that
     if (tile >= tiles) return;
 #ifdef GX_DEV
     unsigned long long phase_cycles[4] = {0, 0, 0, 0};
@@ -326,7 +334,7 @@ k_extract_tile(GxLds L, TileIO io) {
         load_offsets(tile, o0, o1);
         cur = make_round(tile, 0, o0, o1);
     }
-    load_offsets(min(tile + wstride, tiles - 1), no0, no1);
+    load_offsets(min(t1, tiles - 1), no0, no1);
     tile_issue_loads<KCH>(cur, lane, pre, io.image);
 
     for (;;) {
@@ -335,14 +343,16 @@ k_extract_tile(GxLds L, TileIO io) {
         // ---- software pipeline: start fetching the next round (and the offsets of the group after it) ----
         const uint32_t group_lines = static_cast<uint32_t>(min(static_cast<uint64_t>(64), n - (tile << 6)));
         const bool same_group = cur.b < group_lines;
-        const uint64_t ntile = same_group ? tile : tile + wstride;
+        const uint64_t ntile = same_group ? tile : t1;
         const bool has_next = ntile < tiles;
+        const uint64_t t2 = tile_of(__builtin_amdgcn_readfirstlane(j2));
+        const uint64_t after = same_group ? t1 : t2;  // the group after `ntile`
         // Offsets of the group after the next one first, then the prefetch, and nothing in between that depends on
         // vector memory: both are unconditional (index clamped -- the same values again while the group is
         // unchanged; a dummy chunk when there is no next round), because a conditional load needs a register copy
         // at the join, and that copy would wait for every load issued before it.
         uint64_t nno0, nno1;
-        load_offsets(min(ntile + wstride, tiles - 1), nno0, nno1);
+        load_offsets(min(after, tiles - 1), nno0, nno1);
         TileInfo nxt = make_round(has_next ? ntile : tile, has_next ? (same_group ? cur.b : 0u) : cur.a,
                                   has_next && !same_group ? no0 : cur.o0, has_next && !same_group ? no1 : cur.o1);
         if (!has_next) nxt.mode = 3;  // nothing to fetch: the loop ends after this round
@@ -411,6 +421,7 @@ k_extract_tile(GxLds L, TileIO io) {
                     for (uint32_t c = lane; c < 4u * row_b; c += 64u) {  // 64 * row_b / 16 chunks
 #ifdef GX_DEV
                         if (io.dev_flags & 2u) { __builtin_nontemporal_store(lds_ld<u32x4>(stage + (c << 4)), reinterpret_cast<u32x4*>(out + (c << 4))); continue; }
+                        if ((io.dev_flags & 4u) && c != 0u) continue;  // experiment: (almost) no result stores
 #endif
                         *reinterpret_cast<u32x4*>(out + (c << 4)) = lds_ld<u32x4>(stage + (c << 4));
                     }
@@ -453,6 +464,10 @@ k_extract_tile(GxLds L, TileIO io) {
         __builtin_amdgcn_wave_barrier();
         GX_STAMP(3);
         if (!has_next) break;
+        if (!same_group) {  // (wave-uniform)
+            t1 = t2;
+            j2 = grab();
+        }
         cur = nxt;
         tile = ntile;
         no0 = nno0;
