@@ -18,9 +18,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgorp_hip.so")
 LIB_DEV = os.path.join(HERE, "libgorp_hip_dev.so")
-SOURCES = ["gx_regex.cpp", "gx_compile.cpp", "gx_host.cpp", "gx_dsl.cpp", "gx_api.cpp", "gx_tile.hip", "gx_kernels.hip", "gx_ingest.hip",
-           "gx_jsonl.hip"]
-HEADERS = ["gx_common.hpp", "gx_compile.hpp", "gx_device.hpp", "gx_dsl.hpp", "gx_walk.hpp", os.path.join("..", "..", "include", "gorp_hip.h")]
+SOURCES = ["gx_tile_lds.hip", "gx_tile_l2.hip", "gx_tile_rec.hip", "gx_tile_recg.hip", "gx_kernels.hip", "gx_jsonl.hip", "gx_api.cpp",
+           "gx_compile.cpp", "gx_dsl.cpp", "gx_regex.cpp", "gx_host.cpp", "gx_tile.hip", "gx_ingest.hip"]   # (the long ones first)
+HEADERS = ["gx_common.hpp", "gx_compile.hpp", "gx_device.hpp", "gx_dsl.hpp", "gx_walk.hpp", "gx_tile_body.hpp",
+           os.path.join("..", "..", "include", "gorp_hip.h")]
 
 
 def _hipcc():
@@ -61,7 +62,7 @@ def build(force=False, verbose=False, dev=False):
         subprocess.check_call(job[0])
         return job[1]
 
-    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as pool:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
         objs = list(pool.map(run, jobs))
     # -no-hip-rt: do not record a NEEDED entry for a particular libamdhip64.  The process
     # must hold exactly ONE HIP runtime; PyTorch wheels bundle their own copy (different

@@ -1,0 +1,524 @@
+// gx_tile_body.hpp -- the batch kernel of the Gorp match-and-extract hot path on gfx950: one wave per tile of 64 lines.
+//
+// Replaces, per line (lane-per-line, no cross-line state):
+//   hot loop #1  PolyMatcher.match      core/autom/PolyMatcher.java:123-133
+//                Automata.step/accept   core/autom/Automata.java:133-139
+//   hot loop #2  JDKRegexpCookedExtraction.match/_constructMatch
+//                                       core/jdkre/JDKRegexpCookedExtraction.java:36-59
+//   driver       Gorp.extract           core/Gorp.java:159-186
+//
+// One wave owns one tile of 64 consecutive lines at a time.  The tile's bytes are one contiguous span of the CSR
+// buffer: the wave fetches it with 16-byte-per-lane coalesced loads (every HBM byte is read exactly once, in whole
+// cache lines) into registers one tile AHEAD, copies it into its LDS staging area, and then each lane walks its own
+// line out of LDS.  All automaton tables (byte->class map, class-compressed rows, capture programs) live in LDS
+// (TIER_LDS) or, for large definitions, the rows stay in global memory / L2 (TIER_L2).
+//
+// Self-loop acceleration, two levels:
+//  * per state the host precomputes the longest run [lo,hi] of ASCII byte values on which the state loops to itself
+//    with no capture operation.  While a lane sits in such a state it tests 16 staged bytes at once with SWAR
+//    arithmetic and skips them if all lie in [lo,hi]; any other byte falls through to the exact one-byte steps.
+//  * the widest such interval of the definition is the "hot" interval.  While the tile is still in registers, every
+//    lane tests the chunks it holds against the hot interval (all 64 lanes busy on distinct data, no LDS traffic) and
+//    the wave leaves one bit per 16-byte chunk in LDS.  A lane whose state loops on the whole hot interval then
+//    jumps over a run of such chunks with one bitmap lookup instead of testing window after window.
+//  Exactness never depends on either: a set bit / passed test is a fact about bytes on which the state provably
+//  stays put; everything else takes the exact steps.
+#pragma once
+#include "gx_walk.hpp"
+
+namespace gx {
+
+namespace {
+
+// What the kernel reads and writes besides the table layout (GxLds).
+struct TileIO {
+    const uint8_t* image;        // the LDS table image, in global memory
+    const uint8_t* at_global;    // TIER_L2: automaton rows in global memory
+    const uint8_t* data;
+    const void* off;
+    uint64_t n;
+    int32_t* match_id;
+    int32_t* caps;
+    uint16_t* packed;            // compact rows instead of match_id / caps
+    uint32_t* oversize_flag;
+    uint32_t seq;
+    int32_t max_groups;
+    int32_t strip_eol;
+#ifdef GX_DEV
+    unsigned long long* stamps;  // developer build: per-phase cycle totals, [4] per wave
+    uint32_t dev_flags;          // developer build: experiments (bit 1: nontemporal result stores;
+                                 // bit 2: no result stores)
+#endif
+};
+
+// Walk one automaton over the staged line [start, end) (offsets into the wave's staging area at LDS address
+// `stage`), all lanes in lock step over 16-byte windows of their own line.  In every window a lane either proves
+// with one SWAR test that all its bytes stay inside the current state's self-loop interval (state unchanged, 16
+// bytes skipped -- and, in a state that loops on the hot interval, every following chunk whose bit is set in
+// `bitmap` as well), or takes 16 exact steps (the partial last window of a line goes through the identity column
+// or, when it passes the range test dword by dword, is skipped too).  Returns the row of the final state.
+template <int TIER, bool CAPTURE, bool SIMPLE>
+__device__ __forceinline__ uint32_t walk(const WalkTab& W, uint32_t stage, uint32_t bitmap, bool use_map, uint32_t row, uint32_t start,
+                                         uint32_t end, bool on, uint32_t dead_row, uint32_t regs) {
+    uint32_t wb = start;  // windows are relative to the line, not to the staging area: see lds_window
+    const uint32_t len = end - start;
+    const uint32_t full_lim = len >= 16u ? len - 15u : 0u;  // window at line offset rel is full iff rel < full_lim
+    uint32_t acc = state_acc<TIER>(W, row);  // self-loop interval: lo | (0x7F - hi) << 8 | hot << 16
+    uint32_t lo4 = splat_byte0(acc), k4 = splat_byte1(acc);
+    bool more = on && start < end;
+    while (__any(more)) {
+        // a finished lane keeps its last window: the address stays inside the staged tile
+        const uint4 w0 = lds_window_any(stage + wb);
+        const uint32_t rel = wb - start;
+        const bool full0 = rel < full_lim;
+        bool ok0 = false;
+        bool step = more;
+        uint32_t mask = 0xFFFFu;
+        if (__any(more && k4 != HI_BITS)) {  // (no lane in a state with a self-loop interval: straight to the steps)
+            const uint32_t bx = outside_bits(w0.x, lo4, k4), by = outside_bits(w0.y, lo4, k4);
+            const uint32_t bz = outside_bits(w0.z, lo4, k4), bw = outside_bits(w0.w, lo4, k4);
+            ok0 = full0 & (((or3(bx, by, bz) | bw) & HI_BITS) == 0u);
+            step = more && !ok0;
+            if (step && !full0) {
+                mask = window_mask(start, end, wb);
+                step = !partial_window_ok(bx, by, bz, bw, mask);
+            }
+        } else if (!full0) mask = window_mask(start, end, wb);
+        uint32_t nwb = wb + 16u;
+        // The window just tested is verified and the state loops on the whole hot interval: the chunk that begins
+        // inside the window, and every chunk after it, is skipped as long as its bit says "all bytes hot".
+        const bool jump = use_map && more && ok0 && (acc & 0x10000u) != 0u;
+        if (__any(jump)) {
+            const uint32_t c0 = (wb + 15u) >> 4;
+            const uint32_t wa = bitmap + ((c0 >> 5) << 2);
+            const uint32_t m_lo = lds_ld<uint32_t>(wa), m_hi = lds_ld<uint32_t>(wa + 4u);
+            const uint32_t bits = __builtin_amdgcn_alignbit(m_hi, m_lo, c0 & 31u);  // bits of chunks c0 .. c0 + 31
+            const uint32_t run = min(static_cast<uint32_t>(__builtin_ffs(static_cast<int>(~bits)) - 1), 32u);
+            if (jump && run) nwb = min((c0 + run) << 4, end);
+        }
+        // one variant per wave: if any stepping lane has a partial window, every stepping lane takes the masked
+        // steps (its mask is all ones) instead of the wave running both variants one after the other
+        const bool masked = __any(step && !full0);
+        if (step) {
+            if (!masked) row = steps16<TIER, CAPTURE, false, SIMPLE>(w0, mask, W, row, rel, regs);
+            else row = steps16<TIER, CAPTURE, true, SIMPLE>(w0, mask, W, row, rel, regs);
+            acc = state_acc<TIER>(W, row);
+            lo4 = splat_byte0(acc);
+            k4 = splat_byte1(acc);
+        }
+        if (more) wb = nwb;
+        more = more && wb < end && row != dead_row;
+    }
+    return row;
+}
+
+// Staging copy for a span that touches the first or last bytes of the buffer: never reads outside [data, data_end).
+__device__ void stage_span_guarded(const uint8_t* __restrict__ g_al, uint32_t nch, uint32_t stage, uint32_t lane,
+                                   const uint8_t* data, const uint8_t* data_end) {
+    for (uint32_t c = lane; c < nch; c += 64) {
+        const uint8_t* src = g_al + (static_cast<uint64_t>(c) << 4);
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int q = 0; q < 16; ++q)
+            if (src + q >= data && src + q < data_end) w[q >> 2] |= static_cast<uint32_t>(src[q]) << ((q & 3) * 8);
+        lds_st<u32x4>(stage + (c << 4), u32x4{w[0], w[1], w[2], w[3]});
+    }
+}
+
+// What one wave needs to know about a round: the lines of a 64-line group (lane = line) that are staged and
+// walked together.  Normally one round covers the whole group; when the group's bytes do not fit the staging
+// area (lines longer than the hint, mixed lengths) the group is taken in several rounds of consecutive lanes.
+// (32-bit flags and no padding: a struct with padding bytes is copied through scratch memory.)
+struct TileInfo {
+    uint64_t i;            // this lane's line index
+    uint64_t o0, o1;       // its byte range in the CSR buffer
+    const uint8_t* g_al;   // 16-byte aligned start of the round's span in global memory
+    uint32_t nch;          // 16-byte chunks in the span
+    uint32_t start, end;   // this lane's line inside the staging area (0, 0 for a lane outside the round)
+    uint32_t mode;         // 0: prefetched into registers; 1: touches the buffer edge (guarded copy);
+                           // 2: one line that does not fit the staging area (left to the per-line kernel); 3: nothing
+    uint32_t active;       // this lane's line belongs to the round
+    uint32_t a, b;         // the round covers lanes [a, b) of the group (wave-uniform)
+    uint32_t pad_;
+};
+
+// Clamped, unconditional accesses on both sides: a lane beyond the span re-reads / rewrites the last chunk
+// with identical data.  (Per-lane conditions make the compiler spill the array and serialise the batch.)
+// Unconditional as well: a round that is not prefetched (mode != 0, or no next round) loads one dummy chunk instead.
+// A branch around the loads would make the compiler lose count of them at the join and wait for all of them --
+// i.e. for the whole prefetch -- at the next vector-memory dependency, long before the walk.
+template <int KCH>
+__device__ __forceinline__ void tile_issue_loads(const TileInfo& t, uint32_t lane, u32x4 (&pre)[KCH], const uint8_t* __restrict__ dummy) {
+    // wave-uniform: scalar base + 32-bit lane offset (readfirstlane keeps the selects on the scalar unit; folded into
+    // the per-lane offsets they cost two vector instructions per load)
+    const uint64_t src_u = reinterpret_cast<uint64_t>(t.mode == 0 ? t.g_al : dummy);
+    const uint32_t src_lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(src_u));  // (the builtin returns int: no sign extension)
+    const uint32_t src_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(src_u >> 32));
+    const uint64_t src = (static_cast<uint64_t>(src_hi) << 32) | src_lo;
+    const uint32_t last16 = __builtin_amdgcn_readfirstlane(t.mode == 0 ? (t.nch - 1u) << 4 : 0u);
+    const uint32_t lane16 = lane << 4;
+#pragma unroll
+    for (int k = 0; k < KCH; ++k) {
+        const uint32_t o = min(lane16 + 1024u * k, last16);
+        pre[k] = __builtin_nontemporal_load((__attribute__((address_space(1))) const u32x4*)(src + o));  // a global_load, not a flat one
+    }
+}
+// Registers -> staging area, and the hot-interval bit of every chunk -> the wave's bitmap (bit 64 k + lane of the
+// map belongs to the chunk lane `lane` holds in pre[k]; a clamped lane describes a chunk beyond the span, which no
+// line of the round reaches).
+template <int KCH, int MAP>  // MAP 0: no bitmap; 1: general hot interval; 2: hot interval ends at 0x7F
+__device__ __forceinline__ void commit_chunks(const TileInfo& t, uint32_t lane, const u32x4 (&pre)[KCH], uint32_t stage, uint32_t bitmap,
+                                              uint32_t hot_lo4, uint32_t hot_k4) {
+    const uint32_t last = stage + ((t.nch - 1u) << 4), mine = stage + (lane << 4);
+#pragma unroll
+    for (int k = 0; k < KCH; ++k) {
+        lds_st<u32x4>(min(mine + 1024u * k, last), pre[k]);
+        if (MAP) {
+            const unsigned long long m = __ballot(chunk_inside<MAP == 2>(pre[k], hot_lo4, hot_k4));
+            if (lane == 0) lds_st<u32x2>(bitmap + 8u * k, u32x2{static_cast<uint32_t>(m), static_cast<uint32_t>(m >> 32)});
+        }
+    }
+}
+template <int KCH>
+__device__ __forceinline__ void tile_commit(const TileInfo& t, uint32_t lane, const u32x4 (&pre)[KCH], uint32_t stage, uint32_t bitmap,
+                                            bool use_map, uint32_t hot_lo4, uint32_t hot_k4, const uint8_t* data, const uint8_t* data_end) {
+    if (t.mode == 0) {
+        if (!use_map) commit_chunks<KCH, 0>(t, lane, pre, stage, bitmap, hot_lo4, hot_k4);
+        else if (hot_k4 == 0u) commit_chunks<KCH, 2>(t, lane, pre, stage, bitmap, hot_lo4, hot_k4);
+        else commit_chunks<KCH, 1>(t, lane, pre, stage, bitmap, hot_lo4, hot_k4);
+    } else if (t.mode == 1) {
+        stage_span_guarded(t.g_al, t.nch, stage, lane, data, data_end);
+        if (use_map && lane < 2u * KCH) lds_st<uint32_t>(bitmap + 4u * lane, 0u);  // no chunk of a guarded round is skipped
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#ifdef GX_DEV
+#define GX_STAMP(slot)                                                        \
+    do {                                                                      \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
+        phase_cycles[slot] += now_ - stamp_;                                  \
+        stamp_ = now_;                                                        \
+    } while (0)
+#else
+#define GX_STAMP(slot) do { } while (0)
+#endif
+
+// MODE 0: PolyMatcher.match alone (match automaton, first accepting extraction).
+// MODE 1: the fused automaton with branch-free capture steps (every program is "one register := position").
+// MODE 2: everything else: fused automaton with general programs, or match automaton then the winning
+//         extraction's capture automaton (definitions too large to fuse).
+// KCH: 16-byte chunks per lane that cover the staging area (stage_bytes <= KCH * 1024).  A tile's span is
+// fetched into KCH*4 VGPRs per lane one tile AHEAD: the loads are issued before the current tile is walked
+// and land while the wave computes out of LDS, so HBM latency is hidden without a second LDS buffer.
+// PACKED: results leave as compact rows (gx_batch_opts.compact_results) -- a kernel of its own, so that profiles tell
+// the two result formats apart.
+template <typename OFF, int KCH, int TIER, int MODE, bool PACKED>
+__global__ void __launch_bounds__(KCH > 13 ? 512 : 768) __attribute__((amdgpu_waves_per_eu(1, KCH > 13 ? 2 : 3)))
+k_extract_tile(GxLds L, TileIO io) {
+    // ---- prologue: table image -> LDS (the only access through the __shared__ symbol; its address is 0) ----
+    {
+        extern __shared__ __attribute__((aligned(16))) uint8_t gx_smem[];
+        const uint4* src = reinterpret_cast<const uint4*>(io.image);
+        uint4* dst = reinterpret_cast<uint4*>(gx_smem);
+        for (uint32_t c = threadIdx.x; c < L.table_bytes / 16; c += blockDim.x) dst[c] = src[c];
+        if (threadIdx.x == 0) lds_st<uint32_t>(L.counter, 2u * L.nwaves);  // the workgroup's tile counter (below)
+    }
+    __syncthreads();
+
+    constexpr bool GT = TIER == TIER_L2 || TIER == TIER_RECG;  // automaton tables and final records in global memory
+    const uint8_t* __restrict__ data = io.data;
+    const OFF* __restrict__ off = static_cast<const OFF*>(io.off);
+    const uint64_t n = io.n;
+    // match automaton / fused (or per-extraction capture) automaton
+    WalkTab Wm, Wc;
+    Wm.at = GT ? io.at_global + (TIER == TIER_RECG ? L.c_base : 0u) : nullptr;  // (records: one index space per image)
+    Wm.row_bytes = L.row_bytes;
+    Wm.ops_off = L.ops_off;
+    Wm.ops = L.ops;
+    Wm.rec = L.rec;
+    Wm.acc_tab = L.acc_tab;
+    Wm.dead = L.m_dead;
+    Wm.ncls = L.ncls;
+    Wc = Wm;
+    if (GT) Wc.at = io.at_global + L.c_base;
+    Wc.dead = L.u_dead;  // (two-pass layout: set per lane below)
+
+    const uint32_t lane = threadIdx.x & 63u;
+    // (the wave index through readfirstlane: everything derived from it -- tile numbers, LDS areas, the round's span --
+    // is then wave-uniform for the compiler too, i.e. scalar registers and scalar arithmetic)
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t stage = L.stage + wave * L.stage_bytes;
+    const uint32_t bitmap = L.bitmap + wave * GX_BITMAP_WAVE_BYTES;
+    const bool use_map = L.hot_k4 != HI_BITS;
+    // register r of this lane = u16 at regs + r * 128; the column before register 0 is a write-only dummy
+    const uint32_t regs = L.regs + wave * L.regs_wave_bytes + 128u + lane * 2u;
+
+    const int G = io.max_groups;
+    const uint32_t slots = 2u * static_cast<uint32_t>(G);
+    const uint64_t tiles = (n + 63) >> 6;
+    const uint8_t* data_end = data + static_cast<uint64_t>(off[n]);
+
+    auto load_offsets = [&](uint64_t tile, uint64_t& o0, uint64_t& o1) {
+        const uint64_t i = (tile << 6) + lane;
+        const bool valid = i < n;
+        o0 = off[valid ? i : n];
+        o1 = off[valid ? i + 1 : n];
+    };
+    // the value lane `src` (wave-uniform) holds, as a wave-uniform value
+    auto lane_value = [&](uint64_t v, uint32_t src) -> uint64_t {
+        const uint32_t l = __builtin_amdgcn_readfirstlane(src);
+        const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(v), l);
+        const uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(v >> 32), l);
+        return (static_cast<uint64_t>(hi) << 32) | lo;
+    };
+    // Round of group `tile` starting at lane a: as many consecutive lines as fit the staging area.
+    auto make_round = [&](uint64_t tile, uint32_t a, uint64_t o0, uint64_t o1) {
+        TileInfo t;
+        t.i = (tile << 6) + lane;
+        const bool valid = t.i < n;
+        t.pad_ = 0;
+        t.o0 = o0; t.o1 = o1;
+        t.a = a;
+        const uint64_t lo = lane_value(o0, a);  // lane a holds a valid line
+        const uint8_t* g_lo = data + lo;
+        const uint32_t skew = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(g_lo) & 15u);
+        t.g_al = g_lo - skew;  // 16-byte aligned; still a global-address-space pointer for the compiler
+        // offsets ascend, so the lines that fit are a run of lanes starting at a (+48: the walk looks ahead of the line)
+        const bool fits = lane >= a && valid && (o1 - lo) + skew + 48u <= L.stage_bytes;
+        const uint32_t cnt = static_cast<uint32_t>(__popcll(__ballot(fits)));
+        if (cnt == 0) {  // line a alone is longer than the staging area
+            t.b = a + 1u;
+            t.mode = 2;
+            t.nch = 1;
+        } else {
+            t.b = a + cnt;
+            const uint64_t hi = lane_value(o1, t.b - 1u);
+            const uint64_t span = (hi - lo) + skew;
+            t.nch = max(static_cast<uint32_t>((span + 15) >> 4), 1u);
+            t.mode = (t.g_al >= data && t.g_al + (static_cast<uint64_t>(t.nch) << 4) <= data_end) ? 0u : 1u;
+        }
+        t.active = (lane >= a && lane < t.b) ? 1u : 0u;
+        t.start = t.active ? skew + static_cast<uint32_t>(o0 - lo) : 0u;
+        t.end = t.active ? skew + static_cast<uint32_t>(o1 - lo) : 0u;
+        return t;
+    };
+
+    // Tiles are handed out inside the workgroup on demand: workgroup b owns tiles b, b + grid, b + 2 grid, ... (so the
+    // tiles being read at any moment are one dense window of the buffer), and a wave that has finished a tile takes
+    // the workgroup's next one from a counter in LDS.  A static split would leave every wave the same number of tiles,
+    // but the waves of a workgroup do not run at the same speed -- 11 waves sit 3, 3, 3 and 2 to a SIMD -- and the
+    // kernel would end with the slowest.  Each wave looks three tiles ahead (walking / bytes in flight / offsets in
+    // flight), so the counter's answer is never waited for.
+    const uint64_t grid = gridDim.x;
+    auto tile_of = [&](uint32_t j) -> uint64_t { return min(static_cast<uint64_t>(blockIdx.x) + static_cast<uint64_t>(j) * grid, tiles); };
+    auto grab = [&]() -> uint32_t {  // (lane 0's value counts; read with readfirstlane where it is used)
+        uint32_t j = 0;
+        if (lane == 0) j = __hip_atomic_fetch_add((GX_LDS uint32_t*)(uintptr_t)L.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return j;
+    };
+    uint64_t tile = tile_of(wave);
+    uint64_t t1 = tile_of(L.nwaves + wave);   // the group after `tile`: its offsets are loaded one iteration ahead
+    uint32_t j2 = grab();                     // and the one after that
+    if (tile >= tiles) return;
+#ifdef GX_DEV
+    unsigned long long phase_cycles[4] = {0, 0, 0, 0};
+    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+#endif
+    u32x4 pre[KCH];  // the next round's bytes, in flight or landed
+    uint64_t no0 = 0, no1 = 0;
+    TileInfo cur;
+    {
+        uint64_t o0, o1;
+        load_offsets(tile, o0, o1);
+        cur = make_round(tile, 0, o0, o1);
+    }
+    load_offsets(min(t1, tiles - 1), no0, no1);
+    tile_issue_loads<KCH>(cur, lane, pre, io.image);
+
+    for (;;) {
+        tile_commit<KCH>(cur, lane, pre, stage, bitmap, use_map, L.hot_lo4, L.hot_k4, data, data_end);
+        GX_STAMP(0);
+        // ---- software pipeline: start fetching the next round (and the offsets of the group after it) ----
+        const uint32_t group_lines = static_cast<uint32_t>(min(static_cast<uint64_t>(64), n - (tile << 6)));
+        const bool same_group = cur.b < group_lines;
+        const uint64_t ntile = same_group ? tile : t1;
+        const bool has_next = ntile < tiles;
+        const uint64_t t2 = tile_of(__builtin_amdgcn_readfirstlane(j2));
+        const uint64_t after = same_group ? t1 : t2;  // the group after `ntile`
+        // Offsets of the group after the next one first, then the prefetch, and nothing in between that depends on
+        // vector memory: both are unconditional (index clamped -- the same values again while the group is
+        // unchanged; a dummy chunk when there is no next round), because a conditional load needs a register copy
+        // at the join, and that copy would wait for every load issued before it.
+        uint64_t nno0, nno1;
+        load_offsets(min(after, tiles - 1), nno0, nno1);
+        TileInfo nxt = make_round(has_next ? ntile : tile, has_next ? (same_group ? cur.b : 0u) : cur.a,
+                                  has_next && !same_group ? no0 : cur.o0, has_next && !same_group ? no1 : cur.o1);
+        if (!has_next) nxt.mode = 3;  // nothing to fetch: the loop ends after this round
+        tile_issue_loads<KCH>(nxt, lane, pre, io.image);
+        GX_STAMP(1);
+
+        const uint64_t i = cur.i;
+        const bool valid = cur.active != 0u;
+        const uint32_t start = cur.start;
+        uint32_t end = cur.end;
+        if (io.strip_eol && cur.mode != 2) {  // the terminator is staged with the line (trim_eol, from LDS)
+            if (end > start && lds_ld<uint8_t>(stage + end - 1u) == 0x0Au) --end;
+            if (end > start && lds_ld<uint8_t>(stage + end - 1u) == 0x0Du) --end;
+        }
+        if (cur.mode == 2) {
+            // one line that does not fit the staging area: the per-line kernel takes it in a follow-up launch
+            if (lane == cur.a) __hip_atomic_store(io.oversize_flag, io.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (MODE == 0) {
+            // ---- hot loop #1 alone: PolyMatcher.match ----
+            const uint32_t mrow = walk<TIER, false, false>(Wm, stage, bitmap, use_map, L.m_start, start, end, true, L.m_dead, regs);
+            if (valid) io.match_id[i] = state_info<TIER>(Wm, mrow);
+            GX_STAMP(2);
+        } else {
+            int32_t info;  // of the state the line's walk ended in: -1 null, -2-k ExtractionException, else its final record
+            if (MODE == 1 || L.u_start != 0xFFFFFFFFu) {
+                // ---- fused pass: match automaton x joined capture automata, one walk ----
+                uint32_t urow;
+                if (MODE == 1 || L.simple_ops) urow = walk<TIER, true, true>(Wc, stage, bitmap, use_map, L.u_start, start, end, true, L.u_dead, regs);
+                else urow = walk<TIER, true, false>(Wc, stage, bitmap, use_map, L.u_start, start, end, true, L.u_dead, regs);
+                info = state_info<TIER>(Wc, urow);
+            } else {
+                // ---- hot loop #1, then hot loop #2 on extraction k's tagged automaton ----
+                const uint32_t mrow = walk<TIER, false, false>(Wm, stage, bitmap, use_map, L.m_start, start, end, true, L.m_dead, regs);
+                const int32_t k = state_info<TIER>(Wm, mrow);
+                info = k;
+                uint32_t crow = GT ? 0u : L.m_dead;  // any valid row: the walk below is off for lanes without a match
+                if (k >= 0) crow = lds_ld<uint32_t>(L.c_rule + 8u * k);
+                if (TierTraits<TIER>::records) Wc.dead = k >= 0 ? lds_ld<uint32_t>(L.c_rule + 8u * k + 4u) : L.m_dead;  // the rule's own dead state
+                if (L.simple_ops) crow = walk<TIER, true, true>(Wc, stage, bitmap, use_map, crow, start, end, k >= 0, 0xFFFFFFFFu, regs);
+                else crow = walk<TIER, true, false>(Wc, stage, bitmap, use_map, crow, start, end, k >= 0, 0xFFFFFFFFu, regs);
+                if (k >= 0) {
+                    info = state_info<TIER>(Wc, crow);
+                    if (info < 0) info = -2 - k;  // DFA said yes, capture regex says no -> ExtractionException
+                }
+            }
+            GX_STAMP(2);
+            const uint32_t len = end - start;
+            const uint8_t* fin_g = GT ? io.at_global + L.fin_tags : nullptr;
+            // The tile's 64 result rows are one contiguous block of the output.  Transpose them through the staging
+            // area (free now: every lane has finished its walk) so that each store instruction writes 1 KiB of
+            // consecutive bytes, instead of every lane writing pieces of its own row.
+            const bool full_tile = cur.a == 0u && cur.b == 64u;
+            if (PACKED) {
+                const uint32_t row_b = 2u + 2u * slots;  // u16 id + u16 offsets
+                uint16_t* out_rows = io.packed + (cur.i - lane) * static_cast<uint64_t>(1u + slots);
+                if (full_tile && 64u * row_b + 16u <= L.stage_bytes) {  // (64 rows are a multiple of 16 bytes, and so is their address)
+                    const uint32_t my_row = stage + lane * row_b;
+                    const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                        lds_st<uint16_t>(my_row + 2u + 4u * g, static_cast<uint16_t>(pb));
+                        lds_st<uint16_t>(my_row + 4u + 4u * g, static_cast<uint16_t>(pe));
+                    });
+                    lds_st<uint16_t>(my_row, static_cast<uint16_t>(result));
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    uint8_t* out = reinterpret_cast<uint8_t*>(out_rows);
+                    for (uint32_t c = lane; c < 4u * row_b; c += 64u) {  // 64 * row_b / 16 chunks
+#ifdef GX_DEV
+                        if (io.dev_flags & 2u) { __builtin_nontemporal_store(lds_ld<u32x4>(stage + (c << 4)), reinterpret_cast<u32x4*>(out + (c << 4))); continue; }
+                        if ((io.dev_flags & 4u) && c != 0u) continue;  // experiment: (almost) no result stores
+#endif
+                        *reinterpret_cast<u32x4*>(out + (c << 4)) = lds_ld<u32x4>(stage + (c << 4));
+                    }
+                } else if (valid) {
+                    uint16_t* rp = io.packed + i * static_cast<uint64_t>(1u + slots);
+                    const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                        rp[1 + 2 * g] = static_cast<uint16_t>(pb);
+                        rp[2 + 2 * g] = static_cast<uint16_t>(pe);
+                    });
+                    rp[0] = static_cast<uint16_t>(result);
+                }
+            } else {
+                const uint32_t row_b = slots * 4u;
+                const bool caps_aligned = ((reinterpret_cast<uintptr_t>(io.caps) | reinterpret_cast<uintptr_t>(io.match_id)) & 15u) == 0u;
+                if (full_tile && caps_aligned && 64u * row_b + 256u <= L.stage_bytes) {
+                    const uint32_t my_row = stage + lane * row_b;
+                    const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                        lds_st<u32x2>(my_row + 8u * g, u32x2{static_cast<uint32_t>(pb), static_cast<uint32_t>(pe)});
+                    });
+                    const uint32_t ids = stage + 64u * row_b;  // the tile's 64 match ids = 256 bytes
+                    lds_st<uint32_t>(ids + 4u * lane, static_cast<uint32_t>(result));
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    uint8_t* out = reinterpret_cast<uint8_t*>(io.caps + (cur.i - lane) * static_cast<uint64_t>(slots));
+                    for (uint32_t c = lane; c < 4u * row_b; c += 64u)  // 64 * row_b / 16 chunks
+                        *reinterpret_cast<u32x4*>(out + (c << 4)) = lds_ld<u32x4>(stage + (c << 4));  // (nontemporal: measured slower)
+                    if (lane < 16u)
+                        *reinterpret_cast<u32x4*>(io.match_id + (cur.i - lane) + 4u * lane) = lds_ld<u32x4>(ids + 16u * lane);
+                } else if (valid) {
+                    int32_t* cp = io.caps + i * static_cast<uint64_t>(slots);
+                    io.match_id[i] = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                        cp[2 * g] = pb;
+                        cp[2 * g + 1] = pe;
+                    });
+                }
+            }
+        }
+        // the staging area is reused by the next tile: all lanes must be done reading it
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        GX_STAMP(3);
+        if (!has_next) break;
+        if (!same_group) {  // (wave-uniform)
+            t1 = t2;
+            j2 = grab();
+        }
+        cur = nxt;
+        tile = ntile;
+        no0 = nno0;
+        no1 = nno1;
+    }
+#ifdef GX_DEV
+    if (io.stamps && lane == 0) {
+        unsigned long long* s = io.stamps + 4ull * (static_cast<uint64_t>(blockIdx.x) * L.nwaves + wave);
+        for (int q = 0; q < 4; ++q) s[q] = phase_cycles[q];
+    }
+#endif
+}
+
+template <typename OFF, int KCH, int TIER, int MODE, bool PACKED>
+hipError_t launch_tile_p(const GxLds& lds, const TileIO& io, dim3 grid, dim3 block, hipStream_t stream) {
+    hipError_t e = allow_full_lds(&k_extract_tile<OFF, KCH, TIER, MODE, PACKED>);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_extract_tile<OFF, KCH, TIER, MODE, PACKED>), grid, block, lds.total_bytes, stream, lds, io);
+    return hipGetLastError();
+}
+template <typename OFF, int KCH, int TIER, int MODE>
+hipError_t launch_tile_t(const GxLds& lds, const TileIO& io, dim3 grid, dim3 block, hipStream_t stream) {
+    if (MODE != 0 && io.packed) return launch_tile_p<OFF, KCH, TIER, MODE, MODE != 0>(lds, io, grid, block, stream);
+    return launch_tile_p<OFF, KCH, TIER, MODE, false>(lds, io, grid, block, stream);
+}
+template <typename OFF, int TIER, int MODE>
+hipError_t launch_tile_k(const GxLds& lds, const TileIO& io, dim3 grid, dim3 block, hipStream_t stream) {
+    const uint32_t kch = (lds.stage_bytes + 1023u) / 1024u;
+    if (kch <= 4) return launch_tile_t<OFF, 4, TIER, MODE>(lds, io, grid, block, stream);
+    if (kch <= 8) return launch_tile_t<OFF, 8, TIER, MODE>(lds, io, grid, block, stream);
+    if (kch <= 13) return launch_tile_t<OFF, 13, TIER, MODE>(lds, io, grid, block, stream);
+    if (kch <= 16) return launch_tile_t<OFF, 16, TIER, MODE>(lds, io, grid, block, stream);
+    return hipErrorInvalidValue;
+}
+template <typename OFF, int TIER>
+hipError_t launch_tile_m(int mode, const GxLds& lds, const TileIO& io, dim3 grid, dim3 block, hipStream_t stream) {
+    if (mode == 0) return launch_tile_k<OFF, TIER, 0>(lds, io, grid, block, stream);
+    if (mode == 1) return launch_tile_k<OFF, TIER, 1>(lds, io, grid, block, stream);
+    return launch_tile_k<OFF, TIER, 2>(lds, io, grid, block, stream);
+}
+
+
+}  // namespace
+
+// one translation unit per table tier instantiates its kernels (gx_tile_lds.hip, gx_tile_l2.hip, gx_tile_rec.hip,
+// gx_tile_recg.hip: they compile in parallel); gx_tile.hip dispatches
+#define GX_TILE_TIER_ENTRY(NAME, TIER)                                                                                        \
+    hipError_t NAME(int mode, bool off64, const GxLds& lds, const void* io, dim3 grid, dim3 block, hipStream_t stream) {       \
+        const TileIO& t = *static_cast<const TileIO*>(io);                                                                    \
+        if (off64) return launch_tile_m<uint64_t, TIER>(mode, lds, t, grid, block, stream);                                   \
+        return launch_tile_m<uint32_t, TIER>(mode, lds, t, grid, block, stream);                                              \
+    }
+
+}  // namespace gx

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Developer tool, run ON THE GPU BOX from the repo root (e.g. through gpurun):
-#     bash tools/collect_profiles.sh r01
+#     bash tools/collect_profiles.sh r02
 # Produces under gpurun_out/<tag>/: the bench line, the rocprofv3 kernel-trace statistics of the same bench
 # command, and the two PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, no other tracing) of
 # tools/traffic_target.py.  tools/summarize_traffic.py then turns the PMC CSVs into profiles/<tag>_traffic.json.
 set -eo pipefail
-tag=${1:-r01}
+tag=${1:-r02}
 root=$(pwd)
 out=$root/gpurun_out/$tag
 mkdir -p "$out"

@@ -6,6 +6,8 @@ stream on gfx950 and is doubled; the copy kernel in the same run is the calibrat
 import csv, json, os, sys
 
 tag, fetch_csv, write_csv = sys.argv[1], sys.argv[2], sys.argv[3]
+fmt = sys.argv[4] if len(sys.argv) > 4 else "compact"   # result format of the profiled launches
+row_bytes = {"compact": 18, "dense": 36, "match_only": 4}[fmt]
 out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 
 
@@ -16,7 +18,7 @@ def collect(path, counter):
             continue
         name = r["Kernel_Name"]
         v = float(r["Counter_Value"])
-        if "k_extract_tile" in name:
+        if "k_extract_tile" in name and v > 1e4:
             tile.append(v); keep.append(r)
         elif ("copy" in name.lower() or "clone" in name.lower()) and v > 5e5:
             copy.append(v); keep.append(r)
@@ -33,7 +35,8 @@ avg = lambda v: sum(v) / len(v)
 n_lines, line_bytes = 10_000_000, 200
 res = {
     "workload": "config 2: README 3-extraction definition, %d x %d B lines" % (n_lines, line_bytes),
-    "kernel": "k_extract_tile<unsigned int, 13>",
+    "kernel": "k_extract_tile<unsigned int, 13, TIER_LDS, MODE %d>" % (0 if fmt == "match_only" else 1),
+    "results": fmt + " (%d B per line)" % row_bytes,
     "fetch_size_kib_raw": avg(ft), "write_size_kib": avg(wt),
     "calibration_copy": {"bytes_read": n_lines * line_bytes, "bytes_written": n_lines * line_bytes,
                          "fetch_size_kib_raw": avg(fc), "write_size_kib": avg(wc[-3:]),
@@ -43,7 +46,7 @@ res = {
     "hbm_read_bytes_per_launch": avg(ft) * 1024 * 2.0,
     "hbm_write_bytes_per_launch": avg(wt) * 1024,
     "algorithmic_read_bytes": n_lines * line_bytes + 4 * (n_lines + 1),
-    "algorithmic_write_bytes": n_lines * 36,
+    "algorithmic_write_bytes": n_lines * row_bytes,
 }
 res["traffic_bytes_per_launch"] = res["hbm_read_bytes_per_launch"] + res["hbm_write_bytes_per_launch"]
 with open(os.path.join(out_dir, "%s_traffic.json" % tag), "w") as f:
