@@ -813,3 +813,24 @@ def test_host_pipeline_chunks_and_multi_device_shards():
     got = pm.match_batch(d[: 200 * 40000], o[:40001])
     want = [orc.match(bytes(d[o[i]:o[i + 1]]).decode("latin-1")) for i in range(0, 40000, 997)]
     assert [got[i] for i in range(0, 40000, 997)] == want
+
+
+def test_no_hint_no_sync_batches_learn_the_line_length():
+    """Asynchronous device-pointer batches that pass no line_bytes_hint: the first one runs with the 200-byte default
+    (lines of 600 bytes then go in several rounds per group), later ones with the mean the previous batch measured --
+    read back through pinned memory and an event, never a synchronisation.  Same answers every time."""
+    import torch
+    definition = W.readme3_definition()
+    gorp, orc = Gorp.construct(definition), oracle_for(definition)
+    n = 20000
+    data, offsets, cat = W.readme3_lines(n, seed=97, line_bytes=600)
+    omid, ocaps = orc.extract_batch(data.numpy(), offsets.numpy(), nthreads=8)
+    d, o = data.cuda(), offsets.cuda()
+    st = torch.cuda.Stream()
+    for _ in range(4):
+        mid = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+        caps = torch.full((n, 2 * gorp.max_groups), -7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        gorp.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=st.cuda_stream, no_sync=True)
+        st.synchronize()
+        assert np.array_equal(mid.cpu().numpy(), omid) and np.array_equal(caps.cpu().numpy(), ocaps)
