@@ -126,11 +126,12 @@ const uint32_t LDS_BYTES = 163840;     // 160 KiB per CU on gfx950
 const uint32_t LDS_TABLE_BUDGET = 96 * 1024;
 
 // Longest run of ASCII byte values on which `loops(b)` holds, as lo | (0x7F - hi) << 8 (0x8000 = none): the
-// form the kernel's SWAR range test consumes.
+// form the kernel's SWAR range test consumes.  Of equally long runs the later one wins: for \w that is a-z rather
+// than A-Z, and log text is mostly lower case.
 template <typename F> uint16_t self_loop_interval(F loops) {
     int best_lo = 0, best_len = 0, run_lo = 0, run = 0;
     for (int b = 0; b < 128; ++b) {
-        if (loops(b)) { if (run == 0) run_lo = b; ++run; if (run > best_len) { best_len = run; best_lo = run_lo; } }
+        if (loops(b)) { if (run == 0) run_lo = b; ++run; if (run >= best_len) { best_len = run; best_lo = run_lo; } }
         else run = 0;
     }
     if (best_len < 4) return 0x8000;
