@@ -23,7 +23,7 @@ GX_CREATE_NO_TILES = 4
 GX_CREATE_NO_FUSED = 8
 GX_CREATE_TIER_RECORDS = 16
 GX_CREATE_TIER_RECORDS_GLOBAL = 32
-GX_KERNEL_AUTO, GX_KERNEL_TILES, GX_KERNEL_SLICES, GX_KERNEL_PER_LINE = 0, 1, 2, 3
+GX_KERNEL_AUTO, GX_KERNEL_TILES, GX_KERNEL_SLICES, GX_KERNEL_PER_LINE, GX_KERNEL_LANES = 0, 1, 2, 3, 4
 
 # every symbol include/gorp_hip.h declares
 SYMBOLS = [

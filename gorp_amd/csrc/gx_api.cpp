@@ -657,6 +657,28 @@ bool plan_tile_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out, 
     return true;
 }
 
+// Layout for the lane kernel (gx_lanes.hip): per wave the register block and the area its result rows go through.
+bool plan_lanes_launch(const gx_handle* h, GxLds* out, bool match_only, bool compact) {
+    if (!h->tile_ok) return false;
+    GxLds L = match_only && h->has_mo ? h->lds_mo : h->lds;
+    if (L.tier == 0) return false;                                                  // (dense rows in LDS: the tile kernel's case)
+    if (!match_only && h->T.has_capture && L.u_start == 0xFFFFFFFFu) return false;  // walks the fused automaton
+    const uint32_t slots = 2u * static_cast<uint32_t>(h->T.max_groups);
+    const uint32_t rows = match_only ? 0u : compact ? 64u * (2u + 2u * slots) : 64u * slots * 4u + 256u;
+    L.stage_bytes = L.regs_wave_bytes;                       // (the register block)
+    L.regs_wave_bytes = (L.regs_wave_bytes + rows + 16u + 15u) & ~15u;
+    if (L.table_bytes + 32u + 4u * L.regs_wave_bytes > LDS_BYTES) return false;
+    L.nwaves = std::min<uint32_t>(16u, (LDS_BYTES - L.table_bytes - 32u) / L.regs_wave_bytes);
+    L.regs = L.table_bytes;
+    L.bitmap = 0;
+    L.counter = L.regs + L.nwaves * L.regs_wave_bytes;
+    L.stage = 0;
+    L.total_bytes = L.counter + 16u;
+    if (L.total_bytes > LDS_BYTES) return false;
+    *out = L;
+    return true;
+}
+
 // Layout for the slice kernel: a 64 x 80-byte slice buffer per wave, up to 16 waves.
 bool plan_slice_launch(const gx_handle* h, GxLds* out, bool match_only = false) {
     if (!h->tile_ok) return false;
@@ -817,6 +839,19 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
     const uint8_t* at_global = image_tier == 1 || image_tier == 3 ? static_cast<const uint8_t*>(h->d_l2_image) : nullptr;
     if (batchable && slices && plan_slice_launch(h, &L, mo)) {
         GX_HIP(launch_extract_slices(h->dev, L, image, at_global, h->num_cus, b, stream));
+        return;
+    }
+    if (batchable && kernel == GX_KERNEL_LANES && plan_lanes_launch(h, &L, mo, b.packed != nullptr)) {
+        std::lock_guard<std::mutex> lock(h->slot_mu);
+        b.seq = h->next_seq++;
+        if (h->next_seq == 0) h->next_seq = 1;
+        const int slot = static_cast<int>(b.seq % gx_handle::N_SLOTS);
+        if (h->slot_used[slot]) GX_HIP(hipStreamWaitEvent(stream, h->slot_event[slot], 0));
+        h->slot_used[slot] = true;
+        b.oversize_flag = h->d_slots + slot;
+        GX_HIP(launch_extract_lanes(h->dev, L, image, at_global, h->num_cus, b, stream));
+        GX_HIP(launch_extract_oversize(h->dev, b, 65535u + 48u, stream));
+        GX_HIP(hipEventRecord(h->slot_event[slot], stream));
         return;
     }
     if (batchable && plan_tile_launch(h, line_bytes_hint, &L, mo)) {
@@ -1379,7 +1414,7 @@ static int extract_batch_impl(gx_handle* h, const uint8_t* bytes, const void* of
     if (!h->on_device) return fail(GX_E_DEVICE, "handle was created host-only; no device tables (there is no CPU fallback)");
     gx_batch_opts o{};
     if (!read_opts(opts, &o)) return fail(GX_E_ARG, "gx_batch_opts.struct_size mismatch");
-    if (o.kernel > GX_KERNEL_PER_LINE) return fail(GX_E_ARG, "gx_batch_opts.kernel: unknown kernel");
+    if (o.kernel > GX_KERNEL_LANES) return fail(GX_E_ARG, "gx_batch_opts.kernel: unknown kernel");
     const bool match_only = o.match_only || states || !h->T.has_capture;
     const bool compact = o.compact_results && !match_only;  // rows of u16[1 + slots] through `caps`
     if (!compact && !match_id) return fail(GX_E_ARG, "gx_extract_batch: match_id is NULL");

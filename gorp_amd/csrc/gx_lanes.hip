@@ -1,0 +1,267 @@
+// gx_lanes.hip -- a batch kernel for definitions whose dense rows do not fit LDS (tables in global memory, or range
+// records in LDS): every lane keeps ITS OWN line in registers.
+//
+// Replaces, per line, the same reference code as the tile kernel (gx_tile_body.hpp):
+//   PolyMatcher.match core/autom/PolyMatcher.java:123-133, Automata.step/accept core/autom/Automata.java:133-139,
+//   JDKRegexpCookedExtraction.match core/jdkre/JDKRegexpCookedExtraction.java:36-59, Gorp.extract core/Gorp.java:159-186.
+//
+// With the tables in global memory every byte position costs the lock-step wave one dependent gather (hundreds of
+// cycles), and what bounds the throughput is how many lines a CU has in flight.  The tile kernel stages whole tiles
+// in LDS -- 250 bytes of LDS per line in flight, 10 waves per CU.  Here a lane loads its line 16 bytes at a time into
+// KCH x 4 registers (unaligned global loads at the lane's own address: poorly coalesced, but 13 load instructions per
+// tile are nothing beside ~150 gathers, and every cache line is still fetched from HBM once -- the repeats hit L1/L2),
+// walks the KCH windows with static register indexes (all lanes are at the same window of their own line, as in the
+// tile kernel), and loads the next KCH x 16 bytes.  LDS holds only the class map, the capture registers (reused as the
+// transpose buffer of the results) and the programs, so the registers -- not LDS -- bound the waves per CU.
+#include "gx_walk.hpp"
+
+namespace gx {
+
+namespace {
+
+struct LanesIO {
+    const uint8_t* image;        // the LDS table image, in global memory
+    const uint8_t* at_global;    // automaton rows / records in global memory
+    const uint8_t* data;
+    const void* off;
+    uint64_t n;
+    int32_t* match_id;
+    int32_t* caps;
+    uint16_t* packed;
+    uint32_t* oversize_flag;
+    uint32_t seq;
+    int32_t max_groups;
+    int32_t strip_eol;
+};
+
+// One workgroup of up to 16 waves per CU: the waves of a workgroup share one copy of the tables in LDS.
+template <typename OFF, int KCH, int TIER, bool CAPTURE, bool SIMPLE, bool PACKED>
+__global__ void __launch_bounds__(1024)
+k_extract_lanes(GxLds L, LanesIO io) {
+    {
+        extern __shared__ __attribute__((aligned(16))) uint8_t gx_smem[];
+        const uint4* src = reinterpret_cast<const uint4*>(io.image);
+        uint4* dst = reinterpret_cast<uint4*>(gx_smem);
+        for (uint32_t c = threadIdx.x; c < L.table_bytes / 16; c += blockDim.x) dst[c] = src[c];
+        if (threadIdx.x == 0) lds_st<uint32_t>(L.counter, L.nwaves);  // the workgroup's tile counter
+    }
+    __syncthreads();
+
+    const uint8_t* __restrict__ data = io.data;
+    const OFF* __restrict__ off = static_cast<const OFF*>(io.off);
+    const uint64_t n = io.n;
+    WalkTab W;  // the automaton this launch walks: fused (captures) or match
+    constexpr bool GT = TIER == TIER_L2 || TIER == TIER_RECG;  // tables and final records in global memory
+    const uint8_t* base = GT ? io.at_global + (TIER == TIER_RECG ? L.c_base : 0u) : nullptr;
+    W.at = (CAPTURE && TIER == TIER_L2) ? io.at_global + L.c_base : base;
+    W.row_bytes = L.row_bytes;
+    W.ops_off = L.ops_off;
+    W.ops = L.ops;
+    W.rec = L.rec;
+    W.acc_tab = L.acc_tab;
+    W.dead = CAPTURE ? L.u_dead : L.m_dead;
+    W.ncls = L.ncls;
+    const uint32_t row0 = CAPTURE ? L.u_start : L.m_start, dead_row = CAPTURE ? L.u_dead : L.m_dead;
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // per wave: the register block (register r of this lane = u16 at regs + r * 128; the column before register 0 is a
+    // write-only dummy: GxLds::stage_bytes bytes), then the area the tile's result rows are transposed through
+    const uint32_t wave_area = L.regs + wave * L.regs_wave_bytes;
+    const uint32_t regs = wave_area + 128u + lane * 2u;
+    const uint32_t out_area = wave_area + L.stage_bytes;
+    const int G = io.max_groups;
+    const uint32_t slots = 2u * static_cast<uint32_t>(G);
+    const uint64_t tiles = (n + 63) >> 6;
+    const uint8_t* data_end = data + static_cast<uint64_t>(off[n]);
+    const uint8_t* fin_g = GT ? io.at_global + L.fin_tags : nullptr;
+    const uint64_t grid = gridDim.x;
+
+    for (uint32_t j = wave;;) {
+        const uint64_t tile = static_cast<uint64_t>(blockIdx.x) + static_cast<uint64_t>(j) * grid;  // (wave-uniform)
+        if (tile >= tiles) break;
+        const uint64_t i = (tile << 6) + lane;
+        const bool valid = i < n;
+        const uint64_t o0 = off[valid ? i : n], o1 = off[valid ? i + 1 : n];
+        uint64_t len64 = o1 - o0;
+        if (io.strip_eol) {  // the terminator belongs to the line in the CSR buffer (gx_split_lines), not to the String
+            if (len64 > 0 && data[o0 + len64 - 1] == 0x0Au) --len64;
+            if (len64 > 0 && data[o0 + len64 - 1] == 0x0Du) --len64;
+        }
+        // positions are 16-bit in the register block: a longer line is left to the follow-up launch of the per-line kernel
+        const bool oversize = valid && len64 > 65535u;
+        if (oversize) __hip_atomic_store(io.oversize_flag, io.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t len = oversize ? 0u : static_cast<uint32_t>(len64);
+        const uint8_t* line = data + o0;
+
+        uint32_t row = row0;
+        uint32_t acc = state_acc<TIER>(W, row);
+        uint32_t lo4 = splat_byte0(acc), k4 = splat_byte1(acc);
+        bool more = valid && !oversize && len > 0u;
+        for (uint32_t seg = 0; __any(more); seg += KCH * 16u) {
+            u32x4 pre[KCH];  // this lane's bytes [seg, seg + 16 KCH) of its line
+#pragma unroll
+            for (int k = 0; k < KCH; ++k) {
+                const uint32_t at_byte = seg + 16u * k;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (more && at_byte < len) {
+                    const uint8_t* src = line + at_byte;
+                    if (src + 16 <= data_end) v = __builtin_nontemporal_load(&reinterpret_cast<const UnalignedWindow*>(src)->v);
+                    else {
+                        uint32_t w[4] = {0, 0, 0, 0};
+                        for (int b = 0; b < 16; ++b)
+                            if (src + b < data_end) w[b >> 2] |= static_cast<uint32_t>(src[b]) << ((b & 3) * 8);
+                        v = u32x4{w[0], w[1], w[2], w[3]};
+                    }
+                }
+                pre[k] = v;
+            }
+#pragma unroll
+            for (int k = 0; k < KCH; ++k) {
+                const uint32_t rel = seg + 16u * k;
+                const bool act = more && rel < len;
+                if (!__any(act)) break;
+                const uint4 w0 = make_uint4(pre[k].x, pre[k].y, pre[k].z, pre[k].w);
+                const bool full0 = rel + 16u <= len;
+                const uint32_t bx = outside_bits(w0.x, lo4, k4), by = outside_bits(w0.y, lo4, k4);
+                const uint32_t bz = outside_bits(w0.z, lo4, k4), bw = outside_bits(w0.w, lo4, k4);
+                const bool ok0 = full0 & (((or3(bx, by, bz) | bw) & HI_BITS) == 0u);
+                bool step = act && !ok0;
+                uint32_t mask = 0xFFFFu;
+                if (step && !full0) {
+                    mask = window_mask(0u, len, rel);
+                    step = !partial_window_ok(bx, by, bz, bw, mask);
+                }
+                const bool masked = __any(step && !full0);
+                if (step) {
+                    if (!masked) row = steps16<TIER, CAPTURE, false, SIMPLE>(w0, mask, W, row, rel, regs);
+                    else row = steps16<TIER, CAPTURE, true, SIMPLE>(w0, mask, W, row, rel, regs);
+                    acc = state_acc<TIER>(W, row);
+                    lo4 = splat_byte0(acc);
+                    k4 = splat_byte1(acc);
+                }
+                more = more && row != dead_row && rel + 16u < len;
+            }
+        }
+
+        // ---- results ----
+        const int32_t info = state_info<TIER>(W, row);
+        if (!CAPTURE) {
+            if (valid && !oversize) io.match_id[i] = info;
+        } else {
+            const bool full_tile = (tile << 6) + 64u <= n && !__any(oversize);
+            const uint64_t i0 = tile << 6;
+            if (PACKED) {
+                const uint32_t row_b = 2u + 2u * slots;
+                if (full_tile) {
+                    // the tile's 64 rows are one contiguous block of the output: through the wave's row area, then 1 KiB of
+                    // consecutive bytes per store instruction
+                    const uint32_t my_out = out_area + lane * row_b;
+                    const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                        lds_st<uint16_t>(my_out + 2u + 4u * g, static_cast<uint16_t>(pb));
+                        lds_st<uint16_t>(my_out + 4u + 4u * g, static_cast<uint16_t>(pe));
+                    });
+                    lds_st<uint16_t>(my_out, static_cast<uint16_t>(result));
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    uint8_t* out = reinterpret_cast<uint8_t*>(io.packed + i0 * static_cast<uint64_t>(1u + slots));
+                    for (uint32_t c = lane; c < 4u * row_b; c += 64u)
+                        *reinterpret_cast<u32x4*>(out + (c << 4)) = lds_ld<u32x4>(out_area + (c << 4));
+                } else if (valid && !oversize) {
+                    uint16_t* rp = io.packed + i * static_cast<uint64_t>(1u + slots);
+                    const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                        rp[1 + 2 * g] = static_cast<uint16_t>(pb);
+                        rp[2 + 2 * g] = static_cast<uint16_t>(pe);
+                    });
+                    rp[0] = static_cast<uint16_t>(result);
+                }
+            } else {
+                const uint32_t row_b = slots * 4u;
+                const bool caps_aligned = ((reinterpret_cast<uintptr_t>(io.caps) | reinterpret_cast<uintptr_t>(io.match_id)) & 15u) == 0u;
+                if (full_tile && caps_aligned) {
+                    const uint32_t my_out = out_area + lane * row_b;
+                    const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                        lds_st<u32x2>(my_out + 8u * g, u32x2{static_cast<uint32_t>(pb), static_cast<uint32_t>(pe)});
+                    });
+                    const uint32_t ids = out_area + 64u * row_b;
+                    lds_st<uint32_t>(ids + 4u * lane, static_cast<uint32_t>(result));
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    uint8_t* out = reinterpret_cast<uint8_t*>(io.caps + i0 * static_cast<uint64_t>(slots));
+                    for (uint32_t c = lane; c < 4u * row_b; c += 64u)
+                        *reinterpret_cast<u32x4*>(out + (c << 4)) = lds_ld<u32x4>(out_area + (c << 4));
+                    if (lane < 16u) *reinterpret_cast<u32x4*>(io.match_id + i0 + 4u * lane) = lds_ld<u32x4>(ids + 16u * lane);
+                } else if (valid && !oversize) {
+                    int32_t* cp = io.caps + i * static_cast<uint64_t>(slots);
+                    io.match_id[i] = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                        cp[2 * g] = pb;
+                        cp[2 * g + 1] = pe;
+                    });
+                }
+            }
+        }
+        // the wave's LDS area is reused by the next tile
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // the workgroup's next tile
+        uint32_t nj = 0;
+        if (lane == 0) nj = __hip_atomic_fetch_add((GX_LDS uint32_t*)(uintptr_t)L.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        j = __builtin_amdgcn_readfirstlane(nj);
+    }
+}
+
+template <typename OFF, int TIER, bool CAPTURE, bool SIMPLE, bool PACKED>
+hipError_t launch_lanes_t(const GxLds& lds, const LanesIO& io, dim3 grid, hipStream_t stream) {
+    constexpr int KCH = 7;  // 112 bytes of the line in 28 registers
+    hipError_t e = allow_full_lds(&k_extract_lanes<OFF, KCH, TIER, CAPTURE, SIMPLE, PACKED>);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_extract_lanes<OFF, KCH, TIER, CAPTURE, SIMPLE, PACKED>), grid, dim3(lds.nwaves * 64), lds.total_bytes, stream, lds, io);
+    return hipGetLastError();
+}
+template <typename OFF, int TIER>
+hipError_t launch_lanes_m(bool capture, bool simple, bool packed, const GxLds& lds, const LanesIO& io, dim3 grid, hipStream_t stream) {
+    if (!capture) return launch_lanes_t<OFF, TIER, false, false, false>(lds, io, grid, stream);
+    if (simple) return packed ? launch_lanes_t<OFF, TIER, true, true, true>(lds, io, grid, stream) : launch_lanes_t<OFF, TIER, true, true, false>(lds, io, grid, stream);
+    return packed ? launch_lanes_t<OFF, TIER, true, false, true>(lds, io, grid, stream) : launch_lanes_t<OFF, TIER, true, false, false>(lds, io, grid, stream);
+}
+
+}  // namespace
+
+// lds: a layout from plan_lanes_launch (gx_api.cpp): tables, then per wave the register block with the result rows
+// behind it.  Needs tables in global memory (tier 1 or 3) and, for captures, the fused automaton.
+hipError_t launch_extract_lanes(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
+                                const GxBatch& b, hipStream_t stream) {
+    if (b.n == 0) return hipSuccess;
+    const uint64_t tiles = (b.n + 63) >> 6;
+    uint64_t blocks = static_cast<uint64_t>(num_cus);
+    const uint64_t need = (tiles + lds.nwaves - 1) / lds.nwaves;
+    if (blocks > need) blocks = need;
+    LanesIO io{};
+    io.image = lds_image;
+    io.at_global = at_global;
+    io.data = static_cast<const uint8_t*>(b.data);
+    io.off = b.offsets;
+    io.n = b.n;
+    io.match_id = b.match_id;
+    io.caps = b.caps;
+    io.packed = b.packed;
+    io.oversize_flag = b.oversize_flag;
+    io.seq = b.seq;
+    io.max_groups = dev.max_groups;
+    io.strip_eol = b.strip_eol;
+    const bool capture = b.match_only == 0 && dev.has_capture;
+    const dim3 grid(static_cast<unsigned>(blocks));
+    const bool packed = b.packed != nullptr;
+    if (lds.tier == 3) {
+        if (b.offsets64) return launch_lanes_m<uint64_t, TIER_RECG>(capture, lds.simple_ops != 0, packed, lds, io, grid, stream);
+        return launch_lanes_m<uint32_t, TIER_RECG>(capture, lds.simple_ops != 0, packed, lds, io, grid, stream);
+    }
+    if (lds.tier == 2) {
+        if (b.offsets64) return launch_lanes_m<uint64_t, TIER_REC>(capture, lds.simple_ops != 0, packed, lds, io, grid, stream);
+        return launch_lanes_m<uint32_t, TIER_REC>(capture, lds.simple_ops != 0, packed, lds, io, grid, stream);
+    }
+    if (b.offsets64) return launch_lanes_m<uint64_t, TIER_L2>(capture, lds.simple_ops != 0, packed, lds, io, grid, stream);
+    return launch_lanes_m<uint32_t, TIER_L2>(capture, lds.simple_ops != 0, packed, lds, io, grid, stream);
+}
+
+}  // namespace gx

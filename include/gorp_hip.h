@@ -129,7 +129,7 @@ typedef struct gx_batch_opts {
                                   pointer with device_pointers, else a host pointer.  NULL: not counted. */
 } gx_batch_opts;
 
-enum { GX_KERNEL_AUTO = 0, GX_KERNEL_TILES = 1, GX_KERNEL_SLICES = 2, GX_KERNEL_PER_LINE = 3 };
+enum { GX_KERNEL_AUTO = 0, GX_KERNEL_TILES = 1, GX_KERNEL_SLICES = 2, GX_KERNEL_PER_LINE = 3, GX_KERNEL_LANES = 4 };
 
 /* Replaces the per-line loop "for each line: Gorp.extract(line)"
  * (core/Gorp.java:145-186 -> PolyMatcher.match core/autom/PolyMatcher.java:123-133

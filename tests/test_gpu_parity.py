@@ -834,3 +834,43 @@ def test_no_hint_no_sync_batches_learn_the_line_length():
         gorp.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=st.cuda_stream, no_sync=True)
         st.synchronize()
         assert np.array_equal(mid.cpu().numpy(), omid) and np.array_equal(caps.cpu().numpy(), ocaps)
+
+
+@pytest.mark.parametrize("flags", [N.GX_CREATE_TIER_L2, N.GX_CREATE_TIER_RECORDS_GLOBAL, N.GX_CREATE_TIER_RECORDS])
+def test_lane_kernel_agrees_with_oracle(flags):
+    """gx_lanes.hip (tables in global memory, every lane keeps its own line in registers; gx_batch_opts.kernel =
+    GX_KERNEL_LANES): the 64-extraction definition, the README definition with ragged, empty, terminated and very long
+    lines, dense and compact results, match only."""
+    rules, meta = W.syslog_definition(64, seed=3)
+    gorp, orc = Gorp.construct(rules, flags=flags), oracle_for(rules)
+    data, offsets, cats = W.syslog_lines(meta, 20000, seed=7)
+    omid, ocaps = orc.extract_batch(data, offsets, nthreads=8)
+    mid, caps = gorp.extract_batch(data, offsets, kernel=N.GX_KERNEL_LANES)
+    assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+    rows, over = gorp.extract_batch(data, offsets, kernel=N.GX_KERNEL_LANES, compact=True)
+    cm, cc = G.unpack_rows(rows)
+    assert over == 0 and np.array_equal(cm, omid) and np.array_equal(cc, ocaps)
+    m2, _ = gorp.extract_batch(data, offsets, match_only=True, kernel=N.GX_KERNEL_LANES)
+    assert np.array_equal(m2, orc.extract_batch(data, offsets, match_only=True, nthreads=8)[0])
+    data, offsets, cats = W.syslog_lines(meta, 3000, seed=8, min_len=50, max_len=2000)
+    omid, ocaps = orc.extract_batch(data, offsets, nthreads=8)
+    mid, caps = gorp.extract_batch(data, offsets, kernel=N.GX_KERNEL_LANES)
+    assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+    definition = W.readme3_definition()
+    gorp, orc = Gorp.construct(definition, flags=flags), oracle_for(definition)
+    lines = ["", "[1]: GET 5ms /x", "[1]: GET 5ms /" + "x" * 70000, "[12]: PUT 7ms /" + "y" * 3000, "nothing", "[3]: HEAD 1ms /z", "a\rb",
+             "[123456789]: GET 12ms /index.html"] * 9
+    d, o = lines_to_csr(lines)
+    om, oc = orc.extract_batch(d, o)
+    m, c = gorp.extract_batch(d, o, kernel=N.GX_KERNEL_LANES)
+    assert np.array_equal(m, om) and np.array_equal(c, oc)
+    rows, over = gorp.extract_batch(d, o, kernel=N.GX_KERNEL_LANES, compact=True)
+    cm, cc = G.unpack_rows(rows)
+    big = oc > 65534
+    assert over == int(big.sum()) and np.array_equal(cm, om) and np.array_equal(cc, np.where(big, 65534, oc))
+    raw = b"\r\n".join(ln.encode("latin-1") for ln in lines if "\r" not in ln) + b"\n"
+    from gorp_amd.gorp import split_lines
+    off, _ = split_lines(raw)
+    m3, c3 = gorp.extract_batch(np.frombuffer(raw, np.uint8), off, strip_eol=True, kernel=N.GX_KERNEL_LANES)
+    keep = [i for i, ln in enumerate(lines) if "\r" not in ln]
+    assert np.array_equal(m3, om[keep]) and np.array_equal(c3, oc[keep])

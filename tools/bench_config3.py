@@ -9,10 +9,12 @@ import numpy as np, torch
 from gorp_amd import workloads as W
 from gorp_amd.gorp import Gorp
 
+kernel = int(os.environ.get("GX_BENCH_KERNEL", "0"))   # gx_batch_opts.kernel (4 = the lane kernel)
+flags = int(os.environ.get("GX_BENCH_FLAGS", "0"))     # GX_CREATE_* (e.g. 32 = records in global memory)
 nrules = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 2_000_000
 rules, meta = W.syslog_definition(nrules, seed=3)
-g = Gorp.construct(rules)
+g = Gorp.construct(rules, flags=flags)
 print("rules", nrules, "match states", g.stat(0), "classes", g.stat(1), "capture states", g.stat(2), "LDS bytes", g.stat(5), "waves", g.stat(6))
 mixed = len(sys.argv) > 4
 base_n = 20_000 if mixed else 100_000
@@ -35,12 +37,12 @@ caps = torch.empty((n, 2 * g.max_groups), dtype=torch.int32, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 for mo in (False, True):
     for _ in range(2):
-        g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), match_only=mo, stream=st, no_sync=True, line_bytes_hint=int(mean_len + 0.999))
+        g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), match_only=mo, stream=st, no_sync=True, line_bytes_hint=int(mean_len + 0.999), kernel=kernel)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5):
-        g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), match_only=mo, stream=st, no_sync=True, line_bytes_hint=int(mean_len + 0.999))
+        g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), match_only=mo, stream=st, no_sync=True, line_bytes_hint=int(mean_len + 0.999), kernel=kernel)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
     print("match_only=%s: %.3f ms for %d lines -> %.2f G lines/s, %.0f GB/s" % (mo, ms, n, n / ms / 1e6, total * reps / ms / 1e6))
