@@ -664,7 +664,7 @@ bool plan_lanes_launch(const gx_handle* h, GxLds* out, bool match_only, bool com
     if (L.tier == 0) return false;                                                  // (dense rows in LDS: the tile kernel's case)
     if (!match_only && h->T.has_capture && L.u_start == 0xFFFFFFFFu) return false;  // walks the fused automaton
     const uint32_t slots = 2u * static_cast<uint32_t>(h->T.max_groups);
-    const uint32_t rows = match_only ? 0u : compact ? 64u * (2u + 2u * slots) : 64u * slots * 4u + 256u;
+    const uint32_t rows = match_only || !compact ? 0u : 64u * (2u + 2u * slots);  // (dense rows are stored lane by lane)
     L.stage_bytes = L.regs_wave_bytes;                       // (the register block)
     L.regs_wave_bytes = (L.regs_wave_bytes + rows + 16u + 15u) & ~15u;
     if (L.table_bytes + 32u + 4u * L.regs_wave_bytes > LDS_BYTES) return false;

@@ -98,24 +98,27 @@ k_extract_lanes(GxLds L, LanesIO io) {
         uint32_t acc = state_acc<TIER>(W, row);
         uint32_t lo4 = splat_byte0(acc), k4 = splat_byte1(acc);
         bool more = valid && !oversize && len > 0u;
+        // 16 bytes of this lane's line at line offset at_byte (zeros beyond the line; never a byte beyond the buffer)
+        auto line_chunk = [&](uint32_t at_byte, bool wanted) -> u32x4 {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (wanted && at_byte < len) {
+                const uint8_t* src = line + at_byte;
+                if (src + 16 <= data_end) v = __builtin_nontemporal_load(&reinterpret_cast<const UnalignedWindow*>(src)->v);
+                else {
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    for (int b = 0; b < 16; ++b)
+                        if (src + b < data_end) w[b >> 2] |= static_cast<uint32_t>(src[b]) << ((b & 3) * 8);
+                    v = u32x4{w[0], w[1], w[2], w[3]};
+                }
+            }
+            return v;
+        };
         for (uint32_t seg = 0; __any(more); seg += KCH * 16u) {
             u32x4 pre[KCH];  // this lane's bytes [seg, seg + 16 KCH) of its line
+            // (refilling slot k with the next segment's window k right after window k is taken out was measured: slower,
+            // 2.38 against 2.23 ms on config 3 -- the loads inside the window loop cost more than the wait they save)
 #pragma unroll
-            for (int k = 0; k < KCH; ++k) {
-                const uint32_t at_byte = seg + 16u * k;
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (more && at_byte < len) {
-                    const uint8_t* src = line + at_byte;
-                    if (src + 16 <= data_end) v = __builtin_nontemporal_load(&reinterpret_cast<const UnalignedWindow*>(src)->v);
-                    else {
-                        uint32_t w[4] = {0, 0, 0, 0};
-                        for (int b = 0; b < 16; ++b)
-                            if (src + b < data_end) w[b >> 2] |= static_cast<uint32_t>(src[b]) << ((b & 3) * 8);
-                        v = u32x4{w[0], w[1], w[2], w[3]};
-                    }
-                }
-                pre[k] = v;
-            }
+            for (int k = 0; k < KCH; ++k) pre[k] = line_chunk(seg + 16u * k, more);
 #pragma unroll
             for (int k = 0; k < KCH; ++k) {
                 const uint32_t rel = seg + 16u * k;
@@ -176,26 +179,12 @@ k_extract_lanes(GxLds L, LanesIO io) {
                     rp[0] = static_cast<uint16_t>(result);
                 }
             } else {
-                const uint32_t row_b = slots * 4u;
-                const bool caps_aligned = ((reinterpret_cast<uintptr_t>(io.caps) | reinterpret_cast<uintptr_t>(io.match_id)) & 15u) == 0u;
-                if (full_tile && caps_aligned) {
-                    const uint32_t my_out = out_area + lane * row_b;
-                    const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
-                        lds_st<u32x2>(my_out + 8u * g, u32x2{static_cast<uint32_t>(pb), static_cast<uint32_t>(pe)});
-                    });
-                    const uint32_t ids = out_area + 64u * row_b;
-                    lds_st<uint32_t>(ids + 4u * lane, static_cast<uint32_t>(result));
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    uint8_t* out = reinterpret_cast<uint8_t*>(io.caps + i0 * static_cast<uint64_t>(slots));
-                    for (uint32_t c = lane; c < 4u * row_b; c += 64u)
-                        *reinterpret_cast<u32x4*>(out + (c << 4)) = lds_ld<u32x4>(out_area + (c << 4));
-                    if (lane < 16u) *reinterpret_cast<u32x4*>(io.match_id + i0 + 4u * lane) = lds_ld<u32x4>(ids + 16u * lane);
-                } else if (valid && !oversize) {
+                // dense int32 rows: every lane stores its own (8 bytes per group; the rows' area in LDS is sized for the compact
+                // format, and these tiers are bound by the walk, not by the result stores)
+                if (valid && !oversize) {
                     int32_t* cp = io.caps + i * static_cast<uint64_t>(slots);
                     io.match_id[i] = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
-                        cp[2 * g] = pb;
-                        cp[2 * g + 1] = pe;
+                        *reinterpret_cast<u32x2*>(cp + 2 * g) = u32x2{static_cast<uint32_t>(pb), static_cast<uint32_t>(pe)};
                     });
                 }
             }
@@ -212,7 +201,7 @@ k_extract_lanes(GxLds L, LanesIO io) {
 
 template <typename OFF, int TIER, bool CAPTURE, bool SIMPLE, bool PACKED>
 hipError_t launch_lanes_t(const GxLds& lds, const LanesIO& io, dim3 grid, hipStream_t stream) {
-    constexpr int KCH = 7;  // 112 bytes of the line in 28 registers
+    constexpr int KCH = 7;  // 112 bytes of the line in 28 registers (13 was measured: the compiler moves the array to scratch memory)
     hipError_t e = allow_full_lds(&k_extract_lanes<OFF, KCH, TIER, CAPTURE, SIMPLE, PACKED>);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_extract_lanes<OFF, KCH, TIER, CAPTURE, SIMPLE, PACKED>), grid, dim3(lds.nwaves * 64), lds.total_bytes, stream, lds, io);
