@@ -144,16 +144,21 @@ template <typename F> uint16_t self_loop_interval(F loops) {
 // wherever one ordering can serve them all (greedy partition refinement, heaviest sets first); a set that stays
 // split simply takes several ranges.  A state is then
 //     [header: 8 bytes, only when its info word is not -1]
-//     item 0:  self range (plain self-loop, no program) + one exit range with its successor and program
-//     items 1..: one more range each (exit slot only), the last one flagged
-// every class in no range leads to the automaton's dead state.  An item is two dwords:
+//     record 0:  self range (plain self-loop, no program) + one exit range with its successor and program
+//     record 1:  one more exit range (record 0 says that it exists)
+// or, with three ranges and more besides the self range (the branching nodes of a trie of literals), one record per
+// class, behind all the others: the walk reads record [state + class].  Every class in no range leads to the dead
+// state, which is record 0 of the image for all its automata (a dead state has no successors and accepts nothing, so
+// they are all alike).  A record is two dwords:
 //     w0 = self_lo | self_span << 8 | exit_lo << 16 | exit_span << 24      (class c is inside iff c - lo <= span, unsigned;
 //                                                                           lo = 255, span = 0: empty)
-//     w1 = successor (item index, 16 bits) | program << 16 (8 bits) | flags << 24 (1: last item, 2: a header precedes)
-// A state's index is the index of its item 0; the self-loop byte interval (GxLds rows' ACC word) is looked up by the
-// self range's first class in a small table.  The builder checks its own output against the dense rows, class by
-// class, before it is used.
-constexpr uint32_t REC_LAST = 1u << 24, REC_HDR = 2u << 24, REC_IDC = 254u, REC_EMPTY = 255u;
+//     w1 = successor (record index, 16 bits) | program << 16 (8 bits) | flags << 24 (0x80: a second record follows,
+//          2: a header precedes)
+// A state's index is the index of its record 0; the self-loop byte interval (GxLds rows' ACC word) is looked up by the
+// self range's first class in a small table.  The class map has 32-bit entries, class | class * 8 << 16 (the walk's
+// range tests take the low byte, its address arithmetic the upper half).  The builder checks its own output against
+// the dense rows, class by class, before it is used.
+constexpr uint32_t REC_MORE = 0x80u << 24, REC_HDR = 2u << 24, REC_IDC = 254u, REC_EMPTY = 255u, REC_AT = 1088u;
 
 bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t rows, uint32_t cols, const std::vector<uint32_t>& dead_of_row,
                         const std::vector<std::array<uint64_t, 2>>& loop_set, bool simple, Image& img, GxLds& L, std::vector<uint32_t>& c_rule,
@@ -239,6 +244,7 @@ bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t ro
     std::vector<std::pair<int, int>> self0(rows, {-1, -1});
     std::vector<uint32_t> index_of(rows);
     size_t n_items = 0;
+    L.rec_indexed = 0xFFFFFFFFu;  // (first index of the class-indexed states; none)
     // which exit shares item 0 with the self range decides how often a lane needs a second record: the one that
     // printable text takes most likely first (a field's blank before some control character's odd successor)
     std::vector<int> printable(ncls, 0), bytes_of(ncls, 0);
@@ -260,11 +266,28 @@ bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t ro
             if (g.entry == static_cast<uint32_t>(r) && self0[r].first < 0) { self0[r] = rs[0]; from = 1; }
             for (size_t q = from; q < rs.size(); ++q) exits[r].push_back(Slot{rs[q].first, rs[q].second, g.entry});
         }
-        const bool hdr = at[r * cols + INFO] != 0xFFFFFFFFu;
-        if (hdr) ++n_items;
-        index_of[r] = static_cast<uint32_t>(n_items);
-        n_items += std::max<size_t>(1, exits[r].size());
     }
+    // States with three or more records (the branching nodes of a trie of literals, the start state) are laid out
+    // INDEXED BY CLASS instead: one record per class, behind all the others, so that the walk finds the class's
+    // successor with its first read (state index + class; a state's index says which layout it has).
+    std::vector<char> indexed(rows, 0);
+    // the dead states: every class leads back to the state itself (no group above), nothing accepted; they share record 0
+    auto pure_dead = [&](size_t r) { return dead_of_row[r] == r && groups[r].empty() && at[r * cols + INFO] == 0xFFFFFFFFu; };
+    for (size_t r = 0; r < rows; ++r)
+        if (dead_of_row[r] >= rows || !pure_dead(dead_of_row[r])) return false;  // (every automaton the compiler emits has one)
+    n_items = 1;
+    for (int pass = 0; pass < 2; ++pass)
+        for (size_t r = 0; r < rows; ++r) {
+            if (pure_dead(r)) { index_of[r] = 0; continue; }
+            const bool ix = exits[r].size() >= 3;
+            indexed[r] = ix;
+            if (ix != (pass == 1)) continue;
+            const bool hdr = at[r * cols + INFO] != 0xFFFFFFFFu;
+            if (pass == 1 && L.rec_indexed == 0xFFFFFFFFu) L.rec_indexed = static_cast<uint32_t>(n_items);
+            if (hdr) ++n_items;
+            index_of[r] = static_cast<uint32_t>(n_items);
+            n_items += ix ? static_cast<size_t>(ncls) : std::max<size_t>(1, exits[r].size());
+        }
     if (n_items > 65535u) return false;
     if (getenv("GX_REC_STATS")) {
         size_t multi = 0, self_split = 0, self_states = 0;
@@ -281,11 +304,36 @@ bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t ro
         fprintf(stderr, "  class order: %s\n", order.c_str());
     }
     // pass 2: emit
-    std::vector<uint32_t> items(2 * n_items, 0);
+    std::vector<uint32_t> items(2 * n_items + 2, 0);  // (+ one: the second-record pass reads record [state + 1] of every state)
+    items[0] = REC_EMPTY | (REC_EMPTY << 16);  // record 0: the dead state
     for (size_t r = 0; r < rows; ++r) {
+        if (pure_dead(r)) continue;
         const uint32_t info = at[r * cols + INFO];
         const bool hdr = info != 0xFFFFFFFFu;
         if (hdr) { items[2 * (index_of[r] - 1)] = 0; items[2 * (index_of[r] - 1) + 1] = info; }
+        auto op_field = [&](uint32_t entry, uint32_t& op) {  // the program as the records carry it
+            op = entry >> 16;
+            if (simple) op /= 128u;       // register + 1
+            else if (op & 0x8000u) { if ((op & 0x7FFFu) > 127u) return false; op = 0x80u | (op & 0x7Fu); }
+            else if (op > 127u) return false;
+            return op <= 255u;
+        };
+        if (indexed[r]) {
+            for (int c = 0; c < ncls; ++c) {  // record new_id[c]: class c's successor as a one-class exit (none: dead)
+                const uint32_t id = static_cast<uint32_t>(new_id[c]), e = at[r * cols + c];
+                uint32_t w0 = REC_EMPTY | (REC_EMPTY << 16), w1 = 0;
+                if (e != dead_of_row[r]) {
+                    uint32_t op;
+                    if (!op_field(e, op)) return false;
+                    w0 = REC_EMPTY | (id << 16);
+                    w1 |= index_of[e & 0xFFFFu] | (op << 16);
+                }
+                if (id == 0 && hdr) w1 |= REC_HDR;
+                items[2 * (index_of[r] + id)] = w0;
+                items[2 * (index_of[r] + id) + 1] = w1;
+            }
+            continue;
+        }
         const size_t n = std::max<size_t>(1, exits[r].size());
         for (size_t q = 0; q < n; ++q) {
             uint32_t w0 = REC_EMPTY | (REC_EMPTY << 16), w1 = 0;
@@ -293,14 +341,11 @@ bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t ro
             if (q < exits[r].size()) {
                 const Slot& e = exits[r][q];
                 w0 = (w0 & 0xFFFFu) | (static_cast<uint32_t>(e.lo) << 16) | (static_cast<uint32_t>(e.hi - e.lo) << 24);
-                uint32_t op = e.entry >> 16;  // as the dense rows carry it
-                if (simple) op /= 128u;       // register + 1
-                else if (op & 0x8000u) { if ((op & 0x7FFFu) > 127u) return false; op = 0x80u | (op & 0x7Fu); }
-                else if (op > 127u) return false;
-                if (op > 255u) return false;
+                uint32_t op;
+                if (!op_field(e.entry, op)) return false;
                 w1 = index_of[e.entry & 0xFFFFu] | (op << 16);
             }
-            if (q + 1 == n) w1 |= REC_LAST;
+            if (q + 1 < n) w1 |= REC_MORE;
             if (q == 0 && hdr) w1 |= REC_HDR;
             items[2 * (index_of[r] + q)] = w0;
             items[2 * (index_of[r] + q) + 1] = w1;
@@ -334,12 +379,12 @@ bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t ro
     for (size_t r = 0; r < rows; ++r)
         for (int c = 0; c < ncls; ++c) {
             const uint32_t id = static_cast<uint32_t>(new_id[c]);
-            uint32_t next = index_of[dead_of_row[r] & 0xFFFFu], op = 0;
-            for (uint32_t q = index_of[r];; ++q) {
+            uint32_t next = 0, op = 0;
+            for (uint32_t q = index_of[r] + (index_of[r] >= L.rec_indexed ? id : 0u);; ++q) {
                 const uint32_t w0 = items[2 * q], w1 = items[2 * q + 1];
                 if (id - ((w0 >> 16) & 0xFFu) <= (w0 >> 24)) { next = w1 & 0xFFFFu; op = (w1 >> 16) & 0xFFu; break; }
                 if (id - (w0 & 0xFFu) <= ((w0 >> 8) & 0xFFu)) { next = index_of[r]; break; }
-                if (w1 & REC_LAST) break;
+                if (!(w1 & REC_MORE)) break;
             }
             const uint32_t e = at[r * cols + c];
             uint32_t want_op = e >> 16;
@@ -347,19 +392,17 @@ bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t ro
             if (next != index_of[e & 0xFFFFu] || op != want_op) throw GxError(GX_E_ARG, "internal: record tier does not reproduce the dense rows");
         }
     // image: class map (new ids; entry 256 = the identity class of masked bytes), interval table, items
-    std::vector<uint16_t> cmap(272, static_cast<uint16_t>(REC_IDC));
-    for (int b = 0; b < 256; ++b) cmap[b] = static_cast<uint16_t>(new_id[T.cls256[b]]);
+    std::vector<uint32_t> cmap(REC_AT / 4, REC_IDC);
+    for (int b = 0; b < 256; ++b) { const uint32_t id = static_cast<uint32_t>(new_id[T.cls256[b]]); cmap[b] = id | (id * 8u) << 16; }
     L.cmap = static_cast<uint32_t>(img.put(cmap));
-    L.acc_tab = static_cast<uint32_t>(img.put(acc_tab));
     if (items_global) { L.rec = 0; items_global->swap(items); }  // records in global memory (tier 3)
-    else L.rec = static_cast<uint32_t>(img.put(items));
+    else { L.rec = static_cast<uint32_t>(img.put(items)); if (L.rec != REC_AT) throw GxError(GX_E_ARG, "internal: record image layout"); }
+    L.acc_tab = static_cast<uint32_t>(img.put(acc_tab));
     L.at = 0;
     if (L.m_dead < rows) { L.m_start = index_of[L.m_start]; L.m_dead = index_of[L.m_dead]; }  // (absent from a capture-only image)
     if (L.u_start != 0xFFFFFFFFu) { L.u_start = index_of[L.u_start]; L.u_dead = index_of[L.u_dead]; }
     else for (size_t k = 0; k + 1 < c_rule.size(); k += 2) {
-        // per-extraction capture automata: (start state, the rule's own dead state)
-        c_rule[k + 1] = index_of[dead_of_row[c_rule[k]] & 0xFFFFu];
-        c_rule[k] = index_of[c_rule[k]];
+        c_rule[k] = index_of[c_rule[k]];  // per-extraction capture automata: the start states
     }
     return true;
 }
@@ -669,6 +712,7 @@ bool plan_lanes_launch(const gx_handle* h, GxLds* out, bool match_only, bool com
     L.regs_wave_bytes = (L.regs_wave_bytes + rows + 16u + 15u) & ~15u;
     if (L.table_bytes + 32u + 4u * L.regs_wave_bytes > LDS_BYTES) return false;
     L.nwaves = std::min<uint32_t>(16u, (LDS_BYTES - L.table_bytes - 32u) / L.regs_wave_bytes);
+    if (getenv("GX_EXP_NWAVES")) L.nwaves = std::min<uint32_t>(L.nwaves, atoi(getenv("GX_EXP_NWAVES")));
     L.regs = L.table_bytes;
     L.bitmap = 0;
     L.counter = L.regs + L.nwaves * L.regs_wave_bytes;
@@ -980,6 +1024,10 @@ int64_t gx_stat(const gx_handle* h, int32_t which) {
     case 6: { GxLds L; return plan_tile_launch(h, 0, &L) ? static_cast<int64_t>(L.nwaves) : 0; }
     case 7: return !h->tile_ok ? 0 : h->lds.tier == 3 ? 4 : h->tile_global ? 2 : h->lds.tier == 2 ? 3 : 1;
     case 8: return h->T.has_capture ? 1 : 0;
+    case 10: { GxLds L; return plan_lanes_launch(h, &L, false, true) ? static_cast<int64_t>(L.nwaves) : 0; }   // lane kernel: waves per CU, compact rows
+    case 11: { GxLds L; return plan_lanes_launch(h, &L, true, false) ? static_cast<int64_t>(L.nwaves) : 0; }   // ... match-only
+    case 12: return h->tile_ok ? static_cast<int64_t>(h->lds.table_bytes) : 0;
+    case 13: return h->tile_ok ? static_cast<int64_t>(h->lds.regs_wave_bytes) : 0;
     case 9: return !h->tile_ok ? 0 : !h->has_mo ? gx_stat(h, 7) : h->lds_mo.tier == 3 ? 4 : h->lds_mo.tier == 2 ? 3 : h->lds_mo.tier == 1 ? 2 : 1;
     default: return -1;
     }

@@ -83,6 +83,7 @@ struct GxLds {
     // range] is the state's self-loop interval word.
     uint32_t tier;        // 0: dense rows in LDS, 1: dense rows in global memory, 2: records in LDS
     uint32_t rec, acc_tab;
+    uint32_t rec_indexed; // states with an index >= this keep one record per class (state index + class), behind all the others
 };
 constexpr uint32_t GX_BITMAP_WAVE_BYTES = 144;  // 16 x u64 (1024 chunks = 16 KB of staging) + one word read ahead
 

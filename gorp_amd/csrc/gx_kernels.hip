@@ -222,10 +222,9 @@ k_extract_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const 
     W.row_bytes = L.row_bytes;
     W.ops_off = L.ops_off;
     W.ops = L.ops;
-    W.rec = L.rec;
     W.acc_tab = L.acc_tab;
-    W.dead = want_caps ? L.u_dead : L.m_dead;
     W.ncls = L.ncls;
+    W.indexed = L.rec_indexed;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t slice = L.stage + wave * L.stage_bytes;

@@ -57,10 +57,9 @@ k_extract_lanes(GxLds L, LanesIO io) {
     W.row_bytes = L.row_bytes;
     W.ops_off = L.ops_off;
     W.ops = L.ops;
-    W.rec = L.rec;
     W.acc_tab = L.acc_tab;
-    W.dead = CAPTURE ? L.u_dead : L.m_dead;
     W.ncls = L.ncls;
+    W.indexed = L.rec_indexed;
     const uint32_t row0 = CAPTURE ? L.u_start : L.m_start, dead_row = CAPTURE ? L.u_dead : L.m_dead;
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -119,12 +118,17 @@ k_extract_lanes(GxLds L, LanesIO io) {
             // 2.38 against 2.23 ms on config 3 -- the loads inside the window loop cost more than the wait they save)
 #pragma unroll
             for (int k = 0; k < KCH; ++k) pre[k] = line_chunk(seg + 16u * k, more);
-#pragma unroll
+            // One copy of the window code, run KCH times: the window is always taken from slot 0 and the others move down
+            // (6 x 4 register moves per window).  Unrolled with static slots instead, the loop body is 80 KB of code --
+            // more than the instruction cache two CUs share -- and the waves wait for instruction fetches.
+#pragma unroll 1
             for (int k = 0; k < KCH; ++k) {
                 const uint32_t rel = seg + 16u * k;
                 const bool act = more && rel < len;
                 if (!__any(act)) break;
-                const uint4 w0 = make_uint4(pre[k].x, pre[k].y, pre[k].z, pre[k].w);
+                const uint4 w0 = make_uint4(pre[0].x, pre[0].y, pre[0].z, pre[0].w);
+#pragma unroll
+                for (int q = 0; q + 1 < KCH; ++q) pre[q] = pre[q + 1];
                 const bool full0 = rel + 16u <= len;
                 const uint32_t bx = outside_bits(w0.x, lo4, k4), by = outside_bits(w0.y, lo4, k4);
                 const uint32_t bz = outside_bits(w0.z, lo4, k4), bw = outside_bits(w0.w, lo4, k4);

@@ -237,13 +237,11 @@ k_extract_tile(GxLds L, TileIO io) {
     Wm.row_bytes = L.row_bytes;
     Wm.ops_off = L.ops_off;
     Wm.ops = L.ops;
-    Wm.rec = L.rec;
     Wm.acc_tab = L.acc_tab;
-    Wm.dead = L.m_dead;
     Wm.ncls = L.ncls;
+    Wm.indexed = L.rec_indexed;
     Wc = Wm;
-    if (GT) Wc.at = io.at_global + L.c_base;
-    Wc.dead = L.u_dead;  // (two-pass layout: set per lane below)
+    if (GT) Wc.at = io.at_global + L.c_base;  // (two-pass layout: set per lane below)
 
     const uint32_t lane = threadIdx.x & 63u;
     // (the wave index through readfirstlane: everything derived from it -- tile numbers, LDS areas, the round's span --
@@ -390,7 +388,6 @@ k_extract_tile(GxLds L, TileIO io) {
                 info = k;
                 uint32_t crow = GT ? 0u : L.m_dead;  // any valid row: the walk below is off for lanes without a match
                 if (k >= 0) crow = lds_ld<uint32_t>(L.c_rule + 8u * k);
-                if (TierTraits<TIER>::records) Wc.dead = k >= 0 ? lds_ld<uint32_t>(L.c_rule + 8u * k + 4u) : L.m_dead;  // the rule's own dead state
                 if (L.simple_ops) crow = walk<TIER, true, true>(Wc, stage, bitmap, use_map, crow, start, end, k >= 0, 0xFFFFFFFFu, regs);
                 else crow = walk<TIER, true, false>(Wc, stage, bitmap, use_map, crow, start, end, k >= 0, 0xFFFFFFFFu, regs);
                 if (k >= 0) {

@@ -110,12 +110,16 @@ struct WalkTab {
     const uint8_t* at;     // TIER_L2: base of the rows in global memory; TIER_RECG: base of the records
     uint32_t row_bytes;    // dense row stride
     uint32_t ops_off, ops; // LDS addresses of the capture program lists
-    uint32_t rec, acc_tab; // TIER_REC: LDS addresses of the records and of the interval table
-    uint32_t dead;         // TIER_REC: the automaton's dead state (where every class in no range leads)
+    uint32_t acc_tab;      // record tiers: LDS address of the interval table
     uint32_t ncls;         // TIER_REC
+    uint32_t indexed;      // TIER_REC: states from this index on keep one record per class (read record [state + class])
 };
 
-constexpr uint32_t REC_LAST = 1u << 24, REC_HDR = 2u << 24, REC_IDC = 254u;
+// Record tiers (gx_api.cpp: records_from_dense).  The class map at LDS address 0 has 32-bit entries, class | class * 8
+// << 16 (entry 256, for bytes outside the line: REC_IDC, and 0 in the upper half); the records of the LDS tier follow it
+// at the fixed address REC_AT, so that a record read is "ds_read_b64 index * 8, offset: REC_AT".  Record 0 is the one
+// dead state all automata of the image share.
+constexpr uint32_t REC_MORE = 0x80u << 24, REC_HDR = 2u << 24, REC_IDC = 254u, REC_AT = 1088u;
 
 template <int TIER>
 __device__ __forceinline__ uint32_t tab_word(const WalkTab& W, uint32_t row, uint32_t off) {
@@ -126,7 +130,7 @@ __device__ __forceinline__ uint32_t tab_word(const WalkTab& W, uint32_t row, uin
 template <int TIER>
 __device__ __forceinline__ u32x2 rec_ld(const WalkTab& W, uint32_t idx) {
     if (TIER == TIER_RECG) return *reinterpret_cast<const u32x2*>(W.at + (static_cast<uint64_t>(idx) << 3));
-    return lds_ld<u32x2>(W.rec + (idx << 3));
+    return lds_ld<u32x2>(REC_AT + (idx << 3));
 }
 // a state's self-loop interval word (lo | (0x7F - hi) << 8 | hot << 16) and its info word
 template <int TIER>
@@ -181,34 +185,69 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
             asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(in_line) : "v"(mask), "n"(j));
             asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(b) : "v"(in_line), "v"(b), "v"(256u));
         }
-        c4[j] = lds_ld<uint16_t>(b << 1);
+        c4[j] = TierTraits<TIER>::records ? lds_ld<uint32_t>(b << 2) : lds_ld<uint16_t>(b << 1);
     }
     const uint32_t dummy_col = regs - 128u;
     if (TierTraits<TIER>::records) {
-        // c4[] holds class ids here.  One record read per byte, two range tests (c - lo <= span, the byte fields picked
-        // by operand selectors), two selects.  The sixteen steps are straight-line code; a lane that meets a state
-        // with more ranges than one record holds and finds its class in none of the first record's goes to the dead
-        // state (and writes nothing but the dummy column from there on) and raises `more`: the window is then walked
-        // again with the general steps below, which follow a state's further records -- same start, same writes, so
-        // the second pass simply overwrites the first.
-        const uint32_t row0 = row;
-        bool more = false;
+        // c4[] holds class-map entries (class | class * 8 << 16).  One record read per byte, two range tests (c - lo <=
+        // span, the byte fields picked by operand selectors), three selects: straight-line code.  A state has one or two
+        // records, or -- with three exit ranges and more -- one record per class (read at [state + class]); when some
+        // lane of the wave finds its class in neither range of a first record that has a second, the wave reads the
+        // second records too (a wave-uniform branch, taken once in a few hundred bytes per lane).
+        constexpr bool ASM_STEP = TIER == TIER_REC && !MASKED && (SIMPLE || !CAPTURE);
+        uint32_t zero = 0u;
+        if (ASM_STEP) asm volatile("v_mov_b32 %0, 0" : "=v"(zero));  // (kept in a register: SDWA operands are registers)
+        const uint32_t row_in = row;
+        uint64_t more = 0ull;  // lanes that needed a second record somewhere in the window
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const uint32_t c = c4[j];
-            const u32x2 it = rec_ld<TIER>(W, row);
-            const bool in_exit = (c - ((it.x >> 16) & 0xFFu)) <= (it.x >> 24);
-            const bool in_self = (c - (it.x & 0xFFu)) <= ((it.x >> 8) & 0xFFu);
-            uint32_t next = in_exit ? (it.y & 0xFFFFu) : (in_self ? row : W.dead);
-            uint32_t op = in_exit ? ((it.y >> 16) & 0xFFu) : 0u;
-            bool pending = !in_exit && !in_self && (it.y & REC_LAST) == 0u;
-            if (MASKED) {
-                const bool idc = c == REC_IDC;  // a byte outside the line: stay, no program
-                next = idc ? row : next;
-                op = idc ? 0u : op;
-                pending = pending && !idc;
+            const uint32_t ce = c4[j];
+            uint32_t next, op;
+            if (ASM_STEP) {
+                // The step as the instructions it should be (the compiler's version of the C++ below costs 19 vector
+                // instructions a byte, and the walk is bound by their issue): 12 for captures, 10 without.
+                uint32_t a, x, y;
+                uint64_t in_self, pending;
+                asm("v_cmp_le_u32 vcc, %1, %2\n\t"
+                    "v_cndmask_b32_sdwa %0, %3, %4, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+                    "v_lshl_add_u32 %0, %2, 3, %0"
+                    : "=&v"(a) : "s"(W.indexed), "v"(row), "v"(zero), "v"(ce) : "vcc");
+                const u32x2 it = lds_ld<u32x2>(REC_AT + a);
+                asm("v_sub_u32_sdwa %0, %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+                    "v_sub_u32_sdwa %1, %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_2\n\t"
+                    "v_cmp_le_u32_sdwa %4, %0, %8 src0_sel:DWORD src1_sel:BYTE_1\n\t"
+                    "v_cmp_le_u32_sdwa vcc, %1, %8 src0_sel:DWORD src1_sel:BYTE_3\n\t"
+                    "v_cmp_gt_i32_e64 %5, 0, %9\n\t"
+                    "v_cndmask_b32_e64 %2, 0, %10, %4\n\t"
+                    "v_cndmask_b32_sdwa %2, %2, %9, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+                    "v_cndmask_b32_sdwa %3, %6, %9, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+                    "s_andn2_b64 %5, %5, vcc\n\t"
+                    "s_andn2_b64 %5, %5, %4"
+                    : "=&v"(x), "=&v"(y), "=&v"(next), "=&v"(op), "=&s"(in_self), "=&s"(pending)
+                    : "v"(zero), "v"(ce), "v"(it.x), "v"(it.y), "v"(row) : "vcc", "scc");
+                more |= pending;
+            } else {
+                const uint32_t c = ce & 0xFFu;
+                const uint32_t a = row + (row >= W.indexed ? ce >> 19 : 0u);
+                const u32x2 it = rec_ld<TIER>(W, a);
+                const bool in_exit = (c - ((it.x >> 16) & 0xFFu)) <= (it.x >> 24);
+                const bool in_self = (c - (it.x & 0xFFu)) <= ((it.x >> 8) & 0xFFu);
+                next = in_exit ? (it.y & 0xFFFFu) : (in_self ? row : 0u);
+                op = in_exit ? ((it.y >> 16) & 0xFFu) : 0u;
+                bool pending = !in_exit && !in_self && (it.y & REC_MORE) != 0u;
+                if (MASKED) {
+                    const bool idc = c == REC_IDC;  // a byte outside the line: stay, no program
+                    next = idc ? row : next;
+                    op = idc ? 0u : op;
+                    pending = pending && !idc;
+                }
+                if (__any(pending)) {
+                    const u32x2 it2 = rec_ld<TIER>(W, a + 1u);
+                    const bool in2 = pending && (c - ((it2.x >> 16) & 0xFFu)) <= (it2.x >> 24);
+                    next = in2 ? (it2.y & 0xFFFFu) : next;
+                    op = in2 ? ((it2.y >> 16) & 0xFFu) : op;
+                }
             }
-            more = more || pending;
             row = next;
             if (CAPTURE) {
                 const uint16_t pos = static_cast<uint16_t>(rel + j);
@@ -220,44 +259,26 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
                 }
             }
         }
-        if (!__any(more)) return row;
-        row = row0;
-        for (int j = 0; j < 16; ++j) {  // (a real loop: this path is rare and long; no register array indexed by j)
-            const uint32_t dw = j < 8 ? (j < 4 ? win.x : win.y) : (j < 12 ? win.z : win.w);
-            uint32_t b = (dw >> ((j & 3) * 8)) & 0xFFu;
-            if (MASKED && ((mask >> j) & 1u) == 0u) b = 256u;
-            const uint32_t c = lds_ld<uint16_t>(b << 1);
-            uint32_t a = row;
-            u32x2 it = rec_ld<TIER>(W, a);
-            bool in_exit = (c - ((it.x >> 16) & 0xFFu)) <= (it.x >> 24);
-            const bool in_self = (c - (it.x & 0xFFu)) <= ((it.x >> 8) & 0xFFu);
-            uint32_t next = in_exit ? (it.y & 0xFFFFu) : (in_self ? row : W.dead);
-            uint32_t op = in_exit ? ((it.y >> 16) & 0xFFu) : 0u;
-            bool pending = !in_exit && !in_self && (it.y & REC_LAST) == 0u;
-            if (MASKED) {
-                const bool idc = c == REC_IDC;
-                next = idc ? row : next;
-                op = idc ? 0u : op;
-                pending = pending && !idc;
-            }
-            while (__any(pending)) {
-                a += pending ? 1u : 0u;
-                it = rec_ld<TIER>(W, a);
-                in_exit = (c - ((it.x >> 16) & 0xFFu)) <= (it.x >> 24);
-                if (pending && in_exit) { next = it.y & 0xFFFFu; op = (it.y >> 16) & 0xFFu; }
-                pending = pending && !in_exit && (it.y & REC_LAST) == 0u;
-            }
-            row = next;
-            if (CAPTURE) {
-                const uint16_t pos = static_cast<uint16_t>(rel + j);
-                if (SIMPLE) {
-                    lds_st<uint16_t>(dummy_col + (op << 7), pos);
-                } else if (op) {
-                    if (op & 0x80u) lds_st<uint16_t>(regs + (op & 0x7Fu) * 128u, pos);
-                    else run_op_list(W, regs, op, pos);
-                }
+#ifndef GX_EXP_NORERUN
+        if (ASM_STEP && more != 0ull) {
+            // Some lane met a state with two records and found its class in neither range of the first: that lane went to
+            // the dead state above (and wrote nothing but the dummy column from there on).  Walk the window again with
+            // the second records -- same start, same writes, so this pass simply overwrites the first.
+            row = row_in;
+            for (int j = 0; j < 16; ++j) {  // (a real loop: no register array indexed by j)
+                const uint32_t dw = j < 8 ? (j < 4 ? win.x : win.y) : (j < 12 ? win.z : win.w);
+                const uint32_t ce = lds_ld<uint32_t>(((dw >> ((j & 3) * 8)) & 0xFFu) << 2), c = ce & 0xFFu;
+                const uint32_t a = row + (row >= W.indexed ? ce >> 19 : 0u);
+                const u32x2 it = rec_ld<TIER>(W, a), it2 = rec_ld<TIER>(W, a + 1u);
+                const bool in_exit = (c - ((it.x >> 16) & 0xFFu)) <= (it.x >> 24);
+                const bool in_self = (c - (it.x & 0xFFu)) <= ((it.x >> 8) & 0xFFu);
+                const bool in2 = !in_exit && !in_self && (it.y & REC_MORE) != 0u && (c - ((it2.x >> 16) & 0xFFu)) <= (it2.x >> 24);
+                const uint32_t op = in_exit ? ((it.y >> 16) & 0xFFu) : in2 ? ((it2.y >> 16) & 0xFFu) : 0u;
+                row = in_exit ? (it.y & 0xFFFFu) : in_self ? row : in2 ? (it2.y & 0xFFFFu) : 0u;
+                if (CAPTURE) lds_st<uint16_t>(dummy_col + (op << 7), static_cast<uint16_t>(rel + j));  // (SIMPLE programs only here)
             }
         }
+#endif
         return row;
     }
 #pragma unroll

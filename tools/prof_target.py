@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: a few launches of the batch kernel on config 2 for rocprofv3 counter runs.
-Usage: prof_target.py [lines] [dense|compact|match_only] [rules (0 = README definition)]"""
+Usage: prof_target.py [lines] [dense|compact|match_only] [rules (0 = README definition)]
+Environment: GX_BENCH_KERNEL (gx_batch_opts.kernel), GX_BENCH_FLAGS (GX_CREATE_*), as tools/bench_config3.py."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,9 +11,11 @@ from gorp_amd.gorp import Gorp
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 fmt = sys.argv[2] if len(sys.argv) > 2 else "dense"
 nrules = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+kernel = int(os.environ.get("GX_BENCH_KERNEL", "0"))
+flags = int(os.environ.get("GX_BENCH_FLAGS", "0"))
 if nrules:
     rules, meta = W.syslog_definition(nrules, seed=3)
-    g = Gorp.construct(rules)
+    g = Gorp.construct(rules, flags=flags)
     dh, oh, cats = W.syslog_lines(meta, 100_000, seed=3)
     reps = max(1, n // 100_000)
     data = torch.from_numpy(dh.copy()).cuda().repeat(reps)
@@ -31,10 +34,10 @@ rows = torch.empty((n, 1 + 2 * G), dtype=torch.int16, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
     if fmt == "compact":
-        g.extract_batch_device(data.data_ptr(), off.data_ptr(), n, None, rows.data_ptr(), stream=st, no_sync=True, line_bytes_hint=200, compact=True)
+        g.extract_batch_device(data.data_ptr(), off.data_ptr(), n, None, rows.data_ptr(), stream=st, no_sync=True, line_bytes_hint=200, compact=True, kernel=kernel)
     else:
         g.extract_batch_device(data.data_ptr(), off.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=st, no_sync=True, line_bytes_hint=200,
-                               match_only=fmt == "match_only")
+                               match_only=fmt == "match_only", kernel=kernel)
 torch.cuda.synchronize()
 if cat is not None:
     assert torch.equal(rows[:, 0].to(torch.int32) if fmt == "compact" else mid, cat.to(torch.int32))
