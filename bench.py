@@ -303,7 +303,7 @@ def main():
                                                   else " (int32 id + int32 offsets, %d B/line)" % (4 + 8 * G)),
                        "match_dfa_states": int(gorp.stat(0)), "char_classes": int(gorp.stat(1)),
                        "capture_states": int(gorp.stat(2)), "table_blob_bytes": int(gorp.stat(4)),
-                       "table_tier": {0: "per-line kernel", 1: "LDS", 2: "L2"}.get(int(gorp.stat(7)), str(gorp.stat(7))),
+                       "table_tier": {0: "per-line kernel", 1: "LDS (dense rows)", 2: "L2 (dense rows)", 3: "LDS (range records)", 4: "L2 (range records)"}.get(int(gorp.stat(7)), str(gorp.stat(7))),
                        "parallelism": "lines sharded by rank (dp%d), no collective in a step" % world},
             "gb_per_s_scanned": total_bytes * world * steps / elapsed / 1e9,
             "kernel_ms": {"avg": k_avg, "min": k_sorted[0], "median": k_sorted[len(k_sorted) // 2]},

@@ -712,7 +712,6 @@ bool plan_lanes_launch(const gx_handle* h, GxLds* out, bool match_only, bool com
     L.regs_wave_bytes = (L.regs_wave_bytes + rows + 16u + 15u) & ~15u;
     if (L.table_bytes + 32u + 4u * L.regs_wave_bytes > LDS_BYTES) return false;
     L.nwaves = std::min<uint32_t>(16u, (LDS_BYTES - L.table_bytes - 32u) / L.regs_wave_bytes);
-    if (getenv("GX_EXP_NWAVES")) L.nwaves = std::min<uint32_t>(L.nwaves, atoi(getenv("GX_EXP_NWAVES")));
     L.regs = L.table_bytes;
     L.bitmap = 0;
     L.counter = L.regs + L.nwaves * L.regs_wave_bytes;
@@ -760,14 +759,20 @@ void choose_tile_image(gx_handle* h) {
         else if (force_recg) ok = records(3) || build_tile_image(h, 1);
         else if (force_rec) ok = records(2) || records(3) || build_tile_image(h, 1);
         else {
-            // Measured on the 64-extraction definition of BASELINE configs[2] (10 M x 200-byte lines): captures -- dense
-            // rows in L2 3.0 ms, records in LDS 3.9 ms (6 waves and a longer decode per byte), records in global memory
-            // 4.0 ms; match only -- records in LDS 2.2 ms against 3.0 ms.  Hence: dense rows in LDS when they fit, else
-            // dense rows in global memory for the capture side and, when they fit, LDS records for match-only batches.
+            // Measured on the 64-extraction definition of BASELINE configs[2] (10 M x 200-byte lines), captures / match only:
+            // range records in LDS walked by the lane kernel 1.9 / 1.4 ms; dense rows in global memory (L2) under the tile
+            // kernel 3.0 / 3.0 ms; records in LDS under the tile kernel 3.9 / 1.9 ms; records in global memory 4.0 ms.
+            // Hence: dense rows in LDS when they fit; else records in LDS when they fit beside at least 8 waves of the
+            // lane kernel; else dense rows in global memory for the capture side and, when they fit, LDS records for
+            // match-only batches.
             ok = build_tile_image(h, 0);
             if (!ok) {
-                ok = build_tile_image(h, 1);
-                if (ok) (void)build_tile_image(h, 2, 2);
+                GxLds L;
+                ok = records(2) && plan_lanes_launch(h, &L, false, true) && L.nwaves >= 8u;
+                if (!ok) {
+                    ok = build_tile_image(h, 1);
+                    if (ok) (void)build_tile_image(h, 2, 2);
+                }
             }
         }
     }
@@ -885,7 +890,9 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
         GX_HIP(launch_extract_slices(h->dev, L, image, at_global, h->num_cus, b, stream));
         return;
     }
-    if (batchable && kernel == GX_KERNEL_LANES && plan_lanes_launch(h, &L, mo, b.packed != nullptr)) {
+    // records in LDS: the lane kernel (every lane keeps its own line in registers, 16 waves share the tables)
+    const bool lanes = kernel == GX_KERNEL_LANES || (kernel == GX_KERNEL_AUTO && image_tier == 2);
+    if (batchable && lanes && plan_lanes_launch(h, &L, mo, b.packed != nullptr)) {
         std::lock_guard<std::mutex> lock(h->slot_mu);
         b.seq = h->next_seq++;
         if (h->next_seq == 0) h->next_seq = 1;
@@ -893,7 +900,11 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
         if (h->slot_used[slot]) GX_HIP(hipStreamWaitEvent(stream, h->slot_event[slot], 0));
         h->slot_used[slot] = true;
         b.oversize_flag = h->d_slots + slot;
-        GX_HIP(launch_extract_lanes(h->dev, L, image, at_global, h->num_cus, b, stream));
+        unsigned long long* stamps = nullptr;
+#ifdef GX_DEV
+        stamps = h->dev_stamps;
+#endif
+        GX_HIP(launch_extract_lanes(h->dev, L, image, at_global, h->num_cus, b, stream, stamps));
         GX_HIP(launch_extract_oversize(h->dev, b, 65535u + 48u, stream));
         GX_HIP(hipEventRecord(h->slot_event[slot], stream));
         return;

@@ -138,7 +138,7 @@ hipError_t launch_extract_oversize(const GxDev& dev, const GxBatch& b, uint32_t 
 // lds.nwaves waves per workgroup; lds.regs_wave_bytes = the wave's LDS area (register block of lds.stage_bytes bytes + result rows).
 // Lines longer than 65 535 bytes are left to launch_extract_oversize (stage_bytes = 65 535 + 48).
 hipError_t launch_extract_lanes(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
-                                const GxBatch& b, hipStream_t stream);
+                                const GxBatch& b, hipStream_t stream, unsigned long long* dev_stamps);
 // Slice kernel: the same tables, lines staged 64 bytes at a time (GxLds::stage_bytes = 64 * 80); fused automaton or match only.
 hipError_t launch_extract_slices(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
                                  const GxBatch& b, hipStream_t stream);

@@ -32,12 +32,18 @@ struct LanesIO {
     uint32_t seq;
     int32_t max_groups;
     int32_t strip_eol;
+#ifdef GX_DEV
+    unsigned long long* stamps;  // per workgroup: core-clock cycles and 100 MHz ticks spent in the kernel
+#endif
 };
 
 // One workgroup of up to 16 waves per CU: the waves of a workgroup share one copy of the tables in LDS.
 template <typename OFF, int KCH, int TIER, bool CAPTURE, bool SIMPLE, bool PACKED>
 __global__ void __launch_bounds__(1024)
 k_extract_lanes(GxLds L, LanesIO io) {
+#ifdef GX_DEV
+    const uint64_t dev_t0 = __builtin_amdgcn_s_memtime(), dev_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     {
         extern __shared__ __attribute__((aligned(16))) uint8_t gx_smem[];
         const uint4* src = reinterpret_cast<const uint4*>(io.image);
@@ -201,6 +207,12 @@ k_extract_lanes(GxLds L, LanesIO io) {
         if (lane == 0) nj = __hip_atomic_fetch_add((GX_LDS uint32_t*)(uintptr_t)L.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         j = __builtin_amdgcn_readfirstlane(nj);
     }
+#ifdef GX_DEV
+    if (io.stamps && threadIdx.x == 0) {
+        io.stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - dev_t0;
+        io.stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - dev_r0;
+    }
+#endif
 }
 
 template <typename OFF, int TIER, bool CAPTURE, bool SIMPLE, bool PACKED>
@@ -223,7 +235,7 @@ hipError_t launch_lanes_m(bool capture, bool simple, bool packed, const GxLds& l
 // lds: a layout from plan_lanes_launch (gx_api.cpp): tables, then per wave the register block with the result rows
 // behind it.  Needs tables in global memory (tier 1 or 3) and, for captures, the fused automaton.
 hipError_t launch_extract_lanes(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
-                                const GxBatch& b, hipStream_t stream) {
+                                const GxBatch& b, hipStream_t stream, unsigned long long* dev_stamps) {
     if (b.n == 0) return hipSuccess;
     const uint64_t tiles = (b.n + 63) >> 6;
     uint64_t blocks = static_cast<uint64_t>(num_cus);
@@ -242,6 +254,11 @@ hipError_t launch_extract_lanes(const GxDev& dev, const GxLds& lds, const uint8_
     io.seq = b.seq;
     io.max_groups = dev.max_groups;
     io.strip_eol = b.strip_eol;
+#ifdef GX_DEV
+    io.stamps = dev_stamps;
+#else
+    (void)dev_stamps;
+#endif
     const bool capture = b.match_only == 0 && dev.has_capture;
     const dim3 grid(static_cast<unsigned>(blocks));
     const bool packed = b.packed != nullptr;

@@ -328,6 +328,8 @@ def test_tile_image_tiers_by_definition_size():
         assert Gorp.construct(W.readme3_definition(), host_only=True, flags=flags).stat(7) == tier
     rules, _ = W.syslog_definition(64, seed=3)
     g = Gorp.construct(rules, host_only=True)
-    assert g.stat(7) == 2 and g.stat(9) == 3       # dense rows in global memory for captures, LDS records for match-only
+    assert g.stat(7) == 3 and g.stat(9) == 3 and g.stat(10) == 16 and g.stat(11) == 16  # records in LDS, 16 waves of the lane kernel
+    g = Gorp.construct(rules, host_only=True, flags=N.GX_CREATE_TIER_L2)
+    assert g.stat(7) == 2 and g.stat(9) == 2       # forced: dense rows in global memory
     g = Gorp.construct(rules, host_only=True, flags=N.GX_CREATE_TIER_RECORDS)
     assert g.stat(7) == 3 and g.stat(6) >= 5       # records in LDS, at least 5 waves of staging left

@@ -288,14 +288,17 @@ def test_syslog_16_rules():
     assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
 
 
-@pytest.mark.parametrize("tier", [2, 3, 4, 5])
+@pytest.mark.parametrize("tier", [2, 3, 4, 5, 6])
 def test_table_tiers_agree_with_oracle(tier, monkeypatch):
     """The same definitions through the L2-tier tile kernel (automaton rows in global memory), through the per-line
-    generic kernel and through the record tier (sparse range records in LDS); the default for these small definitions
-    is the LDS tier with dense rows, covered everywhere else."""
+    generic kernel and through the record tier (sparse range records in LDS: 4 = under the lane kernel, its default;
+    6 = under the tile kernel; 5 = records in global memory); the default for these small definitions is the LDS tier
+    with dense rows, covered everywhere else."""
     monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", {2: N.GX_CREATE_TIER_L2, 3: N.GX_CREATE_NO_TILES, 4: N.GX_CREATE_TIER_RECORDS,
-                                                    5: N.GX_CREATE_TIER_RECORDS_GLOBAL}[tier])
-    want = {2: 2, 3: 0, 4: 3, 5: 4}[tier]
+                                                    5: N.GX_CREATE_TIER_RECORDS_GLOBAL, 6: N.GX_CREATE_TIER_RECORDS}[tier])
+    if tier == 6:
+        monkeypatch.setattr(G, "DEFAULT_KERNEL", N.GX_KERNEL_TILES)
+    want = {2: 2, 3: 0, 4: 3, 5: 4, 6: 3}[tier]
     # config 1
     definition = W.simple_grp_definition()
     gorp, orc = Gorp.construct(definition), oracle_for(definition)
@@ -341,13 +344,13 @@ def test_table_tiers_agree_with_oracle(tier, monkeypatch):
 
 @pytest.mark.parametrize("flags", [0, N.GX_CREATE_TIER_L2, N.GX_CREATE_TIER_RECORDS])
 def test_config3_64_rules_parity(flags):
-    """BASELINE.json configs[2]: 64 extractions.  The dense rows (2.3 MB) do not fit LDS: by default the capture side keeps
-    them in global memory / L2 and match-only batches walk range records in LDS; forced: dense rows for both, records
-    in LDS for both."""
+    """BASELINE.json configs[2]: 64 extractions.  The dense rows (2.3 MB) do not fit LDS: by default the states become range
+    records that do (gx_stat 7 and 9 = 3), walked by the lane kernel; forced: dense rows in global memory / L2 under the
+    tile kernel.  The tile kernel on the records is checked as well."""
     rules, meta = W.syslog_definition(64, seed=3)
     gorp, orc = Gorp.construct(rules, flags=flags), oracle_for(rules)
     assert gorp.stat(0) > 1000  # match-automaton states
-    assert gorp.stat(7) == {0: 2, N.GX_CREATE_TIER_L2: 2, N.GX_CREATE_TIER_RECORDS: 3}[flags]
+    assert gorp.stat(7) == {0: 3, N.GX_CREATE_TIER_L2: 2, N.GX_CREATE_TIER_RECORDS: 3}[flags]
     assert gorp.stat(9) == {0: 3, N.GX_CREATE_TIER_L2: 2, N.GX_CREATE_TIER_RECORDS: 3}[flags]
     data, offsets, cats = W.syslog_lines(meta, 30000, seed=3)
     mid, caps = gorp.extract_batch(data, offsets)
@@ -358,6 +361,11 @@ def test_config3_64_rules_parity(flags):
     assert len(set(mid[mid >= 0].tolist())) == 64  # every extraction wins somewhere
     m2, _ = gorp.extract_batch(data, offsets, match_only=True)   # (record tier: the match automaton's own image)
     assert np.array_equal(m2, orc.extract_batch(data, offsets, match_only=True, nthreads=8)[0])
+    if flags != N.GX_CREATE_TIER_L2:
+        mid, caps = gorp.extract_batch(data, offsets, kernel=N.GX_KERNEL_TILES)
+        assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+        m2, _ = gorp.extract_batch(data, offsets, match_only=True, kernel=N.GX_KERNEL_TILES)
+        assert np.array_equal(m2, orc.extract_batch(data, offsets, match_only=True, nthreads=8)[0])
     rows, over = gorp.extract_batch(data, offsets, compact=True)
     cm, cc = G.unpack_rows(rows)
     assert over == 0 and np.array_equal(cm, omid) and np.array_equal(cc, ocaps)

@@ -18,8 +18,10 @@ rng = random.Random(seed)
 variants = [(0, 0, False), (N.GX_CREATE_TIER_L2, 0, False), (0, N.GX_KERNEL_SLICES, False), (N.GX_CREATE_TIER_L2, N.GX_KERNEL_SLICES, False),
             (N.GX_CREATE_NO_TILES, 0, False), (N.GX_CREATE_NO_FUSED, 0, False), (N.GX_CREATE_NO_FUSED | N.GX_CREATE_TIER_L2, 0, False),
             (0, 0, True), (N.GX_CREATE_TIER_L2, 0, True), (0, N.GX_KERNEL_SLICES, True), (N.GX_CREATE_NO_FUSED, 0, True),
-            (N.GX_CREATE_TIER_RECORDS, 0, False), (N.GX_CREATE_TIER_RECORDS, N.GX_KERNEL_SLICES, False),
+            (N.GX_CREATE_TIER_RECORDS, 0, False), (N.GX_CREATE_TIER_RECORDS, N.GX_KERNEL_SLICES, False),   # (records in LDS: kernel 0 = the lane kernel)
             (N.GX_CREATE_TIER_RECORDS | N.GX_CREATE_NO_FUSED, 0, False), (N.GX_CREATE_TIER_RECORDS, 0, True),
+            (N.GX_CREATE_TIER_RECORDS, N.GX_KERNEL_TILES, False), (N.GX_CREATE_TIER_RECORDS, N.GX_KERNEL_TILES, True),
+            (N.GX_CREATE_TIER_L2, N.GX_KERNEL_LANES, False), (N.GX_CREATE_TIER_RECORDS_GLOBAL, N.GX_KERNEL_LANES, True),
             (N.GX_CREATE_TIER_RECORDS_GLOBAL, 0, False), (N.GX_CREATE_TIER_RECORDS_GLOBAL, N.GX_KERNEL_SLICES, False),
             (N.GX_CREATE_TIER_RECORDS_GLOBAL | N.GX_CREATE_NO_FUSED, 0, True)]
 done = bad = 0
