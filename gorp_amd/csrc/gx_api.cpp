@@ -879,19 +879,23 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
     GxLds L;
     const bool batchable = !b.wide && !b.state_out && b.match_only >= 0 && kernel != GX_KERNEL_PER_LINE;
     // Lines whose 64-line groups do not fit the tile kernel's staging area (mean length above 255 bytes) go to the
-    // slice kernel, which stages 64 bytes of every line at a time: measured 2.4x faster on config 5 (512 extractions,
-    // 50-2000-byte lines), but 0.8x on 200-byte lines, where the tile kernel's one contiguous span per group wins.
-    const bool slices = kernel == GX_KERNEL_SLICES || (kernel == GX_KERNEL_AUTO && line_bytes_hint > 255u);
+    // slice kernel, which stages 64 bytes of every line at a time and hands a lane its next line as soon as it is done, or
+    // to the lane kernel.  Measured (ms; captures / match only):
+    //   512 extractions, 2 M lines of 50-2000 bytes (configs[4]), dense rows in L2: tiles 4.4 / 4.0, slices 2.39 / 2.20, lanes 2.19 / 2.07
+    //   64 extractions, 1 M such lines, records in LDS: slices 1.12 / 0.80, lanes 1.41 / 1.22
+    //   64 extractions, 10 M lines of 200 bytes (configs[2]): records in LDS + lanes 1.52 / 1.18, dense rows in L2 + tiles 3.0 / 3.0
+    const bool long_lines = line_bytes_hint > 255u;
     const bool mo = b.match_only != 0 || !h->T.has_capture;
     const uint8_t* image = static_cast<const uint8_t*>(mo && h->has_mo ? h->d_lds_image_mo : h->d_lds_image);
     const uint32_t image_tier = mo && h->has_mo ? h->lds_mo.tier : h->lds.tier;
     const uint8_t* at_global = image_tier == 1 || image_tier == 3 ? static_cast<const uint8_t*>(h->d_l2_image) : nullptr;
+    const bool slices = kernel == GX_KERNEL_SLICES || (kernel == GX_KERNEL_AUTO && long_lines && image_tier != 1);
     if (batchable && slices && plan_slice_launch(h, &L, mo)) {
         GX_HIP(launch_extract_slices(h->dev, L, image, at_global, h->num_cus, b, stream));
         return;
     }
     // records in LDS: the lane kernel (every lane keeps its own line in registers, 16 waves share the tables)
-    const bool lanes = kernel == GX_KERNEL_LANES || (kernel == GX_KERNEL_AUTO && image_tier == 2);
+    const bool lanes = kernel == GX_KERNEL_LANES || (kernel == GX_KERNEL_AUTO && (image_tier == 2 || (image_tier == 1 && long_lines)));
     if (batchable && lanes && plan_lanes_launch(h, &L, mo, b.packed != nullptr)) {
         std::lock_guard<std::mutex> lock(h->slot_mu);
         b.seq = h->next_seq++;

@@ -306,7 +306,7 @@ k_extract_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const 
             u32x4 v = {0u, 0u, 0u, 0u};
             if (at_byte < lq) {
                 const uint8_t* src = data + oq + at_byte;
-                if (src + 16 <= data_end) v = __builtin_nontemporal_load(&reinterpret_cast<const UnalignedWindow*>(src)->v);
+                if (src + 16 <= data_end) v = reinterpret_cast<const UnalignedWindow*>(src)->v;
                 else {
                     uint32_t w[4] = {0, 0, 0, 0};
                     for (int b = 0; b < 16; ++b)

@@ -108,7 +108,7 @@ k_extract_lanes(GxLds L, LanesIO io) {
             u32x4 v = {0u, 0u, 0u, 0u};
             if (wanted && at_byte < len) {
                 const uint8_t* src = line + at_byte;
-                if (src + 16 <= data_end) v = __builtin_nontemporal_load(&reinterpret_cast<const UnalignedWindow*>(src)->v);
+                if (src + 16 <= data_end) v = reinterpret_cast<const UnalignedWindow*>(src)->v;  // (a plain load: see KCH below)
                 else {
                     uint32_t w[4] = {0, 0, 0, 0};
                     for (int b = 0; b < 16; ++b)
@@ -120,13 +120,11 @@ k_extract_lanes(GxLds L, LanesIO io) {
         };
         for (uint32_t seg = 0; __any(more); seg += KCH * 16u) {
             u32x4 pre[KCH];  // this lane's bytes [seg, seg + 16 KCH) of its line
-            // (refilling slot k with the next segment's window k right after window k is taken out was measured: slower,
-            // 2.38 against 2.23 ms on config 3 -- the loads inside the window loop cost more than the wait they save)
 #pragma unroll
             for (int k = 0; k < KCH; ++k) pre[k] = line_chunk(seg + 16u * k, more);
             // One copy of the window code, run KCH times: the window is always taken from slot 0 and the others move down
-            // (6 x 4 register moves per window).  Unrolled with static slots instead, the loop body is 80 KB of code --
-            // more than the instruction cache two CUs share -- and the waves wait for instruction fetches.
+            // (4 register moves per slot and window).  Unrolled with static slots instead, the loop body was 80 KB of code
+            // at 7 windows, for no gain.
 #pragma unroll 1
             for (int k = 0; k < KCH; ++k) {
                 const uint32_t rel = seg + 16u * k;
@@ -217,7 +215,17 @@ k_extract_lanes(GxLds L, LanesIO io) {
 
 template <typename OFF, int TIER, bool CAPTURE, bool SIMPLE, bool PACKED>
 hipError_t launch_lanes_t(const GxLds& lds, const LanesIO& io, dim3 grid, hipStream_t stream) {
-    constexpr int KCH = 7;  // 112 bytes of the line in 28 registers (13 was measured: the compiler moves the array to scratch memory)
+    // 208 bytes of the line in 52 registers.  Measured on config 3 (captures, dense rows), variants side by side on one device:
+    //   windows per segment: 5 2.09 ms, 7 1.89 ms, 13 1.80 ms;
+    //   loads with the non-temporal hint (as the tile kernel's, which read every byte once) 1.80 ms, plain 1.56 ms: a lane comes
+    //   back to the same cache line for its next 16 bytes, and plain loads find it in the vector L1;
+    //   the four lanes of a quad fetching 64 contiguous bytes of one line each and exchanging inside the quad: 1.66 ms;
+    //   the next tile's offsets and first windows loaded while this tile's results are put together: 1.94-2.02 ms (the kernel
+    //   then needs more than its 128 registers); no interval test for a window in which some lane's state has no interval:
+    //   1.94 against 1.89 ms.
+    //   Timing-only builds (wrong results): no line loads at all 1.28 ms, the same bytes loaded in lane order 1.39 ms, no
+    //   record reads 1.84 ms (no change: the dependent LDS read per byte is not what bounds the walk).
+    constexpr int KCH = 13;
     hipError_t e = allow_full_lds(&k_extract_lanes<OFF, KCH, TIER, CAPTURE, SIMPLE, PACKED>);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_extract_lanes<OFF, KCH, TIER, CAPTURE, SIMPLE, PACKED>), grid, dim3(lds.nwaves * 64), lds.total_bytes, stream, lds, io);
