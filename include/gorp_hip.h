@@ -56,9 +56,9 @@ enum {
 #define GX_CREATE_TIER_L2   2u     /* keep the automaton rows in global memory even when they would fit LDS */
 #define GX_CREATE_NO_TILES  4u     /* per-line kernel only */
 #define GX_CREATE_NO_FUSED  8u     /* two passes: match automaton, then the winning extraction's capture automaton */
-#define GX_CREATE_TIER_RECORDS 16u /* sparse range records in LDS even when the dense rows would fit */
-#define GX_CREATE_TIER_RECORDS_GLOBAL 32u /* sparse range records in global memory (L1 / L2 resident; the choice for automata
-                                      whose dense rows do not fit LDS) even when the dense rows would fit */
+#define GX_CREATE_TIER_RECORDS 16u /* sparse range records in LDS even when the dense rows would fit (the default when they do
+                                      not: BASELINE configs[2], 64 extractions) */
+#define GX_CREATE_TIER_RECORDS_GLOBAL 32u /* sparse range records in global memory (L1 / L2 resident) */
 
 /* Replaces Gorp.construct's per-extraction back half (core/Gorp.java:58-92):
  * PolyMatcher.create(automatonInputs) (core/autom/PolyMatcher.java:64-84 ->
@@ -91,7 +91,8 @@ int32_t gx_max_groups(const gx_handle* h);
  * 6 = waves per workgroup of the batch kernel, 7 = table tier of the batch kernel (1 = automaton rows in LDS,
  * 2 = rows in global memory / L2, 3 = sparse range records in LDS, 4 = range records in global memory, 0 = per-line
  * generic kernel), 9 = the same for match-only batches (a large definition keeps a second, smaller table image for them),
- * 8 = 1 when the handle has capture regexps */
+ * 8 = 1 when the handle has capture regexps, 10 / 11 = waves per workgroup of the lane kernel (captures with compact rows /
+ * match only; 0 where it does not apply), 12 = bytes of the batch kernels' table image, 13 = bytes of a wave's register block */
 int64_t gx_stat(const gx_handle* h, int32_t which);
 
 typedef struct gx_batch_opts {
