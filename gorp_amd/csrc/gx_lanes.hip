@@ -187,8 +187,8 @@ k_extract_lanes(GxLds L, LanesIO io) {
                     rp[0] = static_cast<uint16_t>(result);
                 }
             } else {
-                // dense int32 rows: every lane stores its own (8 bytes per group; the rows' area in LDS is sized for the compact
-                // format, and these tiers are bound by the walk, not by the result stores)
+                // dense int32 rows: every lane stores its own (8 bytes per group).  Taking them through the wave's row area 32
+                // lines at a time, as contiguous 16-byte stores, was measured: no faster (1.558 against 1.551 ms on config 3)
                 if (valid && !oversize) {
                     int32_t* cp = io.caps + i * static_cast<uint64_t>(slots);
                     io.match_id[i] = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
