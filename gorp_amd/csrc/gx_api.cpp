@@ -1133,6 +1133,7 @@ static const GxJsonl& jsonl_templates(gx_handle* h, const char* id_as) {
         std::string lit = "{";
         uint32_t fixed = 0;
         auto close_segment = [&](int g) {
+            while (lits.size() % 4) lits.push_back(0);  // the write kernel reads literals as aligned 32-bit words
             lit_off.push_back(static_cast<uint32_t>(lits.size()));
             lit_len.push_back(static_cast<uint32_t>(lit.size()));
             group.push_back(g);
@@ -1150,7 +1151,7 @@ static const GxJsonl& jsonl_templates(gx_handle* h, const char* id_as) {
         seg_off.push_back(static_cast<uint32_t>(group.size()));
         fixed_len.push_back(fixed);
     }
-    if (lits.empty()) lits.push_back(0);
+    while (lits.empty() || lits.size() % 4) lits.push_back(0);
     Image img;
     const size_t o_seg = img.put(seg_off), o_lo = img.put(lit_off), o_ll = img.put(lit_len), o_g = img.put(group), o_f = img.put(fixed_len),
                  o_l = img.put(lits);

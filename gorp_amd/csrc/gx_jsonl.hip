@@ -270,38 +270,98 @@ struct JsonlTileCfg {
                           // or 0xFFFFFFFF: read them from global memory
     uint32_t n_rules, n_segs;
     uint32_t caps_bytes;  // per-wave staging of the tile's capture rows (64 * slots * 4), 0: read them from global memory
+    uint32_t perm_lds;    // LDS offset of the write pass's 16 byte-permute selectors (128 bytes)
 };
 
 // four bytes of LDS at any alignment (gfx950 reads LDS unaligned)
 struct __attribute__((packed)) UnalignedU32 { uint32_t v; };
-__device__ __forceinline__ uint32_t load_u32(const uint8_t* p) { return reinterpret_cast<const UnalignedU32*>(p)->v; }
-__device__ __forceinline__ void store_u32(uint8_t* p, uint32_t v) { reinterpret_cast<UnalignedU32*>(p)->v = v; }
 
-// some byte of w is a control character (< 0x20) or >= 0x80
-__device__ __forceinline__ bool ctrl_or_high4(uint32_t w) {
-    const uint32_t t = (w & 0x7F7F7F7Fu) + 0x60606060u;  // bit 7 of a byte set iff its low 7 bits >= 0x20
-    return ((~t | w) & 0x80808080u) != 0u;
+// The per-lane code addresses LDS by byte address (address-space-3 pointers made from integers: ds_* instructions, not
+// flat ones) and only with ALIGNED 32-bit words: a 32-bit LDS access off its alignment is replayed at 64 cycles, reads
+// and writes alike (measured here: SQ_LDS_UNALIGNED_STALL was 88 % of the LDS-active cycles of the write pass when
+// it read the captures and wrote the text at byte addresses).  Unaligned text is read as aligned words joined by
+// v_alignbyte and written through a three-byte carry (k_jsonl_tile).
+#define JX_LDS __attribute__((address_space(3)))
+__device__ __forceinline__ void lds_put_u32(uint32_t a, uint32_t v) { ((JX_LDS volatile UnalignedU32*)(uintptr_t)a)->v = v; }
+__device__ __forceinline__ uint32_t lds_w(uint32_t a) { return *(JX_LDS const uint32_t*)(uintptr_t)a; }  // a 4-byte aligned word
+__device__ __forceinline__ void lds_put_u8(uint32_t a, uint32_t v) { *(JX_LDS uint8_t*)(uintptr_t)a = static_cast<uint8_t>(v); }
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((JX_LDS const uint8_t*)p)); }
+
+// the bytes of one character inside a JSON string, low byte first, and how many (1..6)
+__device__ __forceinline__ uint64_t esc_bytes(uint32_t b, bool passthrough, uint32_t& count) {
+    if (b >= 0x80u) {
+        if (passthrough) { count = 1u; return b; }
+        count = 2u;
+        return (0xC0u | (b >> 6)) | (0x80u | (b & 0x3Fu)) << 8;
+    }
+    if (b >= 0x20u) {
+        if (b == 0x22u || b == 0x5Cu) { count = 2u; return 0x5Cu | b << 8; }
+        count = 1u;
+        return b;
+    }
+    uint32_t letter = 0u;
+    switch (b) {
+    case 0x08u: letter = 'b'; break;
+    case 0x09u: letter = 't'; break;
+    case 0x0Au: letter = 'n'; break;
+    case 0x0Cu: letter = 'f'; break;
+    case 0x0Du: letter = 'r'; break;
+    default: break;
+    }
+    if (letter) { count = 2u; return 0x5Cu | letter << 8; }
+    count = 6u;
+    const uint32_t lo = b & 15u;
+    const uint64_t hex = static_cast<uint64_t>('0' + (b >> 4)) | static_cast<uint64_t>(lo < 10u ? '0' + lo : 'A' + (lo - 10u)) << 8;
+    return 0x5Cu | static_cast<uint64_t>('u') << 8 | static_cast<uint64_t>('0') << 16 | static_cast<uint64_t>('0') << 24 | hex << 32;
 }
 
 // global -> LDS copy of the span [lo, hi) of `data`, 16 bytes per lane, skewed so that LDS and global addresses
-// agree modulo 16; chunks that stick out of [data, data_end) are read byte by byte.
+// agree modulo 16; chunks that stick out of [data, data_end) are read byte by byte.  All of a lane's loads (up to 16: the
+// staging area is at most 16 KB) are issued before the first store waits for one: a wave of these kernels has its
+// SIMD to itself, and a load-store-load-store chain costs a trip to memory per chunk.
 __device__ __forceinline__ void stage_in(const uint8_t* __restrict__ data, const uint8_t* data_end, uint64_t lo, uint64_t hi, uint8_t* stage,
                                          uint32_t lane) {
     const uint8_t* g_lo = data + lo;
     const uint32_t skew = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(g_lo) & 15u);
     const uint8_t* g_al = g_lo - skew;
     const uint32_t nch = static_cast<uint32_t>(((hi - lo) + skew + 15u) >> 4);
-    for (uint32_t c = lane; c < nch; c += 64u) {
-        const uint8_t* src = g_al + (static_cast<uint64_t>(c) << 4);
-        uint4 v;
-        if (src >= data && src + 16 <= data_end) v = *reinterpret_cast<const uint4*>(src);
-        else {
-            uint32_t w[4] = {0, 0, 0, 0};
-            for (int q = 0; q < 16; ++q)
-                if (src + q >= data && src + q < data_end) w[q >> 2] |= static_cast<uint32_t>(src[q]) << ((q & 3) * 8);
-            v = make_uint4(w[0], w[1], w[2], w[3]);
+    for (uint32_t c0 = 0; c0 < nch; c0 += 64u * 16u) {
+        uint4 v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t c = c0 + 64u * q + lane;
+            v[q] = make_uint4(0u, 0u, 0u, 0u);
+            if (c < nch) {
+                const uint8_t* src = g_al + (static_cast<uint64_t>(c) << 4);
+                if (src >= data && src + 16 <= data_end) v[q] = *reinterpret_cast<const uint4*>(src);
+                else {
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    for (int r = 0; r < 16; ++r)
+                        if (src + r >= data && src + r < data_end) w[r >> 2] |= static_cast<uint32_t>(src[r]) << ((r & 3) * 8);
+                    v[q] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
         }
-        *reinterpret_cast<uint4*>(stage + (c << 4)) = v;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t c = c0 + 64u * q + lane;
+            if (c < nch) *reinterpret_cast<uint4*>(stage + (c << 4)) = v[q];
+        }
+    }
+}
+
+// global -> LDS copy of `words` (<= 2048) int32, every lane's loads issued before its first store
+__device__ __forceinline__ void stage_words(const int32_t* __restrict__ src, uint32_t words, int32_t* stage, uint32_t lane) {
+    int32_t v[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        const uint32_t x = 64u * q + lane;
+        v[q] = x < words ? src[x] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        const uint32_t x = 64u * q + lane;
+        if (x < words) stage[x] = v[q];
     }
 }
 
@@ -319,6 +379,20 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
     uint32_t* tl_lit_off = tl_fixed + cfg.n_rules;
     uint32_t* tl_lit_len = tl_lit_off + cfg.n_segs;
     int32_t* tl_group = reinterpret_cast<int32_t*>(tl_lit_len + cfg.n_segs);
+    const uint32_t smem0 = lds_addr(jx_smem);
+    const uint32_t perm_tab = smem0 + cfg.perm_lds;
+    if (WRITE && threadIdx.x < 16u) {
+        // byte-permute selectors by escape mask (bit j: character j of the word takes a backslash): selector bytes 0..3 = the
+        // characters, 4 = the backslash, 0x0C = a zero byte behind the text
+        uint32_t sel[8], at = 0;
+        for (uint32_t j = 0; j < 4u; ++j) {
+            if ((threadIdx.x >> j) & 1u) sel[at++] = 4u;
+            sel[at++] = j;
+        }
+        while (at < 8u) sel[at++] = 0x0Cu;
+        lds_put_u32(perm_tab + threadIdx.x * 8u, sel[0] | sel[1] << 8 | sel[2] << 16 | sel[3] << 24);
+        lds_put_u32(perm_tab + threadIdx.x * 8u + 4u, sel[4] | sel[5] << 8 | sel[6] << 16 | sel[7] << 24);
+    }
     if (cfg.lits_lds != 0xFFFFFFFFu)
         for (uint32_t q = threadIdx.x; q < cfg.lits_bytes; q += blockDim.x) jx_smem[cfg.lits_lds + q] = tm.lits[q];
     if (cfg.tm_lds != 0xFFFFFFFFu) {
@@ -383,17 +457,42 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
                 const uint64_t row0 = ((tile << 6) + a) * static_cast<uint64_t>(slots);     // in int32 units
                 const uint32_t words = (b - a) * static_cast<uint32_t>(slots);
                 const int32_t* src = caps + row0;
-                int32_t* cst = reinterpret_cast<int32_t*>(caps_stage);
-                for (uint32_t q = lane; q < words; q += 64u) cst[q] = src[q];
+                stage_words(src, words, reinterpret_cast<int32_t*>(caps_stage), lane);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
             // ---- lane = line ----
             if (active) {
-                const uint8_t* line = in_stage + skew + static_cast<uint32_t>(o0 - lo);
+                const uint32_t line = lds_addr(in_stage) + skew + static_cast<uint32_t>(o0 - lo);  // LDS byte addresses
                 uint32_t total = 0;
-                uint8_t* dst = WRITE ? out_stage + oskew + static_cast<uint32_t>(oo0 - olo) : nullptr;
+                // The write pass: a lane's text leaves through ALIGNED 32-bit stores (a 32-bit LDS store off its alignment is
+                // replayed at 64 cycles, measured: SQ_LDS_UNALIGNED_STALL was 88 % of the LDS-active cycles).  Up to three
+                // bytes wait in `carry`; the first store of a lane also covers the last bytes of the lane before it with
+                // zeros, and those are written by that lane's byte stores at the end -- after the segment loop, where
+                // all lanes have come together again, so later than every first store of the round.
+                const uint32_t dst0 = WRITE ? lds_addr(out_stage) + oskew + static_cast<uint32_t>(oo0 - olo) : 0u;
+                uint32_t wp = dst0 & ~3u, carry = 0u, pend = dst0 & 3u;
+                auto put_4 = [&](uint32_t e) {  // four bytes
+                    const uint64_t t = static_cast<uint64_t>(e) << (8u * pend);
+                    *(JX_LDS uint32_t*)(uintptr_t)wp = carry | static_cast<uint32_t>(t);
+                    wp += 4u;
+                    carry = static_cast<uint32_t>(t >> 32);
+                };
+                auto put_n = [&](uint32_t e, uint32_t count) {  // the low `count` (0..4) bytes of e; its other bytes are zero
+                    const uint64_t t = static_cast<uint64_t>(e) << (8u * pend);
+                    const uint32_t acc = carry | static_cast<uint32_t>(t);
+                    const uint32_t np = pend + count;
+                    if (np >= 4u) {
+                        *(JX_LDS uint32_t*)(uintptr_t)wp = acc;
+                        wp += 4u;
+                        carry = static_cast<uint32_t>(t >> 32);
+                        pend = np - 4u;
+                    } else {
+                        carry = acc;
+                        pend = np;
+                    }
+                };
                 if (k >= 0) {
                     const int32_t* cp_g = caps + i * static_cast<uint64_t>(slots);
                     const int32_t* cp_l = reinterpret_cast<const int32_t*>(caps_stage) + (lane - a) * static_cast<uint32_t>(slots);
@@ -409,74 +508,89 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
                         if (WRITE) {
                             const uint32_t ll = t_lit_len(s), lo_l = t_lit_off(s);
                             if (cfg.lits_lds != 0xFFFFFFFFu) {
-                                const uint8_t* lit = jx_smem + cfg.lits_lds + lo_l;
+                                const uint32_t lit = smem0 + cfg.lits_lds + lo_l;
                                 uint32_t q = 0;
-                                for (; q + 8u <= ll; q += 8u) {  // two unaligned words per LDS round trip
-                                    const uint32_t a = load_u32(lit + q), b2 = load_u32(lit + q + 4u);
-                                    store_u32(dst + q, a);
-                                    store_u32(dst + q + 4u, b2);
+                                for (; q + 16u <= ll; q += 16u) {  // four words per LDS round trip (the host aligns every literal to 4 bytes)
+                                    const uint32_t w0 = lds_w(lit + q), w1 = lds_w(lit + q + 4u), w2 = lds_w(lit + q + 8u), w3 = lds_w(lit + q + 12u);
+                                    put_4(w0); put_4(w1); put_4(w2); put_4(w3);
                                 }
-                                for (; q + 4u <= ll; q += 4u) store_u32(dst + q, load_u32(lit + q));
-                                for (; q < ll; ++q) dst[q] = lit[q];
+                                for (; q + 4u <= ll; q += 4u) put_4(lds_w(lit + q));
+                                if (q < ll) put_n(lds_w(lit + q) & ((1u << (8u * (ll - q))) - 1u), ll - q);  // (the word's other bytes: the host's padding)
                             } else {
                                 const uint8_t* lit = tm.lits + lo_l;
-                                for (uint32_t q = 0; q < ll; ++q) dst[q] = lit[q];
+                                for (uint32_t q = 0; q < ll; ++q) put_n(lit[q], 1u);
                             }
-                            dst += ll;
                         }
                         const int32_t g = t_group(s);
                         if (g < 0) continue;
                         const int32_t cb = cap(2 * g), ce = cap(2 * g + 1);
                         if (cb < 0) {
-                            if (WRITE) { dst[0] = 'n'; dst[1] = 'u'; dst[2] = 'l'; dst[3] = 'l'; dst += 4; }
+                            if (WRITE) put_4(0x6C6C756Eu);  // null
                             else total += 4u;
                             continue;
                         }
                         if (WRITE) {
-                            *dst++ = '"';
-                            // Lanes run in lock step, so whatever one lane needs every lane pays for: the common
-                            // characters -- plain ones and the two that only take a backslash -- go through one
-                            // branch-free sequence (two byte stores, the second overwriting the first for a plain
-                            // character); only control characters and bytes >= 0x80 take the branchy path.
-                            auto put4 = [&](uint32_t w) {  // four plain-or-backslashed characters
-                                const uint32_t v0 = w & 0xFFu, v1 = (w >> 8) & 0xFFu, v2 = (w >> 16) & 0xFFu, v3 = w >> 24;
-                                const uint32_t q0 = (v0 == 0x22u || v0 == 0x5Cu) ? 1u : 0u, q1 = (v1 == 0x22u || v1 == 0x5Cu) ? 1u : 0u;
-                                const uint32_t q2 = (v2 == 0x22u || v2 == 0x5Cu) ? 1u : 0u, q3 = (v3 == 0x22u || v3 == 0x5Cu) ? 1u : 0u;
-                                dst[0] = static_cast<uint8_t>(q0 ? 0x5Cu : v0); dst[q0] = static_cast<uint8_t>(v0); dst += 1u + q0;
-                                dst[0] = static_cast<uint8_t>(q1 ? 0x5Cu : v1); dst[q1] = static_cast<uint8_t>(v1); dst += 1u + q1;
-                                dst[0] = static_cast<uint8_t>(q2 ? 0x5Cu : v2); dst[q2] = static_cast<uint8_t>(v2); dst += 1u + q2;
-                                dst[0] = static_cast<uint8_t>(q3 ? 0x5Cu : v3); dst[q3] = static_cast<uint8_t>(v3); dst += 1u + q3;
+                            put_n(0x22u, 1u);
+                            // Lanes run in lock step, so whatever one lane needs every lane pays for.  Four characters that
+                            // are plain or only take a backslash -- nearly all of them -- are expanded without a branch: the
+                            // mask of the characters to escape picks one of 16 byte-permute selectors (a 128-byte table
+                            // in LDS) that lay the characters and their backslashes out in 4..8 bytes.  Control characters
+                            // and bytes >= 0x80 take the byte-by-byte path.
+                            auto put1 = [&](uint32_t v) {
+                                uint32_t cnt;
+                                const uint64_t e = esc_bytes(v, pt, cnt);
+                                put_n(static_cast<uint32_t>(e), cnt < 4u ? cnt : 4u);
+                                if (cnt > 4u) put_n(static_cast<uint32_t>(e >> 32), cnt - 4u);
                             };
-                            auto slow4 = [&](uint32_t w) {
-                                for (int q = 0; q < 4; ++q) {
-                                    const uint32_t v = (w >> (8 * q)) & 0xFFu;
-                                    esc_write(dst, v, pt);
-                                    dst += esc_len(v, pt);
+                            auto put4 = [&](uint32_t w) {
+                                const uint32_t t7 = (w & 0x7F7F7F7Fu) + 0x60606060u;
+                                if ((~t7 | w) & 0x80808080u) {  // a control character or a byte >= 0x80
+                                    for (int q = 0; q < 4; ++q) put1((w >> (8 * q)) & 0xFFu);
+                                    return;
                                 }
+                                const uint32_t x = w ^ 0x22222222u, y = w ^ 0x5C5C5C5Cu;
+                                const uint32_t zq = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+                                const uint32_t zb = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
+                                const uint32_t m = (zq | zb) >> 7;           // bit 8 j: character j takes a backslash
+                                const uint32_t t = m | (m >> 7);
+                                const uint32_t idx = (t | (t >> 14)) & 15u;  // bit j: character j
+                                const uint32_t sel = perm_tab + idx * 8u;
+                                const uint32_t s_lo = *(JX_LDS const uint32_t*)(uintptr_t)sel, s_hi = *(JX_LDS const uint32_t*)(uintptr_t)(sel + 4u);
+                                put_4(__builtin_amdgcn_perm(0x5C5C5C5Cu, w, s_lo));
+                                put_n(__builtin_amdgcn_perm(0x5C5C5C5Cu, w, s_hi), __popc(idx));
                             };
+                            // the capture's bytes: aligned 32-bit reads (one off its alignment is replayed too) joined by v_alignbyte
                             int32_t p = cb;
-                            for (; p + 8 <= ce; p += 8) {  // two words per round trip to LDS
-                                const uint32_t w0 = load_u32(line + p), w1 = load_u32(line + p + 4);
-                                if (!ctrl_or_high4(w0)) put4(w0); else slow4(w0);
-                                if (!ctrl_or_high4(w1)) put4(w1); else slow4(w1);
+                            uint32_t ap = (line + static_cast<uint32_t>(cb)) & ~3u;
+                            const uint32_t mis = (line + static_cast<uint32_t>(cb)) & 3u;
+                            uint32_t prev = lds_w(ap);
+                            for (; p + 16 <= ce; p += 16, ap += 16u) {  // four words per LDS round trip
+                                const uint32_t d0 = lds_w(ap + 4u), d1 = lds_w(ap + 8u), d2 = lds_w(ap + 12u), d3 = lds_w(ap + 16u);
+                                put4(__builtin_amdgcn_alignbyte(d0, prev, mis));
+                                put4(__builtin_amdgcn_alignbyte(d1, d0, mis));
+                                put4(__builtin_amdgcn_alignbyte(d2, d1, mis));
+                                put4(__builtin_amdgcn_alignbyte(d3, d2, mis));
+                                prev = d3;
                             }
-                            for (; p + 4 <= ce; p += 4) {
-                                const uint32_t w = load_u32(line + p);
-                                if (!ctrl_or_high4(w)) put4(w); else slow4(w);
+                            for (; p + 4 <= ce; p += 4, ap += 4u) {
+                                const uint32_t d = lds_w(ap + 4u);
+                                put4(__builtin_amdgcn_alignbyte(d, prev, mis));
+                                prev = d;
                             }
-                            for (; p < ce; ++p) {
-                                const uint32_t v = line[p];
-                                esc_write(dst, v, pt);
-                                dst += esc_len(v, pt);
+                            if (p < ce) {
+                                uint32_t w = __builtin_amdgcn_alignbyte(lds_w(ap + 4u), prev, mis);  // (may read past the line: LDS)
+                                for (; p < ce; ++p, w >>= 8) put1(w & 0xFFu);
                             }
-                            *dst++ = '"';
+                            put_n(0x22u, 1u);
                         } else {
                             // four characters at a time: 4 + one per quote / backslash (+ one per byte >= 0x80 that becomes
                             // two bytes of UTF-8); a word with a control character is counted byte by byte
                             uint32_t t = 2u;
                             int32_t p = cb;
-                            for (; p + 4 <= ce; p += 4) {
-                                const uint32_t w = load_u32(line + p);
+                            uint32_t ap = (line + static_cast<uint32_t>(cb)) & ~3u;
+                            const uint32_t mis = (line + static_cast<uint32_t>(cb)) & 3u;
+                            uint32_t prev = lds_w(ap);
+                            auto count4 = [&](uint32_t w) {
                                 const uint32_t tt = (w & 0x7F7F7F7Fu) + 0x60606060u;
                                 if ((~(tt | w)) & 0x80808080u) {  // some byte < 0x20
                                     for (int q = 0; q < 4; ++q) t += esc_len((w >> (8 * q)) & 0xFFu, pt);
@@ -486,11 +600,29 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
                                     const uint32_t zb = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
                                     t += 4u + __popc(zq | zb) + (pt ? 0u : __popc(w & 0x80808080u));
                                 }
+                            };
+                            for (; p + 16 <= ce; p += 16, ap += 16u) {  // four aligned words per LDS round trip
+                                const uint32_t d0 = lds_w(ap + 4u), d1 = lds_w(ap + 8u), d2 = lds_w(ap + 12u), d3 = lds_w(ap + 16u);
+                                count4(__builtin_amdgcn_alignbyte(d0, prev, mis));
+                                count4(__builtin_amdgcn_alignbyte(d1, d0, mis));
+                                count4(__builtin_amdgcn_alignbyte(d2, d1, mis));
+                                count4(__builtin_amdgcn_alignbyte(d3, d2, mis));
+                                prev = d3;
                             }
-                            for (; p < ce; ++p) t += esc_len(line[p], pt);
+                            for (; p + 4 <= ce; p += 4, ap += 4u) {
+                                const uint32_t d = lds_w(ap + 4u);
+                                count4(__builtin_amdgcn_alignbyte(d, prev, mis));
+                                prev = d;
+                            }
+                            if (p < ce) {
+                                uint32_t w = __builtin_amdgcn_alignbyte(lds_w(ap + 4u), prev, mis);
+                                for (; p < ce; ++p, w >>= 8) t += esc_len(w & 0xFFu, pt);
+                            }
                             total += t;
                         }
                     }
+                    // the bytes still waiting: byte stores (the rest of that dword is the next lane's)
+                    if (WRITE) for (uint32_t q = 0; q < pend; ++q) lds_put_u8(wp + q, (carry >> (8u * q)) & 0xFFu);
                 }
                 if (!WRITE) sizes[i] = total;
             }
@@ -707,6 +839,8 @@ bool plan_jsonl_tile(const GxJsonl& tm, int slots, uint32_t mean_in, uint32_t me
     if (tm.lits_bytes <= 24u * 1024u) { c.lits_lds = 0; used = (tm.lits_bytes + 15u) & ~15u; }
     const uint32_t tm_bytes = (2u * tm.n_rules + 1u + 3u * tm.n_segs) * 4u;
     if (tm_bytes <= 16u * 1024u) { c.tm_lds = used; used += (tm_bytes + 15u) & ~15u; }
+    c.perm_lds = used;
+    used += 128u;
     c.caps_bytes = slots > 0 && slots <= 32 ? 64u * static_cast<uint32_t>(slots) * 4u : 0u;
     c.in_bytes = std::min<uint32_t>((64u * std::max<uint32_t>(mean_in, 1u) + 64u + 15u) & ~15u, 16384u);
     c.out_bytes = mean_out ? std::min<uint32_t>((64u * (mean_out + mean_out / 8u) + 64u + 15u) & ~15u, 49152u) : 0u;
