@@ -288,7 +288,11 @@ bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t ro
             index_of[r] = static_cast<uint32_t>(n_items);
             n_items += ix ? static_cast<size_t>(ncls) : std::max<size_t>(1, exits[r].size());
         }
-    if (n_items > 65535u) return false;
+    const bool wide = items_global != nullptr;  // records in global memory: 22-bit successors
+    if (n_items > (wide ? 0x3FFFFFu : 65535u)) return false;
+    auto pack_w1 = [&](uint32_t target, uint32_t op, bool more, bool hdr) {
+        return wide ? (target | op << 22 | (hdr ? 1u << 30 : 0u) | (more ? 1u << 31 : 0u)) : (target | op << 16 | (hdr ? REC_HDR : 0u) | (more ? REC_MORE : 0u));
+    };
     if (getenv("GX_REC_STATS")) {
         size_t multi = 0, self_split = 0, self_states = 0;
         std::map<size_t, size_t> hist;
@@ -321,14 +325,13 @@ bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t ro
         if (indexed[r]) {
             for (int c = 0; c < ncls; ++c) {  // record new_id[c]: class c's successor as a one-class exit (none: dead)
                 const uint32_t id = static_cast<uint32_t>(new_id[c]), e = at[r * cols + c];
-                uint32_t w0 = REC_EMPTY | (REC_EMPTY << 16), w1 = 0;
+                uint32_t w0 = REC_EMPTY | (REC_EMPTY << 16), target = 0, op = 0;
                 if (e != dead_of_row[r]) {
-                    uint32_t op;
                     if (!op_field(e, op)) return false;
                     w0 = REC_EMPTY | (id << 16);
-                    w1 |= index_of[e & 0xFFFFu] | (op << 16);
+                    target = index_of[e & 0xFFFFu];
                 }
-                if (id == 0 && hdr) w1 |= REC_HDR;
+                const uint32_t w1 = pack_w1(target, op, false, id == 0 && hdr);
                 items[2 * (index_of[r] + id)] = w0;
                 items[2 * (index_of[r] + id) + 1] = w1;
             }
@@ -336,17 +339,15 @@ bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t ro
         }
         const size_t n = std::max<size_t>(1, exits[r].size());
         for (size_t q = 0; q < n; ++q) {
-            uint32_t w0 = REC_EMPTY | (REC_EMPTY << 16), w1 = 0;
+            uint32_t w0 = REC_EMPTY | (REC_EMPTY << 16), target = 0, op = 0;
             if (q == 0 && self0[r].first >= 0) w0 = (w0 & 0xFFFF0000u) | self0[r].first | (static_cast<uint32_t>(self0[r].second - self0[r].first) << 8);
             if (q < exits[r].size()) {
                 const Slot& e = exits[r][q];
                 w0 = (w0 & 0xFFFFu) | (static_cast<uint32_t>(e.lo) << 16) | (static_cast<uint32_t>(e.hi - e.lo) << 24);
-                uint32_t op;
                 if (!op_field(e.entry, op)) return false;
-                w1 = index_of[e.entry & 0xFFFFu] | (op << 16);
+                target = index_of[e.entry & 0xFFFFu];
             }
-            if (q + 1 < n) w1 |= REC_MORE;
-            if (q == 0 && hdr) w1 |= REC_HDR;
+            const uint32_t w1 = pack_w1(target, op, q + 1 < n, q == 0 && hdr);
             items[2 * (index_of[r] + q)] = w0;
             items[2 * (index_of[r] + q) + 1] = w1;
         }
@@ -382,9 +383,9 @@ bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t ro
             uint32_t next = 0, op = 0;
             for (uint32_t q = index_of[r] + (index_of[r] >= L.rec_indexed ? id : 0u);; ++q) {
                 const uint32_t w0 = items[2 * q], w1 = items[2 * q + 1];
-                if (id - ((w0 >> 16) & 0xFFu) <= (w0 >> 24)) { next = w1 & 0xFFFFu; op = (w1 >> 16) & 0xFFu; break; }
+                if (id - ((w0 >> 16) & 0xFFu) <= (w0 >> 24)) { next = wide ? (w1 & 0x3FFFFFu) : (w1 & 0xFFFFu); op = wide ? ((w1 >> 22) & 0xFFu) : ((w1 >> 16) & 0xFFu); break; }
                 if (id - (w0 & 0xFFu) <= ((w0 >> 8) & 0xFFu)) { next = index_of[r]; break; }
-                if (!(w1 & REC_MORE)) break;
+                if (!(w1 & (wide ? 1u << 31 : REC_MORE))) break;
             }
             const uint32_t e = at[r * cols + c];
             uint32_t want_op = e >> 16;
@@ -447,7 +448,8 @@ bool build_tile_image(gx_handle* h, int tier, int part = 0) {
     if (T.ncls > 252) return false;  // keeps the column offsets of a row (class * 4, + 3 extra columns) below 1024
     const uint32_t AT = 544;         // LDS tier: the rows follow the class map (u16[256] + the identity entry, padded)
     if (tier >= 2) {
-        if (rows > 65000u || T.ncls > 250) return false;  // 16-bit record indexes; class ids 254 / 255 are reserved
+        // a dense entry carries its successor's row in 16 bits; records in LDS have 16-bit successors too (in global memory: 22)
+        if (rows > (tier == 3 ? 65536u : 65000u) || T.ncls > 250) return false;  // class ids 254 / 255 are reserved
     } else if (!global) {
         if (AT + rows * RS > 65536u) return false;  // successors are 16-bit LDS addresses
         if (rows * RS + T.ops_off.size() * 4 + T.ops.size() * 2 + 1024 > LDS_TABLE_BUDGET) return false;  // (+ the final records, below)

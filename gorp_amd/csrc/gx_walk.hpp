@@ -120,6 +120,12 @@ struct WalkTab {
 // at the fixed address REC_AT, so that a record read is "ds_read_b64 index * 8, offset: REC_AT".  Record 0 is the one
 // dead state all automata of the image share.
 constexpr uint32_t REC_MORE = 0x80u << 24, REC_HDR = 2u << 24, REC_IDC = 254u, REC_AT = 1088u;
+// Second word of a record.  In LDS: successor (16 bits) | program << 16 | flags << 24 (0x80: a second record follows, 2: a
+// header precedes).  In global memory the successor has 22 bits (automata of up to 65 536 states each can take more than
+// 65 535 records together): successor | program << 22 | header << 30 | second record << 31.
+template <int TIER> __device__ __forceinline__ uint32_t rec_target(uint32_t w1) { return TIER == TIER_RECG ? (w1 & 0x3FFFFFu) : (w1 & 0xFFFFu); }
+template <int TIER> __device__ __forceinline__ uint32_t rec_op(uint32_t w1) { return TIER == TIER_RECG ? ((w1 >> 22) & 0xFFu) : ((w1 >> 16) & 0xFFu); }
+template <int TIER> __device__ __forceinline__ bool rec_has_header(uint32_t w1) { return (w1 & (TIER == TIER_RECG ? (1u << 30) : REC_HDR)) != 0u; }
 
 template <int TIER>
 __device__ __forceinline__ uint32_t tab_word(const WalkTab& W, uint32_t row, uint32_t off) {
@@ -144,7 +150,7 @@ __device__ __forceinline__ uint32_t state_acc(const WalkTab& W, uint32_t row) {
 template <int TIER>
 __device__ __forceinline__ int32_t state_info(const WalkTab& W, uint32_t row) {
     if (TierTraits<TIER>::records) {
-        const bool hdr = (rec_ld<TIER>(W, row).y & REC_HDR) != 0u;
+        const bool hdr = rec_has_header<TIER>(rec_ld<TIER>(W, row).y);
         return hdr ? static_cast<int32_t>(rec_ld<TIER>(W, row - (hdr ? 1u : 0u)).y) : -1;  // the header record precedes the state's first
     }
     return static_cast<int32_t>(tab_word<TIER>(W, row, W.row_bytes - 4u));
@@ -236,8 +242,8 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
                 const u32x2 it = rec_ld<TIER>(W, a);
                 const bool in_exit = (c - ((it.x >> 16) & 0xFFu)) <= (it.x >> 24);
                 const bool in_self = (c - (it.x & 0xFFu)) <= ((it.x >> 8) & 0xFFu);
-                next = in_exit ? (it.y & 0xFFFFu) : (in_self ? row : 0u);
-                op = in_exit ? ((it.y >> 16) & 0xFFu) : 0u;
+                next = in_exit ? rec_target<TIER>(it.y) : (in_self ? row : 0u);
+                op = in_exit ? rec_op<TIER>(it.y) : 0u;
                 bool pending = !in_exit && !in_self && (it.y & REC_MORE) != 0u;
                 if (MASKED) {
                     const bool idc = c == REC_IDC;  // a byte outside the line: stay, no program
@@ -248,8 +254,8 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
                 if (__any(pending)) {
                     const u32x2 it2 = rec_ld<TIER>(W, a + 1u);
                     const bool in2 = pending && (c - ((it2.x >> 16) & 0xFFu)) <= (it2.x >> 24);
-                    next = in2 ? (it2.y & 0xFFFFu) : next;
-                    op = in2 ? ((it2.y >> 16) & 0xFFu) : op;
+                    next = in2 ? rec_target<TIER>(it2.y) : next;
+                    op = in2 ? rec_op<TIER>(it2.y) : op;
                 }
             }
             row = next;
@@ -281,8 +287,8 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
                 const bool in_exit = (c - ((it.x >> 16) & 0xFFu)) <= (it.x >> 24);
                 const bool in_self = (c - (it.x & 0xFFu)) <= ((it.x >> 8) & 0xFFu);
                 const bool in2 = !in_exit && !in_self && (it.y & REC_MORE) != 0u && (c - ((it2.x >> 16) & 0xFFu)) <= (it2.x >> 24);
-                const uint32_t op = in_exit ? ((it.y >> 16) & 0xFFu) : in2 ? ((it2.y >> 16) & 0xFFu) : 0u;
-                row = in_exit ? (it.y & 0xFFFFu) : in_self ? row : in2 ? (it2.y & 0xFFFFu) : 0u;
+                const uint32_t op = in_exit ? rec_op<TIER>(it.y) : in2 ? rec_op<TIER>(it2.y) : 0u;
+                row = in_exit ? rec_target<TIER>(it.y) : in_self ? row : in2 ? rec_target<TIER>(it2.y) : 0u;
                 if (CAPTURE) lds_st<uint16_t>(dummy_col + (op << 7), static_cast<uint16_t>(rel + j));  // (SIMPLE programs only here)
             }
         }
