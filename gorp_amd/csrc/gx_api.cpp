@@ -110,7 +110,8 @@ struct gx_handle {
     // stores its sequence number when it meets a line it cannot stage (gx_device.hpp: GxBatch::oversize_flag).
     // A slot is reused only after the follow-up kernel of its previous user has run (event).
     static const int N_SLOTS = 32;
-    uint32_t* d_slots = nullptr;
+    uint32_t* d_slots = nullptr;          // [N_SLOTS] oversize flags, then [N_SLOTS] chunk counters of the lane kernel
+    uint32_t chunk_tickets[N_SLOTS] = {};  // what each chunk counter will read when the next launch on its slot begins
     hipEvent_t slot_event[N_SLOTS] = {};
     bool slot_used[N_SLOTS] = {};
     uint32_t next_seq = 1;
@@ -703,7 +704,7 @@ bool plan_tile_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out, 
 }
 
 // Layout for the lane kernel (gx_lanes.hip): per wave the register block and the area its result rows go through.
-bool plan_lanes_launch(const gx_handle* h, GxLds* out, bool match_only, bool compact) {
+bool plan_lanes_launch(const gx_handle* h, GxLds* out, bool match_only, bool compact, bool sorted = false) {
     if (!h->tile_ok) return false;
     GxLds L = match_only && h->has_mo ? h->lds_mo : h->lds;
     if (L.tier == 0) return false;                                                  // (dense rows in LDS: the tile kernel's case)
@@ -712,9 +713,19 @@ bool plan_lanes_launch(const gx_handle* h, GxLds* out, bool match_only, bool com
     const uint32_t rows = match_only || !compact ? 0u : 64u * (2u + 2u * slots);  // (dense rows are stored lane by lane)
     L.stage_bytes = L.regs_wave_bytes;                       // (the register block)
     L.regs_wave_bytes = (L.regs_wave_bytes + rows + 16u + 15u) & ~15u;
-    if (L.table_bytes + 32u + 4u * L.regs_wave_bytes > LDS_BYTES) return false;
-    L.nwaves = std::min<uint32_t>(16u, (LDS_BYTES - L.table_bytes - 32u) / L.regs_wave_bytes);
-    L.regs = L.table_bytes;
+    // length-sorted tiles (uneven lines, tables in global memory): a chunk's line order, 2 bytes per line, + two 64-entry tables
+    L.sort_chunk = 0;
+    L.sort_lds = 0;
+    uint32_t sort_bytes = 0;
+    if (sorted) {
+        // (with the tables in LDS too the index array takes the place of a wave or two)
+        for (uint32_t ch = 8192u; ch >= 2048u; ch >>= 1)
+            if (L.table_bytes + 32u + 2u * ch + 512u + (L.tier == 2 ? 14u : 8u) * L.regs_wave_bytes <= LDS_BYTES) { L.sort_chunk = ch; sort_bytes = 2u * ch + 512u; break; }
+    }
+    if (L.table_bytes + 32u + sort_bytes + 4u * L.regs_wave_bytes > LDS_BYTES) return false;
+    L.nwaves = std::min<uint32_t>(16u, (LDS_BYTES - L.table_bytes - 32u - sort_bytes) / L.regs_wave_bytes);
+    L.sort_lds = L.table_bytes;  // (behind the tables)
+    L.regs = L.table_bytes + sort_bytes;
     L.bitmap = 0;
     L.counter = L.regs + L.nwaves * L.regs_wave_bytes;
     L.stage = 0;
@@ -866,8 +877,8 @@ void upload(gx_handle* h) {
             GX_HIP(hipMalloc(&h->d_l2_image, h->l2_image.size()));
             GX_HIP(hipMemcpy(h->d_l2_image, h->l2_image.data(), h->l2_image.size(), hipMemcpyHostToDevice));
         }
-        GX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_slots), gx_handle::N_SLOTS * sizeof(uint32_t)));
-        GX_HIP(hipMemset(h->d_slots, 0, gx_handle::N_SLOTS * sizeof(uint32_t)));
+        GX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_slots), 2 * gx_handle::N_SLOTS * sizeof(uint32_t)));
+        GX_HIP(hipMemset(h->d_slots, 0, 2 * gx_handle::N_SLOTS * sizeof(uint32_t)));
         for (int q = 0; q < gx_handle::N_SLOTS; ++q) GX_HIP(hipEventCreateWithFlags(&h->slot_event[q], hipEventDisableTiming));
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->num_cus = cus;
@@ -880,25 +891,28 @@ void upload(gx_handle* h) {
 void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t kernel, hipStream_t stream) {
     GxLds L;
     const bool batchable = !b.wide && !b.state_out && b.match_only >= 0 && kernel != GX_KERNEL_PER_LINE;
-    // Lines whose 64-line groups do not fit the tile kernel's staging area (mean length above 255 bytes) go to the
-    // slice kernel, which stages 64 bytes of every line at a time and hands a lane its next line as soon as it is done, or
-    // to the lane kernel.  Measured (ms; captures / match only):
-    //   512 extractions, 2 M lines of 50-2000 bytes (configs[4]), dense rows in L2: tiles 4.4 / 4.0, slices 2.39 / 2.20, lanes 2.19 / 2.07
-    //   64 extractions, 1 M such lines, records in LDS: slices 1.12 / 0.80, lanes 1.41 / 1.22
+    // Lines whose 64-line groups do not fit the tile kernel's staging area (mean length above 255 bytes): with dense rows in
+    // LDS the slice kernel, which stages 64 bytes of every line at a time and hands a lane its next line as soon as it is
+    // done; with any other tables the lane kernel on tiles of lines of similar length (gx_lanes.hip, SORTED).  Measured
+    // (ms; captures / match only), one device:
+    //   512 extractions, 2 M lines of 50-2000 bytes (configs[4]), dense rows in L2: tiles 4.4 / 4.0, slices 2.39 / 2.20,
+    //     lanes 2.19 / 2.07, lanes on length-sorted tiles 1.77 / 1.56 (on range records in global memory 2.18 / 1.81)
+    //   64 extractions, 1 M such lines, records in LDS: slices 1.04 / 0.74, lanes 1.41 / 1.22, lanes on sorted tiles 0.82 / 0.68
     //   64 extractions, 10 M lines of 200 bytes (configs[2]): records in LDS + lanes 1.52 / 1.18, dense rows in L2 + tiles 3.0 / 3.0
     const bool long_lines = line_bytes_hint > 255u;
     const bool mo = b.match_only != 0 || !h->T.has_capture;
     const uint8_t* image = static_cast<const uint8_t*>(mo && h->has_mo ? h->d_lds_image_mo : h->d_lds_image);
     const uint32_t image_tier = mo && h->has_mo ? h->lds_mo.tier : h->lds.tier;
     const uint8_t* at_global = image_tier == 1 || image_tier == 3 ? static_cast<const uint8_t*>(h->d_l2_image) : nullptr;
-    const bool slices = kernel == GX_KERNEL_SLICES || (kernel == GX_KERNEL_AUTO && long_lines && image_tier != 1);
+    const bool slices = kernel == GX_KERNEL_SLICES || (kernel == GX_KERNEL_AUTO && long_lines && image_tier == 0);
     if (batchable && slices && plan_slice_launch(h, &L, mo)) {
         GX_HIP(launch_extract_slices(h->dev, L, image, at_global, h->num_cus, b, stream));
         return;
     }
     // records in LDS: the lane kernel (every lane keeps its own line in registers, 16 waves share the tables)
-    const bool lanes = kernel == GX_KERNEL_LANES || (kernel == GX_KERNEL_AUTO && (image_tier == 2 || (image_tier == 1 && long_lines)));
-    if (batchable && lanes && plan_lanes_launch(h, &L, mo, b.packed != nullptr)) {
+    const bool lanes = kernel == GX_KERNEL_LANES || (kernel == GX_KERNEL_AUTO && (image_tier == 2 || (image_tier != 0 && long_lines)));
+    // (uneven lines on tables in global memory: tiles of lines of similar length, see gx_lanes.hip)
+    if (batchable && lanes && plan_lanes_launch(h, &L, mo, b.packed != nullptr, long_lines)) {
         std::lock_guard<std::mutex> lock(h->slot_mu);
         b.seq = h->next_seq++;
         if (h->next_seq == 0) h->next_seq = 1;
@@ -906,6 +920,11 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
         if (h->slot_used[slot]) GX_HIP(hipStreamWaitEvent(stream, h->slot_event[slot], 0));
         h->slot_used[slot] = true;
         b.oversize_flag = h->d_slots + slot;
+        if (L.sort_chunk) {
+            b.chunk_ctr = h->d_slots + gx_handle::N_SLOTS + slot;
+            b.chunk_base = h->chunk_tickets[slot];
+            h->chunk_tickets[slot] += lanes_sorted_tickets(b.n, L.sort_chunk, h->num_cus);
+        }
         unsigned long long* stamps = nullptr;
 #ifdef GX_DEV
         stamps = h->dev_stamps;

@@ -84,6 +84,8 @@ struct GxLds {
     uint32_t tier;        // 0: dense rows in LDS, 1: dense rows in global memory, 2: records in LDS
     uint32_t rec, acc_tab;
     uint32_t rec_indexed; // states with an index >= this keep one record per class (state index + class), behind all the others
+    uint32_t sort_lds;    // lane kernel, length-sorted mode: LDS address of u16 perm[sort_chunk] + u32 hist[64] + u32 cursor[64]
+    uint32_t sort_chunk;  // ... lines per chunk (0: tiles in input order)
 };
 constexpr uint32_t GX_BITMAP_WAVE_BYTES = 144;  // 16 x u64 (1024 chunks = 16 KB of staging) + one word read ahead
 
@@ -106,6 +108,10 @@ struct GxBatch {
     // per-line kernel: the tile kernel stores `seq` into *oversize_flag when it meets one
     uint32_t* oversize_flag;
     uint32_t seq;
+    // lane kernel, length-sorted mode: the launch's chunk counter (never reset: chunk = ticket - chunk_base; a launch draws
+    // one ticket per chunk and one more per workgroup)
+    uint32_t* chunk_ctr;
+    uint32_t chunk_base;
 };
 
 // More than 64 KiB of dynamic LDS needs the attribute, once per kernel (= per instantiation of this template) and
@@ -137,6 +143,8 @@ hipError_t launch_extract_oversize(const GxDev& dev, const GxBatch& b, uint32_t 
 // Lane kernel (gx_lanes.hip): tables in global memory (GxLds::tier 1 or 3), every lane keeps its own line in registers;
 // lds.nwaves waves per workgroup; lds.regs_wave_bytes = the wave's LDS area (register block of lds.stage_bytes bytes + result rows).
 // Lines longer than 65 535 bytes are left to launch_extract_oversize (stage_bytes = 65 535 + 48).
+// (with lds.sort_chunk set the launch draws lanes_sorted_tickets(...) tickets from *b.chunk_ctr)
+uint32_t lanes_sorted_tickets(uint64_t n, uint32_t chunk_lines, int num_cus);
 hipError_t launch_extract_lanes(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
                                 const GxBatch& b, hipStream_t stream, unsigned long long* dev_stamps);
 // Slice kernel: the same tables, lines staged 64 bytes at a time (GxLds::stage_bytes = 64 * 80); fused automaton or match only.

@@ -32,13 +32,17 @@ struct LanesIO {
     uint32_t seq;
     int32_t max_groups;
     int32_t strip_eol;
+    uint32_t chunk_lines;        // SORTED: lines per workgroup chunk (a multiple of 64, at most 65536)
+    uint32_t sort_lds;           // SORTED: LDS address of u16 perm[chunk_lines], then u32 hist[64], u32 cursor[64]
+    uint32_t* chunk_ctr;         // SORTED: the launch's chunk counter in global memory and its value when the launch began
+    uint32_t chunk_base;
 #ifdef GX_DEV
     unsigned long long* stamps;  // per workgroup: core-clock cycles and 100 MHz ticks spent in the kernel
 #endif
 };
 
 // One workgroup of up to 16 waves per CU: the waves of a workgroup share one copy of the tables in LDS.
-template <typename OFF, int KCH, int TIER, bool CAPTURE, bool SIMPLE, bool PACKED>
+template <typename OFF, int KCH, int TIER, bool CAPTURE, bool SIMPLE, bool PACKED, bool SORTED>
 __global__ void __launch_bounds__(1024)
 k_extract_lanes(GxLds L, LanesIO io) {
 #ifdef GX_DEV
@@ -82,128 +86,193 @@ k_extract_lanes(GxLds L, LanesIO io) {
     const uint8_t* fin_g = GT ? io.at_global + L.fin_tags : nullptr;
     const uint64_t grid = gridDim.x;
 
-    for (uint32_t j = wave;;) {
-        const uint64_t tile = static_cast<uint64_t>(blockIdx.x) + static_cast<uint64_t>(j) * grid;  // (wave-uniform)
-        if (tile >= tiles) break;
-        const uint64_t i = (tile << 6) + lane;
-        const bool valid = i < n;
-        const uint64_t o0 = off[valid ? i : n], o1 = off[valid ? i + 1 : n];
-        uint64_t len64 = o1 - o0;
-        if (io.strip_eol) {  // the terminator belongs to the line in the CSR buffer (gx_split_lines), not to the String
-            if (len64 > 0 && data[o0 + len64 - 1] == 0x0Au) --len64;
-            if (len64 > 0 && data[o0 + len64 - 1] == 0x0Du) --len64;
-        }
-        // positions are 16-bit in the register block: a longer line is left to the follow-up launch of the per-line kernel
-        const bool oversize = valid && len64 > 65535u;
-        if (oversize) __hip_atomic_store(io.oversize_flag, io.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t len = oversize ? 0u : static_cast<uint32_t>(len64);
-        const uint8_t* line = data + o0;
-
-        uint32_t row = row0;
-        uint32_t acc = state_acc<TIER>(W, row);
-        uint32_t lo4 = splat_byte0(acc), k4 = splat_byte1(acc);
-        bool more = valid && !oversize && len > 0u;
-        // 16 bytes of this lane's line at line offset at_byte (zeros beyond the line; never a byte beyond the buffer)
-        auto line_chunk = [&](uint32_t at_byte, bool wanted) -> u32x4 {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (wanted && at_byte < len) {
-                const uint8_t* src = line + at_byte;
-                if (src + 16 <= data_end) v = reinterpret_cast<const UnalignedWindow*>(src)->v;  // (a plain load: see KCH below)
-                else {
-                    uint32_t w[4] = {0, 0, 0, 0};
-                    for (int b = 0; b < 16; ++b)
-                        if (src + b < data_end) w[b >> 2] |= static_cast<uint32_t>(src[b]) << ((b & 3) * 8);
-                    v = u32x4{w[0], w[1], w[2], w[3]};
-                }
-            }
-            return v;
-        };
-        for (uint32_t seg = 0; __any(more); seg += KCH * 16u) {
-            u32x4 pre[KCH];  // this lane's bytes [seg, seg + 16 KCH) of its line
+    auto next_ticket = [&]() {  // the workgroup's tile counter
+        uint32_t t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add((GX_LDS uint32_t*)(uintptr_t)L.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(t));
+    };
+    // SORTED (uneven lines): a tile takes as long as its longest line, so the workgroup orders the lines of a chunk by
+    // length first (a counting sort over 64 length classes of 32 bytes, longest first, in LDS) and forms its tiles from
+    // neighbours in that order.  A lane loads its own line whatever its address, so only the result rows lose their
+    // contiguity (every lane stores its own).  Chunks are handed out by a counter in global memory.
+    const uint32_t CH = SORTED ? io.chunk_lines : 64u;
+    const uint32_t perm = io.sort_lds, hist = perm + 2u * CH, cursor = hist + 256u;
+    const uint64_t nchunks = (n + CH - 1) / CH;
+    auto length_class = [&](uint64_t i) {
+        const uint64_t l = static_cast<uint64_t>(off[i + 1]) - static_cast<uint64_t>(off[i]);
+        return 63u - static_cast<uint32_t>(l >> 5 < 63u ? l >> 5 : 63u);
+    };
+    uint32_t j = wave;  // (!SORTED) the wave's ticket: tile blockIdx.x + j * gridDim.x
+    for (;;) {
+        uint64_t first = 0;
+        uint32_t cnt = 0, chunk_tiles = 0;
+        if (SORTED) {
+            if (threadIdx.x == 0)
+                lds_st<uint32_t>(L.counter + 4u, __hip_atomic_fetch_add(io.chunk_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - io.chunk_base);
+            __syncthreads();
+            const uint64_t chunk = lds_ld<uint32_t>(L.counter + 4u);
+            if (chunk >= nchunks) break;
+            first = chunk * CH;
+            cnt = static_cast<uint32_t>(n - first < CH ? n - first : CH);
+            chunk_tiles = (cnt + 63u) >> 6;
+            if (threadIdx.x < 64u) lds_st<uint32_t>(hist + 4u * threadIdx.x, 0u);
+            if (threadIdx.x == 0) lds_st<uint32_t>(L.counter, 0u);
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < cnt; t += blockDim.x)
+                __hip_atomic_fetch_add((GX_LDS uint32_t*)(uintptr_t)(hist + 4u * length_class(first + t)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __syncthreads();
+            if (threadIdx.x < 64u) {  // exclusive scan of the 64 counts (wave 0)
+                const uint32_t v = lds_ld<uint32_t>(hist + 4u * lane);
+                uint32_t incl = v;
 #pragma unroll
-            for (int k = 0; k < KCH; ++k) pre[k] = line_chunk(seg + 16u * k, more);
-            // One copy of the window code, run KCH times: the window is always taken from slot 0 and the others move down
-            // (4 register moves per slot and window).  Unrolled with static slots instead, the loop body was 80 KB of code
-            // at 7 windows, for no gain.
-#pragma unroll 1
-            for (int k = 0; k < KCH; ++k) {
-                const uint32_t rel = seg + 16u * k;
-                const bool act = more && rel < len;
-                if (!__any(act)) break;
-                const uint4 w0 = make_uint4(pre[0].x, pre[0].y, pre[0].z, pre[0].w);
-#pragma unroll
-                for (int q = 0; q + 1 < KCH; ++q) pre[q] = pre[q + 1];
-                const bool full0 = rel + 16u <= len;
-                const uint32_t bx = outside_bits(w0.x, lo4, k4), by = outside_bits(w0.y, lo4, k4);
-                const uint32_t bz = outside_bits(w0.z, lo4, k4), bw = outside_bits(w0.w, lo4, k4);
-                const bool ok0 = full0 & (((or3(bx, by, bz) | bw) & HI_BITS) == 0u);
-                bool step = act && !ok0;
-                uint32_t mask = 0xFFFFu;
-                if (step && !full0) {
-                    mask = window_mask(0u, len, rel);
-                    step = !partial_window_ok(bx, by, bz, bw, mask);
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t up = static_cast<uint32_t>(__shfl_up(static_cast<int>(incl), d));
+                    if (lane >= static_cast<uint32_t>(d)) incl += up;
                 }
-                const bool masked = __any(step && !full0);
-                if (step) {
-                    if (!masked) row = steps16<TIER, CAPTURE, false, SIMPLE>(w0, mask, W, row, rel, regs);
-                    else row = steps16<TIER, CAPTURE, true, SIMPLE>(w0, mask, W, row, rel, regs);
-                    acc = state_acc<TIER>(W, row);
-                    lo4 = splat_byte0(acc);
-                    k4 = splat_byte1(acc);
-                }
-                more = more && row != dead_row && rel + 16u < len;
+                lds_st<uint32_t>(cursor + 4u * lane, incl - v);
             }
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < cnt; t += blockDim.x) {
+                const uint32_t at = __hip_atomic_fetch_add((GX_LDS uint32_t*)(uintptr_t)(cursor + 4u * length_class(first + t)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                lds_st<uint16_t>(perm + 2u * at, static_cast<uint16_t>(t));
+            }
+            __syncthreads();
         }
-
-        // ---- results ----
-        const int32_t info = state_info<TIER>(W, row);
-        if (!CAPTURE) {
-            if (valid && !oversize) io.match_id[i] = info;
-        } else {
-            const bool full_tile = (tile << 6) + 64u <= n && !__any(oversize);
-            const uint64_t i0 = tile << 6;
-            if (PACKED) {
-                const uint32_t row_b = 2u + 2u * slots;
-                if (full_tile) {
-                    // the tile's 64 rows are one contiguous block of the output: through the wave's row area, then 1 KiB of
-                    // consecutive bytes per store instruction
-                    const uint32_t my_out = out_area + lane * row_b;
-                    const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
-                        lds_st<uint16_t>(my_out + 2u + 4u * g, static_cast<uint16_t>(pb));
-                        lds_st<uint16_t>(my_out + 4u + 4u * g, static_cast<uint16_t>(pe));
-                    });
-                    lds_st<uint16_t>(my_out, static_cast<uint16_t>(result));
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    uint8_t* out = reinterpret_cast<uint8_t*>(io.packed + i0 * static_cast<uint64_t>(1u + slots));
-                    for (uint32_t c = lane; c < 4u * row_b; c += 64u)
-                        *reinterpret_cast<u32x4*>(out + (c << 4)) = lds_ld<u32x4>(out_area + (c << 4));
-                } else if (valid && !oversize) {
-                    uint16_t* rp = io.packed + i * static_cast<uint64_t>(1u + slots);
-                    const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
-                        rp[1 + 2 * g] = static_cast<uint16_t>(pb);
-                        rp[2 + 2 * g] = static_cast<uint16_t>(pe);
-                    });
-                    rp[0] = static_cast<uint16_t>(result);
-                }
+        for (;;) {
+            // ---- the next tile: lane l takes line i (valid: it has one); contiguous: the 64 lines are i - lane .. i - lane + 63,
+            // so their result rows are one block of the output ----
+            uint64_t i;
+            bool valid;
+            const bool contiguous = !SORTED;
+            if (SORTED) {
+                const uint32_t t = next_ticket();
+                if (t >= chunk_tiles) break;
+                const uint32_t x = (t << 6) + lane;
+                valid = x < cnt;
+                i = first + (valid ? lds_ld<uint16_t>(perm + 2u * x) : 0u);
             } else {
-                // dense int32 rows: every lane stores its own (8 bytes per group).  Taking them through the wave's row area 32
-                // lines at a time, as contiguous 16-byte stores, was measured: no faster (1.558 against 1.551 ms on config 3)
-                if (valid && !oversize) {
-                    int32_t* cp = io.caps + i * static_cast<uint64_t>(slots);
-                    io.match_id[i] = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
-                        *reinterpret_cast<u32x2*>(cp + 2 * g) = u32x2{static_cast<uint32_t>(pb), static_cast<uint32_t>(pe)};
-                    });
+                const uint64_t tile = static_cast<uint64_t>(blockIdx.x) + static_cast<uint64_t>(j) * grid;  // (wave-uniform)
+                if (tile >= tiles) break;
+                i = (tile << 6) + lane;
+                valid = i < n;
+            }
+            const uint64_t o0 = off[valid ? i : n], o1 = off[valid ? i + 1 : n];
+            uint64_t len64 = o1 - o0;
+            if (io.strip_eol) {  // the terminator belongs to the line in the CSR buffer (gx_split_lines), not to the String
+                if (len64 > 0 && data[o0 + len64 - 1] == 0x0Au) --len64;
+                if (len64 > 0 && data[o0 + len64 - 1] == 0x0Du) --len64;
+            }
+            // positions are 16-bit in the register block: a longer line is left to the follow-up launch of the per-line kernel
+            const bool oversize = valid && len64 > 65535u;
+            if (oversize) __hip_atomic_store(io.oversize_flag, io.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t len = oversize ? 0u : static_cast<uint32_t>(len64);
+            const uint8_t* line = data + o0;
+
+            uint32_t row = row0;
+            uint32_t acc = state_acc<TIER>(W, row);
+            uint32_t lo4 = splat_byte0(acc), k4 = splat_byte1(acc);
+            bool more = valid && !oversize && len > 0u;
+            // 16 bytes of this lane's line at line offset at_byte (zeros beyond the line; never a byte beyond the buffer)
+            auto line_chunk = [&](uint32_t at_byte, bool wanted) -> u32x4 {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (wanted && at_byte < len) {
+                    const uint8_t* src = line + at_byte;
+                    if (src + 16 <= data_end) v = reinterpret_cast<const UnalignedWindow*>(src)->v;  // (a plain load: see KCH below)
+                    else {
+                        uint32_t w[4] = {0, 0, 0, 0};
+                        for (int b = 0; b < 16; ++b)
+                            if (src + b < data_end) w[b >> 2] |= static_cast<uint32_t>(src[b]) << ((b & 3) * 8);
+                        v = u32x4{w[0], w[1], w[2], w[3]};
+                    }
+                }
+                return v;
+            };
+            for (uint32_t seg = 0; __any(more); seg += KCH * 16u) {
+                u32x4 pre[KCH];  // this lane's bytes [seg, seg + 16 KCH) of its line
+    #pragma unroll
+                for (int k = 0; k < KCH; ++k) pre[k] = line_chunk(seg + 16u * k, more);
+                // One copy of the window code, run KCH times: the window is always taken from slot 0 and the others move down
+                // (4 register moves per slot and window).  Unrolled with static slots instead, the loop body was 80 KB of code
+                // at 7 windows, for no gain.
+    #pragma unroll 1
+                for (int k = 0; k < KCH; ++k) {
+                    const uint32_t rel = seg + 16u * k;
+                    const bool act = more && rel < len;
+                    if (!__any(act)) break;
+                    const uint4 w0 = make_uint4(pre[0].x, pre[0].y, pre[0].z, pre[0].w);
+    #pragma unroll
+                    for (int q = 0; q + 1 < KCH; ++q) pre[q] = pre[q + 1];
+                    const bool full0 = rel + 16u <= len;
+                    const uint32_t bx = outside_bits(w0.x, lo4, k4), by = outside_bits(w0.y, lo4, k4);
+                    const uint32_t bz = outside_bits(w0.z, lo4, k4), bw = outside_bits(w0.w, lo4, k4);
+                    const bool ok0 = full0 & (((or3(bx, by, bz) | bw) & HI_BITS) == 0u);
+                    bool step = act && !ok0;
+                    uint32_t mask = 0xFFFFu;
+                    if (step && !full0) {
+                        mask = window_mask(0u, len, rel);
+                        step = !partial_window_ok(bx, by, bz, bw, mask);
+                    }
+                    const bool masked = __any(step && !full0);
+                    if (step) {
+                        if (!masked) row = steps16<TIER, CAPTURE, false, SIMPLE>(w0, mask, W, row, rel, regs);
+                        else row = steps16<TIER, CAPTURE, true, SIMPLE>(w0, mask, W, row, rel, regs);
+                        acc = state_acc<TIER>(W, row);
+                        lo4 = splat_byte0(acc);
+                        k4 = splat_byte1(acc);
+                    }
+                    more = more && row != dead_row && rel + 16u < len;
                 }
             }
+
+            // ---- results ----
+            const int32_t info = state_info<TIER>(W, row);
+            if (!CAPTURE) {
+                if (valid && !oversize) io.match_id[i] = info;
+            } else {
+                const bool full_tile = contiguous && __all(valid) && !__any(oversize);
+                const uint64_t i0 = i - lane;
+                if (PACKED) {
+                    const uint32_t row_b = 2u + 2u * slots;
+                    if (full_tile) {
+                        // the tile's 64 rows are one contiguous block of the output: through the wave's row area, then 1 KiB of
+                        // consecutive bytes per store instruction
+                        const uint32_t my_out = out_area + lane * row_b;
+                        const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                            lds_st<uint16_t>(my_out + 2u + 4u * g, static_cast<uint16_t>(pb));
+                            lds_st<uint16_t>(my_out + 4u + 4u * g, static_cast<uint16_t>(pe));
+                        });
+                        lds_st<uint16_t>(my_out, static_cast<uint16_t>(result));
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        uint8_t* out = reinterpret_cast<uint8_t*>(io.packed + i0 * static_cast<uint64_t>(1u + slots));
+                        for (uint32_t c = lane; c < 4u * row_b; c += 64u)
+                            *reinterpret_cast<u32x4*>(out + (c << 4)) = lds_ld<u32x4>(out_area + (c << 4));
+                    } else if (valid && !oversize) {
+                        uint16_t* rp = io.packed + i * static_cast<uint64_t>(1u + slots);
+                        const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                            rp[1 + 2 * g] = static_cast<uint16_t>(pb);
+                            rp[2 + 2 * g] = static_cast<uint16_t>(pe);
+                        });
+                        rp[0] = static_cast<uint16_t>(result);
+                    }
+                } else {
+                    // dense int32 rows: every lane stores its own (8 bytes per group).  Taking them through the wave's row area 32
+                    // lines at a time, as contiguous 16-byte stores, was measured: no faster (1.558 against 1.551 ms on config 3)
+                    if (valid && !oversize) {
+                        int32_t* cp = io.caps + i * static_cast<uint64_t>(slots);
+                        io.match_id[i] = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                            *reinterpret_cast<u32x2*>(cp + 2 * g) = u32x2{static_cast<uint32_t>(pb), static_cast<uint32_t>(pe)};
+                        });
+                    }
+                }
+            }
+            // the wave's LDS area is reused by the next tile
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (!SORTED) j = next_ticket();
         }
-        // the wave's LDS area is reused by the next tile
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // the workgroup's next tile
-        uint32_t nj = 0;
-        if (lane == 0) nj = __hip_atomic_fetch_add((GX_LDS uint32_t*)(uintptr_t)L.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        j = __builtin_amdgcn_readfirstlane(nj);
+        if (!SORTED) break;
+        __syncthreads();  // (the next chunk rewrites perm and the counter)
     }
 #ifdef GX_DEV
     if (io.stamps && threadIdx.x == 0) {
@@ -213,8 +282,8 @@ k_extract_lanes(GxLds L, LanesIO io) {
 #endif
 }
 
-template <typename OFF, int TIER, bool CAPTURE, bool SIMPLE, bool PACKED>
-hipError_t launch_lanes_t(const GxLds& lds, const LanesIO& io, dim3 grid, hipStream_t stream) {
+template <typename OFF, int TIER, bool CAPTURE, bool SIMPLE, bool PACKED, bool SORTED>
+hipError_t launch_lanes_s(const GxLds& lds, const LanesIO& io, dim3 grid, hipStream_t stream) {
     // 208 bytes of the line in 52 registers.  Measured on config 3 (captures, dense rows), variants side by side on one device:
     //   windows per segment: 5 2.09 ms, 7 1.89 ms, 13 1.80 ms;
     //   loads with the non-temporal hint (as the tile kernel's, which read every byte once) 1.80 ms, plain 1.56 ms: a lane comes
@@ -226,10 +295,15 @@ hipError_t launch_lanes_t(const GxLds& lds, const LanesIO& io, dim3 grid, hipStr
     //   Timing-only builds (wrong results): no line loads at all 1.28 ms, the same bytes loaded in lane order 1.39 ms, no
     //   record reads 1.84 ms (no change: the dependent LDS read per byte is not what bounds the walk).
     constexpr int KCH = 13;
-    hipError_t e = allow_full_lds(&k_extract_lanes<OFF, KCH, TIER, CAPTURE, SIMPLE, PACKED>);
+    hipError_t e = allow_full_lds(&k_extract_lanes<OFF, KCH, TIER, CAPTURE, SIMPLE, PACKED, SORTED>);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_extract_lanes<OFF, KCH, TIER, CAPTURE, SIMPLE, PACKED>), grid, dim3(lds.nwaves * 64), lds.total_bytes, stream, lds, io);
+    hipLaunchKernelGGL((k_extract_lanes<OFF, KCH, TIER, CAPTURE, SIMPLE, PACKED, SORTED>), grid, dim3(lds.nwaves * 64), lds.total_bytes, stream, lds, io);
     return hipGetLastError();
+}
+template <typename OFF, int TIER, bool CAPTURE, bool SIMPLE, bool PACKED>
+hipError_t launch_lanes_t(const GxLds& lds, const LanesIO& io, dim3 grid, hipStream_t stream) {
+    if (io.chunk_lines) return launch_lanes_s<OFF, TIER, CAPTURE, SIMPLE, PACKED, true>(lds, io, grid, stream);
+    return launch_lanes_s<OFF, TIER, CAPTURE, SIMPLE, PACKED, false>(lds, io, grid, stream);
 }
 template <typename OFF, int TIER>
 hipError_t launch_lanes_m(bool capture, bool simple, bool packed, const GxLds& lds, const LanesIO& io, dim3 grid, hipStream_t stream) {
@@ -239,6 +313,11 @@ hipError_t launch_lanes_m(bool capture, bool simple, bool packed, const GxLds& l
 }
 
 }  // namespace
+
+uint32_t lanes_sorted_tickets(uint64_t n, uint32_t chunk_lines, int num_cus) {
+    const uint64_t nchunks = (n + chunk_lines - 1) / chunk_lines;
+    return static_cast<uint32_t>(nchunks + (static_cast<uint64_t>(num_cus) < nchunks ? static_cast<uint64_t>(num_cus) : nchunks));
+}
 
 // lds: a layout from plan_lanes_launch (gx_api.cpp): tables, then per wave the register block with the result rows
 // behind it.  Needs tables in global memory (tier 1 or 3) and, for captures, the fused automaton.
@@ -250,6 +329,14 @@ hipError_t launch_extract_lanes(const GxDev& dev, const GxLds& lds, const uint8_
     const uint64_t need = (tiles + lds.nwaves - 1) / lds.nwaves;
     if (blocks > need) blocks = need;
     LanesIO io{};
+    if (lds.sort_chunk) {
+        const uint64_t nchunks = (b.n + lds.sort_chunk - 1) / lds.sort_chunk;
+        blocks = static_cast<uint64_t>(num_cus) < nchunks ? static_cast<uint64_t>(num_cus) : nchunks;
+        io.chunk_lines = lds.sort_chunk;
+        io.sort_lds = lds.sort_lds;
+        io.chunk_ctr = b.chunk_ctr;
+        io.chunk_base = b.chunk_base;
+    }
     io.image = lds_image;
     io.at_global = at_global;
     io.data = static_cast<const uint8_t*>(b.data);
