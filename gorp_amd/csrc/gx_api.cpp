@@ -707,7 +707,6 @@ bool plan_tile_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out, 
 bool plan_lanes_launch(const gx_handle* h, GxLds* out, bool match_only, bool compact, bool sorted = false) {
     if (!h->tile_ok) return false;
     GxLds L = match_only && h->has_mo ? h->lds_mo : h->lds;
-    if (L.tier == 0) return false;                                                  // (dense rows in LDS: the tile kernel's case)
     if (!match_only && h->T.has_capture && L.u_start == 0xFFFFFFFFu) return false;  // walks the fused automaton
     const uint32_t slots = 2u * static_cast<uint32_t>(h->T.max_groups);
     const uint32_t rows = match_only || !compact ? 0u : 64u * (2u + 2u * slots);  // (dense rows are stored lane by lane)
@@ -891,20 +890,24 @@ void upload(gx_handle* h) {
 void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t kernel, hipStream_t stream) {
     GxLds L;
     const bool batchable = !b.wide && !b.state_out && b.match_only >= 0 && kernel != GX_KERNEL_PER_LINE;
-    // Lines whose 64-line groups do not fit the tile kernel's staging area (mean length above 255 bytes): with dense rows in
-    // LDS the slice kernel, which stages 64 bytes of every line at a time and hands a lane its next line as soon as it is
-    // done; with any other tables the lane kernel on tiles of lines of similar length (gx_lanes.hip, SORTED).  Measured
-    // (ms; captures / match only), one device:
+    // Which kernel (gx_batch_opts.kernel 0), by the tables and the mean line length.  Measured, one device (ms; captures /
+    // match only):
+    //   README definition (dense rows in LDS), 2 M lines of 50-2000 bytes: tiles 0.39, slices 0.73, lanes on sorted tiles 0.75;
+    //     400 k lines of 50-20000 bytes (mean 3.4 KB): tiles 61.7 (lines beyond the staging area go one by one), slices 1.74, lanes 3.4
     //   512 extractions, 2 M lines of 50-2000 bytes (configs[4]), dense rows in L2: tiles 4.4 / 4.0, slices 2.39 / 2.20,
     //     lanes 2.19 / 2.07, lanes on length-sorted tiles 1.77 / 1.56 (on range records in global memory 2.18 / 1.81)
-    //   64 extractions, 1 M such lines, records in LDS: slices 1.04 / 0.74, lanes 1.41 / 1.22, lanes on sorted tiles 0.82 / 0.68
+    //   64 extractions, 1 M such lines, records in LDS: slices 1.04 / 0.74, lanes 1.41 / 1.22, lanes on sorted tiles 0.82 / 0.68;
+    //     200 k lines of 50-20000 bytes: slices 5.1, lanes 9.4
     //   64 extractions, 10 M lines of 200 bytes (configs[2]): records in LDS + lanes 1.52 / 1.18, dense rows in L2 + tiles 3.0 / 3.0
-    const bool long_lines = line_bytes_hint > 255u;
+    // Hence: a mean above 1 KB -> slice kernel (64 bytes of every line at a time, a lane takes its next line as soon as it is
+    // done); dense rows in LDS -> tile kernel; records in LDS -> lane kernel; anything else -> tile kernel, or above 255 bytes
+    // the lane kernel; the lane kernel on tiles of lines of similar length above 255 bytes (gx_lanes.hip, SORTED).
+    const bool long_lines = line_bytes_hint > 255u, very_long = line_bytes_hint > 1024u;
     const bool mo = b.match_only != 0 || !h->T.has_capture;
     const uint8_t* image = static_cast<const uint8_t*>(mo && h->has_mo ? h->d_lds_image_mo : h->d_lds_image);
     const uint32_t image_tier = mo && h->has_mo ? h->lds_mo.tier : h->lds.tier;
     const uint8_t* at_global = image_tier == 1 || image_tier == 3 ? static_cast<const uint8_t*>(h->d_l2_image) : nullptr;
-    const bool slices = kernel == GX_KERNEL_SLICES || (kernel == GX_KERNEL_AUTO && long_lines && image_tier == 0);
+    const bool slices = kernel == GX_KERNEL_SLICES || (kernel == GX_KERNEL_AUTO && very_long);
     if (batchable && slices && plan_slice_launch(h, &L, mo)) {
         GX_HIP(launch_extract_slices(h->dev, L, image, at_global, h->num_cus, b, stream));
         return;

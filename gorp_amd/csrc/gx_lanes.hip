@@ -365,6 +365,10 @@ hipError_t launch_extract_lanes(const GxDev& dev, const GxLds& lds, const uint8_
         if (b.offsets64) return launch_lanes_m<uint64_t, TIER_REC>(capture, lds.simple_ops != 0, packed, lds, io, grid, stream);
         return launch_lanes_m<uint32_t, TIER_REC>(capture, lds.simple_ops != 0, packed, lds, io, grid, stream);
     }
+    if (lds.tier == 0) {  // dense rows in LDS (uneven lines: the tile kernel wants a tile's lines to be neighbours in memory)
+        if (b.offsets64) return launch_lanes_m<uint64_t, TIER_LDS>(capture, lds.simple_ops != 0, packed, lds, io, grid, stream);
+        return launch_lanes_m<uint32_t, TIER_LDS>(capture, lds.simple_ops != 0, packed, lds, io, grid, stream);
+    }
     if (b.offsets64) return launch_lanes_m<uint64_t, TIER_L2>(capture, lds.simple_ops != 0, packed, lds, io, grid, stream);
     return launch_lanes_m<uint32_t, TIER_L2>(capture, lds.simple_ops != 0, packed, lds, io, grid, stream);
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool: the README 3-extraction definition (tables in LDS) over lines of log-uniform length 50-2000
-bytes: tile kernel with rounds (argv[2] = 1) against the slice kernel (argv[2] = 2; the default above 255 bytes)."""
+bytes (argv[3]: another maximum): tile kernel with rounds (argv[2] = 1), slice kernel (2), lane kernel on sorted tiles (4)."""
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,12 +9,13 @@ from gorp_amd.gorp import Gorp, lines_to_csr
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 kernel = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+max_len = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
 g = Gorp.construct(W.readme3_definition())
 rng = random.Random(7)
 base_n = 20_000
 lines = []
 for _ in range(base_n):
-    L = int(50 * (2000 / 50) ** rng.random())
+    L = int(50 * (max_len / 50) ** rng.random())
     verb = rng.choice(["GET", "PUT", "HEAD"])
     head = "[%09d]: %s %dms /" % (rng.randrange(10 ** 9), verb, rng.randrange(9999))
     lines.append((head + "".join(rng.choice("abcdefghijklmnopqrstuvwxyz0123456789/-_.") for _ in range(max(0, L - len(head))))).encode())
@@ -39,5 +40,5 @@ for _ in range(5):
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
 print("kernel=%s mean %d B: %.3f ms for %d lines (%.2f GB) -> %.2f G lines/s, %.0f GB/s" %
-      (["auto", "tiles", "slices", "per-line"][kernel], hint, ms, n, total * reps / 1e9, n / ms / 1e6, total * reps / ms / 1e6))
+      (["auto", "tiles", "slices", "per-line", "lanes"][kernel], hint, ms, n, total * reps / 1e9, n / ms / 1e6, total * reps / ms / 1e6))
 assert int((mid >= 0).sum()) == n
