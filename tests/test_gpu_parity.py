@@ -844,11 +844,12 @@ def test_no_hint_no_sync_batches_learn_the_line_length():
         assert np.array_equal(mid.cpu().numpy(), omid) and np.array_equal(caps.cpu().numpy(), ocaps)
 
 
-@pytest.mark.parametrize("flags", [N.GX_CREATE_TIER_L2, N.GX_CREATE_TIER_RECORDS_GLOBAL, N.GX_CREATE_TIER_RECORDS])
+@pytest.mark.parametrize("flags", [0, N.GX_CREATE_TIER_L2, N.GX_CREATE_TIER_RECORDS_GLOBAL, N.GX_CREATE_TIER_RECORDS])
 def test_lane_kernel_agrees_with_oracle(flags):
-    """gx_lanes.hip (tables in global memory, every lane keeps its own line in registers; gx_batch_opts.kernel =
-    GX_KERNEL_LANES): the 64-extraction definition, the README definition with ragged, empty, terminated and very long
-    lines, dense and compact results, match only."""
+    """gx_lanes.hip (every lane keeps its own line in registers; gx_batch_opts.kernel = GX_KERNEL_LANES) on every kind of
+    table (0: the defaults -- range records in LDS for the 64 extractions, dense rows in LDS for the README definition):
+    the 64-extraction definition on 200-byte lines and on uneven ones (tiles of lines of similar length), the README
+    definition with ragged, empty, terminated and very long lines, dense and compact results, match only."""
     rules, meta = W.syslog_definition(64, seed=3)
     gorp, orc = Gorp.construct(rules, flags=flags), oracle_for(rules)
     data, offsets, cats = W.syslog_lines(meta, 20000, seed=7)
@@ -860,10 +861,16 @@ def test_lane_kernel_agrees_with_oracle(flags):
     assert over == 0 and np.array_equal(cm, omid) and np.array_equal(cc, ocaps)
     m2, _ = gorp.extract_batch(data, offsets, match_only=True, kernel=N.GX_KERNEL_LANES)
     assert np.array_equal(m2, orc.extract_batch(data, offsets, match_only=True, nthreads=8)[0])
-    data, offsets, cats = W.syslog_lines(meta, 3000, seed=8, min_len=50, max_len=2000)
+    # uneven lines: tiles of lines of similar length (several chunks: 20 000 lines), rows stored lane by lane
+    data, offsets, cats = W.syslog_lines(meta, 20000, seed=8, min_len=50, max_len=2000)
     omid, ocaps = orc.extract_batch(data, offsets, nthreads=8)
     mid, caps = gorp.extract_batch(data, offsets, kernel=N.GX_KERNEL_LANES)
     assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+    rows, over = gorp.extract_batch(data, offsets, kernel=N.GX_KERNEL_LANES, compact=True)
+    cm, cc = G.unpack_rows(rows)
+    assert over == 0 and np.array_equal(cm, omid) and np.array_equal(cc, ocaps)
+    m2, _ = gorp.extract_batch(data, offsets, match_only=True, kernel=N.GX_KERNEL_LANES)
+    assert np.array_equal(m2, orc.extract_batch(data, offsets, match_only=True, nthreads=8)[0])
     definition = W.readme3_definition()
     gorp, orc = Gorp.construct(definition, flags=flags), oracle_for(definition)
     lines = ["", "[1]: GET 5ms /x", "[1]: GET 5ms /" + "x" * 70000, "[12]: PUT 7ms /" + "y" * 3000, "nothing", "[3]: HEAD 1ms /z", "a\rb",

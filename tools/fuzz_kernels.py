@@ -22,6 +22,7 @@ variants = [(0, 0, False), (N.GX_CREATE_TIER_L2, 0, False), (0, N.GX_KERNEL_SLIC
             (N.GX_CREATE_TIER_RECORDS | N.GX_CREATE_NO_FUSED, 0, False), (N.GX_CREATE_TIER_RECORDS, 0, True),
             (N.GX_CREATE_TIER_RECORDS, N.GX_KERNEL_TILES, False), (N.GX_CREATE_TIER_RECORDS, N.GX_KERNEL_TILES, True),
             (N.GX_CREATE_TIER_L2, N.GX_KERNEL_LANES, False), (N.GX_CREATE_TIER_RECORDS_GLOBAL, N.GX_KERNEL_LANES, True),
+            (0, N.GX_KERNEL_LANES, False), (0, N.GX_KERNEL_LANES, True),
             (N.GX_CREATE_TIER_RECORDS_GLOBAL, 0, False), (N.GX_CREATE_TIER_RECORDS_GLOBAL, N.GX_KERNEL_SLICES, False),
             (N.GX_CREATE_TIER_RECORDS_GLOBAL | N.GX_CREATE_NO_FUSED, 0, True)]
 done = bad = 0
