@@ -926,13 +926,13 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
         if (L.sort_chunk) {
             b.chunk_ctr = h->d_slots + gx_handle::N_SLOTS + slot;
             b.chunk_base = h->chunk_tickets[slot];
-            h->chunk_tickets[slot] += lanes_sorted_tickets(b.n, L.sort_chunk, h->num_cus);
         }
         unsigned long long* stamps = nullptr;
 #ifdef GX_DEV
         stamps = h->dev_stamps;
 #endif
         GX_HIP(launch_extract_lanes(h->dev, L, image, at_global, h->num_cus, b, stream, stamps));
+        if (L.sort_chunk) h->chunk_tickets[slot] += lanes_sorted_tickets(b.n, L.sort_chunk, h->num_cus);  // (what the launch will draw)
         GX_HIP(launch_extract_oversize(h->dev, b, 65535u + 48u, stream));
         GX_HIP(hipEventRecord(h->slot_event[slot], stream));
         return;
