@@ -914,8 +914,16 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
     }
     // records in LDS: the lane kernel (every lane keeps its own line in registers, 16 waves share the tables)
     const bool lanes = kernel == GX_KERNEL_LANES || (kernel == GX_KERNEL_AUTO && (image_tier == 2 || (image_tier != 0 && long_lines)));
-    // (uneven lines on tables in global memory: tiles of lines of similar length, see gx_lanes.hip)
-    if (batchable && lanes && plan_lanes_launch(h, &L, mo, b.packed != nullptr, long_lines)) {
+    // (long lines: tiles of lines of similar length, see gx_lanes.hip; where LDS has no room for that, the slice kernel)
+    bool lanes_ok = batchable && lanes && plan_lanes_launch(h, &L, mo, b.packed != nullptr, long_lines);
+    if (lanes_ok && kernel == GX_KERNEL_AUTO && long_lines && L.sort_chunk == 0) {
+        GxLds S;
+        if (plan_slice_launch(h, &S, mo)) {
+            GX_HIP(launch_extract_slices(h->dev, S, image, at_global, h->num_cus, b, stream));
+            return;
+        }
+    }
+    if (lanes_ok) {
         std::lock_guard<std::mutex> lock(h->slot_mu);
         b.seq = h->next_seq++;
         if (h->next_seq == 0) h->next_seq = 1;
