@@ -55,7 +55,7 @@ class gx_batch_opts(C.Structure):
         ("utf16", C.c_uint32),
         ("kernel", C.c_uint32),
         ("compact_results", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("uneven_lines", C.c_uint32),
         ("overflow", C.c_void_p),
     ]
 

@@ -887,7 +887,7 @@ void upload(gx_handle* h) {
 
 // One batch on the device: tile kernel (LDS tier when the tables fit LDS, else L2 tier), slice kernel for long lines,
 // per-line kernel otherwise.  kernel: gx_batch_opts.kernel (0 = choose).
-void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t kernel, hipStream_t stream) {
+void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t kernel, hipStream_t stream, bool uneven = false) {
     GxLds L;
     const bool batchable = !b.wide && !b.state_out && b.match_only >= 0 && kernel != GX_KERNEL_PER_LINE;
     // Which kernel (gx_batch_opts.kernel 0), by the tables and the mean line length.  Measured, one device (ms; captures /
@@ -903,6 +903,7 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
     // done); dense rows in LDS -> tile kernel; records in LDS -> lane kernel; anything else -> tile kernel, or above 255 bytes
     // the lane kernel; the lane kernel on tiles of lines of similar length above 255 bytes (gx_lanes.hip, SORTED).
     const bool long_lines = line_bytes_hint > 255u, very_long = line_bytes_hint > 1024u;
+    const bool sorted = long_lines || uneven;  // tiles of lines of similar length (the lane kernel's SORTED mode)
     const bool mo = b.match_only != 0 || !h->T.has_capture;
     const uint8_t* image = static_cast<const uint8_t*>(mo && h->has_mo ? h->d_lds_image_mo : h->d_lds_image);
     const uint32_t image_tier = mo && h->has_mo ? h->lds_mo.tier : h->lds.tier;
@@ -915,7 +916,7 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
     // records in LDS: the lane kernel (every lane keeps its own line in registers, 16 waves share the tables)
     const bool lanes = kernel == GX_KERNEL_LANES || (kernel == GX_KERNEL_AUTO && (image_tier == 2 || (image_tier != 0 && long_lines)));
     // (long lines: tiles of lines of similar length, see gx_lanes.hip; where LDS has no room for that, the slice kernel)
-    bool lanes_ok = batchable && lanes && plan_lanes_launch(h, &L, mo, b.packed != nullptr, long_lines);
+    bool lanes_ok = batchable && lanes && plan_lanes_launch(h, &L, mo, b.packed != nullptr, sorted);
     if (lanes_ok && kernel == GX_KERNEL_AUTO && long_lines && L.sort_chunk == 0) {
         GxLds S;
         if (plan_slice_launch(h, &S, mo)) {
@@ -1409,7 +1410,7 @@ int gx_set_extraction_meta(gx_handle* h, int32_t k, const char* name, const char
 // chunk's first offset instead of rebased offsets.
 static void host_pipeline(gx_handle* h, const GxBatch& proto, const uint8_t* bytes, const void* offsets, uint64_t n, uint64_t total,
                           int32_t* match_id, int32_t* caps, int32_t* states, bool compact, bool match_only, uint32_t hint, uint32_t kernel,
-                          uint64_t* over_total) {
+                          bool uneven, uint64_t* over_total) {
     if (n == 0) return;
     const size_t unit = proto.wide ? 2 : 1, off_w = proto.offsets64 ? 8 : 4;
     const size_t slots = 2 * static_cast<size_t>(h->T.max_groups);
@@ -1471,7 +1472,7 @@ static void host_pipeline(gx_handle* h, const GxBatch& proto, const uint8_t* byt
                     b.match_id = static_cast<int32_t*>(sl.d_res);
                     if (!match_only) { grow(sl.d_caps, sl.cap_caps, m * slots * 4 + 16); b.caps = static_cast<int32_t*>(sl.d_caps); }
                 }
-                launch_batch(h, b, hint, kernel, sl.stream);
+                launch_batch(h, b, hint, kernel, sl.stream, uneven);
                 unsigned long long over = 0;
                 if (compact) {
                     GX_HIP(hipMemcpyAsync(reinterpret_cast<uint16_t*>(caps) + a * (1 + slots), sl.d_res, m * (1 + slots) * 2, hipMemcpyDeviceToHost, sl.stream));
@@ -1500,6 +1501,24 @@ static void host_pipeline(gx_handle* h, const GxBatch& proto, const uint8_t* byt
     }
     if (err_code != GX_OK) throw GxError(err_code, err_msg);
     *over_total = over_sum.load();
+}
+
+// Do the lines of a batch differ much in length?  Lines run in lock step in groups of 64, a group takes as long as its longest
+// line: over a sample of up to 64 groups spread over the batch, (sum of 64 x longest line) / (sum of lengths) > 1.25.
+// offsets: n + 1 offsets in HOST memory.
+static bool lines_are_uneven(const void* offsets, uint64_t n, bool off64) {
+    if (n < 128) return false;
+    auto at = [&](uint64_t i) -> uint64_t { return off64 ? static_cast<const uint64_t*>(offsets)[i] : static_cast<const uint32_t*>(offsets)[i]; };
+    const uint64_t groups = n / 64, sample = std::min<uint64_t>(groups, 64), stride = groups / sample;
+    uint64_t lock_step = 0, bytes = 0;
+    for (uint64_t g = 0; g < sample; ++g) {
+        const uint64_t i0 = g * stride * 64;
+        uint64_t longest = 0;
+        for (uint64_t i = i0; i < i0 + 64; ++i) longest = std::max(longest, at(i + 1) - at(i));
+        lock_step += 64 * longest;
+        bytes += at(i0 + 64) - at(i0);
+    }
+    return bytes > 0 && lock_step * 4 > bytes * 5;
 }
 
 // gx_extract_batch, and gx_match_batch when `states` is given (final product-DFA state per line, -1 = dead: the
@@ -1538,6 +1557,7 @@ static int extract_batch_impl(gx_handle* h, const uint8_t* bytes, const void* of
                 b.caps = match_only ? nullptr : caps;
             }
             uint32_t hint = o.line_bytes_hint;
+            bool uneven = o.uneven_lines == 2;
             if (hint == 0 && n && o.no_sync) {
                 // no hint and no synchronisation allowed: what the previous such batch measured (200 until one has), and
                 // a probe of this batch for the next call
@@ -1573,8 +1593,16 @@ static int extract_batch_impl(gx_handle* h, const uint8_t* bytes, const void* of
                 GX_HIP(hipStreamSynchronize(stream));
                 hint = static_cast<uint32_t>(std::min<uint64_t>((last - first + n - 1) / n, 4096));
                 if (hint == 0) hint = 1;
+                if (o.uneven_lines == 0 && n >= 128) {
+                    // ... and whether the lines differ much in length: the first 4096 of them
+                    const uint64_t m = std::min<uint64_t>(n, 4096);
+                    std::vector<uint8_t> sample((m + 1) * off_w);
+                    GX_HIP(hipMemcpyAsync(sample.data(), offsets, sample.size(), hipMemcpyDeviceToHost, stream));
+                    GX_HIP(hipStreamSynchronize(stream));
+                    uneven = lines_are_uneven(sample.data(), m, o.offsets64 != 0);
+                }
             }
-            launch_batch(h, b, hint, o.kernel, stream);
+            launch_batch(h, b, hint, o.kernel, stream, uneven);
             if (!o.no_sync) GX_HIP(hipStreamSynchronize(stream));
             return GX_OK;
         }
@@ -1586,7 +1614,8 @@ static int extract_batch_impl(gx_handle* h, const uint8_t* bytes, const void* of
         uint32_t hint = o.line_bytes_hint;
         if (hint == 0 && n) hint = static_cast<uint32_t>(std::min<uint64_t>((total + n - 1) / n, 1u << 20));
         uint64_t over_total = 0;
-        host_pipeline(h, b, bytes, offsets, n, total, match_id, caps, states, compact, match_only, hint, o.kernel, &over_total);
+        const bool uneven = o.uneven_lines == 2 || (o.uneven_lines == 0 && lines_are_uneven(offsets, n, o.offsets64 != 0));
+        host_pipeline(h, b, bytes, offsets, n, total, match_id, caps, states, compact, match_only, hint, o.kernel, uneven, &over_total);
         if (compact && o.overflow) *static_cast<uint64_t*>(o.overflow) += over_total;
         return GX_OK;
     } catch (GxError& e) { return fail(e.code, e.what()); }

@@ -537,7 +537,7 @@ class Gorp:
         return ExtractionResult(extr.getName(), line, extr, extr._extractorNames, values)
 
     # -- batch API -----------------------------------------------------------
-    def extract_batch(self, data, offsets, match_only=False, strip_eol=False, kernel=0, line_bytes_hint=0, compact=False):
+    def extract_batch(self, data, offsets, match_only=False, strip_eol=False, kernel=0, line_bytes_hint=0, compact=False, uneven=0):
         """Host buffers: data uint8[total] (Latin-1 code units) or uint16[total] (UTF-16 code units),
         offsets uint32|uint64[n+1] in code units.
         Returns (match_id int32[n], caps int32[n, 2*max_groups]); with compact=True the compact rows
@@ -559,6 +559,7 @@ class Gorp:
         o.utf16 = 1 if utf16 else 0
         o.kernel = int(kernel) or DEFAULT_KERNEL
         o.line_bytes_hint = int(line_bytes_hint)
+        o.uneven_lines = int(uneven)  # gx_batch_opts.uneven_lines: 0 = the library looks at the offsets itself
         if compact and not match_only and self.stat(8):
             rows = np.zeros((n, 1 + 2 * self.max_groups), np.uint16)
             over = C.c_uint64(0)
@@ -573,7 +574,7 @@ class Gorp:
 
     def extract_batch_device(self, data_ptr, offsets_ptr, n, match_id_ptr, caps_ptr, offsets64=False, match_only=False,
                              stream=None, no_sync=False, strip_eol=False, line_bytes_hint=0, kernel=0, compact=False,
-                             overflow_ptr=None):
+                             overflow_ptr=None, uneven=0):
         """Device pointers (ints), e.g. torch tensors' data_ptr(); results stay in HBM.  line_bytes_hint sizes
         the kernel's staging area (0: 200 bytes with no_sync, else the batch's mean line length).
         compact=True: caps_ptr receives compact rows uint16[n, 1 + 2*max_groups] (match_id_ptr may be None),
@@ -590,6 +591,7 @@ class Gorp:
         o.kernel = int(kernel) or DEFAULT_KERNEL
         o.compact_results = 1 if compact else 0
         o.overflow = overflow_ptr
+        o.uneven_lines = int(uneven)  # 2: lines differ much in length (0 with a hint or no_sync: taken as 1, similar lengths)
         _check(N.lib().gx_extract_batch(self._h.ptr, data_ptr, offsets_ptr, n, match_id_ptr, caps_ptr, C.byref(o)))
 
     def results(self, data, offsets, match_id, caps, safe=False):

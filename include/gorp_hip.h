@@ -125,7 +125,11 @@ typedef struct gx_batch_opts {
                                   result bytes of the dense format; what the gather between GPUs sends.  An offset above
                                   65534 does not fit: it is stored as 65534 and counted in *overflow (take such a batch again
                                   in the dense format).  Ignored with match_only. */
-    uint32_t reserved;         /* 0 */
+    uint32_t uneven_lines;     /* gx_extract_batch only.  Lines run in lock step in groups of 64: a group takes as long as its longest
+                                  line.  2: the lines differ much in length -- the kernels then group lines of similar length where
+                                  they can (results are the same); 1: they do not; 0: the library looks itself where it can see
+                                  the offsets without waiting (host pointers; device pointers without no_sync and without a hint),
+                                  and assumes 1 elsewhere.  Batches with a mean length above 255 bytes are taken as uneven. */
     void*    overflow;         /* with compact_results: uint64_t counter that the call ADDS to (the caller zeroes it); a device
                                   pointer with device_pointers, else a host pointer.  NULL: not counted. */
 } gx_batch_opts;

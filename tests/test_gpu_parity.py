@@ -361,6 +361,16 @@ def test_config3_64_rules_parity(flags):
     assert len(set(mid[mid >= 0].tolist())) == 64  # every extraction wins somewhere
     m2, _ = gorp.extract_batch(data, offsets, match_only=True)   # (record tier: the match automaton's own image)
     assert np.array_equal(m2, orc.extract_batch(data, offsets, match_only=True, nthreads=8)[0])
+    # lines of 50-400 bytes: the library sees from the offsets that they are uneven and (on the records) forms its tiles from
+    # lines of similar length; the same asked for and refused through gx_batch_opts.uneven_lines
+    ud, uo, _ = W.syslog_lines(meta, 20000, seed=9, min_len=50, max_len=400)
+    umid, ucaps = orc.extract_batch(ud, uo, nthreads=8)
+    for uneven in (0, 1, 2):
+        mid_u, caps_u = gorp.extract_batch(ud, uo, uneven=uneven)
+        assert np.array_equal(mid_u, umid) and np.array_equal(caps_u, ucaps)
+    rows, over = gorp.extract_batch(ud, uo, compact=True)
+    cm, cc = G.unpack_rows(rows)
+    assert over == 0 and np.array_equal(cm, umid) and np.array_equal(cc, ucaps)
     if flags != N.GX_CREATE_TIER_L2:
         mid, caps = gorp.extract_batch(data, offsets, kernel=N.GX_KERNEL_TILES)
         assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)

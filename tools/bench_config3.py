@@ -11,6 +11,7 @@ from gorp_amd.gorp import Gorp
 
 kernel = int(os.environ.get("GX_BENCH_KERNEL", "0"))   # gx_batch_opts.kernel (4 = the lane kernel)
 flags = int(os.environ.get("GX_BENCH_FLAGS", "0"))     # GX_CREATE_* (e.g. 32 = records in global memory)
+uneven = int(os.environ.get("GX_BENCH_UNEVEN", "0"))   # gx_batch_opts.uneven_lines
 nrules = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 2_000_000
 rules, meta = W.syslog_definition(nrules, seed=3)
@@ -37,12 +38,12 @@ caps = torch.empty((n, 2 * g.max_groups), dtype=torch.int32, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 for mo in (False, True):
     for _ in range(2):
-        g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), match_only=mo, stream=st, no_sync=True, line_bytes_hint=int(mean_len + 0.999), kernel=kernel)
+        g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), match_only=mo, stream=st, no_sync=True, line_bytes_hint=int(mean_len + 0.999), kernel=kernel, uneven=uneven)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5):
-        g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), match_only=mo, stream=st, no_sync=True, line_bytes_hint=int(mean_len + 0.999), kernel=kernel)
+        g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), match_only=mo, stream=st, no_sync=True, line_bytes_hint=int(mean_len + 0.999), kernel=kernel, uneven=uneven)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
     print("match_only=%s: %.3f ms for %d lines -> %.2f G lines/s, %.0f GB/s" % (mo, ms, n, n / ms / 1e6, total * reps / ms / 1e6))

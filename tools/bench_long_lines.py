@@ -10,6 +10,7 @@ from gorp_amd.gorp import Gorp, lines_to_csr
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 kernel = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 max_len = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
+uneven = int(os.environ.get("GX_BENCH_UNEVEN", "0"))   # gx_batch_opts.uneven_lines
 g = Gorp.construct(W.readme3_definition())
 rng = random.Random(7)
 base_n = 20_000
@@ -31,12 +32,12 @@ caps = torch.empty((n, 8), dtype=torch.int32, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 hint = int(total / base_n + 0.999)
 for _ in range(2):
-    g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=st, no_sync=True, line_bytes_hint=hint, kernel=kernel)
+    g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=st, no_sync=True, line_bytes_hint=hint, kernel=kernel, uneven=uneven)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(5):
-    g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=st, no_sync=True, line_bytes_hint=hint, kernel=kernel)
+    g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=st, no_sync=True, line_bytes_hint=hint, kernel=kernel, uneven=uneven)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
 print("kernel=%s mean %d B: %.3f ms for %d lines (%.2f GB) -> %.2f G lines/s, %.0f GB/s" %
