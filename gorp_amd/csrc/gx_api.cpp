@@ -704,7 +704,7 @@ bool plan_tile_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out, 
 }
 
 // Layout for the lane kernel (gx_lanes.hip): per wave the register block and the area its result rows go through.
-bool plan_lanes_launch(const gx_handle* h, GxLds* out, bool match_only, bool compact, bool sorted = false) {
+bool plan_lanes_launch(const gx_handle* h, GxLds* out, bool match_only, bool compact, bool sorted = false, uint64_t n = 0) {
     if (!h->tile_ok) return false;
     GxLds L = match_only && h->has_mo ? h->lds_mo : h->lds;
     if (!match_only && h->T.has_capture && L.u_start == 0xFFFFFFFFu) return false;  // walks the fused automaton
@@ -718,9 +718,15 @@ bool plan_lanes_launch(const gx_handle* h, GxLds* out, bool match_only, bool com
     uint32_t sort_bytes = 0;
     if (sorted) {
         // (with the tables in LDS too the index array takes the place of a wave or two)
-        for (uint32_t ch = 8192u; ch >= 2048u; ch >>= 1)
+        for (uint32_t ch = L.tier == 2 ? 2048u : 8192u; ch >= 2048u; ch >>= 1)  // (records in LDS: 2 048 lines cost one wave, 8 192 two)
             if (L.table_bytes + 32u + 2u * ch + 512u + (L.tier == 2 ? 14u : 8u) * L.regs_wave_bytes <= LDS_BYTES) { L.sort_chunk = ch; sort_bytes = 2u * ch + 512u; break; }
     }
+    // Chunks are what the workgroups share the batch in, and a chunk ends with a barrier, so its waves want several tiles
+    // each (measured: 1 M lines of 50-2000 bytes on the LDS records: chunks of 8 192 lines 0.82 ms -- 122 chunks for 256
+    // CUs --, 2 048 lines 0.52 ms, 1 024 lines 0.95 ms -- one tile per wave and chunk; configs[4], 2 M lines: 8 192 1.75 ms,
+    // 1 984 1.82 ms).  Small batches take smaller chunks, down to 2 048 lines.
+    if (L.sort_chunk && n)
+        while (L.sort_chunk > 2048u && n / L.sort_chunk < static_cast<uint64_t>(h->num_cus > 0 ? h->num_cus : 256) / 2) L.sort_chunk >>= 1;
     if (L.table_bytes + 32u + sort_bytes + 4u * L.regs_wave_bytes > LDS_BYTES) return false;
     L.nwaves = std::min<uint32_t>(16u, (LDS_BYTES - L.table_bytes - 32u - sort_bytes) / L.regs_wave_bytes);
     L.sort_lds = L.table_bytes;  // (behind the tables)
@@ -896,7 +902,7 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
     //     400 k lines of 50-20000 bytes (mean 3.4 KB): tiles 61.7 (lines beyond the staging area go one by one), slices 1.74, lanes 3.4
     //   512 extractions, 2 M lines of 50-2000 bytes (configs[4]), dense rows in L2: tiles 4.4 / 4.0, slices 2.39 / 2.20,
     //     lanes 2.19 / 2.07, lanes on length-sorted tiles 1.77 / 1.56 (on range records in global memory 2.18 / 1.81)
-    //   64 extractions, 1 M such lines, records in LDS: slices 1.04 / 0.74, lanes 1.41 / 1.22, lanes on sorted tiles 0.82 / 0.68;
+    //   64 extractions, 1 M such lines, records in LDS: slices 1.04 / 0.74, lanes 1.41 / 1.22, lanes on sorted tiles 0.52 / 0.47;
     //     200 k lines of 50-20000 bytes: slices 5.1, lanes 9.4
     //   64 extractions, 10 M lines of 200 bytes (configs[2]): records in LDS + lanes 1.52 / 1.18, dense rows in L2 + tiles 3.0 / 3.0
     // Hence: a mean above 1 KB -> slice kernel (64 bytes of every line at a time, a lane takes its next line as soon as it is
@@ -916,7 +922,7 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
     // records in LDS: the lane kernel (every lane keeps its own line in registers, 16 waves share the tables)
     const bool lanes = kernel == GX_KERNEL_LANES || (kernel == GX_KERNEL_AUTO && (image_tier == 2 || (image_tier != 0 && long_lines)));
     // (long lines: tiles of lines of similar length, see gx_lanes.hip; where LDS has no room for that, the slice kernel)
-    bool lanes_ok = batchable && lanes && plan_lanes_launch(h, &L, mo, b.packed != nullptr, sorted);
+    bool lanes_ok = batchable && lanes && plan_lanes_launch(h, &L, mo, b.packed != nullptr, sorted, b.n);
     if (lanes_ok && kernel == GX_KERNEL_AUTO && long_lines && L.sort_chunk == 0) {
         GxLds S;
         if (plan_slice_launch(h, &S, mo)) {
