@@ -1270,7 +1270,7 @@ int gx_results_to_jsonl(gx_handle* h, const uint8_t* bytes, const void* offsets,
         uint8_t* dst = out;
         if (!o.device_pointers) { d_out.alloc(total); dst = static_cast<uint8_t*>(d_out.p); }
         const uint32_t mean_out = n ? static_cast<uint32_t>(std::min<uint64_t>((total + n - 1) / n, 1u << 20)) : 1u;
-        GX_HIP(launch_jsonl_write(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, mean_in, mean_out, loff, dst, stream));
+        GX_HIP(launch_jsonl_write(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, mean_in, mean_out, loff, dst, ws.p, stream));
         if (!o.device_pointers && total) GX_HIP(hipMemcpyAsync(out, dst, total, hipMemcpyDeviceToHost, stream));
         GX_HIP(hipStreamSynchronize(stream));
         return GX_OK;
@@ -1351,7 +1351,7 @@ int gx_text_to_jsonl(gx_handle* h, const uint8_t* text, uint64_t size, const cha
         uint8_t* dst = out;
         if (!o.device_pointers) { d_out.alloc(total); dst = static_cast<uint8_t*>(d_out.p); }
         const uint32_t mean_out = n ? static_cast<uint32_t>(std::min<uint64_t>((total + n - 1) / n, 1u << 20)) : 1u;
-        GX_HIP(launch_jsonl_write(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, mean_in, mean_out, loff, dst, stream));
+        GX_HIP(launch_jsonl_write(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, mean_in, mean_out, loff, dst, ws_json.p, stream));
         if (!o.device_pointers && total) GX_HIP(hipMemcpyAsync(out, dst, total, hipMemcpyDeviceToHost, stream));
         GX_HIP(hipStreamSynchronize(stream));
         return GX_OK;

@@ -178,6 +178,6 @@ hipError_t launch_pack_results(const int32_t* match_id, const int32_t* caps, uin
                                unsigned long long* d_overflow, hipStream_t stream);
 hipError_t launch_unpack_results(const uint16_t* packed, uint64_t n, int slots, int32_t* match_id, int32_t* caps, hipStream_t stream);
 hipError_t launch_jsonl_write(const GxJsonl& tm, const GxBatch& b, int slots, int passthrough, uint32_t mean_in, uint32_t mean_out,
-                              const uint64_t* line_out_off, uint8_t* out, hipStream_t stream);
+                              const uint64_t* line_out_off, uint8_t* out, void* workspace, hipStream_t stream);
 
 }  // namespace gx

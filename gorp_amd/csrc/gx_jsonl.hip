@@ -320,16 +320,16 @@ __device__ __forceinline__ uint64_t esc_bytes(uint32_t b, bool passthrough, uint
 // staging area is at most 16 KB) are issued before the first store waits for one: a wave of these kernels has its
 // SIMD to itself, and a load-store-load-store chain costs a trip to memory per chunk.
 __device__ __forceinline__ void stage_in(const uint8_t* __restrict__ data, const uint8_t* data_end, uint64_t lo, uint64_t hi, uint8_t* stage,
-                                         uint32_t lane) {
+                                         uint32_t lane, uint32_t threads = 64u) {  // lane: 0 .. threads - 1
     const uint8_t* g_lo = data + lo;
     const uint32_t skew = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(g_lo) & 15u);
     const uint8_t* g_al = g_lo - skew;
     const uint32_t nch = static_cast<uint32_t>(((hi - lo) + skew + 15u) >> 4);
-    for (uint32_t c0 = 0; c0 < nch; c0 += 64u * 16u) {
+    for (uint32_t c0 = 0; c0 < nch; c0 += threads * 16u) {
         uint4 v[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const uint32_t c = c0 + 64u * q + lane;
+            const uint32_t c = c0 + threads * q + lane;
             v[q] = make_uint4(0u, 0u, 0u, 0u);
             if (c < nch) {
                 const uint8_t* src = g_al + (static_cast<uint64_t>(c) << 4);
@@ -344,35 +344,52 @@ __device__ __forceinline__ void stage_in(const uint8_t* __restrict__ data, const
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const uint32_t c = c0 + 64u * q + lane;
+            const uint32_t c = c0 + threads * q + lane;
             if (c < nch) *reinterpret_cast<uint4*>(stage + (c << 4)) = v[q];
         }
     }
 }
 
 // global -> LDS copy of `words` (<= 2048) int32, every lane's loads issued before its first store
-__device__ __forceinline__ void stage_words(const int32_t* __restrict__ src, uint32_t words, int32_t* stage, uint32_t lane) {
+__device__ __forceinline__ void stage_words(const int32_t* __restrict__ src, uint32_t words, int32_t* stage, uint32_t lane, uint32_t threads = 64u) {
     int32_t v[32];
 #pragma unroll
     for (int q = 0; q < 32; ++q) {
-        const uint32_t x = 64u * q + lane;
+        const uint32_t x = threads * q + lane;
         v[q] = x < words ? src[x] : 0;
     }
 #pragma unroll
     for (int q = 0; q < 32; ++q) {
-        const uint32_t x = 64u * q + lane;
+        const uint32_t x = threads * q + lane;
         if (x < words) stage[x] = v[q];
     }
 }
 
-template <typename OFF, bool WRITE>
+// PAIR (write pass) = 2: the workgroup is TWO waves that share one tile and its staging areas.  Lane l of both is on line l;
+// the first writes the text before the line's split point, the second the rest.  The split point (a segment m and a
+// character q of its capture, a multiple of 16) is chosen by both passes the same way from the template and the capture
+// offsets, near the middle of the line's text; the sizes pass leaves the exact number of bytes before it in split[].
+// With a wave per tile the write pass fits 4 waves per CU (13 + 21 KB of staging each), one per SIMD, and a lone wave
+// is bound by its own issue rate; pairs make that 8 waves, each with half the text of a line to write.
+template <typename OFF, bool WRITE, int PAIR>
 __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTileCfg cfg, const uint8_t* __restrict__ data, const OFF* __restrict__ off,
                                                    uint64_t n, const int32_t* __restrict__ match_id, const int32_t* __restrict__ caps, int slots,
                                                    int passthrough, uint32_t* __restrict__ sizes, const uint64_t* __restrict__ out_off,
-                                                   uint8_t* __restrict__ out) {
+                                                   uint8_t* __restrict__ out, uint32_t* __restrict__ split) {
     const bool pt = passthrough != 0;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = uni(threadIdx.x >> 6);
+    const uint32_t wave_in_block = uni(threadIdx.x >> 6);
+    const uint32_t wave = wave_in_block / PAIR;   // the tile slot (staging areas) of this wave
+    const uint32_t part = wave_in_block % PAIR;   // PAIR == 2: which side of the split point
+    const uint32_t ptid = part * 64u + lane;      // lane among the waves that share the tile
+    auto pair_barrier = [&]() {  // the waves that share a tile come together (PAIR == 2: they are the whole workgroup)
+        if (PAIR == 2) __syncthreads();
+        else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    };
     // LDS copies of the template arrays, when they are small enough (plan_jsonl_tile)
     uint32_t* tl_seg_off = reinterpret_cast<uint32_t*>(jx_smem + (cfg.tm_lds == 0xFFFFFFFFu ? 0u : cfg.tm_lds));
     uint32_t* tl_fixed = tl_seg_off + (cfg.n_rules + 1u);
@@ -411,8 +428,8 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
     uint8_t* caps_stage = out_stage + cfg.out_bytes;
     const uint8_t* data_end = data + static_cast<uint64_t>(off[n]);
     const uint64_t tiles = (n + 63) >> 6;
-    const uint64_t wstride = static_cast<uint64_t>(gridDim.x) * cfg.waves;
-    for (uint64_t tile = static_cast<uint64_t>(blockIdx.x) * cfg.waves + wave; tile < tiles; tile += wstride) {
+    const uint64_t wstride = static_cast<uint64_t>(gridDim.x) * (cfg.waves / PAIR);
+    for (uint64_t tile = static_cast<uint64_t>(blockIdx.x) * (cfg.waves / PAIR) + wave; tile < tiles; tile += wstride) {
         const uint64_t i = (tile << 6) + lane;
         const bool valid = i < n;
         const uint64_t o0 = off[valid ? i : n], o1 = off[valid ? i + 1 : n];
@@ -437,7 +454,7 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
             if (cnt == 0) {
                 // line a alone does not fit: the whole wave takes it
                 const uint64_t ia = (tile << 6) + a;
-                if (WRITE) line_write_wave(tm, data, lo, ia, match_id, caps, slots, pt, lane, out + olo);
+                if (WRITE) { if (part == 0u) line_write_wave(tm, data, lo, ia, match_id, caps, slots, pt, lane, out + olo); }
                 else {
                     const uint32_t t = line_size_wave(tm, data, lo, ia, match_id, caps, slots, pt, lane);
                     if (lane == 0) sizes[ia] = t;
@@ -447,32 +464,27 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
             }
             const uint32_t b = a + cnt;
             const uint64_t hi = uni(static_cast<uint64_t>(__shfl(static_cast<unsigned long long>(o1), static_cast<int>(b - 1u))));
-            stage_in(data, data_end, lo, hi, in_stage, lane);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            stage_in(data, data_end, lo, hi, in_stage, ptid, 64u * PAIR);
+            if (!cfg.caps_bytes) pair_barrier();
             const bool active = lane >= a && lane < b;
             if (cfg.caps_bytes) {
                 // the round's capture rows are contiguous: stage them with coalesced 16-byte loads
                 const uint64_t row0 = ((tile << 6) + a) * static_cast<uint64_t>(slots);     // in int32 units
                 const uint32_t words = (b - a) * static_cast<uint32_t>(slots);
                 const int32_t* src = caps + row0;
-                stage_words(src, words, reinterpret_cast<int32_t*>(caps_stage), lane);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                stage_words(src, words, reinterpret_cast<int32_t*>(caps_stage), ptid, 64u * PAIR);
+                pair_barrier();
             }
             // ---- lane = line ----
+            // The write pass: a lane's text leaves through ALIGNED 32-bit stores (a 32-bit LDS store off its alignment is
+            // replayed at 64 cycles, measured: SQ_LDS_UNALIGNED_STALL was 88 % of the LDS-active cycles).  Up to three
+            // bytes wait in `carry`; the first store of a writer also covers the last bytes of the text before it (the
+            // lane before, or the other wave of the pair) with zeros, and those are written by that writer's byte stores
+            // after the barrier below, later than every first store of the round.
+            uint32_t wp = 0u, wp0 = 0u, head0 = 0u, carry = 0u, pend = 0u;
             if (active) {
                 const uint32_t line = lds_addr(in_stage) + skew + static_cast<uint32_t>(o0 - lo);  // LDS byte addresses
                 uint32_t total = 0;
-                // The write pass: a lane's text leaves through ALIGNED 32-bit stores (a 32-bit LDS store off its alignment is
-                // replayed at 64 cycles, measured: SQ_LDS_UNALIGNED_STALL was 88 % of the LDS-active cycles).  Up to three
-                // bytes wait in `carry`; the first store of a lane also covers the last bytes of the lane before it with
-                // zeros, and those are written by that lane's byte stores at the end -- after the segment loop, where
-                // all lanes have come together again, so later than every first store of the round.
-                const uint32_t dst0 = WRITE ? lds_addr(out_stage) + oskew + static_cast<uint32_t>(oo0 - olo) : 0u;
-                uint32_t wp = dst0 & ~3u, carry = 0u, pend = dst0 & 3u;
                 auto put_4 = [&](uint32_t e) {  // four bytes
                     const uint64_t t = static_cast<uint64_t>(e) << (8u * pend);
                     *(JX_LDS uint32_t*)(uintptr_t)wp = carry | static_cast<uint32_t>(t);
@@ -502,10 +514,49 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
                     auto t_lit_off = [&](uint32_t x) { return cfg.tm_lds != 0xFFFFFFFFu ? tl_lit_off[x] : tm.lit_off[x]; };
                     auto t_lit_len = [&](uint32_t x) { return cfg.tm_lds != 0xFFFFFFFFu ? tl_lit_len[x] : tm.lit_len[x]; };
                     auto t_group = [&](uint32_t x) { return cfg.tm_lds != 0xFFFFFFFFu ? tl_group[x] : tm.group[x]; };
-                    const uint32_t s1 = t_seg_off(k + 1);
+                    const uint32_t s0 = t_seg_off(k), s1 = t_seg_off(k + 1);
+                    // ---- the split point (m, q): part 0 writes the segments before m, m's literal and -- m has a capture that
+                    // is not null -- the opening quote and q characters of it (q a multiple of 16); part 1 the rest.  From the
+                    // unescaped sizes: the first place at or past the middle of the text.  m == s1: no split. ----
+                    uint32_t sp_m = s1, sp_q = 0u;
+                    const bool want_split = WRITE ? PAIR == 2 : split != nullptr;
+                    if (want_split) {
+                        uint32_t est_total = 0;
+                        for (uint32_t s = s0; s < s1; ++s) {
+                            const int32_t g = t_group(s);
+                            est_total += t_lit_len(s) + (g < 0 ? 0u : (cap(2 * g) < 0 ? 4u : static_cast<uint32_t>(cap(2 * g + 1) - cap(2 * g)) + 2u));
+                        }
+                        const uint32_t half = est_total / 2u;
+                        uint32_t cum = 0;
+                        for (uint32_t s = s0; s < s1; ++s) {
+                            const int32_t g = t_group(s);
+                            const uint32_t ll = t_lit_len(s);
+                            const bool text = g >= 0 && cap(2 * g) >= 0;
+                            const uint32_t len = text ? static_cast<uint32_t>(cap(2 * g + 1) - cap(2 * g)) : 0u;
+                            const uint32_t e = ll + (g < 0 ? 0u : (text ? len + 2u : 4u));
+                            if (sp_m == s1 && cum + e > half) {
+                                sp_m = s;
+                                const uint32_t at = cum + ll + 1u;  // where the capture's characters begin
+                                sp_q = (text && half > at) ? ((half - at) & ~15u) : 0u;
+                                if (sp_q > (len & ~15u)) sp_q = len & ~15u;
+                            }
+                            cum += e;
+                        }
+                    }
+                    uint32_t s_from = s0, s_to = s1;
+                    if (WRITE && PAIR == 2) {
+                        if (part == 0u) s_to = sp_m < s1 ? sp_m + 1u : s1;
+                        else s_from = sp_m;   // (sp_m == s1: nothing)
+                    }
+                    const uint32_t dst0 = WRITE ? lds_addr(out_stage) + oskew + static_cast<uint32_t>(oo0 - olo) + ((PAIR == 2 && part == 1u) ? split[i] : 0u) : 0u;
+                    wp = wp0 = dst0 & ~3u;
+                    pend = head0 = dst0 & 3u;
+                    uint32_t lit_cum = 0u, before = 0u;  // sizes pass: literal bytes so far, bytes before the split point
                     if (!WRITE) total = t_fixed(k);
-                    for (uint32_t s = t_seg_off(k); s < s1; ++s) {
-                        if (WRITE) {
+                    for (uint32_t s = s_from; s < s_to; ++s) {
+                        const bool at_split = WRITE && PAIR == 2 && s == sp_m;
+                        const bool skip_literal = at_split && part == 1u;   // part 1 enters segment m behind its literal and quote
+                        if (WRITE && !skip_literal) {
                             const uint32_t ll = t_lit_len(s), lo_l = t_lit_off(s);
                             if (cfg.lits_lds != 0xFFFFFFFFu) {
                                 const uint32_t lit = smem0 + cfg.lits_lds + lo_l;
@@ -521,16 +572,20 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
                                 for (uint32_t q = 0; q < ll; ++q) put_n(lit[q], 1u);
                             }
                         }
+                        if (!WRITE && split != nullptr) lit_cum += t_lit_len(s);
                         const int32_t g = t_group(s);
-                        if (g < 0) continue;
+                        if (g < 0) { if (!WRITE && s == sp_m) before = lit_cum + (total - t_fixed(k)); continue; }
                         const int32_t cb = cap(2 * g), ce = cap(2 * g + 1);
                         if (cb < 0) {
-                            if (WRITE) put_4(0x6C6C756Eu);  // null
-                            else total += 4u;
+                            if (WRITE) { if (!skip_literal) put_4(0x6C6C756Eu); }  // null (part 0's, with the literal)
+                            else { total += 4u; if (s == sp_m) before = lit_cum + (total - t_fixed(k)); }
                             continue;
                         }
+                        // the characters [c_from, c_to) of the capture
+                        const int32_t c_from = skip_literal ? cb + static_cast<int32_t>(sp_q) : cb;
+                        const int32_t c_to = (at_split && part == 0u) ? cb + static_cast<int32_t>(sp_q) : ce;
                         if (WRITE) {
-                            put_n(0x22u, 1u);
+                            if (!skip_literal) put_n(0x22u, 1u);
                             // Lanes run in lock step, so whatever one lane needs every lane pays for.  Four characters that
                             // are plain or only take a backslash -- nearly all of them -- are expanded without a branch: the
                             // mask of the characters to escape picks one of 16 byte-permute selectors (a 128-byte table
@@ -560,11 +615,11 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
                                 put_n(__builtin_amdgcn_perm(0x5C5C5C5Cu, w, s_hi), __popc(idx));
                             };
                             // the capture's bytes: aligned 32-bit reads (one off its alignment is replayed too) joined by v_alignbyte
-                            int32_t p = cb;
-                            uint32_t ap = (line + static_cast<uint32_t>(cb)) & ~3u;
-                            const uint32_t mis = (line + static_cast<uint32_t>(cb)) & 3u;
+                            int32_t p = c_from;
+                            uint32_t ap = (line + static_cast<uint32_t>(c_from)) & ~3u;
+                            const uint32_t mis = (line + static_cast<uint32_t>(c_from)) & 3u;
                             uint32_t prev = lds_w(ap);
-                            for (; p + 16 <= ce; p += 16, ap += 16u) {  // four words per LDS round trip
+                            for (; p + 16 <= c_to; p += 16, ap += 16u) {  // four words per LDS round trip
                                 const uint32_t d0 = lds_w(ap + 4u), d1 = lds_w(ap + 8u), d2 = lds_w(ap + 12u), d3 = lds_w(ap + 16u);
                                 put4(__builtin_amdgcn_alignbyte(d0, prev, mis));
                                 put4(__builtin_amdgcn_alignbyte(d1, d0, mis));
@@ -572,16 +627,16 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
                                 put4(__builtin_amdgcn_alignbyte(d3, d2, mis));
                                 prev = d3;
                             }
-                            for (; p + 4 <= ce; p += 4, ap += 4u) {
+                            for (; p + 4 <= c_to; p += 4, ap += 4u) {
                                 const uint32_t d = lds_w(ap + 4u);
                                 put4(__builtin_amdgcn_alignbyte(d, prev, mis));
                                 prev = d;
                             }
-                            if (p < ce) {
+                            if (p < c_to) {
                                 uint32_t w = __builtin_amdgcn_alignbyte(lds_w(ap + 4u), prev, mis);  // (may read past the line: LDS)
-                                for (; p < ce; ++p, w >>= 8) put1(w & 0xFFu);
+                                for (; p < c_to; ++p, w >>= 8) put1(w & 0xFFu);
                             }
-                            put_n(0x22u, 1u);
+                            if (!(at_split && part == 0u)) put_n(0x22u, 1u);
                         } else {
                             // four characters at a time: 4 + one per quote / backslash (+ one per byte >= 0x80 that becomes
                             // two bytes of UTF-8); a word with a control character is counted byte by byte
@@ -590,6 +645,8 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
                             uint32_t ap = (line + static_cast<uint32_t>(cb)) & ~3u;
                             const uint32_t mis = (line + static_cast<uint32_t>(cb)) & 3u;
                             uint32_t prev = lds_w(ap);
+                            const bool is_m = s == sp_m;
+                            const int32_t p_split = cb + static_cast<int32_t>(sp_q);
                             auto count4 = [&](uint32_t w) {
                                 const uint32_t tt = (w & 0x7F7F7F7Fu) + 0x60606060u;
                                 if ((~(tt | w)) & 0x80808080u) {  // some byte < 0x20
@@ -601,7 +658,11 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
                                     t += 4u + __popc(zq | zb) + (pt ? 0u : __popc(w & 0x80808080u));
                                 }
                             };
+                            // bytes before the split point: the literals so far, the captures before this one, the opening quote and
+                            // the characters before p_split (t counts both quotes: t - 1)
+                            auto mark = [&]() { before = lit_cum + (total - t_fixed(k)) + t - 1u; };
                             for (; p + 16 <= ce; p += 16, ap += 16u) {  // four aligned words per LDS round trip
+                                if (is_m && p == p_split) mark();
                                 const uint32_t d0 = lds_w(ap + 4u), d1 = lds_w(ap + 8u), d2 = lds_w(ap + 12u), d3 = lds_w(ap + 16u);
                                 count4(__builtin_amdgcn_alignbyte(d0, prev, mis));
                                 count4(__builtin_amdgcn_alignbyte(d1, d0, mis));
@@ -609,6 +670,7 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
                                 count4(__builtin_amdgcn_alignbyte(d3, d2, mis));
                                 prev = d3;
                             }
+                            if (is_m && p == p_split) mark();  // (the split point is the end of the 16-byte steps)
                             for (; p + 4 <= ce; p += 4, ap += 4u) {
                                 const uint32_t d = lds_w(ap + 4u);
                                 count4(__builtin_amdgcn_alignbyte(d, prev, mis));
@@ -621,21 +683,25 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
                             total += t;
                         }
                     }
-                    // the bytes still waiting: byte stores (the rest of that dword is the next lane's)
-                    if (WRITE) for (uint32_t q = 0; q < pend; ++q) lds_put_u8(wp + q, (carry >> (8u * q)) & 0xFFu);
+                    if (!WRITE && split != nullptr) split[i] = sp_m < s1 ? before : total;
                 }
                 if (!WRITE) sizes[i] = total;
             }
             if (WRITE) {
+                // the bytes still waiting in the carries: byte stores (the rest of such a dword is the next writer's), once every
+                // writer of the round has done its dword stores.  (A writer that wrote no dword leaves the bytes before its text alone.)
+                pair_barrier();
+                if (active && k >= 0)
+                    for (uint32_t q = (wp == wp0 ? head0 : 0u); q < pend; ++q) lds_put_u8(wp + q, (carry >> (8u * q)) & 0xFFu);
+            }
+            if (WRITE) {
                 // ---- flush: the round's text is the contiguous span [olo, ohi) of the output ----
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                pair_barrier();
                 const uint64_t ohi = uni(static_cast<uint64_t>(__shfl(static_cast<unsigned long long>(oo1), static_cast<int>(b - 1u))));
                 const uint32_t span = static_cast<uint32_t>(ohi - olo);
                 uint8_t* g_al = out + olo - oskew;  // 16-byte aligned
                 const uint32_t nch = (span + oskew + 15u) >> 4;
-                for (uint32_t c = lane; c < nch; c += 64u) {
+                for (uint32_t c = ptid; c < nch; c += 64u * PAIR) {
                     const uint32_t first = c << 4;
                     if (first >= oskew && first + 16u <= oskew + span)
                         *reinterpret_cast<uint4*>(g_al + first) = *reinterpret_cast<const uint4*>(out_stage + first);
@@ -645,8 +711,7 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
                 }
             }
             // the staging areas are reused by the next round
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            pair_barrier();
             a = b;
         }
     }
@@ -820,10 +885,13 @@ hipError_t launch_count_outcomes(const int32_t* match_id, uint64_t n, unsigned l
     return hipGetLastError();
 }
 
-size_t jsonl_workspace_bytes(uint64_t n) {
+// workspace: u32 sizes[n] | u64 block_sums[nblocks + 2] | u32 split[n] (bytes of a line's text before its split point)
+static uint64_t jsonl_ws_sums(uint64_t n) { return (n * 4 + 15) & ~static_cast<uint64_t>(15); }
+static uint64_t jsonl_ws_split(uint64_t n) {
     const uint64_t nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    return static_cast<size_t>(n * 4 + (nblocks + 2) * 8 + 64);
+    return jsonl_ws_sums(n) + (((nblocks + 2) * 8 + 15) & ~static_cast<uint64_t>(15));
 }
+size_t jsonl_workspace_bytes(uint64_t n) { return static_cast<size_t>(jsonl_ws_split(n) + n * 4 + 64); }
 
 namespace {
 // LDS plan of the tile kernels for lines of mean_in bytes producing mean_out bytes of text (0: sizes pass).
@@ -861,7 +929,8 @@ hipError_t launch_jsonl_sizes(const GxJsonl& tm, const GxBatch& b, int slots, in
     if (b.n == 0) return hipMemsetAsync(line_out_off, 0, 8, stream);
     const uint64_t nblocks = (b.n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     uint32_t* sizes = static_cast<uint32_t*>(workspace);
-    uint64_t* block_sums = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(workspace) + ((b.n * 4 + 15) & ~static_cast<uint64_t>(15)));
+    uint64_t* block_sums = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(workspace) + jsonl_ws_sums(b.n));
+    uint32_t* split = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(workspace) + jsonl_ws_split(b.n));
     JsonlTemplates t{tm.seg_off, tm.lit_off, tm.lit_len, tm.group, tm.fixed_len, tm.lits};
     JsonlTileCfg cfg;
     if (!plan_jsonl_tile(tm, slots, mean_in, 0, &cfg)) return hipErrorInvalidValue;
@@ -871,17 +940,17 @@ hipError_t launch_jsonl_sizes(const GxJsonl& tm, const GxBatch& b, int slots, in
         uint64_t blocks = std::min<uint64_t>((tiles + cfg.waves - 1) / cfg.waves, 256u * 4u);
         hipError_t e;
         if (b.offsets64) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jsonl_tile<uint64_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jsonl_tile<uint64_t, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((k_jsonl_tile<uint64_t, false>), dim3(static_cast<unsigned>(blocks)), dim3(cfg.waves * 64), lds, stream, t, cfg,
+            hipLaunchKernelGGL((k_jsonl_tile<uint64_t, false, 1>), dim3(static_cast<unsigned>(blocks)), dim3(cfg.waves * 64), lds, stream, t, cfg,
                                static_cast<const uint8_t*>(b.data), static_cast<const uint64_t*>(b.offsets), b.n, b.match_id, b.caps, slots, passthrough,
-                               sizes, nullptr, nullptr);
+                               sizes, nullptr, nullptr, split);
         } else {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jsonl_tile<uint32_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jsonl_tile<uint32_t, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((k_jsonl_tile<uint32_t, false>), dim3(static_cast<unsigned>(blocks)), dim3(cfg.waves * 64), lds, stream, t, cfg,
+            hipLaunchKernelGGL((k_jsonl_tile<uint32_t, false, 1>), dim3(static_cast<unsigned>(blocks)), dim3(cfg.waves * 64), lds, stream, t, cfg,
                                static_cast<const uint8_t*>(b.data), static_cast<const uint32_t*>(b.offsets), b.n, b.match_id, b.caps, slots, passthrough,
-                               sizes, nullptr, nullptr);
+                               sizes, nullptr, nullptr, split);
         }
     }
     if (nblocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
@@ -893,27 +962,31 @@ hipError_t launch_jsonl_sizes(const GxJsonl& tm, const GxBatch& b, int slots, in
 
 // Pass 2: write the text.
 hipError_t launch_jsonl_write(const GxJsonl& tm, const GxBatch& b, int slots, int passthrough, uint32_t mean_in, uint32_t mean_out,
-                              const uint64_t* line_out_off, uint8_t* out, hipStream_t stream) {
+                              const uint64_t* line_out_off, uint8_t* out, void* workspace, hipStream_t stream) {
     if (b.n == 0) return hipSuccess;
     JsonlTemplates t{tm.seg_off, tm.lit_off, tm.lit_len, tm.group, tm.fixed_len, tm.lits};
     JsonlTileCfg cfg;
     if (!plan_jsonl_tile(tm, slots, mean_in, std::max<uint32_t>(mean_out, 1u), &cfg)) return hipErrorInvalidValue;
-    const uint32_t lds = cfg.stage0 + cfg.waves * (cfg.in_bytes + cfg.out_bytes + cfg.caps_bytes);
+    // two waves per tile (k_jsonl_tile, PAIR): a workgroup is one pair with one set of staging areas; the split points are
+    // in the workspace the sizes pass of this batch used
+    cfg.waves = 2;
+    uint32_t* split = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(workspace) + jsonl_ws_split(b.n));
+    const uint32_t lds = cfg.stage0 + cfg.in_bytes + cfg.out_bytes + cfg.caps_bytes;
     const uint64_t tiles = (b.n + 63) >> 6;
-    uint64_t blocks = std::min<uint64_t>((tiles + cfg.waves - 1) / cfg.waves, 256u * 4u);
+    const uint64_t blocks = std::min<uint64_t>(tiles, 256u * 16u);
     hipError_t e;
     if (b.offsets64) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jsonl_tile<uint64_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jsonl_tile<uint64_t, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_jsonl_tile<uint64_t, true>), dim3(static_cast<unsigned>(blocks)), dim3(cfg.waves * 64), lds, stream, t, cfg,
+        hipLaunchKernelGGL((k_jsonl_tile<uint64_t, true, 2>), dim3(static_cast<unsigned>(blocks)), dim3(128), lds, stream, t, cfg,
                            static_cast<const uint8_t*>(b.data), static_cast<const uint64_t*>(b.offsets), b.n, b.match_id, b.caps, slots, passthrough,
-                           nullptr, line_out_off, out);
+                           nullptr, line_out_off, out, split);
     } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jsonl_tile<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jsonl_tile<uint32_t, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_jsonl_tile<uint32_t, true>), dim3(static_cast<unsigned>(blocks)), dim3(cfg.waves * 64), lds, stream, t, cfg,
+        hipLaunchKernelGGL((k_jsonl_tile<uint32_t, true, 2>), dim3(static_cast<unsigned>(blocks)), dim3(128), lds, stream, t, cfg,
                            static_cast<const uint8_t*>(b.data), static_cast<const uint32_t*>(b.offsets), b.n, b.match_id, b.caps, slots, passthrough,
-                           nullptr, line_out_off, out);
+                           nullptr, line_out_off, out, split);
     }
     return hipGetLastError();
 }
