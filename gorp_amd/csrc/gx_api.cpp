@@ -1546,12 +1546,10 @@ static int extract_batch_impl(gx_handle* h, const uint8_t* bytes, const void* of
         GxBatch b{};
         b.n = n;
         b.wide = o.utf16 ? 1 : 0;
-        const size_t unit = o.utf16 ? 2 : 1;  // bytes per code unit
         b.offsets64 = o.offsets64 ? 1 : 0;
         b.match_only = match_only ? 1 : 0;
         b.strip_eol = o.strip_eol ? 1 : 0;
         const size_t off_w = o.offsets64 ? 8 : 4;
-        const size_t slots = 2 * static_cast<size_t>(h->T.max_groups);
         if (o.device_pointers) {
             b.data = bytes; b.offsets = offsets;
             b.state_out = states;

@@ -113,7 +113,7 @@ __device__ __forceinline__ uint32_t walk(const WalkTab& W, uint32_t stage, uint3
 }
 
 // Staging copy for a span that touches the first or last bytes of the buffer: never reads outside [data, data_end).
-__device__ void stage_span_guarded(const uint8_t* __restrict__ g_al, uint32_t nch, uint32_t stage, uint32_t lane,
+__device__ __attribute__((unused)) void stage_span_guarded(const uint8_t* __restrict__ g_al, uint32_t nch, uint32_t stage, uint32_t lane,
                                    const uint8_t* data, const uint8_t* data_end) {
     for (uint32_t c = lane; c < nch; c += 64) {
         const uint8_t* src = g_al + (static_cast<uint64_t>(c) << 4);
