@@ -833,6 +833,27 @@ def test_host_pipeline_chunks_and_multi_device_shards():
     assert [got[i] for i in range(0, 40000, 997)] == want
 
 
+def test_host_pipeline_with_the_lane_kernel_on_uneven_lines():
+    """The 64-extraction definition through the host path: several chunks on four worker streams at once, each a launch of
+    the lane kernel on tiles of lines of similar length (the library sees the uneven offsets itself) with its own chunk
+    counter; and the same batch over two handles from two threads."""
+    from gorp_amd.gorp import extract_batch_multi
+    rules, meta = W.syslog_definition(64, seed=3)
+    g1, g2, orc = Gorp.construct(rules), Gorp.construct(rules), oracle_for(rules)
+    data, offsets, cats = W.syslog_lines(meta, 200_000, seed=17, min_len=50, max_len=400)   # 45 MB: five chunks
+    omid, ocaps = orc.extract_batch(data, offsets, nthreads=8)
+    for _ in range(2):   # (the second call reuses the launch slots and their counters)
+        mid, caps = g1.extract_batch(data, offsets)
+        assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+    rows, over = g1.extract_batch(data, offsets, compact=True)
+    cm, cc = G.unpack_rows(rows)
+    assert over == 0 and np.array_equal(cm, omid) and np.array_equal(cc, ocaps)
+    mid, caps = extract_batch_multi([g1, g2], data, offsets)
+    assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+    known = cats != -9
+    assert np.array_equal(mid[known], cats[known])
+
+
 def test_no_hint_no_sync_batches_learn_the_line_length():
     """Asynchronous device-pointer batches that pass no line_bytes_hint: the first one runs with the 200-byte default
     (lines of 600 bytes then go in several rounds per group), later ones with the mean the previous batch measured --
