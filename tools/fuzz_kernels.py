@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: a longer differential run than the test-suite's -- random definitions through every kernel
-variant (LDS tier, L2 tier, slice kernel on both, generic, two-pass layout on both tiers) against the oracle.  Usage: fuzz_kernels.py [defs] [seed]"""
+variant (tile, slice, lane and per-line kernels; dense rows in LDS / L2, range records in LDS / global memory; fused and
+two-pass layouts; dense and compact result rows -- the `variants` list below) against the oracle.  Usage: fuzz_kernels.py [defs] [seed]"""
 import os, sys, random
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool: what a plain read-only sweep of the 2 GB line buffer achieves on this box (torch reductions),
-next to the copy calibration of tools/ablate.py."""
+next to a plain copy of it."""
 import torch
 n = 2_000_000_000
 x = torch.randint(0, 255, (n,), dtype=torch.uint8, device="cuda")
