@@ -23,6 +23,12 @@ if mixed:
     data, off, cats = W.syslog_lines(meta, base_n, seed=5, min_len=int(sys.argv[3]), max_len=int(sys.argv[4]))
 else:
     data, off, cats = W.syslog_lines(meta, base_n, seed=3)
+if os.environ.get("GX_BENCH_BY_RULE"):  # lines of one extraction next to each other (a log with bursts of one source), not shuffled
+    order = np.argsort(cats, kind="stable")
+    lens = np.diff(off.astype(np.int64))[order]
+    data = np.concatenate([data[off[i]:off[i + 1]] for i in order])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(off.dtype)
+    cats = cats[order]
 reps = max(1, n // base_n)
 d = torch.from_numpy(data.copy()).cuda().repeat(reps)
 total = int(off[-1])
