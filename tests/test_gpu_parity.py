@@ -371,6 +371,13 @@ def test_config3_64_rules_parity(flags):
     rows, over = gorp.extract_batch(ud, uo, compact=True)
     cm, cc = G.unpack_rows(rows)
     assert over == 0 and np.array_equal(cm, umid) and np.array_equal(cc, ucaps)
+    # device buffers, no hint, synchronous: the library reads the mean length and a sample of the offsets itself
+    import torch
+    dd, do = torch.from_numpy(ud.copy()).cuda(), torch.from_numpy(uo.astype(np.int64)).cuda().to(torch.uint32)
+    dm = torch.empty(len(uo) - 1, dtype=torch.int32, device="cuda")
+    dc = torch.empty((len(uo) - 1, 2 * gorp.max_groups), dtype=torch.int32, device="cuda")
+    gorp.extract_batch_device(dd.data_ptr(), do.data_ptr(), len(uo) - 1, dm.data_ptr(), dc.data_ptr())
+    assert np.array_equal(dm.cpu().numpy(), umid) and np.array_equal(dc.cpu().numpy(), ucaps)
     if flags != N.GX_CREATE_TIER_L2:
         mid, caps = gorp.extract_batch(data, offsets, kernel=N.GX_KERNEL_TILES)
         assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
