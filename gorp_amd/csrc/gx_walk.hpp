@@ -191,11 +191,7 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
             asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(in_line) : "v"(mask), "n"(j));
             asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(b) : "v"(in_line), "v"(b), "v"(256u));
         }
-#if GX_EXP == 2
-        c4[j] = (b & 31u) * 0x80001u;
-#else
         c4[j] = TierTraits<TIER>::records ? lds_ld<uint32_t>(b << 2) : lds_ld<uint16_t>(b << 1);
-#endif
     }
     const uint32_t dummy_col = regs - 128u;
     if (TierTraits<TIER>::records) {
@@ -262,18 +258,13 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
             if (CAPTURE) {
                 const uint16_t pos = static_cast<uint16_t>(rel + j);
                 if (SIMPLE) {
-#if GX_EXP == 1
-                    asm volatile("" :: "v"(dummy_col + (op << 7)), "v"(pos));
-#else
                     lds_st<uint16_t>(dummy_col + (op << 7), pos);
-#endif
                 } else if (op) {
                     if (op & 0x80u) lds_st<uint16_t>(regs + (op & 0x7Fu) * 128u, pos);
                     else run_op_list(W, regs, op, pos);
                 }
             }
         }
-#ifndef GX_EXP_NORERUN
         if (ASM_STEP && more != 0ull) {
             // Some lane met a state with two records and found its class in neither range of the first: that lane went to
             // the dead state above (and wrote nothing but the dummy column from there on).  Walk the window again with
@@ -292,7 +283,6 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
                 if (CAPTURE) lds_st<uint16_t>(dummy_col + (op << 7), static_cast<uint16_t>(rel + j));  // (SIMPLE programs only here)
             }
         }
-#endif
         return row;
     }
 #pragma unroll
