@@ -400,7 +400,7 @@ def _tiled_on_device(data, offsets, reps):
     return d, o.to(torch.uint32)
 
 
-def _full_size_properties(gorp, orc, data, offsets, cats, reps, hint):
+def _full_size_properties(gorp, orc, data, offsets, cats, reps, hint, uneven=0):
     """Size-independent checks of a tiled batch at its full benchmark size: the generator's answers, every copy of the
     sample identical to the first, idempotence, both result formats agreeing, and an oracle-checked strided sample."""
     import torch
@@ -411,7 +411,7 @@ def _full_size_properties(gorp, orc, data, offsets, cats, reps, hint):
     mid = torch.empty(n, dtype=torch.int32, device="cuda")
     caps = torch.empty((n, 2 * G_), dtype=torch.int32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    gorp.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=st, line_bytes_hint=hint)
+    gorp.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=st, line_bytes_hint=hint, uneven=uneven)
     torch.cuda.synchronize()
     known = torch.from_numpy(cats != -9).cuda().repeat(reps)
     want = torch.from_numpy(cats).cuda().repeat(reps)
@@ -419,13 +419,13 @@ def _full_size_properties(gorp, orc, data, offsets, cats, reps, hint):
     assert torch.equal(mid.view(reps, base_n), mid[:base_n].expand(reps, base_n))   # every copy like the first ...
     assert torch.equal(caps.view(reps, base_n, 2 * G_), caps[:base_n].expand(reps, base_n, 2 * G_))  # ... offsets included
     mid2, caps2 = torch.empty_like(mid), torch.empty_like(caps)
-    gorp.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid2.data_ptr(), caps2.data_ptr(), stream=st, line_bytes_hint=hint)
+    gorp.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid2.data_ptr(), caps2.data_ptr(), stream=st, line_bytes_hint=hint, uneven=uneven)
     torch.cuda.synchronize()
     assert torch.equal(mid, mid2) and torch.equal(caps, caps2)        # idempotence
     rows = torch.empty((n, 1 + 2 * G_), dtype=torch.int16, device="cuda")
     over = torch.zeros(1, dtype=torch.int64, device="cuda")
     gorp.extract_batch_device(d.data_ptr(), o.data_ptr(), n, None, rows.data_ptr(), stream=st, line_bytes_hint=hint, compact=True,
-                              overflow_ptr=over.data_ptr())
+                              overflow_ptr=over.data_ptr(), uneven=uneven)
     torch.cuda.synchronize()
     assert int(over.item()) == 0 and torch.equal(rows[:, 0].to(torch.int32), mid)
     assert torch.equal(rows[:, 1:].to(torch.int32), caps)             # (-1 stays -1 through int16; offsets < 32768 here)
@@ -451,6 +451,16 @@ def test_config3_full_size_properties():
     gorp, orc = Gorp.construct(rules), oracle_for(rules)
     data, offsets, cats = W.syslog_lines(meta, 100_000, seed=3)
     _full_size_properties(gorp, orc, data, offsets, cats, 100, 200)
+
+
+def test_config3_uneven_lines_full_size_properties():
+    """The 64 extractions over 8.5 M lines of 50-400 bytes (1.9 GB), announced as uneven: the lane kernel on tiles of lines of
+    similar length (4 000 chunks handed out by the launch's counter), at full size."""
+    rules, meta = W.syslog_definition(64, seed=3)
+    gorp, orc = Gorp.construct(rules), oracle_for(rules)
+    data, offsets, cats = W.syslog_lines(meta, 100_000, seed=21, min_len=50, max_len=400)
+    total = int(offsets[-1])
+    _full_size_properties(gorp, orc, data, offsets, cats, 1_900_000_000 // total, int(total / 100_000 + 0.999), uneven=2)
 
 
 def test_config5_full_size_properties():
