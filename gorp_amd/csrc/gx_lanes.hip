@@ -1,18 +1,21 @@
-// gx_lanes.hip -- a batch kernel for definitions whose dense rows do not fit LDS (tables in global memory, or range
-// records in LDS): every lane keeps ITS OWN line in registers.
+// gx_lanes.hip -- the batch kernel for definitions whose dense rows do not fit LDS (range records in LDS; dense rows or
+// records in global memory) and for uneven lines on any tables: every lane keeps ITS OWN line in registers.
 //
 // Replaces, per line, the same reference code as the tile kernel (gx_tile_body.hpp):
 //   PolyMatcher.match core/autom/PolyMatcher.java:123-133, Automata.step/accept core/autom/Automata.java:133-139,
 //   JDKRegexpCookedExtraction.match core/jdkre/JDKRegexpCookedExtraction.java:36-59, Gorp.extract core/Gorp.java:159-186.
 //
-// With the tables in global memory every byte position costs the lock-step wave one dependent gather (hundreds of
-// cycles), and what bounds the throughput is how many lines a CU has in flight.  The tile kernel stages whole tiles
-// in LDS -- 250 bytes of LDS per line in flight, 10 waves per CU.  Here a lane loads its line 16 bytes at a time into
-// KCH x 4 registers (unaligned global loads at the lane's own address: poorly coalesced, but 13 load instructions per
-// tile are nothing beside ~150 gathers, and every cache line is still fetched from HBM once -- the repeats hit L1/L2),
-// walks the KCH windows with static register indexes (all lanes are at the same window of their own line, as in the
-// tile kernel), and loads the next KCH x 16 bytes.  LDS holds only the class map, the capture registers (reused as the
-// transpose buffer of the results) and the programs, so the registers -- not LDS -- bound the waves per CU.
+// With large tables every byte position costs the lock-step wave one dependent lookup (an LDS record read, or a gather
+// from L2), and what bounds the throughput is how many lines a CU has in flight.  The tile kernel stages whole tiles in
+// LDS -- 250 bytes of LDS per line in flight, 6-10 waves per CU beside the tables.  Here a lane loads its line 16 bytes
+// at a time into KCH x 4 registers (plain loads at the lane's own address: a lane returns to the same cache line for its
+// next 16 bytes and finds it in the vector L1), the wave walks the KCH windows in lock step with ONE copy of the window
+// code (the window is always taken from register slot 0, the others move down), and loads the next KCH x 16 bytes.  LDS
+// holds only the tables, the capture registers and the wave's result rows, so one workgroup of 16 waves shares one
+// copy of the tables.
+// SORTED: a lane does not need its tile's lines to be neighbours in memory, so for uneven lines a workgroup orders the
+// lines of a chunk by length first and forms its tiles from lines of similar length (a tile takes as long as its longest
+// line); chunks are handed out by a counter in global memory.
 #include "gx_walk.hpp"
 
 namespace gx {
