@@ -90,6 +90,22 @@ def cpu_baseline(definition, data_cpu, offsets_cpu, budget_s=20.0):
             "reference_jvm": reference_jvm_probe()}, mid, caps, n
 
 
+def self_launch(n_ranks):
+    """Start `n_ranks` ranks of this script (one per GPU) through torch.distributed.run in a CHILD process -- never an
+    exec: this parent stays as it is, waits, passes the ranks' output through and returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def build_workload(config, n, rank, dev):
     """(definition, data u8[total] on dev, offsets u32[n+1] on dev, n, expected match ids or None, known mask or None,
     line_bytes_hint, description)."""
@@ -139,12 +155,15 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` with no launcher: this process has not touched the GPU (torch is not even imported
+        # yet), so it starts the N ranks as fresh child processes and relays rank 0's line and the exit code.
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 bench.py --gpus N ...` (one rank per GPU)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's world size and --gpus must agree" % (args.gpus, world))
     config = args.config or (2 if world == 1 else 4)
 
     import numpy as np

@@ -294,6 +294,7 @@ bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t ro
     auto pack_w1 = [&](uint32_t target, uint32_t op, bool more, bool hdr) {
         return wide ? (target | op << 22 | (hdr ? 1u << 30 : 0u) | (more ? 1u << 31 : 0u)) : (target | op << 16 | (hdr ? REC_HDR : 0u) | (more ? REC_MORE : 0u));
     };
+#ifdef GX_DEV
     if (getenv("GX_REC_STATS")) {
         size_t multi = 0, self_split = 0, self_states = 0;
         std::map<size_t, size_t> hist;
@@ -308,6 +309,7 @@ bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t ro
         for (auto& b : blocks) { order += "["; for (int c : b) { for (int by = 0; by < 256; ++by) if (T.cls256[by] == c) { order += (by > 32 && by < 127) ? static_cast<char>(by) : '.'; break; } } order += "]"; }
         fprintf(stderr, "  class order: %s\n", order.c_str());
     }
+#endif
     // pass 2: emit
     std::vector<uint32_t> items(2 * n_items + 2, 0);  // (+ one: the second-record pass reads record [state + 1] of every state)
     items[0] = REC_EMPTY | (REC_EMPTY << 16);  // record 0: the dead state
@@ -948,7 +950,8 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
 #endif
         GX_HIP(launch_extract_lanes(h->dev, L, image, at_global, h->num_cus, b, stream, stamps));
         if (L.sort_chunk) h->chunk_tickets[slot] += lanes_sorted_tickets(b.n, L.sort_chunk, h->num_cus);  // (what the launch will draw)
-        GX_HIP(launch_extract_oversize(h->dev, b, 65535u + 48u, stream));
+        // (the lines the lane kernel leaves: longer than its 16-bit positions -- with compact rows, than the 65 534 they can hold)
+        GX_HIP(launch_extract_oversize(h->dev, b, (b.packed ? 65534u : 65535u) + 48u, stream));
         GX_HIP(hipEventRecord(h->slot_event[slot], stream));
         return;
     }

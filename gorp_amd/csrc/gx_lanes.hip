@@ -165,8 +165,11 @@ k_extract_lanes(GxLds L, LanesIO io) {
                 if (len64 > 0 && data[o0 + len64 - 1] == 0x0Au) --len64;
                 if (len64 > 0 && data[o0 + len64 - 1] == 0x0Du) --len64;
             }
-            // positions are 16-bit in the register block: a longer line is left to the follow-up launch of the per-line kernel
-            const bool oversize = valid && len64 > 65535u;
+            // positions are 16-bit in the register block: a longer line is left to the follow-up launch of the per-line kernel.
+            // Compact rows keep 0xFFFF for "unset" and promise that an offset above 65 534 is stored as 65 534 and counted
+            // (include/gorp_hip.h): a line of exactly 65 535 bytes can have such an offset, so it goes the same way (the
+            // per-line kernel writes through LineOut, which clamps and counts).
+            const bool oversize = valid && len64 > (PACKED ? 65534u : 65535u);
             if (oversize) __hip_atomic_store(io.oversize_flag, io.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t len = oversize ? 0u : static_cast<uint32_t>(len64);
             const uint8_t* line = data + o0;
@@ -236,7 +239,8 @@ k_extract_lanes(GxLds L, LanesIO io) {
                 const uint64_t i0 = i - lane;
                 if (PACKED) {
                     const uint32_t row_b = 2u + 2u * slots;
-                    if (full_tile) {
+                    const bool rows_aligned = (reinterpret_cast<uintptr_t>(io.packed) & 15u) == 0u;  // (16-byte stores below)
+                    if (full_tile && rows_aligned) {
                         // the tile's 64 rows are one contiguous block of the output: through the wave's row area, then 1 KiB of
                         // consecutive bytes per store instruction
                         const uint32_t my_out = out_area + lane * row_b;

@@ -405,7 +405,8 @@ k_extract_tile(GxLds L, TileIO io) {
             if (PACKED) {
                 const uint32_t row_b = 2u + 2u * slots;  // u16 id + u16 offsets
                 uint16_t* out_rows = io.packed + (cur.i - lane) * static_cast<uint64_t>(1u + slots);
-                if (full_tile && 64u * row_b + 16u <= L.stage_bytes) {  // (64 rows are a multiple of 16 bytes, and so is their address)
+                const bool rows_aligned = (reinterpret_cast<uintptr_t>(io.packed) & 15u) == 0u;  // (64 rows are a multiple of 16 bytes)
+                if (full_tile && rows_aligned && 64u * row_b + 16u <= L.stage_bytes) {
                     const uint32_t my_row = stage + lane * row_b;
                     const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
                         lds_st<uint16_t>(my_row + 2u + 4u * g, static_cast<uint16_t>(pb));

@@ -47,3 +47,16 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in src.lower(), os.path.join(dirpath, f)
+
+
+def test_release_library_reads_no_environment_variables():
+    """the product library carries no developer hooks.  No GX_* environment name is in the shipped
+    binary (they live behind -DGX_DEV in libgorp_hip_dev.so) and `getenv` is not among its imports."""
+    import re
+    import subprocess
+    from gorp_amd import build as gbuild
+    blob = open(gbuild.LIB, "rb").read()
+    names = set(re.findall(rb"GX_(?:DEV|REC|DEBUG|BENCH|PROF)[A-Z0-9_]*", blob))
+    assert not names, names
+    syms = subprocess.run(["nm", "-D", "--undefined-only", gbuild.LIB], capture_output=True, text=True).stdout
+    assert "getenv" not in syms

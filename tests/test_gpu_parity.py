@@ -611,6 +611,28 @@ def test_two_ranks_share_one_gpu():
     assert r.returncode == 0 and "dist_gpu_worker ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
+def test_bench_two_ranks_self_launched():
+    """`python bench.py --gpus 2` with no launcher, as the driver spells the scaling runs: the parent starts the ranks as
+    fresh child processes and relays rank 0's line.  Both ranks share the one GPU of the box, so the process group is gloo
+    (RCCL refuses two ranks on one device); everything else -- blob broadcast, per-rank shards, the timed steps with
+    barriers and max over ranks, the final gathers -- is config 4's path."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["GORP_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--lines", "200000", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["baseline_config"] == 4 and out["scaling"] == "weak"
+    assert out["table_bcast_ms"] is not None and out["gather_ms"] is not None and out["value"] > 0
+
+
 def test_utf16_batch_input():
     """gx_batch_opts.utf16: the batch entry point over UTF-16 code units (what the Java Strings hold)."""
     definition = [FlattenedExtraction("kv", [["text", "k="], ["extractor", "v", [["pattern", "[^ ]+"]]], ["pattern", "( .*)?"]]),
@@ -671,6 +693,37 @@ def test_slice_kernel_agrees_with_oracle(tier, monkeypatch):
     cd, co = lines_to_csr(want_lines)
     om3, oc3 = orc.extract_batch(cd, co, nthreads=8)
     assert np.array_equal(m3, om3) and np.array_equal(c3, oc3)
+
+
+@pytest.mark.parametrize("kernel", [N.GX_KERNEL_LANES, N.GX_KERNEL_TILES, N.GX_KERNEL_SLICES, N.GX_KERNEL_PER_LINE])
+def test_compact_rows_at_the_16_bit_boundary(kernel):
+    """A capture that ends at offset 65 535 does not fit a compact row (0xFFFF = unset): every kernel stores 65 534 and
+    counts it (include/gorp_hip.h), also the lane kernel, whose positions are 16-bit (round-2 advisor finding)."""
+    definition = W.readme3_definition()
+    gorp, orc = Gorp.construct(definition), oracle_for(definition)
+    head = "[1]: GET 5ms /"
+    lines = [head + "x" * (n - len(head)) for n in (65533, 65534, 65535, 65536, 65537)] + ["[2]: PUT 1ms /y"] * 70
+    data, offsets = lines_to_csr(lines)
+    omid, ocaps = orc.extract_batch(data, offsets)
+    assert [int(c[7]) for c in ocaps[:5]] == [65533, 65534, 65535, 65536, 65537]
+    rows, over = gorp.extract_batch(data, offsets, compact=True, kernel=kernel)
+    cm, cc = G.unpack_rows(rows)
+    big = ocaps > 65534
+    assert over == int(big.sum()) == 3
+    assert np.array_equal(cm, omid) and np.array_equal(cc, np.where(big, 65534, ocaps))
+    mid, caps = gorp.extract_batch(data, offsets, kernel=kernel)
+    assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+    # rows at an address that is not 16-byte aligned (the kernels' 16-byte row stores need the guard)
+    import torch
+    n = len(lines)
+    slots = 2 * gorp.max_groups
+    buf = torch.zeros(n * (1 + slots) + 8, dtype=torch.int16, device="cuda")
+    d_dev, o_dev = torch.from_numpy(data).cuda(), torch.from_numpy(offsets.astype(np.int64)).to(torch.uint32).cuda()
+    view = buf[1:1 + n * (1 + slots)]
+    gorp.extract_batch_device(d_dev.data_ptr(), o_dev.data_ptr(), n, None, view.data_ptr(), compact=True, kernel=kernel)
+    torch.cuda.synchronize()
+    um, uc = G.unpack_rows(view.cpu().numpy().view(np.uint16).reshape(n, 1 + slots))
+    assert np.array_equal(um, omid) and np.array_equal(uc, np.where(big, 65534, ocaps))
 
 
 def test_cooked_extraction_match_is_the_capture_regexp_alone(golden):
