@@ -11,9 +11,11 @@ synthetic log lines that is already resident in HBM.  Workloads (BASELINE.json `
   4  config 3's definition, 10 M lines PER GPU, table blob broadcast + final gather  (default at N > 1)
   5  512 extractions, lines of 50-2000 bytes, ~2 GB
 
-Results leave the kernel as compact rows (int16 match id + uint16 capture offsets per line: what the gather between
-GPUs sends, gx_batch_opts.compact_results) unless --results dense; the other format is timed beside it and reported
-in `other_format`.
+Result formats (gx_batch_opts.compact_results): `dense` int32 match id + int32 offsets (4 + 8 G bytes per line), `compact`
+rows of int16 id + uint16 offsets (2 + 4 G; what the gather between GPUs sends), `narrow` rows of int8 id + uint8 offsets
+(1 + 2 G; for batches whose lines are shorter than 255 bytes and definitions of at most 126 extractions).  --results auto
+(the default) takes the narrowest format the workload allows; ALL applicable formats are timed with the full step count
+and reported in `formats`, the headline one is named in `metric` and `config.results`.
 
 Multi-GPU (launched by torch.distributed.run, one rank per GPU, RCCL): rank 0 compiles the tables and broadcasts the
 packed blob; every rank builds its handle from the blob, generates its own shard (seeded by rank), and runs the same
@@ -150,7 +152,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5], help="BASELINE.md config (0: 2 at one GPU, 4 at several)")
     ap.add_argument("--lines", type=int, default=0, help="lines per GPU (0: the config's size)")
-    ap.add_argument("--results", default="compact", choices=["compact", "dense"])
+    ap.add_argument("--results", default="auto", choices=["auto", "narrow", "compact", "dense"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     args = ap.parse_args()
@@ -209,6 +211,13 @@ def main():
     mid = torch.empty(n, dtype=torch.int32, device=dev)
     caps = torch.empty((n, 2 * G), dtype=torch.int32, device=dev)
     rows = torch.empty((n, 1 + 2 * G), dtype=torch.int16, device=dev)
+    rows8 = torch.empty((n, 1 + 2 * G), dtype=torch.uint8, device=dev)
+    max_line = int((offsets[1:].to(torch.int64) - offsets[:-1].to(torch.int64)).max().item())
+    narrow_ok = max_line < 255 and len(definition) <= 126
+    formats = (["narrow"] if narrow_ok else []) + ["compact", "dense"]
+    headline = args.results if args.results != "auto" else formats[0]
+    if headline not in formats:
+        raise SystemExit("--results narrow needs lines shorter than 255 bytes and at most 126 extractions")
     overflow = torch.zeros(1, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -216,6 +225,9 @@ def main():
         if fmt == "compact":
             gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, None, rows.data_ptr(), stream=stream, no_sync=True,
                                       line_bytes_hint=hint, compact=True, overflow_ptr=overflow.data_ptr())
+        elif fmt == "narrow":
+            gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, None, rows8.data_ptr(), stream=stream, no_sync=True,
+                                      line_bytes_hint=hint, compact=2, overflow_ptr=overflow.data_ptr())
         else:
             gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=stream, no_sync=True,
                                       line_bytes_hint=hint)
@@ -244,12 +256,13 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()), [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
 
-    other = "dense" if args.results == "compact" else "compact"
-    other_elapsed, other_ms = timed(other, max(3, min(args.steps, 5)), 2)   # the other result format, a few steps, reported beside
-    elapsed, kernel_ms = timed(args.results, args.steps, args.warmup)        # THE timed region
+    runs = {}
+    for fmt in [f for f in formats if f != headline]:
+        runs[fmt] = timed(fmt, args.steps, args.warmup)                      # the other result formats, same step count, reported beside
+    elapsed, kernel_ms = runs[headline] = timed(headline, args.steps, args.warmup)   # THE timed region
 
     # ---- correctness of what was timed: the generator knows every (uncorrupted) line's answer ----
-    got = rows[:, 0].to(torch.int32) if args.results == "compact" else mid
+    got = {"compact": lambda: rows[:, 0].to(torch.int32), "narrow": lambda: rows8[:, 0].view(torch.int8).to(torch.int32), "dense": lambda: mid}[headline]()
     ok = bool(torch.equal(got, want)) if known is None else bool(torch.equal(got[known], want[known]))
     ok = ok and int(overflow.item()) == 0
     okt = torch.tensor([1 if ok else 0], device=dev)
@@ -261,8 +274,10 @@ def main():
     # ---- final gather of results to rank 0 over xGMI (reported, not in `value`) ----
     gather_ms = None
     gather_dense_ms = None
+    gather_narrow_ms = None
     if distributed and not args.no_gather:
-        step("compact"); step("dense")
+        for fmt in formats:
+            step(fmt)
         torch.cuda.synchronize()
         dist.barrier()
         tg = time.perf_counter()
@@ -278,6 +293,16 @@ def main():
         if rank == 0:
             assert gr.shape[0] == gm.shape[0] and torch.equal(gr[:n], rows) and torch.equal(gm[:n], mid) and torch.equal(gc[:n], caps)
             assert torch.equal(gr[:, 0].to(torch.int32), gm)
+        if narrow_ok:
+            torch.cuda.synchronize()
+            dist.barrier()
+            tg = time.perf_counter()
+            g8 = gdist.gather_rows(rows8, dst=0)          # the u8 rows: a quarter of the dense bytes on the links
+            torch.cuda.synchronize()
+            gather_narrow_ms = (time.perf_counter() - tg) * 1e3
+            if rank == 0:
+                assert torch.equal(g8[:n], rows8) and torch.equal(g8[:, 0].view(torch.int8).to(torch.int32), gm)
+            del g8
         del gr, gm, gc
 
     if rank == 0:
@@ -287,24 +312,35 @@ def main():
         k_avg = sum(kernel_ms) / len(kernel_ms)
         k_sorted = sorted(kernel_ms)
         algo_read = total_bytes + 4 * (n + 1)            # line bytes + u32 offsets
-        write_bytes = {"compact": n * (2 + 4 * G), "dense": n * (4 + 8 * G)}
+        write_bytes = {"narrow": n * (1 + 2 * G), "compact": n * (2 + 4 * G), "dense": n * (4 + 8 * G)}
+        fmt_desc = {"narrow": "narrow rows (int8 id + uint8 offsets, %d B/line)" % (1 + 2 * G),
+                    "compact": "compact rows (int16 id + uint16 offsets, %d B/line)" % (2 + 4 * G),
+                    "dense": "dense (int32 id + int32 offsets, %d B/line)" % (4 + 8 * G)}
         achieved = algo_read / (k_avg * 1e-3) / 1e9
         # HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this kernel on this exact workload
         # (tools/collect_profiles.sh: FETCH_SIZE doubled per the gfx950 correction, calibrated against a same-size copy
         # kernel in the same run).  Counters cannot be read from inside this process: the RECORDED figure of the committed
         # summary is reported when its workload and result format match this run, else null.
         traffic, traffic_src = None, None
-        try:
-            path = os.path.join(ROOT, "profiles", "r02_traffic.json")
-            tj = json.load(open(path))
-            if tj["algorithmic_read_bytes"] == algo_read and tj["algorithmic_write_bytes"] == write_bytes[args.results]:
-                traffic = tj["traffic_bytes_per_launch"]
-                traffic_src = "recorded: profiles/r02_traffic.json (%s)" % time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(path)))
-        except (OSError, ValueError, KeyError):
-            pass
-        o_avg = sum(other_ms) / len(other_ms)
+        for name in ("r03_traffic.json", "r02_traffic.json"):
+            try:
+                path = os.path.join(ROOT, "profiles", name)
+                tj = json.load(open(path))
+                if tj["algorithmic_read_bytes"] == algo_read and tj["algorithmic_write_bytes"] == write_bytes[headline]:
+                    traffic = tj["traffic_bytes_per_launch"]
+                    traffic_src = "recorded: profiles/%s (%s)" % (name, time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(path))))
+                    break
+            except (OSError, ValueError, KeyError):
+                pass
+        per_format = {}
+        for fmt, (f_elapsed, f_ms) in runs.items():
+            f_avg = sum(f_ms) / len(f_ms)
+            per_format[fmt] = {"results": fmt_desc[fmt], "steps": len(f_ms), "lines_per_s": n * world * len(f_ms) / f_elapsed,
+                               "ms_per_step": f_elapsed * 1e3 / len(f_ms), "kernel_ms_avg": f_avg,
+                               "algorithmic_write_bytes": write_bytes[fmt], "read_gb_per_s": algo_read / (f_avg * 1e-3) / 1e9,
+                               "frac": algo_read / (f_avg * 1e-3) / 1e9 / HBM_PEAK_GBS}
         out = {
-            "metric": "lines/sec (Gorp.extract: product-DFA match + capture offsets)",
+            "metric": "lines/sec (Gorp.extract: product-DFA match + capture offsets; results as %s)" % fmt_desc[headline],
             "value": value,
             "unit": "lines/s",
             "n_gpus": world,
@@ -318,8 +354,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc, "baseline_config": config,
                        "lines_per_gpu": n, "mean_line_bytes": total_bytes / n, "offsets": "u32",
-                       "results": args.results + (" rows (int16 id + uint16 offsets, %d B/line)" % (2 + 4 * G) if args.results == "compact"
-                                                  else " (int32 id + int32 offsets, %d B/line)" % (4 + 8 * G)),
+                       "results": fmt_desc[headline], "max_line_bytes": max_line,
                        "match_dfa_states": int(gorp.stat(0)), "char_classes": int(gorp.stat(1)),
                        "capture_states": int(gorp.stat(2)), "table_blob_bytes": int(gorp.stat(4)),
                        "table_tier": {0: "per-line kernel", 1: "LDS (dense rows)", 2: "L2 (dense rows)", 3: "LDS (range records)", 4: "L2 (range records)"}.get(int(gorp.stat(7)), str(gorp.stat(7))),
@@ -329,15 +364,14 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,
-                         "algorithmic_read_bytes": algo_read, "algorithmic_write_bytes": write_bytes[args.results],
+                         "algorithmic_read_bytes": algo_read, "algorithmic_write_bytes": write_bytes[headline],
                          "frac_of_measured_copy_ceiling": achieved / 6290.0},
-            "other_format": {"results": other, "kernel_ms_avg": o_avg, "lines_per_s": n * world * len(other_ms) / other_elapsed,
-                             "algorithmic_write_bytes": write_bytes[other], "read_gb_per_s": algo_read / (o_avg * 1e-3) / 1e9,
-                             "frac": algo_read / (o_avg * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "formats": per_format,
             "setup_s": setup_s,
             "table_bcast_ms": bcast_ms,
             "gather_ms": gather_ms,
             "gather_dense_ms": gather_dense_ms,
+            "gather_narrow_ms": gather_narrow_ms,
         }
         if not args.no_cpu_baseline and world == 1:
             sample = min(n, 10_000_000 if config == 2 else 2_000_000)
@@ -346,11 +380,16 @@ def main():
             o_cpu = offsets[: sample + 1].cpu().numpy().astype(np.uint32)
             base, omid, ocaps, ns = cpu_baseline(definition, d_cpu, o_cpu)
             # the baseline run doubles as a parity check of the timed GPU output (both formats)
-            step("compact"); step("dense")
+            for fmt in formats:
+                step(fmt)
             torch.cuda.synchronize()
             cm, cc = unpack_rows(rows[:ns].cpu().numpy().view(np.uint16))
-            if not (np.array_equal(mid[:ns].cpu().numpy(), omid) and np.array_equal(caps[:ns].cpu().numpy(), ocaps) and
-                    np.array_equal(cm, omid) and np.array_equal(cc, ocaps)):
+            same = (np.array_equal(mid[:ns].cpu().numpy(), omid) and np.array_equal(caps[:ns].cpu().numpy(), ocaps) and
+                    np.array_equal(cm, omid) and np.array_equal(cc, ocaps))
+            if narrow_ok:
+                nm, nc = unpack_rows(rows8[:ns].cpu().numpy())
+                same = same and np.array_equal(nm, omid) and np.array_equal(nc, ocaps)
+            if not same:
                 raise SystemExit("bench: GPU results differ from the oracle on the baseline sample")
             out["cpu_baseline"] = base
         print(json.dumps(out), flush=True)

@@ -35,7 +35,7 @@ SYMBOLS = [
     "gx_extraction_name", "gx_extractor_name", "gx_extraction_append_json",
     "gx_split_lines", "gx_results_to_jsonl", "gx_set_extraction_meta",
     "gx_extraction_append_count", "gx_extraction_append_key", "gx_extraction_append_value_json",
-    "gx_pack_results", "gx_unpack_results", "gx_text_to_jsonl", "gx_capture_one_utf16",
+    "gx_pack_results", "gx_unpack_results", "gx_unpack_results8", "gx_text_to_jsonl", "gx_capture_one_utf16",
     "gx_match_batch", "gx_state_accepts", "gx_set_device", "gx_handle_device", "gx_extract_batch_multi",
     "gx_host_register", "gx_host_unregister",
 ]
@@ -180,6 +180,8 @@ def lib():
     L.gx_pack_results.restype = C.c_int
     L.gx_unpack_results.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(gx_batch_opts)]
     L.gx_unpack_results.restype = C.c_int
+    L.gx_unpack_results8.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(gx_batch_opts)]
+    L.gx_unpack_results8.restype = C.c_int
     L.gx_extraction_append_count.argtypes = [C.c_void_p, C.c_int32]
     L.gx_extraction_append_count.restype = C.c_int32
     for f in ("gx_extraction_append_key", "gx_extraction_append_value_json"):

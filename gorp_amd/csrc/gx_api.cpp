@@ -1393,6 +1393,18 @@ int gx_unpack_results(const uint16_t* packed, uint64_t n, int32_t slots, int32_t
     } catch (GxError& e) { return fail(e.code, e.what()); }
 }
 
+int gx_unpack_results8(const uint8_t* rows, uint64_t n, int32_t slots, int32_t* match_id, int32_t* caps, const gx_batch_opts* opts) {
+    if (slots < 0 || (n && (!match_id || !rows || (slots && !caps)))) return fail(GX_E_ARG, "gx_unpack_results8: bad argument");
+    gx_batch_opts o{};
+    if (!read_opts(opts, &o)) return fail(GX_E_ARG, "gx_batch_opts.struct_size mismatch");
+    try {
+        hipStream_t stream = static_cast<hipStream_t>(o.stream);
+        GX_HIP(launch_unpack_results8(rows, n, slots, match_id, caps, stream));
+        if (!o.no_sync) GX_HIP(hipStreamSynchronize(stream));
+        return GX_OK;
+    } catch (GxError& e) { return fail(e.code, e.what()); }
+}
+
 int gx_set_extraction_meta(gx_handle* h, int32_t k, const char* name, const char* const* extractor_names, int32_t n_names,
                            const char* append_json) {
     if (!h || !name || k < 0 || k >= h->T.n_rules || n_names < 0 || (n_names && !extractor_names))
@@ -1471,8 +1483,9 @@ static void host_pipeline(gx_handle* h, const GxBatch& proto, const uint8_t* byt
                 if (nbytes) GX_HIP(hipMemcpyAsync(place, bytes + b0, nbytes, hipMemcpyHostToDevice, sl.stream));
                 GX_HIP(hipMemcpyAsync(sl.d_off, static_cast<const uint8_t*>(offsets) + a * off_w, (m + 1) * off_w, hipMemcpyHostToDevice, sl.stream));
                 if (states) { grow(sl.d_states, sl.cap_states, m * 4); b.state_out = static_cast<int32_t*>(sl.d_states); }
+                const size_t row_bytes = (1 + slots) * (proto.narrow ? 1 : 2);  // compact rows: u8 or u16 entries
                 if (compact) {
-                    grow(sl.d_res, sl.cap_res, m * (1 + slots) * 2);
+                    grow(sl.d_res, sl.cap_res, m * row_bytes);
                     GX_HIP(hipMemsetAsync(sl.d_over, 0, 8, sl.stream));
                     b.packed = static_cast<uint16_t*>(sl.d_res);
                     b.overflow = sl.d_over;
@@ -1484,7 +1497,7 @@ static void host_pipeline(gx_handle* h, const GxBatch& proto, const uint8_t* byt
                 launch_batch(h, b, hint, kernel, sl.stream, uneven);
                 unsigned long long over = 0;
                 if (compact) {
-                    GX_HIP(hipMemcpyAsync(reinterpret_cast<uint16_t*>(caps) + a * (1 + slots), sl.d_res, m * (1 + slots) * 2, hipMemcpyDeviceToHost, sl.stream));
+                    GX_HIP(hipMemcpyAsync(reinterpret_cast<uint8_t*>(caps) + a * row_bytes, sl.d_res, m * row_bytes, hipMemcpyDeviceToHost, sl.stream));
                     GX_HIP(hipMemcpyAsync(&over, sl.d_over, 8, hipMemcpyDeviceToHost, sl.stream));
                 } else {
                     GX_HIP(hipMemcpyAsync(match_id + a, sl.d_res, m * 4, hipMemcpyDeviceToHost, sl.stream));
@@ -1540,7 +1553,10 @@ static int extract_batch_impl(gx_handle* h, const uint8_t* bytes, const void* of
     if (!read_opts(opts, &o)) return fail(GX_E_ARG, "gx_batch_opts.struct_size mismatch");
     if (o.kernel > GX_KERNEL_LANES) return fail(GX_E_ARG, "gx_batch_opts.kernel: unknown kernel");
     const bool match_only = o.match_only || states || !h->T.has_capture;
-    const bool compact = o.compact_results && !match_only;  // rows of u16[1 + slots] through `caps`
+    const bool compact = o.compact_results && !match_only;  // rows of u16[1 + slots] (2: u8[1 + slots]) through `caps`
+    if (o.compact_results > 2) return fail(GX_E_ARG, "gx_batch_opts.compact_results: 0, 1 (u16 rows) or 2 (u8 rows)");
+    if (compact && o.compact_results == 2 && h->T.n_rules > 126)
+        return fail(GX_E_ARG, "gx_batch_opts.compact_results = 2: u8 rows hold match ids -128 .. 127 (at most 126 extractions)");
     if (!compact && !match_id) return fail(GX_E_ARG, "gx_extract_batch: match_id is NULL");
     if (!match_only && !caps && n > 0 && (compact || h->T.max_groups > 0)) return fail(GX_E_ARG, "gx_extract_batch: caps is NULL");
     try {
@@ -1552,6 +1568,7 @@ static int extract_batch_impl(gx_handle* h, const uint8_t* bytes, const void* of
         b.offsets64 = o.offsets64 ? 1 : 0;
         b.match_only = match_only ? 1 : 0;
         b.strip_eol = o.strip_eol ? 1 : 0;
+        b.narrow = (compact && o.compact_results == 2) ? 1 : 0;
         const size_t off_w = o.offsets64 ? 8 : 4;
         if (o.device_pointers) {
             b.data = bytes; b.offsets = offsets;
@@ -1705,7 +1722,8 @@ int gx_extract_batch_multi(gx_handle* const* handles, int32_t n_handles, const u
             ok.stream = nullptr;
             ok.overflow = compact ? &over[k] : nullptr;
             int32_t* mid_k = match_id ? match_id + a : nullptr;
-            int32_t* caps_k = !caps ? nullptr : compact ? reinterpret_cast<int32_t*>(reinterpret_cast<uint16_t*>(caps) + a * (1 + slots)) : caps + a * slots;
+            const size_t row_bytes = (1 + slots) * (o.compact_results == 2 ? 1 : 2);
+            int32_t* caps_k = !caps ? nullptr : compact ? reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(caps) + a * row_bytes) : caps + a * slots;
             rc[k] = gx_extract_batch(handles[k], bytes, static_cast<const uint8_t*>(offsets) + a * off_w, m, mid_k, caps_k, &ok);
             if (rc[k] != GX_OK) msg[k] = gx_last_error();
         });

@@ -104,6 +104,9 @@ struct GxBatch {
     // capture offsets (0xFFFF = unset) -- written instead of match_id / caps when `packed` is set
     uint16_t* packed;
     unsigned long long* overflow;  // with `packed`: += number of offsets above 65534 (stored saturated)
+    // narrow rows (compact_results = 2): `packed` holds u8[1 + 2 * max_groups] per line instead -- int8 match id, offsets with
+    // 0xFF = unset, an offset above 254 stored as 254 and counted in *overflow
+    int32_t narrow;
     // lines the tile kernel cannot stage (longer than its staging area) are left to a follow-up launch of the
     // per-line kernel: the tile kernel stores `seq` into *oversize_flag when it meets one
     uint32_t* oversize_flag;
@@ -177,6 +180,7 @@ hipError_t launch_count_outcomes(const int32_t* match_id, uint64_t n, unsigned l
 hipError_t launch_pack_results(const int32_t* match_id, const int32_t* caps, uint64_t n, int slots, uint16_t* packed,
                                unsigned long long* d_overflow, hipStream_t stream);
 hipError_t launch_unpack_results(const uint16_t* packed, uint64_t n, int slots, int32_t* match_id, int32_t* caps, hipStream_t stream);
+hipError_t launch_unpack_results8(const uint8_t* rows, uint64_t n, int slots, int32_t* match_id, int32_t* caps, hipStream_t stream);
 hipError_t launch_jsonl_write(const GxJsonl& tm, const GxBatch& b, int slots, int passthrough, uint32_t mean_in, uint32_t mean_out,
                               const uint64_t* line_out_off, uint8_t* out, void* workspace, hipStream_t stream);
 

@@ -839,8 +839,29 @@ __global__ void __launch_bounds__(256) k_unpack_results(const uint16_t* __restri
         else caps[line * static_cast<uint64_t>(slots) + (col - 1)] = v == 0xFFFFu ? -1 : static_cast<int32_t>(v);
     }
 }
+// the same from u8 rows (gx_batch_opts.compact_results = 2: int8 id, offsets with 0xFF = unset)
+__global__ void __launch_bounds__(256) k_unpack_results8(const uint8_t* __restrict__ rows, uint64_t n, int slots, int32_t* __restrict__ match_id,
+                                                        int32_t* __restrict__ caps) {
+    const uint64_t width = static_cast<uint64_t>(slots) + 1;
+    const uint64_t total = n * width;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const uint64_t line = t / width;
+        const uint32_t col = static_cast<uint32_t>(t - line * width);
+        const uint8_t v = rows[t];
+        if (col == 0) match_id[line] = static_cast<int8_t>(v);
+        else caps[line * static_cast<uint64_t>(slots) + (col - 1)] = v == 0xFFu ? -1 : static_cast<int32_t>(v);
+    }
+}
 }  // namespace
 
+hipError_t launch_unpack_results8(const uint8_t* rows, uint64_t n, int slots, int32_t* match_id, int32_t* caps, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n * (static_cast<uint64_t>(slots) + 1) + 255) / 256;
+    if (blocks > 256u * 64u) blocks = 256u * 64u;
+    hipLaunchKernelGGL(k_unpack_results8, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, rows, n, slots, match_id, caps);
+    return hipGetLastError();
+}
 hipError_t launch_pack_results(const int32_t* match_id, const int32_t* caps, uint64_t n, int slots, uint16_t* packed,
                                unsigned long long* d_overflow, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(d_overflow, 0, 8, stream);

@@ -37,12 +37,21 @@ struct LineOut {
     uint16_t* packed;
     unsigned long long* overflow;
     int slots;
+    int narrow;  // `packed` holds u8 rows (int8 id, offsets with 0xFF = unset, above 254: stored as 254 and counted)
     __device__ __forceinline__ void id(uint64_t i, int32_t k) const {
-        if (packed) packed[i * static_cast<uint64_t>(1 + slots)] = static_cast<uint16_t>(k);
+        if (packed && narrow) reinterpret_cast<uint8_t*>(packed)[i * static_cast<uint64_t>(1 + slots)] = static_cast<uint8_t>(k);
+        else if (packed) packed[i * static_cast<uint64_t>(1 + slots)] = static_cast<uint16_t>(k);
         else match_id[i] = k;
     }
     __device__ __forceinline__ void cap(uint64_t i, int t, int32_t v) const {
-        if (packed) {
+        if (packed && narrow) {
+            uint8_t w = 0xFFu;
+            if (v >= 0) {
+                if (v > 254) { v = 254; if (overflow) atomicAdd(overflow, 1ull); }
+                w = static_cast<uint8_t>(v);
+            }
+            reinterpret_cast<uint8_t*>(packed)[i * static_cast<uint64_t>(1 + slots) + 1 + t] = w;
+        } else if (packed) {
             uint16_t w = 0xFFFFu;
             if (v >= 0) {
                 if (v > 65534) { v = 65534; if (overflow) atomicAdd(overflow, 1ull); }
@@ -167,6 +176,7 @@ LineOut line_out(const GxDev& dev, const GxBatch& b) {
     o.caps = b.caps;
     o.packed = b.packed;
     o.overflow = b.overflow;
+    o.narrow = b.narrow;
     o.slots = 2 * dev.max_groups;
     return o;
 }

@@ -31,6 +31,8 @@ struct LanesIO {
     int32_t* match_id;
     int32_t* caps;
     uint16_t* packed;
+    unsigned long long* overflow;
+    int32_t narrow;              // compact rows as u8 (gx_device.hpp: GxBatch::narrow)
     uint32_t* oversize_flag;
     uint32_t seq;
     int32_t max_groups;
@@ -238,30 +240,54 @@ k_extract_lanes(GxLds L, LanesIO io) {
                 const bool full_tile = contiguous && __all(valid) && !__any(oversize);
                 const uint64_t i0 = i - lane;
                 if (PACKED) {
-                    const uint32_t row_b = 2u + 2u * slots;
+                    // u16 rows, or -- io.narrow, wave-uniform -- u8 rows (an offset above 254 stored as 254 and counted)
+                    const bool narrow = io.narrow != 0;
+                    const uint32_t row_b = narrow ? 1u + slots : 2u + 2u * slots;
                     const bool rows_aligned = (reinterpret_cast<uintptr_t>(io.packed) & 15u) == 0u;  // (16-byte stores below)
+                    uint8_t* rows8 = reinterpret_cast<uint8_t*>(io.packed);
+                    uint32_t clamped = 0;
                     if (full_tile && rows_aligned) {
                         // the tile's 64 rows are one contiguous block of the output: through the wave's row area, then 1 KiB of
                         // consecutive bytes per store instruction
                         const uint32_t my_out = out_area + lane * row_b;
-                        const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
-                            lds_st<uint16_t>(my_out + 2u + 4u * g, static_cast<uint16_t>(pb));
-                            lds_st<uint16_t>(my_out + 4u + 4u * g, static_cast<uint16_t>(pe));
-                        });
-                        lds_st<uint16_t>(my_out, static_cast<uint16_t>(result));
+                        if (narrow) {
+                            const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                                clamped += (pb > 254 ? 1u : 0u) + (pe > 254 ? 1u : 0u);
+                                lds_st<uint8_t>(my_out + 1u + 2u * g, static_cast<uint8_t>(pb > 254 ? 254 : pb));
+                                lds_st<uint8_t>(my_out + 2u + 2u * g, static_cast<uint8_t>(pe > 254 ? 254 : pe));
+                            });
+                            lds_st<uint8_t>(my_out, static_cast<uint8_t>(result));
+                        } else {
+                            const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                                lds_st<uint16_t>(my_out + 2u + 4u * g, static_cast<uint16_t>(pb));
+                                lds_st<uint16_t>(my_out + 4u + 4u * g, static_cast<uint16_t>(pe));
+                            });
+                            lds_st<uint16_t>(my_out, static_cast<uint16_t>(result));
+                        }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
-                        uint8_t* out = reinterpret_cast<uint8_t*>(io.packed + i0 * static_cast<uint64_t>(1u + slots));
+                        uint8_t* out = rows8 + i0 * static_cast<uint64_t>(row_b);
                         for (uint32_t c = lane; c < 4u * row_b; c += 64u)
                             *reinterpret_cast<u32x4*>(out + (c << 4)) = lds_ld<u32x4>(out_area + (c << 4));
                     } else if (valid && !oversize) {
-                        uint16_t* rp = io.packed + i * static_cast<uint64_t>(1u + slots);
-                        const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
-                            rp[1 + 2 * g] = static_cast<uint16_t>(pb);
-                            rp[2 + 2 * g] = static_cast<uint16_t>(pe);
-                        });
-                        rp[0] = static_cast<uint16_t>(result);
+                        if (narrow) {
+                            uint8_t* rp = rows8 + i * static_cast<uint64_t>(row_b);
+                            const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                                clamped += (pb > 254 ? 1u : 0u) + (pe > 254 ? 1u : 0u);
+                                rp[1 + 2 * g] = static_cast<uint8_t>(pb > 254 ? 254 : pb);
+                                rp[2 + 2 * g] = static_cast<uint8_t>(pe > 254 ? 254 : pe);
+                            });
+                            rp[0] = static_cast<uint8_t>(result);
+                        } else {
+                            uint16_t* rp = io.packed + i * static_cast<uint64_t>(1u + slots);
+                            const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                                rp[1 + 2 * g] = static_cast<uint16_t>(pb);
+                                rp[2 + 2 * g] = static_cast<uint16_t>(pe);
+                            });
+                            rp[0] = static_cast<uint16_t>(result);
+                        }
                     }
+                    if (narrow && clamped && io.overflow) atomicAdd(io.overflow, static_cast<unsigned long long>(clamped));
                 } else {
                     // dense int32 rows: every lane stores its own (8 bytes per group).  Taking them through the wave's row area 32
                     // lines at a time, as contiguous 16-byte stores, was measured: no faster (1.558 against 1.551 ms on config 3)
@@ -352,6 +378,8 @@ hipError_t launch_extract_lanes(const GxDev& dev, const GxLds& lds, const uint8_
     io.match_id = b.match_id;
     io.caps = b.caps;
     io.packed = b.packed;
+    io.overflow = b.overflow;
+    io.narrow = b.narrow;
     io.oversize_flag = b.oversize_flag;
     io.seq = b.seq;
     io.max_groups = dev.max_groups;

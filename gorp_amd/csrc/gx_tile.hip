@@ -32,6 +32,8 @@ hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t
     io.match_id = b.match_id;
     io.caps = b.caps;
     io.packed = b.packed;
+    io.overflow = b.overflow;
+    io.narrow = b.narrow;
     io.oversize_flag = b.oversize_flag;
     io.seq = b.seq;
     io.max_groups = dev.max_groups;

@@ -40,6 +40,8 @@ struct TileIO {
     int32_t* match_id;
     int32_t* caps;
     uint16_t* packed;            // compact rows instead of match_id / caps
+    unsigned long long* overflow;
+    int32_t narrow;              // ... as u8 rows (gx_device.hpp: GxBatch::narrow)
     uint32_t* oversize_flag;
     uint32_t seq;
     int32_t max_groups;
@@ -403,34 +405,58 @@ k_extract_tile(GxLds L, TileIO io) {
             // consecutive bytes, instead of every lane writing pieces of its own row.
             const bool full_tile = cur.a == 0u && cur.b == 64u;
             if (PACKED) {
-                const uint32_t row_b = 2u + 2u * slots;  // u16 id + u16 offsets
-                uint16_t* out_rows = io.packed + (cur.i - lane) * static_cast<uint64_t>(1u + slots);
+                // u16 rows (int16 id + u16 offsets), or -- io.narrow, wave-uniform -- u8 rows (int8 id + u8 offsets, an offset
+                // above 254 stored as 254 and counted).  A staged line is shorter than 65 535 bytes, so u16 rows never clamp here.
+                const bool narrow = io.narrow != 0;
+                const uint32_t row_b = narrow ? 1u + slots : 2u + 2u * slots;
+                uint8_t* out_rows = reinterpret_cast<uint8_t*>(io.packed) + (cur.i - lane) * static_cast<uint64_t>(row_b);
                 const bool rows_aligned = (reinterpret_cast<uintptr_t>(io.packed) & 15u) == 0u;  // (64 rows are a multiple of 16 bytes)
+                uint32_t clamped = 0;
                 if (full_tile && rows_aligned && 64u * row_b + 16u <= L.stage_bytes) {
                     const uint32_t my_row = stage + lane * row_b;
-                    const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
-                        lds_st<uint16_t>(my_row + 2u + 4u * g, static_cast<uint16_t>(pb));
-                        lds_st<uint16_t>(my_row + 4u + 4u * g, static_cast<uint16_t>(pe));
-                    });
-                    lds_st<uint16_t>(my_row, static_cast<uint16_t>(result));
+                    int32_t result;
+                    if (narrow) {
+                        result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                            clamped += (pb > 254 ? 1u : 0u) + (pe > 254 ? 1u : 0u);
+                            lds_st<uint8_t>(my_row + 1u + 2u * g, static_cast<uint8_t>(pb > 254 ? 254 : pb));
+                            lds_st<uint8_t>(my_row + 2u + 2u * g, static_cast<uint8_t>(pe > 254 ? 254 : pe));
+                        });
+                        lds_st<uint8_t>(my_row, static_cast<uint8_t>(result));
+                    } else {
+                        result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                            lds_st<uint16_t>(my_row + 2u + 4u * g, static_cast<uint16_t>(pb));
+                            lds_st<uint16_t>(my_row + 4u + 4u * g, static_cast<uint16_t>(pe));
+                        });
+                        lds_st<uint16_t>(my_row, static_cast<uint16_t>(result));
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    uint8_t* out = reinterpret_cast<uint8_t*>(out_rows);
                     for (uint32_t c = lane; c < 4u * row_b; c += 64u) {  // 64 * row_b / 16 chunks
 #ifdef GX_DEV
-                        if (io.dev_flags & 2u) { __builtin_nontemporal_store(lds_ld<u32x4>(stage + (c << 4)), reinterpret_cast<u32x4*>(out + (c << 4))); continue; }
+                        if (io.dev_flags & 2u) { __builtin_nontemporal_store(lds_ld<u32x4>(stage + (c << 4)), reinterpret_cast<u32x4*>(out_rows + (c << 4))); continue; }
                         if ((io.dev_flags & 4u) && c != 0u) continue;  // experiment: (almost) no result stores
 #endif
-                        *reinterpret_cast<u32x4*>(out + (c << 4)) = lds_ld<u32x4>(stage + (c << 4));
+                        *reinterpret_cast<u32x4*>(out_rows + (c << 4)) = lds_ld<u32x4>(stage + (c << 4));
                     }
                 } else if (valid) {
-                    uint16_t* rp = io.packed + i * static_cast<uint64_t>(1u + slots);
-                    const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
-                        rp[1 + 2 * g] = static_cast<uint16_t>(pb);
-                        rp[2 + 2 * g] = static_cast<uint16_t>(pe);
-                    });
-                    rp[0] = static_cast<uint16_t>(result);
+                    if (narrow) {
+                        uint8_t* rp = reinterpret_cast<uint8_t*>(io.packed) + i * static_cast<uint64_t>(row_b);
+                        const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                            clamped += (pb > 254 ? 1u : 0u) + (pe > 254 ? 1u : 0u);
+                            rp[1 + 2 * g] = static_cast<uint8_t>(pb > 254 ? 254 : pb);
+                            rp[2 + 2 * g] = static_cast<uint8_t>(pe > 254 ? 254 : pe);
+                        });
+                        rp[0] = static_cast<uint8_t>(result);
+                    } else {
+                        uint16_t* rp = io.packed + i * static_cast<uint64_t>(1u + slots);
+                        const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                            rp[1 + 2 * g] = static_cast<uint16_t>(pb);
+                            rp[2 + 2 * g] = static_cast<uint16_t>(pe);
+                        });
+                        rp[0] = static_cast<uint16_t>(result);
+                    }
                 }
+                if (narrow && clamped && io.overflow) atomicAdd(io.overflow, static_cast<unsigned long long>(clamped));
             } else {
                 const uint32_t row_b = slots * 4u;
                 const bool caps_aligned = ((reinterpret_cast<uintptr_t>(io.caps) | reinterpret_cast<uintptr_t>(io.match_id)) & 15u) == 0u;

@@ -540,8 +540,9 @@ class Gorp:
     def extract_batch(self, data, offsets, match_only=False, strip_eol=False, kernel=0, line_bytes_hint=0, compact=False, uneven=0):
         """Host buffers: data uint8[total] (Latin-1 code units) or uint16[total] (UTF-16 code units),
         offsets uint32|uint64[n+1] in code units.
-        Returns (match_id int32[n], caps int32[n, 2*max_groups]); with compact=True the compact rows
-        uint16[n, 1 + 2*max_groups] and the number of offsets that did not fit them (see unpack_rows).
+        Returns (match_id int32[n], caps int32[n, 2*max_groups]); with compact=True (or 1) the compact rows
+        uint16[n, 1 + 2*max_groups] and the number of offsets that did not fit them (see unpack_rows); with compact=2
+        the u8 rows uint8[n, 1 + 2*max_groups] (lines shorter than 255 bytes, at most 126 extractions).
         kernel: GX_KERNEL_* (0 = the library chooses)."""
         utf16 = getattr(data, "dtype", None) == np.uint16
         data = np.ascontiguousarray(data, dtype=np.uint16 if utf16 else np.uint8)
@@ -561,9 +562,9 @@ class Gorp:
         o.line_bytes_hint = int(line_bytes_hint)
         o.uneven_lines = int(uneven)  # gx_batch_opts.uneven_lines: 0 = the library looks at the offsets itself
         if compact and not match_only and self.stat(8):
-            rows = np.zeros((n, 1 + 2 * self.max_groups), np.uint16)
+            rows = np.zeros((n, 1 + 2 * self.max_groups), np.uint8 if int(compact) == 2 else np.uint16)
             over = C.c_uint64(0)
-            o.compact_results = 1
+            o.compact_results = int(compact)
             o.overflow = C.cast(C.pointer(over), C.c_void_p)
             _check(N.lib().gx_extract_batch(self._h.ptr, data.ctypes.data if data.size else None, offsets.ctypes.data, n,
                                             None, rows.ctypes.data, C.byref(o)))
@@ -589,7 +590,7 @@ class Gorp:
         o.strip_eol = 1 if strip_eol else 0
         o.line_bytes_hint = int(line_bytes_hint)
         o.kernel = int(kernel) or DEFAULT_KERNEL
-        o.compact_results = 1 if compact else 0
+        o.compact_results = int(compact)   # 1 / True: u16 rows; 2: u8 rows
         o.overflow = overflow_ptr
         o.uneven_lines = int(uneven)  # 2: lines differ much in length (0 with a hint or no_sync: taken as 1, similar lengths)
         _check(N.lib().gx_extract_batch(self._h.ptr, data_ptr, offsets_ptr, n, match_id_ptr, caps_ptr, C.byref(o)))
@@ -618,9 +619,9 @@ def extract_batch_multi(gorps, data, offsets, match_only=False, strip_eol=False,
     o.strip_eol = 1 if strip_eol else 0
     hs = (C.c_void_p * len(gorps))(*[g._h.ptr for g in gorps])
     if compact and not match_only:
-        rows = np.zeros((n, 1 + 2 * G), np.uint16)
+        rows = np.zeros((n, 1 + 2 * G), np.uint8 if int(compact) == 2 else np.uint16)
         over = C.c_uint64(0)
-        o.compact_results = 1
+        o.compact_results = int(compact)
         o.overflow = C.cast(C.pointer(over), C.c_void_p)
         _check(N.lib().gx_extract_batch_multi(hs, len(gorps), data.ctypes.data if data.size else None, offsets.ctypes.data, n, None,
                                               rows.ctypes.data, C.byref(o)))
@@ -633,8 +634,16 @@ def extract_batch_multi(gorps, data, offsets, match_only=False, strip_eol=False,
 
 
 def unpack_rows(rows):
-    """Compact rows uint16[n, 1 + slots] -> (match_id int32[n], caps int32[n, slots]) on the host (numpy)."""
-    rows = np.asarray(rows, dtype=np.uint16)
+    """Compact rows uint16[n, 1 + slots] (or the u8 rows of compact=2) -> (match_id int32[n], caps int32[n, slots]) on the
+    host (numpy)."""
+    rows = np.asarray(rows)
+    if rows.dtype in (np.uint8, np.int8):
+        rows = rows.view(np.uint8)
+        mid = rows[:, 0].astype(np.int8).astype(np.int32)
+        caps = rows[:, 1:].astype(np.int32)
+        caps[caps == 0xFF] = -1
+        return mid, caps
+    rows = rows.view(np.uint16) if rows.dtype == np.int16 else np.asarray(rows, dtype=np.uint16)
     mid = rows[:, 0].astype(np.int16).astype(np.int32)
     caps = rows[:, 1:].astype(np.int32)
     caps[caps == 0xFFFF] = -1
@@ -669,12 +678,14 @@ def pack_results_device(match_id_ptr, caps_ptr, n, slots, packed_ptr, stream=Non
     return over.value
 
 
-def unpack_results_device(packed_ptr, n, slots, match_id_ptr, caps_ptr, stream=None):
+def unpack_results_device(packed_ptr, n, slots, match_id_ptr, caps_ptr, stream=None, narrow=False):
+    """gx_unpack_results (u16 rows) / gx_unpack_results8 (narrow=True: the u8 rows of compact=2) on the device."""
     o = N.gx_batch_opts()
     o.struct_size = C.sizeof(N.gx_batch_opts)
     o.device_pointers = 1
     o.stream = stream
-    _check(N.lib().gx_unpack_results(packed_ptr, n, slots, match_id_ptr, caps_ptr, C.byref(o)))
+    fn = N.lib().gx_unpack_results8 if narrow else N.lib().gx_unpack_results
+    _check(fn(packed_ptr, n, slots, match_id_ptr, caps_ptr, C.byref(o)))
 
 
 def split_lines_device(data_ptr, size, offsets_ptr, cap_lines, flags_ptr=None, offsets64=False, stream=None):

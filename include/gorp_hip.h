@@ -124,7 +124,11 @@ typedef struct gx_batch_opts {
                                   offsets, 0xFFFF = unset (the layout of gx_pack_results); match_id may be NULL.  Half the
                                   result bytes of the dense format; what the gather between GPUs sends.  An offset above
                                   65534 does not fit: it is stored as 65534 and counted in *overflow (take such a batch again
-                                  in the dense format).  Ignored with match_only. */
+                                  in the dense format).  2: u8 rows instead -- `caps` points to uint8_t[n * (1 + 2*gx_max_groups(h))],
+                                  the match id as int8 and the offsets with 0xFF = unset: a quarter of the dense bytes, for
+                                  batches whose lines are shorter than 255 bytes (log lines mostly are) and definitions of at
+                                  most 126 extractions (GX_E_ARG beyond).  An offset above 254 is stored as 254 and counted in
+                                  *overflow.  Ignored with match_only. */
     uint32_t uneven_lines;     /* gx_extract_batch only.  Lines run in lock step in groups of 64: a group takes as long as its longest
                                   line.  2: the lines differ much in length -- the kernels then group lines of similar length where
                                   they can (results are the same); 1: they do not; 0: the library looks itself where it can see
@@ -192,6 +196,9 @@ int gx_pack_results(const int32_t* match_id, const int32_t* caps, uint64_t n, in
                     uint64_t* n_overflow, const gx_batch_opts* opts);
 int gx_unpack_results(const uint16_t* packed, uint64_t n, int32_t slots, int32_t* match_id, int32_t* caps,
                       const gx_batch_opts* opts);
+/* The same from the u8 rows of gx_batch_opts.compact_results = 2 (int8 id, uint8 offsets, 0xFF = unset). */
+int gx_unpack_results8(const uint8_t* rows, uint64_t n, int32_t slots, int32_t* match_id, int32_t* caps,
+                       const gx_batch_opts* opts);
 
 /* Names for a handle built from regex strings (the caller did DefinitionReader's work itself and holds the
  * CookedExtraction data, core/model/CookedExtraction.java:18-66): extraction name, extractor names in group

@@ -43,6 +43,14 @@ def check_batch(gorp, orc, lines):
         big = ocaps > 65534
         assert over == int(big.sum())
         assert np.array_equal(cm, omid) and np.array_equal(cc, np.where(big, 65534, ocaps))
+        if len(gorp.getExtractions()) <= 126:
+            # and as u8 rows (compact_results = 2: int8 id + uint8 offsets, an offset above 254 stored as 254 and counted)
+            rows8, over8 = gorp.extract_batch(data, offsets, compact=2)
+            assert rows8.dtype == np.uint8
+            nm, nc = G.unpack_rows(rows8)
+            big8 = ocaps > 254
+            assert over8 == int(big8.sum())
+            assert np.array_equal(nm, omid) and np.array_equal(nc, np.where(big8, 254, ocaps))
     m2, _ = gorp.extract_batch(data, offsets, match_only=True)
     assert np.array_equal(m2, orc.extract_batch(data, offsets, match_only=True)[0])
     return mid, caps
@@ -558,6 +566,23 @@ def test_compact_rows_from_the_kernels(variant, monkeypatch):
                               line_bytes_hint=200)
     cm, cc = G.unpack_rows(rows.cpu().numpy().view(np.uint16))
     assert int(over.item()) == 0 and np.array_equal(cm, omid) and np.array_equal(cc, ocaps)
+    # the u8 rows: same kernels, device buffers; the lines are 200 bytes, so every offset fits
+    rows8 = torch.zeros((n, 1 + 2 * gorp.max_groups), dtype=torch.uint8, device="cuda")
+    gorp.extract_batch_device(dd.data_ptr(), oo.data_ptr(), n, None, rows8.data_ptr(), compact=2, overflow_ptr=over.data_ptr(),
+                              line_bytes_hint=200)
+    nm, nc = G.unpack_rows(rows8.cpu().numpy())
+    assert int(over.item()) == 0 and np.array_equal(nm, omid) and np.array_equal(nc, ocaps)
+    m8 = torch.empty(n, dtype=torch.int32, device="cuda")
+    c8 = torch.empty((n, 2 * gorp.max_groups), dtype=torch.int32, device="cuda")
+    G.unpack_results_device(rows8.data_ptr(), n, 2 * gorp.max_groups, m8.data_ptr(), c8.data_ptr(), narrow=True)   # gx_unpack_results8
+    assert np.array_equal(m8.cpu().numpy(), omid) and np.array_equal(c8.cpu().numpy(), ocaps)
+    # lines of 250-260 bytes: offsets 255 and above do not fit a u8 row -- stored as 254 and counted, everything else exact
+    data2, offsets2, _ = W.readme3_lines(4096, seed=82, line_bytes=257)
+    d2, o2 = data2.numpy(), offsets2.numpy()
+    om2, oc2 = orc.extract_batch(d2, o2, nthreads=8)
+    r2, over2 = gorp.extract_batch(d2, o2, compact=2)
+    nm, nc = G.unpack_rows(r2)
+    assert over2 == int((oc2 > 254).sum()) > 0 and np.array_equal(nm, om2) and np.array_equal(nc, np.where(oc2 > 254, 254, oc2))
     # ragged, empty, longer than the staging area, longer than the 16-bit offsets
     lines = ["", "[1]: GET 5ms /x", "[1]: GET 5ms /" + "x" * 70000, "[12]: PUT 7ms /" + "y" * 3000, "nothing", "[3]: HEAD 1ms /z"] * 7
     check_batch(gorp, orc, lines)
@@ -990,3 +1015,14 @@ def test_lane_kernel_agrees_with_oracle(flags):
     m3, c3 = gorp.extract_batch(np.frombuffer(raw, np.uint8), off, strip_eol=True, kernel=N.GX_KERNEL_LANES)
     keep = [i for i, ln in enumerate(lines) if "\r" not in ln]
     assert np.array_equal(m3, om[keep]) and np.array_equal(c3, oc[keep])
+
+
+def test_narrow_rows_need_few_extractions():
+    """u8 rows hold match ids -128 .. 127: a definition of more than 126 extractions is refused, not truncated."""
+    rules, meta = W.syslog_definition(130, seed=9, n_keys=1)
+    gorp = Gorp.construct(rules)
+    d, o, _ = W.syslog_lines(meta, 64, seed=9, line_bytes=100)
+    with pytest.raises(G.GorpError, match="126 extractions"):
+        gorp.extract_batch(d, o, compact=2)
+    rows, over = gorp.extract_batch(d, o, compact=True)
+    assert over == 0 and (G.unpack_rows(rows)[0] >= 0).sum() > 50
