@@ -18,6 +18,7 @@
 #include "gx_compile.hpp"
 #include "gx_device.hpp"
 #include "gx_dsl.hpp"
+#include "gx_hop.hpp"
 
 using namespace gx;
 
@@ -73,6 +74,13 @@ struct gx_handle {
     void* d_lds_image_mo = nullptr;
     std::vector<uint8_t> l2_image;
     void* d_l2_image = nullptr;
+    // hop tier (gx_hop.hpp): a further image of the fused automaton for capture batches of definitions whose dense rows do
+    // not fit LDS -- hop records (hot ones in LDS) over dense rows in global memory, walked by the tile kernel
+    bool hop_ok = false;
+    GxLds lds_hop{};
+    HopImage hop;
+    void* d_lds_image_hop = nullptr;
+    void* d_hop_global = nullptr;
     int num_cus = 256;
     std::vector<dsl::Extraction> meta;  // names / extractor names / append (from definition text or gx_set_extraction_meta)
     void* one_dev = nullptr;     // scratch of the one-String entry points (device) ...
@@ -167,7 +175,6 @@ bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t ro
     const Tables& T = h->T;
     const int ncls = T.ncls;
     const uint32_t ACC = ncls + 1, INFO = ncls + 2;
-    typedef std::array<uint64_t, 4> ClassSet;
     auto has = [](const ClassSet& s, int c) { return (s[c >> 6] >> (c & 63)) & 1ull; };
     // the groups of every row: successor entry -> classes (the dead default is not a group)
     struct Group { uint32_t entry; ClassSet set; };
@@ -187,50 +194,8 @@ bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t ro
             ++weight[g.second];
         }
     }
-    // class order: ordered partition, refined set by set
-    std::vector<std::vector<int>> blocks(1);
-    for (int c = 0; c < ncls; ++c) blocks[0].push_back(c);
-    std::vector<std::pair<uint64_t, ClassSet>> by_weight;
-    for (auto& w : weight) {
-        int size = 0;
-        for (int c = 0; c < ncls; ++c) size += has(w.first, c) ? 1 : 0;
-        if (size > 1 && size < ncls) by_weight.push_back({w.second * static_cast<uint64_t>(size), w.first});
-    }
-    std::sort(by_weight.begin(), by_weight.end(), [](const std::pair<uint64_t, ClassSet>& a, const std::pair<uint64_t, ClassSet>& b) {
-        return a.first != b.first ? a.first > b.first : a.second < b.second;
-    });
-    for (auto& ws : by_weight) {
-        const ClassSet& S = ws.second;
-        int first = -1, last = -1;
-        bool ok = true;
-        std::vector<int> inside(blocks.size());
-        for (size_t b = 0; b < blocks.size(); ++b) {
-            int in = 0;
-            for (int c : blocks[b]) in += has(S, c) ? 1 : 0;
-            inside[b] = in;
-            if (in) { if (first < 0) first = static_cast<int>(b); last = static_cast<int>(b); }
-        }
-        for (int b = first + 1; b < last && ok; ++b) if (inside[b] != static_cast<int>(blocks[b].size())) ok = false;  // a hole in the middle
-        if (!ok || first < 0) continue;
-        auto split = [&](int b, bool inside_last) {  // block b -> (outside, inside) or (inside, outside)
-            std::vector<int> in, out;
-            for (int c : blocks[b]) (has(S, c) ? in : out).push_back(c);
-            if (in.empty() || out.empty()) return 0;
-            blocks[b] = inside_last ? out : in;
-            blocks.insert(blocks.begin() + b + 1, inside_last ? in : out);
-            return 1;
-        };
-        if (first == last) split(first, false);
-        else {
-            split(last, false);          // the inside part first, next to the run
-            split(first, true);          // the inside part last
-        }
-    }
-    std::vector<int> new_id(ncls);
-    {
-        int id = 0;
-        for (auto& b : blocks) for (int c : b) new_id[c] = id++;
-    }
+    // class order: as many of the sets as possible become id ranges (gx_hop.cpp: order_classes)
+    const std::vector<int> new_id = order_classes(weight, ncls);
     // ranges (in new ids) of a class set
     auto ranges_of = [&](const ClassSet& S) {
         std::vector<char> in(ncls, 0);
@@ -303,11 +268,8 @@ bool records_from_dense(gx_handle* h, const std::vector<uint32_t>& at, size_t ro
             if (exits[r].size() > 1) ++multi;
             if (self0[r].first >= 0) { ++self_states; for (auto& e : exits[r]) if (e.entry == static_cast<uint32_t>(r)) { ++self_split; break; } }
         }
-        fprintf(stderr, "records: rows %zu items %zu multi-item states %zu self-loop states %zu of which split %zu; blocks %zu\n", rows, n_items, multi, self_states, self_split, blocks.size());
+        fprintf(stderr, "records: rows %zu items %zu multi-item states %zu self-loop states %zu of which split %zu\n", rows, n_items, multi, self_states, self_split);
         for (auto& hh : hist) fprintf(stderr, "  %zu items: %zu states\n", hh.first, hh.second);
-        std::string order;
-        for (auto& b : blocks) { order += "["; for (int c : b) { for (int by = 0; by < 256; ++by) if (T.cls256[by] == c) { order += (by > 32 && by < 127) ? static_cast<char>(by) : '.'; break; } } order += "]"; }
-        fprintf(stderr, "  class order: %s\n", order.c_str());
     }
 #endif
     // pass 2: emit
@@ -669,9 +631,16 @@ bool build_tile_image(gx_handle* h, int tier, int part = 0) {
 }
 
 // Complete the layout for one batch: staging sized for 64 lines of the hinted length.
+bool plan_tile_layout(GxLds L, uint32_t line_bytes_hint, GxLds* out);
 bool plan_tile_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out, bool match_only = false) {
     if (!h->tile_ok) return false;
-    GxLds L = match_only && h->has_mo ? h->lds_mo : h->lds;
+    return plan_tile_layout(match_only && h->has_mo ? h->lds_mo : h->lds, line_bytes_hint, out);
+}
+// the hop tier's layout: the same kernel, its own tables
+bool plan_hop_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out) {
+    return h->hop_ok && plan_tile_layout(h->lds_hop, line_bytes_hint, out);
+}
+bool plan_tile_layout(GxLds L, uint32_t line_bytes_hint, GxLds* out) {
     if (line_bytes_hint == 0) line_bytes_hint = 200;
     if (line_bytes_hint > 2000) line_bytes_hint = 2000;
     L.stage_bytes = (64u * line_bytes_hint + 64u + 15u) & ~15u;  // + slack: the walk reads ahead of the line
@@ -797,6 +766,32 @@ void choose_tile_image(gx_handle* h) {
         }
     }
     if (!ok) h->tile_ok = false;
+    // The hop tier beside it, for capture batches: whenever the dense rows do not fit LDS (or on request).  Its hot records
+    // may take what LDS leaves beside eight waves' staging areas of 200-byte lines.
+    h->hop_ok = false;
+    const bool forced = force_l2 || force_rec || force_recg;  // (a caller that names a tier gets that tier's kernels)
+    const bool want_hop = (h->create_flags & GX_CREATE_TIER_HOP) != 0 || (ok && !forced && (h->lds.tier != 0 || h->tile_global));
+    if (!no_tiles && want_hop && h->T.has_capture && !(h->create_flags & GX_CREATE_NO_FUSED) && build_hop_image(h->T, 48u * 1024u, h->hop)) {
+        GxLds L{};
+        L.ncls = h->hop.ncls;
+        L.row_bytes = h->hop.row_bytes;
+        L.c_base = h->hop.hops_off;
+        L.m_start = L.m_dead = 0;
+        L.u_start = h->hop.start;
+        L.u_dead = h->hop.dead;
+        L.fin_tags = h->hop.fin_off;
+        L.table_bytes = static_cast<uint32_t>(h->hop.lds.size());
+        L.simple_ops = 1;
+        L.tier = 4;
+        L.rec = HOP_AT;
+        L.rec_indexed = h->hop.n_hot;
+        L.hot_lo4 = 0;
+        L.hot_k4 = 0x80808080u;
+        L.regs_wave_bytes = static_cast<uint32_t>(((h->hop.n_regs + 1) * 64 * 2 + 15) & ~15u);
+        h->lds_hop = L;
+        GxLds P;
+        h->hop_ok = plan_tile_layout(L, 200, &P);
+    }
 }
 
 void upload(gx_handle* h) {
@@ -884,6 +879,12 @@ void upload(gx_handle* h) {
             GX_HIP(hipMalloc(&h->d_l2_image, h->l2_image.size()));
             GX_HIP(hipMemcpy(h->d_l2_image, h->l2_image.data(), h->l2_image.size(), hipMemcpyHostToDevice));
         }
+        if (h->hop_ok) {
+            GX_HIP(hipMalloc(&h->d_lds_image_hop, h->hop.lds.size()));
+            GX_HIP(hipMemcpy(h->d_lds_image_hop, h->hop.lds.data(), h->hop.lds.size(), hipMemcpyHostToDevice));
+            GX_HIP(hipMalloc(&h->d_hop_global, h->hop.global.size()));
+            GX_HIP(hipMemcpy(h->d_hop_global, h->hop.global.data(), h->hop.global.size(), hipMemcpyHostToDevice));
+        }
         GX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_slots), 2 * gx_handle::N_SLOTS * sizeof(uint32_t)));
         GX_HIP(hipMemset(h->d_slots, 0, 2 * gx_handle::N_SLOTS * sizeof(uint32_t)));
         for (int q = 0; q < gx_handle::N_SLOTS; ++q) GX_HIP(hipEventCreateWithFlags(&h->slot_event[q], hipEventDisableTiming));
@@ -916,6 +917,22 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
     const uint8_t* image = static_cast<const uint8_t*>(mo && h->has_mo ? h->d_lds_image_mo : h->d_lds_image);
     const uint32_t image_tier = mo && h->has_mo ? h->lds_mo.tier : h->lds.tier;
     const uint8_t* at_global = image_tier == 1 || image_tier == 3 ? static_cast<const uint8_t*>(h->d_l2_image) : nullptr;
+    // hop tier: capture batches of definitions whose dense rows do not fit LDS, lines of ordinary length and evenness (the
+    // tile kernel wants a tile's lines to be neighbours in memory and about as long as each other)
+    const bool hops = h->hop_ok && !mo && !b.wide && (kernel == GX_KERNEL_HOPS || (kernel == GX_KERNEL_AUTO && !long_lines && !uneven));
+    if (batchable && hops && plan_hop_launch(h, line_bytes_hint, &L)) {
+        std::lock_guard<std::mutex> lock(h->slot_mu);
+        b.seq = h->next_seq++;
+        if (h->next_seq == 0) h->next_seq = 1;
+        const int slot = static_cast<int>(b.seq % gx_handle::N_SLOTS);
+        if (h->slot_used[slot]) GX_HIP(hipStreamWaitEvent(stream, h->slot_event[slot], 0));
+        h->slot_used[slot] = true;
+        b.oversize_flag = h->d_slots + slot;
+        GX_HIP(launch_extract_tile(h->dev, L, static_cast<const uint8_t*>(h->d_lds_image_hop), static_cast<const uint8_t*>(h->d_hop_global), h->num_cus, b, stream, nullptr));
+        GX_HIP(launch_extract_oversize(h->dev, b, L.stage_bytes, stream));
+        GX_HIP(hipEventRecord(h->slot_event[slot], stream));
+        return;
+    }
     const bool slices = kernel == GX_KERNEL_SLICES || (kernel == GX_KERNEL_AUTO && very_long);
     if (batchable && slices && plan_slice_launch(h, &L, mo)) {
         GX_HIP(launch_extract_slices(h->dev, L, image, at_global, h->num_cus, b, stream));
@@ -1047,6 +1064,8 @@ void gx_destroy(gx_handle* h) {
     if (h->d_lds_image) (void)hipFree(h->d_lds_image);
     if (h->d_lds_image_mo) (void)hipFree(h->d_lds_image_mo);
     if (h->d_l2_image) (void)hipFree(h->d_l2_image);
+    if (h->d_lds_image_hop) (void)hipFree(h->d_lds_image_hop);
+    if (h->d_hop_global) (void)hipFree(h->d_hop_global);
     if (h->hint_probe) { (void)hipHostFree(h->hint_probe); (void)hipEventDestroy(h->hint_event); }
     for (auto& sl : h->host_slot) {
         for (void* p : {sl.d_bytes, sl.d_off, sl.d_res, sl.d_caps, sl.d_states, static_cast<void*>(sl.d_over)}) if (p) (void)hipFree(p);
@@ -1085,6 +1104,11 @@ int64_t gx_stat(const gx_handle* h, int32_t which) {
     case 11: { GxLds L; return plan_lanes_launch(h, &L, true, false) ? static_cast<int64_t>(L.nwaves) : 0; }   // ... match-only
     case 12: return h->tile_ok ? static_cast<int64_t>(h->lds.table_bytes) : 0;
     case 13: return h->tile_ok ? static_cast<int64_t>(h->lds.regs_wave_bytes) : 0;
+    case 14: return h->hop_ok ? static_cast<int64_t>(h->hop.n_states) : 0;         // hop tier: states (0: no hop image)
+    case 15: return h->hop_ok ? static_cast<int64_t>(h->hop.n_hot) : 0;            // ... whose records live in LDS
+    case 16: return h->hop_ok ? static_cast<int64_t>(h->hop.n_reachable_hot) : 0;  // ... that well-formed lines reach
+    case 17: return h->hop_ok ? static_cast<int64_t>(h->hop.n_chains) : 0;         // ... that have a chain
+    case 18: { GxLds L; return plan_hop_launch(h, 0, &L) ? static_cast<int64_t>(L.nwaves) : 0; }  // hop tier: waves per CU
     case 9: return !h->tile_ok ? 0 : !h->has_mo ? gx_stat(h, 7) : h->lds_mo.tier == 3 ? 4 : h->lds_mo.tier == 2 ? 3 : h->lds_mo.tier == 1 ? 2 : 1;
     default: return -1;
     }
@@ -1551,7 +1575,7 @@ static int extract_batch_impl(gx_handle* h, const uint8_t* bytes, const void* of
     if (!h->on_device) return fail(GX_E_DEVICE, "handle was created host-only; no device tables (there is no CPU fallback)");
     gx_batch_opts o{};
     if (!read_opts(opts, &o)) return fail(GX_E_ARG, "gx_batch_opts.struct_size mismatch");
-    if (o.kernel > GX_KERNEL_LANES) return fail(GX_E_ARG, "gx_batch_opts.kernel: unknown kernel");
+    if (o.kernel > GX_KERNEL_HOPS) return fail(GX_E_ARG, "gx_batch_opts.kernel: unknown kernel");
     const bool match_only = o.match_only || states || !h->T.has_capture;
     const bool compact = o.compact_results && !match_only;  // rows of u16[1 + slots] (2: u8[1 + slots]) through `caps`
     if (o.compact_results > 2) return fail(GX_E_ARG, "gx_batch_opts.compact_results: 0, 1 (u16 rows) or 2 (u8 rows)");

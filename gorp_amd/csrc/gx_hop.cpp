@@ -1,0 +1,309 @@
+// gx_hop.cpp -- builds the HOP tier's tables from the fused automaton (see gx_hop.hpp for what they are and why every
+// shortcut in them is a fact about the dense rows).  Host code, once per definition.
+#include "gx_hop.hpp"
+
+#include <deque>
+
+namespace gx {
+
+namespace {
+inline bool has(const ClassSet& s, int c) { return (s[c >> 6] >> (c & 63)) & 1ull; }
+inline void put(ClassSet& s, int c) { s[c >> 6] |= 1ull << (c & 63); }
+}  // namespace
+
+std::vector<int> order_classes(const std::map<ClassSet, uint64_t>& weight, int ncls) {
+    // ordered partition of the classes, refined set by set: a set that is a union of whole blocks plus parts of the two
+    // blocks at its ends can be made contiguous by splitting those two blocks; a set with a hole in the middle stays split
+    std::vector<std::vector<int>> blocks(1);
+    for (int c = 0; c < ncls; ++c) blocks[0].push_back(c);
+    std::vector<std::pair<uint64_t, ClassSet>> by_weight;
+    for (auto& w : weight) {
+        int size = 0;
+        for (int c = 0; c < ncls; ++c) size += has(w.first, c) ? 1 : 0;
+        if (size > 1 && size < ncls) by_weight.push_back({w.second * static_cast<uint64_t>(size), w.first});
+    }
+    std::sort(by_weight.begin(), by_weight.end(), [](const std::pair<uint64_t, ClassSet>& a, const std::pair<uint64_t, ClassSet>& b) {
+        return a.first != b.first ? a.first > b.first : a.second < b.second;
+    });
+    for (auto& ws : by_weight) {
+        const ClassSet& S = ws.second;
+        int first = -1, last = -1;
+        bool ok = true;
+        std::vector<int> inside(blocks.size());
+        for (size_t b = 0; b < blocks.size(); ++b) {
+            int in = 0;
+            for (int c : blocks[b]) in += has(S, c) ? 1 : 0;
+            inside[b] = in;
+            if (in) { if (first < 0) first = static_cast<int>(b); last = static_cast<int>(b); }
+        }
+        for (int b = first + 1; b < last && ok; ++b) if (inside[b] != static_cast<int>(blocks[b].size())) ok = false;  // a hole in the middle
+        if (!ok || first < 0) continue;
+        auto split = [&](int b, bool inside_last) {  // block b -> (outside, inside) or (inside, outside)
+            std::vector<int> in, out;
+            for (int c : blocks[b]) (has(S, c) ? in : out).push_back(c);
+            if (in.empty() || out.empty()) return 0;
+            blocks[b] = inside_last ? out : in;
+            blocks.insert(blocks.begin() + b + 1, inside_last ? in : out);
+            return 1;
+        };
+        if (first == last) split(first, false);
+        else {
+            split(last, false);          // the inside part first, next to the run
+            split(first, true);          // the inside part last
+        }
+    }
+    std::vector<int> new_id(ncls);
+    int id = 0;
+    for (auto& b : blocks) for (int c : b) new_id[c] = id++;
+    return new_id;
+}
+
+bool build_hop_image(const Tables& T, uint32_t hot_budget_bytes, HopImage& out) {
+    out = HopImage{};
+    if (!T.union_ok || !T.has_capture) return false;
+    const RuleTables& U = T.uni;
+    const int ncls = T.ncls;
+    const size_t S = static_cast<size_t>(U.n_states);
+    if (ncls < 1 || ncls > 127 || S < 2 || S > 65536u || U.n_regs > 253) return false;
+    const uint32_t dead = static_cast<uint32_t>(U.dead);
+
+    // entry(s, c) = successor | register column << 16 (0: no program); every program must be one "register := position"
+    std::vector<uint32_t> ent(S * ncls);
+    for (size_t i = 0; i < ent.size(); ++i) {
+        const uint32_t w = U.trans[i], op = w >> 16;
+        uint32_t col = 0;
+        if (op) {
+            const uint32_t b = T.ops_off[op], e = T.ops_off[op + 1];
+            if (e - b != 1 || T.ops[2 * b + 1] != GX_SRC_POS || T.ops[2 * b] >= 254u) return false;
+            col = T.ops[2 * b] + 1u;
+        }
+        ent[i] = (w & 0xFFFFu) | (col << 16);
+    }
+
+    // how likely text is to take a class: its printable bytes (and the tab)
+    std::vector<long> printable(ncls, 0);
+    for (int b = 0; b < 256; ++b) if ((b >= 0x20 && b < 0x7F) || b == 0x09) ++printable[T.cls256[b]];
+    auto set_weight = [&](const ClassSet& s) { long p = 0; for (int c = 0; c < ncls; ++c) if (has(s, c)) p += printable[c]; return p; };
+
+    // the groups of every state: entry -> classes (the dead successor is not a group)
+    struct Group { uint32_t entry; ClassSet set; long weight; };
+    std::vector<std::vector<Group>> groups(S);
+    std::map<ClassSet, uint64_t> weight;
+    for (size_t s = 0; s < S; ++s) {
+        std::map<uint32_t, ClassSet> by_entry;
+        for (int c = 0; c < ncls; ++c) {
+            const uint32_t e = ent[s * ncls + c];
+            if ((e & 0xFFFFu) == dead) continue;
+            put(by_entry[e], c);
+        }
+        for (auto& g : by_entry) {
+            groups[s].push_back(Group{g.first, g.second, set_weight(g.second)});
+            ++weight[g.second];
+        }
+    }
+    const std::vector<int> new_id = order_classes(weight, ncls);
+    std::vector<long> printable_new(ncls, 0);
+    for (int c = 0; c < ncls; ++c) printable_new[new_id[c]] = printable[c];
+
+    // the heaviest contiguous id range of a class set (ties: the longer one)
+    struct Range { int lo = 0, hi = -1; long weight = -1; };
+    auto best_range = [&](const ClassSet& s) {
+        std::vector<char> in(ncls, 0);
+        for (int c = 0; c < ncls; ++c) if (has(s, c)) in[new_id[c]] = 1;
+        Range best;
+        for (int i = 0; i < ncls; ++i) {
+            if (!in[i]) continue;
+            int j = i;
+            long w = 0;
+            while (j < ncls && in[j]) { w += printable_new[j]; ++j; }
+            if (w > best.weight || (w == best.weight && j - i > best.hi - best.lo + 1)) best = Range{i, j - 1, w};
+            i = j;
+        }
+        return best;
+    };
+
+    // per state: the run (plain self-loop) and the one plausible exit, if there is exactly one
+    struct Exit { bool any = false; Range r; uint32_t entry = 0; };
+    std::vector<Range> run(S);
+    std::vector<long> run_weight(S, 0);
+    std::vector<Exit> exit_of(S);
+    std::vector<std::vector<uint32_t>> plausible_targets(S);
+    for (size_t s = 0; s < S; ++s) {
+        int n_plausible = 0;
+        const Group* only = nullptr;
+        for (auto& g : groups[s]) {
+            if (g.entry == static_cast<uint32_t>(s)) {  // the plain self-loop: same state, no program
+                run[s] = best_range(g.set);
+                run_weight[s] = g.weight;
+                continue;
+            }
+            if (g.weight > 0) { ++n_plausible; only = &g; plausible_targets[s].push_back(g.entry & 0xFFFFu); }
+        }
+        if (n_plausible == 1) {
+            exit_of[s].any = true;
+            exit_of[s].r = best_range(only->set);
+            exit_of[s].entry = only->entry;
+        }
+    }
+
+    // chains
+    struct Chain { int klen = 0; uint8_t lo[HOP_CHAIN], span[HOP_CHAIN]; uint32_t target = 0, col[2] = {0, 0}, off[2] = {0, 0}; };
+    std::vector<Chain> chain(S);
+    for (size_t s = 0; s < S; ++s) {
+        if (s == dead) continue;
+        Chain& ch = chain[s];
+        size_t cur = s;
+        int nops = 0;
+        for (uint32_t k = 0; k < HOP_CHAIN; ++k) {
+            // a chain does not run through a field state (a state with a wide plausible self-loop): it ends there, and the
+            // next iteration skips the field's bytes as a run.  A blank-run state ([ \t]+ with one blank in the line) it passes.
+            if (k > 0 && run_weight[cur] > 4) break;
+            const Exit& x = exit_of[cur];
+            if (!x.any || x.r.hi < x.r.lo) break;
+            const uint32_t col = x.entry >> 16;
+            if (col) {
+                if (nops == 2) break;
+                ch.col[nops] = col;
+                ch.off[nops] = k;
+                ++nops;
+            }
+            ch.lo[k] = static_cast<uint8_t>(x.r.lo);
+            ch.span[k] = static_cast<uint8_t>(x.r.hi - x.r.lo);
+            ch.klen = static_cast<int>(k) + 1;
+            cur = x.entry & 0xFFFFu;
+        }
+        ch.target = static_cast<uint32_t>(cur);
+    }
+
+    // hot order: breadth-first from the start state over what the walk lands on when lines look like the definition --
+    // a chain's target, or (no chain) the targets of the plausible exits
+    std::vector<uint32_t> order;
+    std::vector<char> seen(S, 0);
+    std::deque<uint32_t> queue;
+    auto visit = [&](uint32_t s) { if (!seen[s]) { seen[s] = 1; queue.push_back(s); } };
+    visit(0);
+    while (!queue.empty()) {
+        const uint32_t s = queue.front();
+        queue.pop_front();
+        order.push_back(s);
+        if (chain[s].klen > 0) visit(chain[s].target);
+        else for (uint32_t t : plausible_targets[s]) visit(t);
+    }
+    out.n_reachable_hot = static_cast<uint32_t>(order.size());
+    for (size_t s = 0; s < S; ++s) if (!seen[s]) order.push_back(static_cast<uint32_t>(s));
+    std::vector<uint32_t> perm(S);
+    for (size_t i = 0; i < S; ++i) perm[order[i]] = static_cast<uint32_t>(i);
+    out.n_hot = std::min<uint32_t>(out.n_reachable_hot, hot_budget_bytes / HOP_REC_BYTES);
+    if (out.n_hot == 0) out.n_hot = 1;
+
+    // final records, as gx_walk.hpp's line_result reads them (the layout build_tile_image gives the other tiers):
+    // u16 [begin tag, end tag] x max_groups padded to four groups, then the extraction; record 0 = nothing set
+    const size_t tag_slots = 8 * static_cast<size_t>((T.max_groups + 3) / 4), rec_len = tag_slots + 8;
+    std::vector<uint16_t> fin_rec(rec_len, 0);
+    fin_rec[tag_slots] = 0xFFFFu;
+    std::map<int32_t, uint32_t> rec_of;
+    auto fin_record = [&](int32_t f) -> uint32_t {
+        auto it = rec_of.find(f);
+        if (it != rec_of.end()) return it->second;
+        const int32_t k = static_cast<int32_t>(T.fin_tags[f]);
+        const size_t at = fin_rec.size();
+        fin_rec.resize(at + rec_len, 0);
+        for (int g = 0; g < T.rules[k].n_groups; ++g)
+            for (int e = 0; e < 2; ++e) {
+                const uint16_t v = T.fin_tags[f + 1 + 2 * g + e];
+                fin_rec[at + 2 * g + e] = v == GX_SRC_NIL ? 0 : v == GX_SRC_POS ? 1 : static_cast<uint16_t>((v + 1u) * 128u);
+            }
+        fin_rec[at + tag_slots] = static_cast<uint16_t>(k);
+        rec_of[f] = static_cast<uint32_t>(at * 2);
+        return static_cast<uint32_t>(at * 2);
+    };
+
+    // dense rows (the exact step): u32[S][ncls + 1], successor | column << 16 by NEW state index and NEW class id; the last
+    // column is the state's info word (byte offset of its final record, or -1 / -2-k)
+    const uint32_t cols = static_cast<uint32_t>(ncls) + 1u;
+    std::vector<uint32_t> rows(S * cols, 0);
+    for (size_t s = 0; s < S; ++s) {
+        uint32_t* row = &rows[static_cast<size_t>(perm[s]) * cols];
+        for (int c = 0; c < ncls; ++c) {
+            const uint32_t e = ent[s * ncls + c];
+            row[new_id[c]] = perm[e & 0xFFFFu] | (e & 0xFFFF0000u);
+        }
+        row[ncls] = U.fin[s] >= 0 ? fin_record(U.fin[s]) : static_cast<uint32_t>(U.fin[s]);
+    }
+    if (fin_rec.size() * 2 > 0xFFFFFFu) return false;
+
+    // hop records
+    std::vector<uint32_t> hops(S * (HOP_REC_BYTES / 4), 0);
+    for (size_t s = 0; s < S; ++s) {
+        uint32_t* r = &hops[static_cast<size_t>(perm[s]) * (HOP_REC_BYTES / 4)];
+        const Chain& ch = chain[s];
+        uint32_t run_lo = 0, run_k = 0x80;  // none: every byte fails the test
+        if (run[s].hi >= run[s].lo && s != dead) { run_lo = static_cast<uint32_t>(run[s].lo); run_k = 0x7Fu - static_cast<uint32_t>(run[s].hi); ++out.n_runs; }
+        r[0] = run_lo | run_k << 8 | static_cast<uint32_t>(ch.klen) << 16 | ch.off[0] << 20 | ch.off[1] << 23;
+        r[1] = perm[ch.klen ? ch.target : static_cast<uint32_t>(s)] | ch.col[0] << 16 | ch.col[1] << 24;
+        uint8_t el[HOP_CHAIN], ns[HOP_CHAIN];
+        for (uint32_t k = 0; k < HOP_CHAIN; ++k) {
+            if (static_cast<int>(k) < ch.klen) { el[k] = static_cast<uint8_t>(0x80u - ch.lo[k]); ns[k] = static_cast<uint8_t>(0x7Fu - ch.span[k]); }
+            else { el[k] = 0x80; ns[k] = 0; }             // any class
+        }
+        if (ch.klen == 0) ns[0] = 0x80;                   // no chain: element 0 never matches
+        else ++out.n_chains;
+        memcpy(&r[2], el, 8);
+        memcpy(&r[4], ns, 8);
+    }
+
+    // self-check against the dense rows: every class of a run loops with no program; every class sequence a chain
+    // accepts leads where the chain says, with the chain's programs at the chain's offsets and no others
+    for (size_t s = 0; s < S; ++s) {
+        const uint32_t* r = &hops[s * (HOP_REC_BYTES / 4)];
+        const uint32_t run_lo = r[0] & 0xFFu, run_k = (r[0] >> 8) & 0xFFu;
+        if (run_k != 0x80u)
+            for (uint32_t c = run_lo; c <= 0x7Fu - run_k; ++c)
+                if (c >= static_cast<uint32_t>(ncls) || rows[s * cols + c] != static_cast<uint32_t>(s)) throw GxError(GX_E_ARG, "internal: hop tier run does not match the dense rows");
+        const uint32_t klen = (r[0] >> 16) & 0xFu;
+        const uint8_t* el = reinterpret_cast<const uint8_t*>(&r[2]);
+        const uint8_t* ns = reinterpret_cast<const uint8_t*>(&r[4]);
+        uint32_t cur = static_cast<uint32_t>(s), nops = 0;
+        const uint32_t want_col[2] = {(r[1] >> 16) & 0xFFu, r[1] >> 24}, want_off[2] = {(r[0] >> 20) & 7u, (r[0] >> 23) & 7u};
+        for (uint32_t k = 0; k < klen; ++k) {
+            const uint32_t lo = 0x80u - el[k], hi = lo + (0x7Fu - ns[k]);
+            if (hi >= static_cast<uint32_t>(ncls)) throw GxError(GX_E_ARG, "internal: hop tier chain element out of range");
+            const uint32_t e0 = rows[cur * cols + lo];
+            for (uint32_t c = lo; c <= hi; ++c) if (rows[cur * cols + c] != e0) throw GxError(GX_E_ARG, "internal: hop tier chain element is not one group");
+            if (e0 >> 16) {
+                if (nops >= 2 || want_col[nops] != (e0 >> 16) || want_off[nops] != k) throw GxError(GX_E_ARG, "internal: hop tier chain programs");
+                ++nops;
+            }
+            cur = e0 & 0xFFFFu;
+        }
+        if (klen && (cur != (r[1] & 0xFFFFu) || (nops < 2 && want_col[nops] != 0))) throw GxError(GX_E_ARG, "internal: hop tier chain target");
+    }
+
+    // images
+    out.ncls = static_cast<uint32_t>(ncls);
+    out.row_bytes = cols * 4u;
+    out.n_states = static_cast<uint32_t>(S);
+    out.start = perm[0];
+    out.dead = perm[dead];
+    out.n_regs = static_cast<uint32_t>(U.n_regs);
+    out.lds.assign(HOP_AT, 0);
+    for (int b = 0; b < 256; ++b) out.lds[b] = static_cast<uint8_t>(new_id[T.cls256[b]]);
+    const uint8_t* hb = reinterpret_cast<const uint8_t*>(hops.data());
+    out.lds.insert(out.lds.end(), hb, hb + static_cast<size_t>(out.n_hot) * HOP_REC_BYTES);
+    while (out.lds.size() % 16) out.lds.push_back(0);
+    const uint8_t* rb = reinterpret_cast<const uint8_t*>(rows.data());
+    out.global.assign(rb, rb + rows.size() * 4);
+    while (out.global.size() % 16) out.global.push_back(0);
+    out.hops_off = static_cast<uint32_t>(out.global.size());
+    out.global.insert(out.global.end(), hb, hb + hops.size() * 4);
+    while (out.global.size() % 16) out.global.push_back(0);
+    out.fin_off = static_cast<uint32_t>(out.global.size());
+    const uint8_t* fr = reinterpret_cast<const uint8_t*>(fin_rec.data());
+    out.global.insert(out.global.end(), fr, fr + fin_rec.size() * 2);
+    while (out.global.size() % 16) out.global.push_back(0);
+    if (out.global.size() > 0xFFFFFFF0ull) return false;
+    out.ok = true;
+    return true;
+}
+
+}  // namespace gx

@@ -1,0 +1,57 @@
+// gx_hop.hpp -- host side of the HOP tier: the fused automaton as "hop records" (run interval + literal chain) over a
+// dense-row backstop, for definitions whose dense rows do not fit LDS (64 extractions and more).
+//
+// What it replaces is still one step per char, Automata.step (core/autom/Automata.java:133-135) folded over the line by
+// PolyMatcher.match (core/autom/PolyMatcher.java:123-133) with the capture scan fused in: the walk below reaches the
+// same state with the same capture registers, but consumes a RUN of bytes (a field: \S+, \d+, \w+) and a CHAIN of up to
+// eight bytes (the literal text between two fields: " key=") per iteration instead of one byte.
+//
+// Everything is in CLASS space: the kernel maps a tile's bytes to character-class ids while it stages them (one lookup
+// per byte and tile), classes are ordered so that the sets the automaton uses are id intervals (order_classes), and
+// every test of the walk is an interval test on four or eight class ids at once.
+//
+// Per state (24 bytes, `HopRec`):
+//   run    [run_lo, run_hi]: classes on which the state loops to itself with no capture program.  The walk skips up to
+//          16 such bytes with one SWAR test.
+//   chain  up to 8 elements (lo, span): "the next klen bytes lie in these class intervals" is a PROVEN shortcut -- the
+//          host follows the state's one plausible exit (and its successor's, ...) through the dense rows and records
+//          where that path ends (target) and the (at most two) capture programs on it with their offsets.  When the bytes
+//          do not match, the walk takes ONE exact step through the state's dense row instead (global memory / L2), so the
+//          result never depends on which chains exist: a chain is a fact about the dense rows.
+// States are renumbered "hot first" (breadth-first over chain targets and plausible exits from the start state): the
+// records of the first n_hot states are copied into LDS by every workgroup, the others are read from global memory.
+#pragma once
+#include <array>
+#include <map>
+
+#include "gx_compile.hpp"
+
+namespace gx {
+
+typedef std::array<uint64_t, 4> ClassSet;  // one bit per class (<= 256)
+
+// An order of the classes in which as many as possible of the weighted sets are contiguous (greedy partition refinement,
+// heaviest sets first).  Returns new_id[class].
+std::vector<int> order_classes(const std::map<ClassSet, uint64_t>& weight, int ncls);
+
+constexpr uint32_t HOP_REC_BYTES = 24;
+constexpr uint32_t HOP_AT = 272;          // LDS address of the hot records (behind the u8[256] class map)
+constexpr uint32_t HOP_CHAIN = 8;         // elements per chain
+
+struct HopImage {
+    bool ok = false;
+    std::vector<uint8_t> lds;      // [0, 256): byte -> class id; [HOP_AT, ...): hop records of the states [0, n_hot)
+    std::vector<uint8_t> global;   // dense rows u32[n_states][ncls + 1] | hop records of ALL states | final records
+    uint32_t ncls = 0, row_bytes = 0, n_states = 0, n_hot = 0;
+    uint32_t hops_off = 0, fin_off = 0;  // byte offsets in `global`
+    uint32_t start = 0, dead = 0;        // state indexes (renumbered)
+    uint32_t n_regs = 0;
+    // diagnostics (gx_stat)
+    uint32_t n_reachable_hot = 0, n_chains = 0, n_runs = 0;
+};
+
+// hot_budget_bytes: LDS bytes the hot records may take.  Returns false (out.ok stays false) when the definition is
+// outside the tier's limits: no fused automaton, general capture programs, more than 127 classes, 65 536 states, 254 registers.
+bool build_hop_image(const Tables& T, uint32_t hot_budget_bytes, HopImage& out);
+
+}  // namespace gx

@@ -1,0 +1,130 @@
+// gx_hop_dev.hpp -- device side of the HOP tier (tables: gx_hop.hpp): the walk of the fused automaton that consumes a
+// run of bytes and a chain of up to eight bytes per iteration instead of one byte per step.
+//
+// Replaces the same reference loops as walk<> (gx_tile_body.hpp): PolyMatcher.match core/autom/PolyMatcher.java:123-133
+// over Automata.step core/autom/Automata.java:133-135, with JDKRegexpCookedExtraction.match
+// core/jdkre/JDKRegexpCookedExtraction.java:36-59 fused in.
+//
+// The staging area holds CLASS IDS (the tile kernel maps the bytes while it stages them: hop_map16), every lane walks its
+// own line at its own position:
+//   1. the state's hop record (24 bytes; LDS for the hot states, global memory / L2 for the others);
+//   2. 16 class ids at the lane's position; one SWAR interval test finds how many of them the state's RUN covers;
+//   3. 8 class ids behind the run; one SWAR test against the chain's 8 (lo, span) elements.  Match: the lane is at the
+//      chain's target, klen bytes further, and the chain's (at most two) capture programs are written;
+//   4. no match: ONE exact step through the state's dense row (global memory / L2) -- a wave-uniform branch that the waves
+//      of a well-formed log take for the branching nodes of the literal trie only.
+// LDS is read in aligned dwords only (an unaligned ds_read stalls the LDS pipe for dozens of cycles on gfx950): a window at
+// byte address p is five (or three) dwords from p & ~3, joined by v_alignbyte.
+#pragma once
+#include "gx_walk.hpp"
+
+namespace gx {
+
+constexpr uint32_t HOP_REC_B = 24, HOP_LDS_AT = 272, LOW7 = 0x7F7F7F7Fu;
+
+struct HopTab {
+    const uint8_t* rows;   // dense rows u32[n_states][ncls + 1] (global): successor | register column << 16; last column: info
+    const uint8_t* hops;   // hop records of all states (global)
+    uint32_t row_bytes;
+    uint32_t info_off;     // byte offset of the info column in a row
+    uint32_t n_hot;        // states [0, n_hot) have their records in LDS at HOP_LDS_AT
+};
+
+// two / one dwords at a 4-byte aligned LDS address (ds_read2_b32 / ds_read_b32)
+struct __attribute__((packed, aligned(4))) HopPair { u32x2 v; };
+__device__ __forceinline__ u32x2 lds_pair4(uint32_t a) { return ((GX_LDS const HopPair*)(uintptr_t)a)->v; }
+__device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// (mask & a) | (~mask & b)
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    return r;
+}
+
+// byte -> class id for the 16 bytes of one staged chunk (class map: u8[256] at LDS address 0)
+__device__ __forceinline__ uint32_t hop_map4(uint32_t d) {
+    const uint32_t c0 = lds_ld<uint8_t>(d & 0xFFu), c1 = lds_ld<uint8_t>((d >> 8) & 0xFFu);
+    const uint32_t c2 = lds_ld<uint8_t>((d >> 16) & 0xFFu), c3 = lds_ld<uint8_t>(d >> 24);
+    return c0 | c1 << 8 | c2 << 16 | c3 << 24;
+}
+__device__ __forceinline__ u32x4 hop_map16(const u32x4& v) { return u32x4{hop_map4(v.x), hop_map4(v.y), hop_map4(v.z), hop_map4(v.w)}; }
+
+// Walks the line [start, end) of the wave's staging area (class ids) from state `s`; returns the final state.  regs = LDS
+// address of this lane's slot in register column 0 (the write-only dummy column sits 128 bytes before it).
+__device__ __forceinline__ uint32_t walk_hop(const HopTab& H, uint32_t stage, uint32_t s, uint32_t start, uint32_t end, bool on,
+                                             uint32_t dead, uint32_t regs) {
+    const uint32_t p0 = stage + start, e = stage + end, dummy_col = regs - 128u;
+    uint32_t p = p0;
+    bool more = on && p < e;
+    while (__any(more)) {
+        // ---- 1. the state's record ----
+        u32x2 h0, h1, h2;
+        const bool cold = more && s >= H.n_hot;
+        const uint32_t la = HOP_LDS_AT + (s < H.n_hot ? s : 0u) * HOP_REC_B;
+        h0 = lds_ld<u32x2>(la);
+        h1 = lds_ld<u32x2>(la + 8u);
+        h2 = lds_ld<u32x2>(la + 16u);
+        if (__any(cold)) {
+            if (cold) {
+                const u32x2* g = reinterpret_cast<const u32x2*>(H.hops + static_cast<uint64_t>(s) * HOP_REC_B);
+                h0 = g[0]; h1 = g[1]; h2 = g[2];
+            }
+        }
+        // ---- 2. the run: how many of the next 16 class ids lie in [run_lo, run_hi] ----
+        const uint32_t a1 = p & ~3u, sh1 = p & 3u;
+        const u32x2 d01 = lds_pair4(a1), d23 = lds_pair4(a1 + 8u);
+        const uint32_t d4 = lds_ld<uint32_t>(a1 + 16u);
+        const uint32_t x0 = __builtin_amdgcn_alignbyte(d01.y, d01.x, sh1), x1 = __builtin_amdgcn_alignbyte(d23.x, d01.y, sh1);
+        const uint32_t x2 = __builtin_amdgcn_alignbyte(d23.y, d23.x, sh1), x3 = __builtin_amdgcn_alignbyte(d4, d23.y, sh1);
+        const uint32_t lo4 = splat_byte0(h0.x), k4 = splat_byte1(h0.x);
+        const uint32_t f0 = static_cast<uint32_t>(__ffs(static_cast<int>(outside_bits(x0, lo4, k4) & HI_BITS)) - 1);  // 7, 15, 23, 31 or 0xFFFFFFFF
+        const uint32_t f1 = static_cast<uint32_t>(__ffs(static_cast<int>(outside_bits(x1, lo4, k4) & HI_BITS)) - 1);
+        const uint32_t f2 = static_cast<uint32_t>(__ffs(static_cast<int>(outside_bits(x2, lo4, k4) & HI_BITS)) - 1);
+        const uint32_t f3 = static_cast<uint32_t>(__ffs(static_cast<int>(outside_bits(x3, lo4, k4) & HI_BITS)) - 1);
+        uint32_t n = min3u(f0, sat_add(f1, 32u), min3u(sat_add(f2, 64u), sat_add(f3, 96u), 128u)) >> 3;  // 0 .. 16
+        n = min(n, e - p);
+        const uint32_t q = p + n;
+        const bool stepping = more && n < 16u && q < e;
+        // ---- 3. the chain: the 8 class ids at q against 8 (lo, span) elements ----
+        const uint32_t a2 = q & ~3u, sh2 = q & 3u;
+        const u32x2 r01 = lds_pair4(a2);
+        const uint32_t r2 = lds_ld<uint32_t>(a2 + 8u);
+        const uint32_t v0 = __builtin_amdgcn_alignbyte(r01.y, r01.x, sh2), v1 = __builtin_amdgcn_alignbyte(r2, r01.y, sh2);
+        // per byte: a = v + (0x80 - lo) has bit 7 set iff v >= lo; t = (a & 0x7F) + (0x7F - span) has bit 7 set iff v - lo > span
+        const uint32_t ca0 = v0 + h1.x, ca1 = v1 + h1.y;
+        const uint32_t ct0 = (ca0 & LOW7) + h2.x, ct1 = (ca1 & LOW7) + h2.y;
+        const uint32_t ok8 = bfi(ct0, 0u, ca0) & bfi(ct1, 0u, ca1) & HI_BITS;  // bit 7 of byte j of either half: element j / j + 4 ...
+        const uint32_t klen = (h0.x >> 16) & 0xFu;
+        const bool chained = stepping && ok8 == HI_BITS && q + klen <= e;
+        // ---- 4. one exact step where the chain does not apply ----
+        const bool exact = stepping && !chained;
+        uint32_t xe = 0;
+        if (__any(exact)) {
+            if (exact) xe = *reinterpret_cast<const uint32_t*>(H.rows + (static_cast<uint64_t>(s) * H.row_bytes + ((v0 & 0xFFu) << 2)));
+        }
+        // ---- capture programs: register column := position (column 0 is the write-only dummy) ----
+        const uint32_t rel = q - p0;
+        const uint32_t col1 = chained ? (h0.y >> 16) & 0xFFu : exact ? xe >> 16 : 0u;
+        const uint32_t col2 = chained ? h0.y >> 24 : 0u;
+        lds_st<uint16_t>(dummy_col + (col1 << 7), static_cast<uint16_t>(rel + (chained ? (h0.x >> 20) & 7u : 0u)));
+        lds_st<uint16_t>(dummy_col + (col2 << 7), static_cast<uint16_t>(rel + ((h0.x >> 23) & 7u)));
+        // ---- advance ----
+        if (more) {
+            p = q + (chained ? klen : exact ? 1u : 0u);
+            s = chained ? (h0.y & 0xFFFFu) : exact ? (xe & 0xFFFFu) : s;
+        }
+        more = more && p < e && s != dead;
+    }
+    return s;
+}
+
+}  // namespace gx

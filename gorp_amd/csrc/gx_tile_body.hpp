@@ -25,6 +25,7 @@
 //  stays put; everything else takes the exact steps.
 #pragma once
 #include "gx_walk.hpp"
+#include "gx_hop_dev.hpp"
 
 namespace gx {
 
@@ -115,6 +116,7 @@ __device__ __forceinline__ uint32_t walk(const WalkTab& W, uint32_t stage, uint3
 }
 
 // Staging copy for a span that touches the first or last bytes of the buffer: never reads outside [data, data_end).
+template <bool CLASSES>  // TIER_HOP: the staging area holds class ids
 __device__ __attribute__((unused)) void stage_span_guarded(const uint8_t* __restrict__ g_al, uint32_t nch, uint32_t stage, uint32_t lane,
                                    const uint8_t* data, const uint8_t* data_end) {
     for (uint32_t c = lane; c < nch; c += 64) {
@@ -122,7 +124,8 @@ __device__ __attribute__((unused)) void stage_span_guarded(const uint8_t* __rest
         uint32_t w[4] = {0, 0, 0, 0};
         for (int q = 0; q < 16; ++q)
             if (src + q >= data && src + q < data_end) w[q >> 2] |= static_cast<uint32_t>(src[q]) << ((q & 3) * 8);
-        lds_st<u32x4>(stage + (c << 4), u32x4{w[0], w[1], w[2], w[3]});
+        const u32x4 v = {w[0], w[1], w[2], w[3]};
+        lds_st<u32x4>(stage + (c << 4), CLASSES ? hop_map16(v) : v);
     }
 }
 
@@ -167,28 +170,29 @@ __device__ __forceinline__ void tile_issue_loads(const TileInfo& t, uint32_t lan
 // Registers -> staging area, and the hot-interval bit of every chunk -> the wave's bitmap (bit 64 k + lane of the
 // map belongs to the chunk lane `lane` holds in pre[k]; a clamped lane describes a chunk beyond the span, which no
 // line of the round reaches).
-template <int KCH, int MAP>  // MAP 0: no bitmap; 1: general hot interval; 2: hot interval ends at 0x7F
+template <int KCH, int MAP>  // MAP 0: no bitmap; 1: general hot interval; 2: hot interval ends at 0x7F; 3: no bitmap, class ids (TIER_HOP)
 __device__ __forceinline__ void commit_chunks(const TileInfo& t, uint32_t lane, const u32x4 (&pre)[KCH], uint32_t stage, uint32_t bitmap,
                                               uint32_t hot_lo4, uint32_t hot_k4) {
     const uint32_t last = stage + ((t.nch - 1u) << 4), mine = stage + (lane << 4);
 #pragma unroll
     for (int k = 0; k < KCH; ++k) {
-        lds_st<u32x4>(min(mine + 1024u * k, last), pre[k]);
-        if (MAP) {
+        lds_st<u32x4>(min(mine + 1024u * k, last), MAP == 3 ? hop_map16(pre[k]) : pre[k]);
+        if (MAP == 1 || MAP == 2) {
             const unsigned long long m = __ballot(chunk_inside<MAP == 2>(pre[k], hot_lo4, hot_k4));
             if (lane == 0) lds_st<u32x2>(bitmap + 8u * k, u32x2{static_cast<uint32_t>(m), static_cast<uint32_t>(m >> 32)});
         }
     }
 }
-template <int KCH>
+template <int KCH, bool CLASSES>
 __device__ __forceinline__ void tile_commit(const TileInfo& t, uint32_t lane, const u32x4 (&pre)[KCH], uint32_t stage, uint32_t bitmap,
                                             bool use_map, uint32_t hot_lo4, uint32_t hot_k4, const uint8_t* data, const uint8_t* data_end) {
     if (t.mode == 0) {
-        if (!use_map) commit_chunks<KCH, 0>(t, lane, pre, stage, bitmap, hot_lo4, hot_k4);
+        if (CLASSES) commit_chunks<KCH, 3>(t, lane, pre, stage, bitmap, hot_lo4, hot_k4);
+        else if (!use_map) commit_chunks<KCH, 0>(t, lane, pre, stage, bitmap, hot_lo4, hot_k4);
         else if (hot_k4 == 0u) commit_chunks<KCH, 2>(t, lane, pre, stage, bitmap, hot_lo4, hot_k4);
         else commit_chunks<KCH, 1>(t, lane, pre, stage, bitmap, hot_lo4, hot_k4);
     } else if (t.mode == 1) {
-        stage_span_guarded(t.g_al, t.nch, stage, lane, data, data_end);
+        stage_span_guarded<CLASSES>(t.g_al, t.nch, stage, lane, data, data_end);
         if (use_map && lane < 2u * KCH) lds_st<uint32_t>(bitmap + 4u * lane, 0u);  // no chunk of a guarded round is skipped
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -229,7 +233,14 @@ k_extract_tile(GxLds L, TileIO io) {
     }
     __syncthreads();
 
-    constexpr bool GT = TIER == TIER_L2 || TIER == TIER_RECG;  // automaton tables and final records in global memory
+    constexpr bool GT = TIER == TIER_L2 || TIER == TIER_RECG || TIER == TIER_HOP;  // automaton tables and final records in global memory
+    constexpr bool HOP = TIER == TIER_HOP;
+    HopTab H;
+    H.rows = io.at_global;
+    H.hops = io.at_global + L.c_base;
+    H.row_bytes = L.row_bytes;
+    H.info_off = L.ncls * 4u;
+    H.n_hot = L.rec_indexed;
     const uint8_t* __restrict__ data = io.data;
     const OFF* __restrict__ off = static_cast<const OFF*>(io.off);
     const uint64_t n = io.n;
@@ -251,7 +262,7 @@ k_extract_tile(GxLds L, TileIO io) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t stage = L.stage + wave * L.stage_bytes;
     const uint32_t bitmap = L.bitmap + wave * GX_BITMAP_WAVE_BYTES;
-    const bool use_map = L.hot_k4 != HI_BITS;
+    const bool use_map = !HOP && L.hot_k4 != HI_BITS;
     // register r of this lane = u16 at regs + r * 128; the column before register 0 is a write-only dummy
     const uint32_t regs = L.regs + wave * L.regs_wave_bytes + 128u + lane * 2u;
 
@@ -338,7 +349,7 @@ k_extract_tile(GxLds L, TileIO io) {
     tile_issue_loads<KCH>(cur, lane, pre, io.image);
 
     for (;;) {
-        tile_commit<KCH>(cur, lane, pre, stage, bitmap, use_map, L.hot_lo4, L.hot_k4, data, data_end);
+        tile_commit<KCH, HOP>(cur, lane, pre, stage, bitmap, use_map, L.hot_lo4, L.hot_k4, data, data_end);
         GX_STAMP(0);
         // ---- software pipeline: start fetching the next round (and the offsets of the group after it) ----
         const uint32_t group_lines = static_cast<uint32_t>(min(static_cast<uint64_t>(64), n - (tile << 6)));
@@ -364,8 +375,14 @@ k_extract_tile(GxLds L, TileIO io) {
         const uint32_t start = cur.start;
         uint32_t end = cur.end;
         if (io.strip_eol && cur.mode != 2) {  // the terminator is staged with the line (trim_eol, from LDS)
-            if (end > start && lds_ld<uint8_t>(stage + end - 1u) == 0x0Au) --end;
-            if (end > start && lds_ld<uint8_t>(stage + end - 1u) == 0x0Du) --end;
+            if (HOP) {  // (the staging area holds class ids: the line's last bytes from global memory)
+                const uint8_t* line = data + cur.o0;
+                if (valid && end > start && line[end - start - 1u] == 0x0Au) --end;
+                if (valid && end > start && line[end - start - 1u] == 0x0Du) --end;
+            } else {
+                if (end > start && lds_ld<uint8_t>(stage + end - 1u) == 0x0Au) --end;
+                if (end > start && lds_ld<uint8_t>(stage + end - 1u) == 0x0Du) --end;
+            }
         }
         if (cur.mode == 2) {
             // one line that does not fit the staging area: the per-line kernel takes it in a follow-up launch
@@ -377,7 +394,11 @@ k_extract_tile(GxLds L, TileIO io) {
             GX_STAMP(2);
         } else {
             int32_t info;  // of the state the line's walk ended in: -1 null, -2-k ExtractionException, else its final record
-            if (MODE == 1 || L.u_start != 0xFFFFFFFFu) {
+            if (HOP) {
+                // ---- fused pass on the hop records: a run and a chain per iteration (gx_hop_dev.hpp) ----
+                const uint32_t urow = walk_hop(H, stage, L.u_start, start, end, true, L.u_dead, regs);
+                info = *reinterpret_cast<const int32_t*>(H.rows + (static_cast<uint64_t>(urow) * H.row_bytes + H.info_off));
+            } else if (MODE == 1 || L.u_start != 0xFFFFFFFFu) {
                 // ---- fused pass: match automaton x joined capture automata, one walk ----
                 uint32_t urow;
                 if (MODE == 1 || L.simple_ops) urow = walk<TIER, true, true>(Wc, stage, bitmap, use_map, L.u_start, start, end, true, L.u_dead, regs);

@@ -102,7 +102,9 @@ __device__ __forceinline__ uint32_t window_mask(uint32_t start, uint32_t end, ui
 // in LDS (gx_api.cpp: records_from_dense), a state is the index of its first 8-byte record.
 // TIER_RECG: the same records in global memory (64 KB - 512 KB: they live in the CUs' vector L1 and the XCD's L2, and
 // LDS is left to the waves' staging areas).
-enum { TIER_LDS = 0, TIER_L2 = 1, TIER_REC = 2, TIER_RECG = 3 };
+// TIER_HOP: hop records (run + chain per state) over dense rows in global memory; the staging area holds class ids
+// (gx_hop.hpp, gx_hop_dev.hpp).
+enum { TIER_LDS = 0, TIER_L2 = 1, TIER_REC = 2, TIER_RECG = 3, TIER_HOP = 4 };
 template <int TIER> struct TierTraits { static constexpr bool records = TIER == TIER_REC || TIER == TIER_RECG; };
 
 // wave-uniform description of the automaton being walked
@@ -327,11 +329,12 @@ __device__ __forceinline__ int32_t line_result(int32_t info, uint32_t fin_lds, c
     const uint32_t dummy_col = regs - 128u;
     const uint32_t id_at = rec + 16u * static_cast<uint32_t>((G + 3) >> 2);
     uint32_t id;
-    if (TIER == TIER_L2 || TIER == TIER_RECG) id = *reinterpret_cast<const uint16_t*>(fin_g + id_at);
+    constexpr bool FIN_GLOBAL = TIER == TIER_L2 || TIER == TIER_RECG || TIER == TIER_HOP;
+    if (FIN_GLOBAL) id = *reinterpret_cast<const uint16_t*>(fin_g + id_at);
     else id = lds_ld<uint16_t>(fin_lds + id_at);
     for (int g0 = 0; g0 < G; g0 += 4) {
         u32x4 t;
-        if (TIER == TIER_L2 || TIER == TIER_RECG) t = *reinterpret_cast<const u32x4*>(fin_g + rec + 4u * g0);
+        if (FIN_GLOBAL) t = *reinterpret_cast<const u32x4*>(fin_g + rec + 4u * g0);
         else t = lds_ld<u32x4>(fin_lds + rec + 4u * g0);
         const uint32_t tw[4] = {t.x, t.y, t.z, t.w};  // one dword = (begin tag, end tag) of one group
         uint32_t vb[4], ve[4];

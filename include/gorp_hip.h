@@ -59,6 +59,9 @@ enum {
 #define GX_CREATE_TIER_RECORDS 16u /* sparse range records in LDS even when the dense rows would fit (the default when they do
                                       not: BASELINE configs[2], 64 extractions) */
 #define GX_CREATE_TIER_RECORDS_GLOBAL 32u /* sparse range records in global memory (L1 / L2 resident) */
+#define GX_CREATE_TIER_HOP  64u    /* build the hop tier's tables (run + literal chain per state, hot states in LDS, dense rows in
+                                      global memory as the backstop) even when the dense rows fit LDS; the default for capture
+                                      batches when they do not */
 
 /* Replaces Gorp.construct's per-extraction back half (core/Gorp.java:58-92):
  * PolyMatcher.create(automatonInputs) (core/autom/PolyMatcher.java:64-84 ->
@@ -138,7 +141,8 @@ typedef struct gx_batch_opts {
                                   pointer with device_pointers, else a host pointer.  NULL: not counted. */
 } gx_batch_opts;
 
-enum { GX_KERNEL_AUTO = 0, GX_KERNEL_TILES = 1, GX_KERNEL_SLICES = 2, GX_KERNEL_PER_LINE = 3, GX_KERNEL_LANES = 4 };
+enum { GX_KERNEL_AUTO = 0, GX_KERNEL_TILES = 1, GX_KERNEL_SLICES = 2, GX_KERNEL_PER_LINE = 3, GX_KERNEL_LANES = 4,
+       GX_KERNEL_HOPS = 5 /* the tile kernel on the hop tier's tables (where the handle has them: gx_stat(h, 14)) */ };
 
 /* Replaces the per-line loop "for each line: Gorp.extract(line)"
  * (core/Gorp.java:145-186 -> PolyMatcher.match core/autom/PolyMatcher.java:123-133

@@ -296,21 +296,24 @@ def test_syslog_16_rules():
     assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
 
 
-@pytest.mark.parametrize("tier", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tier", [2, 3, 4, 5, 6, 7])
 def test_table_tiers_agree_with_oracle(tier, monkeypatch):
     """The same definitions through the L2-tier tile kernel (automaton rows in global memory), through the per-line
     generic kernel and through the record tier (sparse range records in LDS: 4 = under the lane kernel, its default;
     6 = under the tile kernel; 5 = records in global memory); the default for these small definitions is the LDS tier
-    with dense rows, covered everywhere else."""
+    with dense rows, covered everywhere else.  7 = the hop tier (run + chain records over dense rows in global memory) for
+    the capture batches, beside the LDS tier's tables."""
     monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", {2: N.GX_CREATE_TIER_L2, 3: N.GX_CREATE_NO_TILES, 4: N.GX_CREATE_TIER_RECORDS,
-                                                    5: N.GX_CREATE_TIER_RECORDS_GLOBAL, 6: N.GX_CREATE_TIER_RECORDS}[tier])
+                                                    5: N.GX_CREATE_TIER_RECORDS_GLOBAL, 6: N.GX_CREATE_TIER_RECORDS, 7: N.GX_CREATE_TIER_HOP}[tier])
     if tier == 6:
         monkeypatch.setattr(G, "DEFAULT_KERNEL", N.GX_KERNEL_TILES)
-    want = {2: 2, 3: 0, 4: 3, 5: 4, 6: 3}[tier]
+    if tier == 7:
+        monkeypatch.setattr(G, "DEFAULT_KERNEL", N.GX_KERNEL_HOPS)
+    want = {2: 2, 3: 0, 4: 3, 5: 4, 6: 3, 7: 1}[tier]
     # config 1
     definition = W.simple_grp_definition()
     gorp, orc = Gorp.construct(definition), oracle_for(definition)
-    assert gorp.stat(7) == want
+    assert gorp.stat(7) == want and (gorp.stat(14) > 0) == (tier == 7)   # (the hop tier's tables only where asked for)
     check_batch(gorp, orc, W.simple_grp_lines(5000, seed=11))
     # config 2 + ragged / empty / very long lines + 64-bit offsets + match-only
     definition = W.readme3_definition()
@@ -513,12 +516,15 @@ def test_config1_from_definition_text(tmp_path):
     assert r.getId() == "sampleMatch" and r.asMap()["authStatus"] == "Accepted"
 
 
-@pytest.mark.parametrize("tier", [1, 2, 3, 4])
+@pytest.mark.parametrize("tier", [1, 2, 3, 4, 5])
 def test_mixed_lengths_take_several_rounds_per_group(tier, monkeypatch):
     """Lines of 0-3000 bytes against a staging area sized for the mean: groups are walked in several rounds of
     consecutive lanes, a line longer than the staging area alone takes the per-lane path; all bit-exact."""
     if tier != 1:
-        monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", {2: N.GX_CREATE_TIER_L2, 3: N.GX_CREATE_TIER_RECORDS, 4: N.GX_CREATE_TIER_RECORDS_GLOBAL}[tier])
+        monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", {2: N.GX_CREATE_TIER_L2, 3: N.GX_CREATE_TIER_RECORDS, 4: N.GX_CREATE_TIER_RECORDS_GLOBAL,
+                                                        5: N.GX_CREATE_TIER_HOP}[tier])
+    if tier == 5:
+        monkeypatch.setattr(G, "DEFAULT_KERNEL", N.GX_KERNEL_HOPS)
     definition = W.readme3_definition()
     gorp, orc = Gorp.construct(definition), oracle_for(definition)
     rng = random.Random(99)
@@ -1026,3 +1032,55 @@ def test_narrow_rows_need_few_extractions():
         gorp.extract_batch(d, o, compact=2)
     rows, over = gorp.extract_batch(d, o, compact=True)
     assert over == 0 and (G.unpack_rows(rows)[0] >= 0).sum() > 50
+
+
+def test_hop_tier_agrees_with_oracle():
+    """The hop tier (gx_hop.hpp: a run and a chain of up to eight bytes per iteration, hot records in LDS, the dense rows in
+    global memory as the backstop) on the definition it is the default for -- 64 extractions, BASELINE configs[2] -- and on
+    lines that leave its fast path everywhere: corrupted bytes, double blanks, values its runs do not cover, empty and
+    truncated lines, terminators, lines of every length."""
+    rules, meta = W.syslog_definition(64, seed=3)
+    gorp, orc = Gorp.construct(rules), oracle_for(rules)
+    assert gorp.stat(14) > 0 and 0 < gorp.stat(15) <= gorp.stat(16) < gorp.stat(14) and gorp.stat(18) >= 6
+    d, o, cats = W.syslog_lines(meta, 30000, seed=41, corrupt_frac=0.1)
+    mid, caps = gorp.extract_batch(d, o, line_bytes_hint=200)
+    omid, ocaps = orc.extract_batch(d, o, nthreads=8)
+    assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+    assert (mid >= 0).sum() > 20000
+    known = cats != -9
+    assert np.array_equal(mid[known], cats[known])
+    forced = gorp.extract_batch(d, o, kernel=N.GX_KERNEL_HOPS)
+    assert np.array_equal(forced[0], omid) and np.array_equal(forced[1], ocaps)
+    rng = random.Random(4)
+    base = [bytes(d[o[i]:o[i + 1]]).decode("latin-1") for i in range(400)]
+    lines = []
+    for ln in base:
+        r = rng.random()
+        if r < 0.15:
+            ln = ln.replace(" ", "  ", rng.randint(1, 3))                 # [ \t]+ : the chain assumes one blank
+        elif r < 0.3:
+            ln = ln.replace(" ", "\t", rng.randint(1, 4))
+        elif r < 0.45:
+            ln = ln[:rng.randint(0, len(ln))]                              # ends inside a run / a chain / the trie
+        elif r < 0.6:
+            k = rng.randint(0, len(ln) - 1)
+            ln = ln[:k] + rng.choice("_Z9\x7f\xe9=[] ") + ln[k + 1:]
+        elif r < 0.7:
+            ln = ln + " trailing"
+        lines.append(ln)
+    lines += ["", " ", "<", "<1>", "<1>a b app"]
+    check_batch(gorp, orc, lines)
+    # terminated text (the staging area holds class ids: the terminator test reads the line's last bytes from global memory)
+    from gorp_amd.gorp import split_lines
+    raw = b"".join(ln.encode("latin-1") + rng.choice([b"\n", b"\r\n", b"\r"]) for ln in base)
+    off, _ = split_lines(raw)
+    _, want_lines, _ = O.read_lines(raw)
+    m3, c3 = gorp.extract_batch(np.frombuffer(raw, np.uint8), off, strip_eol=True, kernel=N.GX_KERNEL_HOPS)
+    cd, co = lines_to_csr(want_lines)
+    om3, oc3 = orc.extract_batch(cd, co, nthreads=8)
+    assert np.array_equal(m3, om3) and np.array_equal(c3, oc3)
+    # lines of 50-2000 bytes through the rounds of the tile kernel
+    d2, o2, _ = W.syslog_lines(meta, 3000, seed=43, min_len=50, max_len=2000)
+    m4, c4 = gorp.extract_batch(d2, o2, kernel=N.GX_KERNEL_HOPS)
+    om4, oc4 = orc.extract_batch(d2, o2, nthreads=8)
+    assert np.array_equal(m4, om4) and np.array_equal(c4, oc4)
