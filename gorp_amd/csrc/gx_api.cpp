@@ -785,6 +785,8 @@ void choose_tile_image(gx_handle* h) {
         L.tier = 4;
         L.rec = HOP_AT;
         L.rec_indexed = h->hop.n_hot;
+        L.acc_tab = h->hop.info_lds;   // int16 info words of the hot states
+        L.at = h->hop.fin_lds;         // final records in LDS (0: in the global image at fin_tags)
         L.hot_lo4 = 0;
         L.hot_k4 = 0x80808080u;
         L.regs_wave_bytes = static_cast<uint32_t>(((h->hop.n_regs + 1) * 64 * 2 + 15) & ~15u);
@@ -928,7 +930,11 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
         if (h->slot_used[slot]) GX_HIP(hipStreamWaitEvent(stream, h->slot_event[slot], 0));
         h->slot_used[slot] = true;
         b.oversize_flag = h->d_slots + slot;
-        GX_HIP(launch_extract_tile(h->dev, L, static_cast<const uint8_t*>(h->d_lds_image_hop), static_cast<const uint8_t*>(h->d_hop_global), h->num_cus, b, stream, nullptr));
+        unsigned long long* stamps = nullptr;
+#ifdef GX_DEV
+        stamps = h->dev_stamps;
+#endif
+        GX_HIP(launch_extract_tile(h->dev, L, static_cast<const uint8_t*>(h->d_lds_image_hop), static_cast<const uint8_t*>(h->d_hop_global), h->num_cus, b, stream, stamps));
         GX_HIP(launch_extract_oversize(h->dev, b, L.stage_bytes, stream));
         GX_HIP(hipEventRecord(h->slot_event[slot], stream));
         return;

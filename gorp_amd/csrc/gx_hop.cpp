@@ -230,7 +230,7 @@ bool build_hop_image(const Tables& T, uint32_t hot_budget_bytes, HopImage& out) 
         }
         row[ncls] = U.fin[s] >= 0 ? fin_record(U.fin[s]) : static_cast<uint32_t>(U.fin[s]);
     }
-    if (fin_rec.size() * 2 > 0xFFFFFFu) return false;
+    if (fin_rec.size() * 2 > 0x7FFFu * 16u || T.n_rules > 32000) return false;  // (a hot state's info word is an int16: offset / 16, or -2-k)
 
     // hop records
     std::vector<uint32_t> hops(S * (HOP_REC_BYTES / 4), 0);
@@ -291,6 +291,20 @@ bool build_hop_image(const Tables& T, uint32_t hot_budget_bytes, HopImage& out) 
     const uint8_t* hb = reinterpret_cast<const uint8_t*>(hops.data());
     out.lds.insert(out.lds.end(), hb, hb + static_cast<size_t>(out.n_hot) * HOP_REC_BYTES);
     while (out.lds.size() % 16) out.lds.push_back(0);
+    out.info_lds = static_cast<uint32_t>(out.lds.size());
+    for (uint32_t s = 0; s < out.n_hot; ++s) {
+        const int32_t info = static_cast<int32_t>(rows[static_cast<size_t>(s) * cols + ncls]);
+        const int16_t v = static_cast<int16_t>(info >= 0 ? info / 16 : info);
+        out.lds.push_back(static_cast<uint8_t>(v & 0xFF));
+        out.lds.push_back(static_cast<uint8_t>((v >> 8) & 0xFF));
+    }
+    while (out.lds.size() % 16) out.lds.push_back(0);
+    if (fin_rec.size() * 2 <= 8192u) {  // the final records beside them: a line's result then needs no global read
+        out.fin_lds = static_cast<uint32_t>(out.lds.size());
+        const uint8_t* fl = reinterpret_cast<const uint8_t*>(fin_rec.data());
+        out.lds.insert(out.lds.end(), fl, fl + fin_rec.size() * 2);
+        while (out.lds.size() % 16) out.lds.push_back(0);
+    }
     const uint8_t* rb = reinterpret_cast<const uint8_t*>(rows.data());
     out.global.assign(rb, rb + rows.size() * 4);
     while (out.global.size() % 16) out.global.push_back(0);

@@ -40,10 +40,13 @@ constexpr uint32_t HOP_CHAIN = 8;         // elements per chain
 
 struct HopImage {
     bool ok = false;
-    std::vector<uint8_t> lds;      // [0, 256): byte -> class id; [HOP_AT, ...): hop records of the states [0, n_hot)
+    std::vector<uint8_t> lds;      // [0, 256): byte -> class id; [HOP_AT, ...): hop records of the states [0, n_hot); then their
+                                   // info words as int16 (final record offset / 16, or -1 / -2-k) at info_lds; then, when they
+                                   // are small, the final records at fin_lds (0: read them from `global`)
     std::vector<uint8_t> global;   // dense rows u32[n_states][ncls + 1] | hop records of ALL states | final records
     uint32_t ncls = 0, row_bytes = 0, n_states = 0, n_hot = 0;
     uint32_t hops_off = 0, fin_off = 0;  // byte offsets in `global`
+    uint32_t info_lds = 0, fin_lds = 0;  // LDS addresses
     uint32_t start = 0, dead = 0;        // state indexes (renumbered)
     uint32_t n_regs = 0;
     // diagnostics (gx_stat)

@@ -50,6 +50,9 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
     return r;
 }
 
+// (the compiler turns __any into a select, a compare and a scalar test; the ballot is the scalar test alone)
+__device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+
 // byte -> class id for the 16 bytes of one staged chunk (class map: u8[256] at LDS address 0)
 __device__ __forceinline__ uint32_t hop_map4(uint32_t d) {
     const uint32_t c0 = lds_ld<uint8_t>(d & 0xFFu), c1 = lds_ld<uint8_t>((d >> 8) & 0xFFu);
@@ -60,21 +63,27 @@ __device__ __forceinline__ u32x4 hop_map16(const u32x4& v) { return u32x4{hop_ma
 
 // Walks the line [start, end) of the wave's staging area (class ids) from state `s`; returns the final state.  regs = LDS
 // address of this lane's slot in register column 0 (the write-only dummy column sits 128 bytes before it).
+// A lane that is done keeps running the loop with the wave: at the end of its line its position no longer moves (no
+// bytes left), and a lane that steps into the dead state is moved to the end of its line.  Wave-level tests are ANDs of the
+// lane masks of single compares (the compiler turns the ballot of a compound condition into a select and a compare).
+__device__ __forceinline__ uint32_t run_flags(uint32_t x, uint32_t lo4, uint32_t k4) {
+    // bit 7 of a byte of the result is set iff that class id lies outside [lo, hi] (ids are below 0x80, so x itself never
+    // contributes: (x - lo4 | x + k4) & 0x80808080, one v_bitop3); exact for the lowest offending byte, which is all the walk uses
+    return ((x - lo4) | (x + k4)) & HI_BITS;
+}
 __device__ __forceinline__ uint32_t walk_hop(const HopTab& H, uint32_t stage, uint32_t s, uint32_t start, uint32_t end, bool on,
                                              uint32_t dead, uint32_t regs) {
     const uint32_t p0 = stage + start, e = stage + end, dummy_col = regs - 128u;
-    uint32_t p = p0;
-    bool more = on && p < e;
-    while (__any(more)) {
+    const uint32_t last_hot = H.n_hot - 1u;
+    uint32_t p = on ? p0 : e;
+    for (;;) {
+        const uint64_t unfinished = __builtin_amdgcn_ballot_w64(p < e);
+        if (unfinished == 0ull) break;
         // ---- 1. the state's record ----
-        u32x2 h0, h1, h2;
-        const bool cold = more && s >= H.n_hot;
-        const uint32_t la = HOP_LDS_AT + (s < H.n_hot ? s : 0u) * HOP_REC_B;
-        h0 = lds_ld<u32x2>(la);
-        h1 = lds_ld<u32x2>(la + 8u);
-        h2 = lds_ld<u32x2>(la + 16u);
-        if (__any(cold)) {
-            if (cold) {
+        const uint32_t la = __umul24(min(s, last_hot), HOP_REC_B) + HOP_LDS_AT;
+        u32x2 h0 = lds_ld<u32x2>(la), h1 = lds_ld<u32x2>(la + 8u), h2 = lds_ld<u32x2>(la + 16u);
+        if ((__builtin_amdgcn_ballot_w64(s > last_hot) & unfinished) != 0ull) {
+            if (s > last_hot && p < e) {
                 const u32x2* g = reinterpret_cast<const u32x2*>(H.hops + static_cast<uint64_t>(s) * HOP_REC_B);
                 h0 = g[0]; h1 = g[1]; h2 = g[2];
             }
@@ -86,15 +95,18 @@ __device__ __forceinline__ uint32_t walk_hop(const HopTab& H, uint32_t stage, ui
         const uint32_t x0 = __builtin_amdgcn_alignbyte(d01.y, d01.x, sh1), x1 = __builtin_amdgcn_alignbyte(d23.x, d01.y, sh1);
         const uint32_t x2 = __builtin_amdgcn_alignbyte(d23.y, d23.x, sh1), x3 = __builtin_amdgcn_alignbyte(d4, d23.y, sh1);
         const uint32_t lo4 = splat_byte0(h0.x), k4 = splat_byte1(h0.x);
-        const uint32_t f0 = static_cast<uint32_t>(__ffs(static_cast<int>(outside_bits(x0, lo4, k4) & HI_BITS)) - 1);  // 7, 15, 23, 31 or 0xFFFFFFFF
-        const uint32_t f1 = static_cast<uint32_t>(__ffs(static_cast<int>(outside_bits(x1, lo4, k4) & HI_BITS)) - 1);
-        const uint32_t f2 = static_cast<uint32_t>(__ffs(static_cast<int>(outside_bits(x2, lo4, k4) & HI_BITS)) - 1);
-        const uint32_t f3 = static_cast<uint32_t>(__ffs(static_cast<int>(outside_bits(x3, lo4, k4) & HI_BITS)) - 1);
+        const uint32_t f0 = static_cast<uint32_t>(__ffs(static_cast<int>(run_flags(x0, lo4, k4))) - 1);  // 7, 15, 23, 31 or 0xFFFFFFFF
+        const uint32_t f1 = static_cast<uint32_t>(__ffs(static_cast<int>(run_flags(x1, lo4, k4))) - 1);
+        const uint32_t f2 = static_cast<uint32_t>(__ffs(static_cast<int>(run_flags(x2, lo4, k4))) - 1);
+        const uint32_t f3 = static_cast<uint32_t>(__ffs(static_cast<int>(run_flags(x3, lo4, k4))) - 1);
         uint32_t n = min3u(f0, sat_add(f1, 32u), min3u(sat_add(f2, 64u), sat_add(f3, 96u), 128u)) >> 3;  // 0 .. 16
         n = min(n, e - p);
         const uint32_t q = p + n;
-        const bool stepping = more && n < 16u && q < e;
+        // (a lane steps when its run ended inside the window and inside the line)
+        const uint64_t m_step = __builtin_amdgcn_ballot_w64(n < 16u) & __builtin_amdgcn_ballot_w64(q < e);
         // ---- 3. the chain: the 8 class ids at q against 8 (lo, span) elements ----
+        // (a second, dependent LDS read: picking the bytes out of a 24-byte first window with selects was measured -- 1.106
+        // against 1.084 ms on config 3, one device -- the walk is bound by issue slots, not by this round trip)
         const uint32_t a2 = q & ~3u, sh2 = q & 3u;
         const u32x2 r01 = lds_pair4(a2);
         const uint32_t r2 = lds_ld<uint32_t>(a2 + 8u);
@@ -102,27 +114,28 @@ __device__ __forceinline__ uint32_t walk_hop(const HopTab& H, uint32_t stage, ui
         // per byte: a = v + (0x80 - lo) has bit 7 set iff v >= lo; t = (a & 0x7F) + (0x7F - span) has bit 7 set iff v - lo > span
         const uint32_t ca0 = v0 + h1.x, ca1 = v1 + h1.y;
         const uint32_t ct0 = (ca0 & LOW7) + h2.x, ct1 = (ca1 & LOW7) + h2.y;
-        const uint32_t ok8 = bfi(ct0, 0u, ca0) & bfi(ct1, 0u, ca1) & HI_BITS;  // bit 7 of byte j of either half: element j / j + 4 ...
-        const uint32_t klen = (h0.x >> 16) & 0xFu;
-        const bool chained = stepping && ok8 == HI_BITS && q + klen <= e;
-        // ---- 4. one exact step where the chain does not apply ----
-        const bool exact = stepping && !chained;
-        uint32_t xe = 0;
-        if (__any(exact)) {
-            if (exact) xe = *reinterpret_cast<const uint32_t*>(H.rows + (static_cast<uint64_t>(s) * H.row_bytes + ((v0 & 0xFFu) << 2)));
-        }
-        // ---- capture programs: register column := position (column 0 is the write-only dummy) ----
+        const uint32_t ok8 = bfi(ct0, 0u, ca0) & bfi(ct1, 0u, ca1) & HI_BITS;  // byte j: elements j and j + 4 both hold
+        const uint64_t m_chain = m_step & __builtin_amdgcn_ballot_w64(ok8 == HI_BITS) & __builtin_amdgcn_ballot_w64(q + ((h0.x >> 16) & 0xFu) <= e);
+        const bool stepping = n < 16u && q < e;  // (the same compares, per lane: their masks ARE the select conditions)
+        const bool chained = stepping && ok8 == HI_BITS && q + ((h0.x >> 16) & 0xFu) <= e;
+        // a lane that does not take its chain reads its record as "no bytes, same state, no programs"
+        const uint32_t c0 = chained ? h0.x : 0u, c1 = chained ? h0.y : s;
+        // ---- capture programs of the chain: register column := position (column 0 is the write-only dummy) ----
         const uint32_t rel = q - p0;
-        const uint32_t col1 = chained ? (h0.y >> 16) & 0xFFu : exact ? xe >> 16 : 0u;
-        const uint32_t col2 = chained ? h0.y >> 24 : 0u;
-        lds_st<uint16_t>(dummy_col + (col1 << 7), static_cast<uint16_t>(rel + (chained ? (h0.x >> 20) & 7u : 0u)));
-        lds_st<uint16_t>(dummy_col + (col2 << 7), static_cast<uint16_t>(rel + ((h0.x >> 23) & 7u)));
-        // ---- advance ----
-        if (more) {
-            p = q + (chained ? klen : exact ? 1u : 0u);
-            s = chained ? (h0.y & 0xFFFFu) : exact ? (xe & 0xFFFFu) : s;
+        lds_st<uint16_t>(dummy_col + (((c1 >> 16) & 0xFFu) << 7), static_cast<uint16_t>(rel + ((c0 >> 20) & 7u)));
+        lds_st<uint16_t>(dummy_col + ((c1 >> 24) << 7), static_cast<uint16_t>(rel + ((c0 >> 23) & 7u)));
+        p = q + ((c0 >> 16) & 0xFu);
+        s = c1 & 0xFFFFu;
+        // ---- 4. one exact step where the chain does not apply ----
+        const uint64_t m_exact = m_step & ~m_chain;
+        if (m_exact != 0ull) {
+            if (stepping && !chained) {
+                const uint32_t xe = *reinterpret_cast<const uint32_t*>(H.rows + (static_cast<uint64_t>(s) * H.row_bytes + ((v0 & 0xFFu) << 2)));
+                lds_st<uint16_t>(dummy_col + ((xe >> 16) << 7), static_cast<uint16_t>(rel));
+                s = xe & 0xFFFFu;
+                p = s == dead ? e : q + 1u;  // (nothing leaves the dead state: the line is over)
+            }
         }
-        more = more && p < e && s != dead;
     }
     return s;
 }

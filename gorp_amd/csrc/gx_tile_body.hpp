@@ -397,7 +397,12 @@ k_extract_tile(GxLds L, TileIO io) {
             if (HOP) {
                 // ---- fused pass on the hop records: a run and a chain per iteration (gx_hop_dev.hpp) ----
                 const uint32_t urow = walk_hop(H, stage, L.u_start, start, end, true, L.u_dead, regs);
-                info = *reinterpret_cast<const int32_t*>(H.rows + (static_cast<uint64_t>(urow) * H.row_bytes + H.info_off));
+                // the final state's info word: int16 in LDS for the hot states (offset / 16, or -1 / -2-k), else its dense row's last column
+                const int32_t hot_info = static_cast<int16_t>(lds_ld<uint16_t>(L.acc_tab + 2u * min(urow, H.n_hot - 1u)));
+                info = hot_info >= 0 ? hot_info * 16 : hot_info;
+                if (wave_any(urow >= H.n_hot)) {
+                    if (urow >= H.n_hot) info = *reinterpret_cast<const int32_t*>(H.rows + (static_cast<uint64_t>(urow) * H.row_bytes + H.info_off));
+                }
             } else if (MODE == 1 || L.u_start != 0xFFFFFFFFu) {
                 // ---- fused pass: match automaton x joined capture automata, one walk ----
                 uint32_t urow;
@@ -420,7 +425,8 @@ k_extract_tile(GxLds L, TileIO io) {
             }
             GX_STAMP(2);
             const uint32_t len = end - start;
-            const uint8_t* fin_g = GT ? io.at_global + L.fin_tags : nullptr;
+            const uint8_t* fin_g = GT && !(HOP && L.at != 0u) ? io.at_global + L.fin_tags : nullptr;
+            const uint32_t fin_lds = HOP ? L.at : L.fin_tags;
             // The tile's 64 result rows are one contiguous block of the output.  Transpose them through the staging
             // area (free now: every lane has finished its walk) so that each store instruction writes 1 KiB of
             // consecutive bytes, instead of every lane writing pieces of its own row.
@@ -437,14 +443,14 @@ k_extract_tile(GxLds L, TileIO io) {
                     const uint32_t my_row = stage + lane * row_b;
                     int32_t result;
                     if (narrow) {
-                        result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                        result = line_result<TIER>(info, fin_lds, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
                             clamped += (pb > 254 ? 1u : 0u) + (pe > 254 ? 1u : 0u);
                             lds_st<uint8_t>(my_row + 1u + 2u * g, static_cast<uint8_t>(pb > 254 ? 254 : pb));
                             lds_st<uint8_t>(my_row + 2u + 2u * g, static_cast<uint8_t>(pe > 254 ? 254 : pe));
                         });
                         lds_st<uint8_t>(my_row, static_cast<uint8_t>(result));
                     } else {
-                        result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                        result = line_result<TIER>(info, fin_lds, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
                             lds_st<uint16_t>(my_row + 2u + 4u * g, static_cast<uint16_t>(pb));
                             lds_st<uint16_t>(my_row + 4u + 4u * g, static_cast<uint16_t>(pe));
                         });
@@ -462,7 +468,7 @@ k_extract_tile(GxLds L, TileIO io) {
                 } else if (valid) {
                     if (narrow) {
                         uint8_t* rp = reinterpret_cast<uint8_t*>(io.packed) + i * static_cast<uint64_t>(row_b);
-                        const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                        const int32_t result = line_result<TIER>(info, fin_lds, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
                             clamped += (pb > 254 ? 1u : 0u) + (pe > 254 ? 1u : 0u);
                             rp[1 + 2 * g] = static_cast<uint8_t>(pb > 254 ? 254 : pb);
                             rp[2 + 2 * g] = static_cast<uint8_t>(pe > 254 ? 254 : pe);
@@ -470,7 +476,7 @@ k_extract_tile(GxLds L, TileIO io) {
                         rp[0] = static_cast<uint8_t>(result);
                     } else {
                         uint16_t* rp = io.packed + i * static_cast<uint64_t>(1u + slots);
-                        const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                        const int32_t result = line_result<TIER>(info, fin_lds, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
                             rp[1 + 2 * g] = static_cast<uint16_t>(pb);
                             rp[2 + 2 * g] = static_cast<uint16_t>(pe);
                         });
@@ -483,7 +489,7 @@ k_extract_tile(GxLds L, TileIO io) {
                 const bool caps_aligned = ((reinterpret_cast<uintptr_t>(io.caps) | reinterpret_cast<uintptr_t>(io.match_id)) & 15u) == 0u;
                 if (full_tile && caps_aligned && 64u * row_b + 256u <= L.stage_bytes) {
                     const uint32_t my_row = stage + lane * row_b;
-                    const int32_t result = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                    const int32_t result = line_result<TIER>(info, fin_lds, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
                         lds_st<u32x2>(my_row + 8u * g, u32x2{static_cast<uint32_t>(pb), static_cast<uint32_t>(pe)});
                     });
                     const uint32_t ids = stage + 64u * row_b;  // the tile's 64 match ids = 256 bytes
@@ -497,7 +503,7 @@ k_extract_tile(GxLds L, TileIO io) {
                         *reinterpret_cast<u32x4*>(io.match_id + (cur.i - lane) + 4u * lane) = lds_ld<u32x4>(ids + 16u * lane);
                 } else if (valid) {
                     int32_t* cp = io.caps + i * static_cast<uint64_t>(slots);
-                    io.match_id[i] = line_result<TIER>(info, L.fin_tags, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                    io.match_id[i] = line_result<TIER>(info, fin_lds, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
                         cp[2 * g] = pb;
                         cp[2 * g + 1] = pe;
                     });

@@ -329,7 +329,8 @@ __device__ __forceinline__ int32_t line_result(int32_t info, uint32_t fin_lds, c
     const uint32_t dummy_col = regs - 128u;
     const uint32_t id_at = rec + 16u * static_cast<uint32_t>((G + 3) >> 2);
     uint32_t id;
-    constexpr bool FIN_GLOBAL = TIER == TIER_L2 || TIER == TIER_RECG || TIER == TIER_HOP;
+    // (TIER_HOP keeps small final records in LDS: fin_g == nullptr says so -- wave-uniform)
+    const bool FIN_GLOBAL = TIER == TIER_L2 || TIER == TIER_RECG || (TIER == TIER_HOP && fin_g != nullptr);
     if (FIN_GLOBAL) id = *reinterpret_cast<const uint16_t*>(fin_g + id_at);
     else id = lds_ld<uint16_t>(fin_lds + id_at);
     for (int g0 = 0; g0 < G; g0 += 4) {
