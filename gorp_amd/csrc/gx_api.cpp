@@ -730,6 +730,24 @@ bool plan_slice_launch(const gx_handle* h, GxLds* out, bool match_only = false) 
     return true;
 }
 
+// Layout for the hop slice kernel: the hop tier's tables, per wave a register block and a [64][144]-byte piece buffer.
+bool plan_hop_slice_launch(const gx_handle* h, GxLds* out) {
+    if (!h->hop_ok) return false;
+    GxLds L = h->lds_hop;
+    L.stage_bytes = 64u * 144u + 16u;  // (+ 16: a window read at a row's last bytes runs a few bytes past it)
+    const uint32_t per_wave = L.stage_bytes + L.regs_wave_bytes;
+    if (L.table_bytes + 4u * per_wave > LDS_BYTES) return false;
+    uint32_t nw = (LDS_BYTES - L.table_bytes) / per_wave;
+    if (nw > 16) nw = 16;
+    L.nwaves = nw;
+    L.regs = L.table_bytes;
+    L.bitmap = 0;
+    L.stage = L.regs + nw * L.regs_wave_bytes;
+    L.total_bytes = L.stage + nw * L.stage_bytes;
+    *out = L;
+    return true;
+}
+
 // kernel choice: automaton rows in LDS when they fit, else sparse range records in LDS, else dense rows in global
 // memory (L2), else the per-line kernel alone.  Host work only (also done for host-only handles, where it is a check
 // of the builders and feeds gx_stat).
@@ -921,6 +939,12 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
     const uint8_t* at_global = image_tier == 1 || image_tier == 3 ? static_cast<const uint8_t*>(h->d_l2_image) : nullptr;
     // hop tier: capture batches of definitions whose dense rows do not fit LDS, lines of ordinary length and evenness (the
     // tile kernel wants a tile's lines to be neighbours in memory and about as long as each other)
+    // ... and for long or uneven lines the hop slice kernel: a piece of every lane's own line at a time, lanes refilled
+    const bool hop_slices = h->hop_ok && !mo && !b.wide && (kernel == GX_KERNEL_HOP_SLICES || (kernel == GX_KERNEL_AUTO && (long_lines || uneven)));
+    if (batchable && hop_slices && plan_hop_slice_launch(h, &L)) {
+        GX_HIP(launch_extract_hop_slices(h->dev, L, static_cast<const uint8_t*>(h->d_lds_image_hop), static_cast<const uint8_t*>(h->d_hop_global), h->num_cus, b, stream));
+        return;
+    }
     const bool hops = h->hop_ok && !mo && !b.wide && (kernel == GX_KERNEL_HOPS || (kernel == GX_KERNEL_AUTO && !long_lines && !uneven));
     if (batchable && hops && plan_hop_launch(h, line_bytes_hint, &L)) {
         std::lock_guard<std::mutex> lock(h->slot_mu);
@@ -1115,6 +1139,7 @@ int64_t gx_stat(const gx_handle* h, int32_t which) {
     case 16: return h->hop_ok ? static_cast<int64_t>(h->hop.n_reachable_hot) : 0;  // ... that well-formed lines reach
     case 17: return h->hop_ok ? static_cast<int64_t>(h->hop.n_chains) : 0;         // ... that have a chain
     case 18: { GxLds L; return plan_hop_launch(h, 0, &L) ? static_cast<int64_t>(L.nwaves) : 0; }  // hop tier: waves per CU
+    case 19: { GxLds L; return plan_hop_slice_launch(h, &L) ? static_cast<int64_t>(L.nwaves) : 0; }  // ... of the hop slice kernel
     case 9: return !h->tile_ok ? 0 : !h->has_mo ? gx_stat(h, 7) : h->lds_mo.tier == 3 ? 4 : h->lds_mo.tier == 2 ? 3 : h->lds_mo.tier == 1 ? 2 : 1;
     default: return -1;
     }
@@ -1581,7 +1606,7 @@ static int extract_batch_impl(gx_handle* h, const uint8_t* bytes, const void* of
     if (!h->on_device) return fail(GX_E_DEVICE, "handle was created host-only; no device tables (there is no CPU fallback)");
     gx_batch_opts o{};
     if (!read_opts(opts, &o)) return fail(GX_E_ARG, "gx_batch_opts.struct_size mismatch");
-    if (o.kernel > GX_KERNEL_HOPS) return fail(GX_E_ARG, "gx_batch_opts.kernel: unknown kernel");
+    if (o.kernel > GX_KERNEL_HOP_SLICES) return fail(GX_E_ARG, "gx_batch_opts.kernel: unknown kernel");
     const bool match_only = o.match_only || states || !h->T.has_capture;
     const bool compact = o.compact_results && !match_only;  // rows of u16[1 + slots] (2: u8[1 + slots]) through `caps`
     if (o.compact_results > 2) return fail(GX_E_ARG, "gx_batch_opts.compact_results: 0, 1 (u16 rows) or 2 (u8 rows)");

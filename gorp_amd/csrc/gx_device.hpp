@@ -154,6 +154,11 @@ hipError_t launch_extract_lanes(const GxDev& dev, const GxLds& lds, const uint8_
 hipError_t launch_extract_slices(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
                                  const GxBatch& b, hipStream_t stream);
 
+// Hop slice kernel: the hop tier's tables (GxLds::tier 4), lines staged 128 bytes at a time from each lane's own position
+// (GxLds::stage_bytes = 64 * 144 + 16); captures only.
+hipError_t launch_extract_hop_slices(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
+                                     const GxBatch& b, hipStream_t stream);
+
 // Line ingestion (gx_ingest.hip): raw bytes -> CSR offsets of readLine()-style lines, terminators included.
 // `workspace` holds split_workspace_bytes(size) bytes; *d_n_lines receives the device address of the line count.
 size_t split_workspace_bytes(uint64_t size);

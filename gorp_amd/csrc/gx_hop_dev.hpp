@@ -71,19 +71,22 @@ __device__ __forceinline__ uint32_t run_flags(uint32_t x, uint32_t lo4, uint32_t
     // contributes: (x - lo4 | x + k4) & 0x80808080, one v_bitop3); exact for the lowest offending byte, which is all the walk uses
     return ((x - lo4) | (x + k4)) & HI_BITS;
 }
-__device__ __forceinline__ uint32_t walk_hop(const HopTab& H, uint32_t stage, uint32_t s, uint32_t start, uint32_t end, bool on,
-                                             uint32_t dead, uint32_t regs) {
-    const uint32_t p0 = stage + start, e = stage + end, dummy_col = regs - 128u;
+// General form (the slice kernel stages a piece of the line at a time): the lane is at LDS address p; staged class ids end
+// at `e` (run lengths are cut there); it iterates while p < limit (limit = e when the line ends at e, else 24 bytes
+// before it, so that a whole window and a whole chain are staged); a chain must end at or before e_chain (the end of the
+// LINE; no constraint when the line goes on beyond the staged piece); a capture program's position is its LDS address minus p0.
+__device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, uint32_t e, uint32_t limit, uint32_t e_chain, uint32_t p0,
+                                                  uint32_t s, uint32_t dead, uint32_t regs) {
+    const uint32_t dummy_col = regs - 128u;
     const uint32_t last_hot = H.n_hot - 1u;
-    uint32_t p = on ? p0 : e;
     for (;;) {
-        const uint64_t unfinished = __builtin_amdgcn_ballot_w64(p < e);
+        const uint64_t unfinished = __builtin_amdgcn_ballot_w64(p < limit);
         if (unfinished == 0ull) break;
         // ---- 1. the state's record ----
         const uint32_t la = __umul24(min(s, last_hot), HOP_REC_B) + HOP_LDS_AT;
         u32x2 h0 = lds_ld<u32x2>(la), h1 = lds_ld<u32x2>(la + 8u), h2 = lds_ld<u32x2>(la + 16u);
         if ((__builtin_amdgcn_ballot_w64(s > last_hot) & unfinished) != 0ull) {
-            if (s > last_hot && p < e) {
+            if (s > last_hot && p < limit) {
                 const u32x2* g = reinterpret_cast<const u32x2*>(H.hops + static_cast<uint64_t>(s) * HOP_REC_B);
                 h0 = g[0]; h1 = g[1]; h2 = g[2];
             }
@@ -102,8 +105,8 @@ __device__ __forceinline__ uint32_t walk_hop(const HopTab& H, uint32_t stage, ui
         uint32_t n = min3u(f0, sat_add(f1, 32u), min3u(sat_add(f2, 64u), sat_add(f3, 96u), 128u)) >> 3;  // 0 .. 16
         n = min(n, e - p);
         const uint32_t q = p + n;
-        // (a lane steps when its run ended inside the window and inside the line)
-        const uint64_t m_step = __builtin_amdgcn_ballot_w64(n < 16u) & __builtin_amdgcn_ballot_w64(q < e);
+        // (a lane steps when its run ended inside the window and inside the staged bytes; a lane past its limit does not)
+        const uint64_t m_step = __builtin_amdgcn_ballot_w64(n < 16u) & __builtin_amdgcn_ballot_w64(q < e) & unfinished;
         // ---- 3. the chain: the 8 class ids at q against 8 (lo, span) elements ----
         // (a second, dependent LDS read: picking the bytes out of a 24-byte first window with selects was measured -- 1.106
         // against 1.084 ms on config 3, one device -- the walk is bound by issue slots, not by this round trip)
@@ -115,16 +118,16 @@ __device__ __forceinline__ uint32_t walk_hop(const HopTab& H, uint32_t stage, ui
         const uint32_t ca0 = v0 + h1.x, ca1 = v1 + h1.y;
         const uint32_t ct0 = (ca0 & LOW7) + h2.x, ct1 = (ca1 & LOW7) + h2.y;
         const uint32_t ok8 = bfi(ct0, 0u, ca0) & bfi(ct1, 0u, ca1) & HI_BITS;  // byte j: elements j and j + 4 both hold
-        const uint64_t m_chain = m_step & __builtin_amdgcn_ballot_w64(ok8 == HI_BITS) & __builtin_amdgcn_ballot_w64(q + ((h0.x >> 16) & 0xFu) <= e);
-        const bool stepping = n < 16u && q < e;  // (the same compares, per lane: their masks ARE the select conditions)
-        const bool chained = stepping && ok8 == HI_BITS && q + ((h0.x >> 16) & 0xFu) <= e;
+        const uint64_t m_chain = m_step & __builtin_amdgcn_ballot_w64(ok8 == HI_BITS) & __builtin_amdgcn_ballot_w64(q + ((h0.x >> 16) & 0xFu) <= e_chain);
+        const bool stepping = n < 16u && q < e && p < limit;  // (the same compares, per lane: their masks ARE the select conditions)
+        const bool chained = stepping && ok8 == HI_BITS && q + ((h0.x >> 16) & 0xFu) <= e_chain;
         // a lane that does not take its chain reads its record as "no bytes, same state, no programs"
         const uint32_t c0 = chained ? h0.x : 0u, c1 = chained ? h0.y : s;
         // ---- capture programs of the chain: register column := position (column 0 is the write-only dummy) ----
-        const uint32_t rel = q - p0;
+        const uint32_t rel = q - p0;  // (the position in the line)
         lds_st<uint16_t>(dummy_col + (((c1 >> 16) & 0xFFu) << 7), static_cast<uint16_t>(rel + ((c0 >> 20) & 7u)));
         lds_st<uint16_t>(dummy_col + ((c1 >> 24) << 7), static_cast<uint16_t>(rel + ((c0 >> 23) & 7u)));
-        p = q + ((c0 >> 16) & 0xFu);
+        p = p < limit ? q + ((c0 >> 16) & 0xFu) : p;
         s = c1 & 0xFFFFu;
         // ---- 4. one exact step where the chain does not apply ----
         const uint64_t m_exact = m_step & ~m_chain;
@@ -133,11 +136,19 @@ __device__ __forceinline__ uint32_t walk_hop(const HopTab& H, uint32_t stage, ui
                 const uint32_t xe = *reinterpret_cast<const uint32_t*>(H.rows + (static_cast<uint64_t>(s) * H.row_bytes + ((v0 & 0xFFu) << 2)));
                 lds_st<uint16_t>(dummy_col + ((xe >> 16) << 7), static_cast<uint16_t>(rel));
                 s = xe & 0xFFFFu;
-                p = s == dead ? e : q + 1u;  // (nothing leaves the dead state: the line is over)
+                p = s == dead ? max(limit, q + 1u) : q + 1u;  // (nothing leaves the dead state: the line is over)
             }
         }
     }
     return s;
+}
+
+// The tile kernel's case: the whole line [start, end) is staged.
+__device__ __forceinline__ uint32_t walk_hop(const HopTab& H, uint32_t stage, uint32_t s, uint32_t start, uint32_t end, bool on,
+                                             uint32_t dead, uint32_t regs) {
+    const uint32_t p0 = stage + start, e = stage + end;
+    uint32_t p = on ? p0 : e;
+    return walk_hop_span(H, p, e, e, e, p0, s, dead, regs);
 }
 
 }  // namespace gx

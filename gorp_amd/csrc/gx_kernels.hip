@@ -8,6 +8,7 @@
 //                                       core/jdkre/JDKRegexpCookedExtraction.java:36-59
 //   driver       Gorp.extract           core/Gorp.java:159-186
 #include "gx_walk.hpp"
+#include "gx_hop_dev.hpp"
 
 namespace gx {
 
@@ -384,7 +385,161 @@ hipError_t launch_slices_t(const GxDev& dev, const GxLds& lds, const uint8_t* ld
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Hop slice kernel: the slice kernel's staging and lane refill, the hop tier's walk (gx_hop_dev.hpp)
+// ---------------------------------------------------------------------------
+// For long and uneven lines on definitions that have the hop tier's tables (64 extractions and more): a wave owns a
+// contiguous range of lines, every lane stages the next 128 bytes of ITS line from its own position (mapped to class ids
+// on the way into LDS, eight lanes per line fetching 16 bytes each), walks them with a run and a chain per iteration,
+// and comes back for the next piece 24 bytes before the end of what is staged (a whole window and a whole chain are
+// always there); a lane whose line has ended writes its result and takes the wave's next line.  A line's padding, fields
+// and literals cost iterations, not bytes, so lanes of a wave stay roughly level however long their lines are.
+constexpr uint32_t HOP_SLICE = 128, HOP_SLICE_ROW = 144, HOP_SLICE_KEEP = 24;
+
+template <typename OFF>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4)))
+k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const uint8_t* __restrict__ at_global,
+                     const uint8_t* __restrict__ data, const OFF* __restrict__ off, uint64_t n, LineOut out, int strip_eol) {
+    {
+        extern __shared__ __attribute__((aligned(16))) uint8_t gx_smem[];
+        const uint4* src = reinterpret_cast<const uint4*>(lds_image);
+        uint4* dst = reinterpret_cast<uint4*>(gx_smem);
+        for (uint32_t c = threadIdx.x; c < L.table_bytes / 16; c += blockDim.x) dst[c] = src[c];
+    }
+    __syncthreads();
+    HopTab H;
+    H.rows = at_global;
+    H.hops = at_global + L.c_base;
+    H.row_bytes = L.row_bytes;
+    H.info_off = L.ncls * 4u;
+    H.n_hot = L.rec_indexed;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t slice = L.stage + wave * L.stage_bytes;
+    const uint32_t regs = L.regs + wave * L.regs_wave_bytes + 128u + lane * 2u;
+    const uint8_t* data_end = data + static_cast<uint64_t>(off[n]);
+    const uint32_t row0 = L.u_start, dead_row = L.u_dead;
+    const uint8_t* fin_g = L.at != 0u ? nullptr : at_global + L.fin_tags;
+    const uint32_t fin_lds = L.at;
+
+    const uint64_t nwaves = static_cast<uint64_t>(gridDim.x) * L.nwaves;
+    const uint64_t per_wave = (n + nwaves - 1) / nwaves;
+    const uint64_t wid = static_cast<uint64_t>(blockIdx.x) * L.nwaves + wave;
+    const uint64_t range_lo = min(n, wid * per_wave), range_hi = min(n, range_lo + per_wave);
+    uint64_t next = range_lo;   // first line of the range not yet handed to a lane (wave-uniform)
+
+    bool has_line = false;
+    uint64_t i = 0, o0 = 0;
+    uint32_t len = 0, pos = 0, row = row0;
+    const uint32_t my = slice + lane * HOP_SLICE_ROW;
+
+    for (;;) {
+        // ---- finished lanes write their results once a quarter of the wave is idle (k_extract_slices says why) ----
+        const bool finished = has_line && (pos >= len || row == dead_row);
+        const uint32_t idle = static_cast<uint32_t>(__popcll(__ballot(finished || !has_line)));
+        const bool service = idle >= 16u || !__any(has_line && !finished);
+        if (service && finished) {
+            const int32_t hot_info = static_cast<int16_t>(lds_ld<uint16_t>(L.acc_tab + 2u * min(row, H.n_hot - 1u)));
+            int32_t info = hot_info >= 0 ? hot_info * 16 : hot_info;
+            if (row >= H.n_hot) info = *reinterpret_cast<const int32_t*>(H.rows + (static_cast<uint64_t>(row) * H.row_bytes + H.info_off));
+            out.id(i, line_result<TIER_HOP>(info, fin_lds, fin_g, regs, len, T.max_groups, [&](int g, int32_t pb, int32_t pe) {
+                out.cap(i, 2 * g, pb);
+                out.cap(i, 2 * g + 1, pe);
+            }));
+            has_line = false;
+        }
+        // ---- free lanes take the next lines of the range, in lane order ----
+        const uint64_t free_mask = __ballot(!has_line);
+        if (service && free_mask && next < range_hi) {
+            const uint32_t rank = static_cast<uint32_t>(__popcll(free_mask & ((1ull << lane) - 1ull)));
+            const uint64_t cand = next + rank;
+            if (!has_line && cand < range_hi) {
+                i = cand;
+                o0 = off[i];
+                int64_t len64 = static_cast<int64_t>(static_cast<uint64_t>(off[i + 1]) - o0);
+                if (strip_eol) len64 = trim_eol(data + o0, len64);
+                if (len64 > 65535) {
+                    // positions are 16-bit in the register block: such a line takes the per-lane path, whole
+                    if (T.m_next16) extract_line_global<uint8_t, uint16_t>(T, T.m_next16, data + o0, len64, i, out, nullptr, 0);
+                    else extract_line_global<uint8_t, uint32_t>(T, T.m_next32, data + o0, len64, i, out, nullptr, 0);
+                } else {
+                    has_line = true;
+                    len = static_cast<uint32_t>(len64);
+                    pos = 0;
+                    row = row0;
+                }
+            }
+            next = min(range_hi, next + static_cast<uint64_t>(__popcll(free_mask)));
+        }
+        if (!__any(has_line)) {
+            if (next >= range_hi) break;
+            continue;  // (only lines for the per-lane path were handed out: hand out more)
+        }
+        // ---- stage the next piece of every lane's line, from the lane's own position: lane l fetches 16 bytes (l & 7) of the
+        // line of lane (l >> 3) + 8 r, as class ids ----
+        const bool walking = has_line && pos < len && row != dead_row;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int q = static_cast<int>(lane >> 3) + 8 * r;
+            const uint64_t oq = __shfl(static_cast<unsigned long long>(o0), q);
+            const uint32_t pq = static_cast<uint32_t>(__shfl(static_cast<int>(pos), q));
+            const uint32_t lq = static_cast<uint32_t>(__shfl(static_cast<int>(walking ? len : 0u), q));
+            const uint32_t at_byte = pq + (lane & 7u) * 16u;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (at_byte < lq) {
+                const uint8_t* src = data + oq + at_byte;
+                if (src + 16 <= data_end) v = reinterpret_cast<const UnalignedWindow*>(src)->v;
+                else {
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    for (int b = 0; b < 16; ++b)
+                        if (src + b < data_end) w[b >> 2] |= static_cast<uint32_t>(src[b]) << ((b & 3) * 8);
+                    v = u32x4{w[0], w[1], w[2], w[3]};
+                }
+            }
+            lds_st<u32x4>(slice + static_cast<uint32_t>(q) * HOP_SLICE_ROW + (lane & 7u) * 16u, hop_map16(v));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- walk the piece ----
+        {
+            const uint32_t left = walking ? len - pos : 0u;          // bytes of the line from pos on
+            const bool whole = left <= HOP_SLICE;                   // the line ends inside the piece
+            const uint32_t e = my + (whole ? left : HOP_SLICE);
+            const uint32_t limit = whole ? e : e - HOP_SLICE_KEEP;
+            uint32_t p = my;
+            row = walk_hop_span(H, p, e, limit, whole ? e : 0xFFFFFFF0u, my - pos, row, dead_row, regs);
+            pos += p - my;
+        }
+        // the slice buffer is rewritten by the next iteration
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace
+
+// lds: a layout from plan_hop_slice_launch (gx_api.cpp): the hop tier's tables, per wave a register block and a [64][144]-byte piece buffer
+hipError_t launch_extract_hop_slices(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
+                                     const GxBatch& b, hipStream_t stream) {
+    if (b.n == 0) return hipSuccess;
+    uint64_t blocks = static_cast<uint64_t>(num_cus);
+    const uint64_t need = (b.n + 256ull * lds.nwaves - 1) / (256ull * lds.nwaves);
+    if (blocks > need) blocks = need;
+    const dim3 grid(static_cast<unsigned>(blocks)), block(lds.nwaves * 64);
+    if (b.offsets64) {
+        hipError_t e = allow_full_lds(&k_extract_hop_slices<uint64_t>);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_extract_hop_slices<uint64_t>), grid, block, lds.total_bytes, stream, dev, lds, lds_image, at_global,
+                           static_cast<const uint8_t*>(b.data), static_cast<const uint64_t*>(b.offsets), b.n, line_out(dev, b), b.strip_eol);
+    } else {
+        hipError_t e = allow_full_lds(&k_extract_hop_slices<uint32_t>);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_extract_hop_slices<uint32_t>), grid, block, lds.total_bytes, stream, dev, lds, lds_image, at_global,
+                           static_cast<const uint8_t*>(b.data), static_cast<const uint32_t*>(b.offsets), b.n, line_out(dev, b), b.strip_eol);
+    }
+    return hipGetLastError();
+}
 
 hipError_t launch_extract_generic(const GxDev& dev, const GxBatch& b, hipStream_t stream) {
     if (b.wide) {

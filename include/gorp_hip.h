@@ -142,7 +142,8 @@ typedef struct gx_batch_opts {
 } gx_batch_opts;
 
 enum { GX_KERNEL_AUTO = 0, GX_KERNEL_TILES = 1, GX_KERNEL_SLICES = 2, GX_KERNEL_PER_LINE = 3, GX_KERNEL_LANES = 4,
-       GX_KERNEL_HOPS = 5 /* the tile kernel on the hop tier's tables (where the handle has them: gx_stat(h, 14)) */ };
+       GX_KERNEL_HOPS = 5 /* the tile kernel on the hop tier's tables (where the handle has them: gx_stat(h, 14)) */,
+       GX_KERNEL_HOP_SLICES = 6 /* the same tables under the slice kernel's staging: long and uneven lines */ };
 
 /* Replaces the per-line loop "for each line: Gorp.extract(line)"
  * (core/Gorp.java:145-186 -> PolyMatcher.match core/autom/PolyMatcher.java:123-133

@@ -296,24 +296,27 @@ def test_syslog_16_rules():
     assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
 
 
-@pytest.mark.parametrize("tier", [2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("tier", [2, 3, 4, 5, 6, 7, 8])
 def test_table_tiers_agree_with_oracle(tier, monkeypatch):
     """The same definitions through the L2-tier tile kernel (automaton rows in global memory), through the per-line
     generic kernel and through the record tier (sparse range records in LDS: 4 = under the lane kernel, its default;
     6 = under the tile kernel; 5 = records in global memory); the default for these small definitions is the LDS tier
     with dense rows, covered everywhere else.  7 = the hop tier (run + chain records over dense rows in global memory) for
-    the capture batches, beside the LDS tier's tables."""
+    the capture batches, beside the LDS tier's tables; 8 = the same tables under the hop slice kernel."""
     monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", {2: N.GX_CREATE_TIER_L2, 3: N.GX_CREATE_NO_TILES, 4: N.GX_CREATE_TIER_RECORDS,
-                                                    5: N.GX_CREATE_TIER_RECORDS_GLOBAL, 6: N.GX_CREATE_TIER_RECORDS, 7: N.GX_CREATE_TIER_HOP}[tier])
+                                                    5: N.GX_CREATE_TIER_RECORDS_GLOBAL, 6: N.GX_CREATE_TIER_RECORDS, 7: N.GX_CREATE_TIER_HOP,
+                                                    8: N.GX_CREATE_TIER_HOP}[tier])
     if tier == 6:
         monkeypatch.setattr(G, "DEFAULT_KERNEL", N.GX_KERNEL_TILES)
     if tier == 7:
         monkeypatch.setattr(G, "DEFAULT_KERNEL", N.GX_KERNEL_HOPS)
-    want = {2: 2, 3: 0, 4: 3, 5: 4, 6: 3, 7: 1}[tier]
+    if tier == 8:
+        monkeypatch.setattr(G, "DEFAULT_KERNEL", N.GX_KERNEL_HOP_SLICES)
+    want = {2: 2, 3: 0, 4: 3, 5: 4, 6: 3, 7: 1, 8: 1}[tier]
     # config 1
     definition = W.simple_grp_definition()
     gorp, orc = Gorp.construct(definition), oracle_for(definition)
-    assert gorp.stat(7) == want and (gorp.stat(14) > 0) == (tier == 7)   # (the hop tier's tables only where asked for)
+    assert gorp.stat(7) == want and (gorp.stat(14) > 0) == (tier in (7, 8))   # (the hop tier's tables only where asked for)
     check_batch(gorp, orc, W.simple_grp_lines(5000, seed=11))
     # config 2 + ragged / empty / very long lines + 64-bit offsets + match-only
     definition = W.readme3_definition()
@@ -516,15 +519,15 @@ def test_config1_from_definition_text(tmp_path):
     assert r.getId() == "sampleMatch" and r.asMap()["authStatus"] == "Accepted"
 
 
-@pytest.mark.parametrize("tier", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tier", [1, 2, 3, 4, 5, 6])
 def test_mixed_lengths_take_several_rounds_per_group(tier, monkeypatch):
     """Lines of 0-3000 bytes against a staging area sized for the mean: groups are walked in several rounds of
     consecutive lanes, a line longer than the staging area alone takes the per-lane path; all bit-exact."""
     if tier != 1:
         monkeypatch.setattr(G, "DEFAULT_CREATE_FLAGS", {2: N.GX_CREATE_TIER_L2, 3: N.GX_CREATE_TIER_RECORDS, 4: N.GX_CREATE_TIER_RECORDS_GLOBAL,
-                                                        5: N.GX_CREATE_TIER_HOP}[tier])
-    if tier == 5:
-        monkeypatch.setattr(G, "DEFAULT_KERNEL", N.GX_KERNEL_HOPS)
+                                                        5: N.GX_CREATE_TIER_HOP, 6: N.GX_CREATE_TIER_HOP}[tier])
+    if tier >= 5:
+        monkeypatch.setattr(G, "DEFAULT_KERNEL", {5: N.GX_KERNEL_HOPS, 6: N.GX_KERNEL_HOP_SLICES}[tier])
     definition = W.readme3_definition()
     gorp, orc = Gorp.construct(definition), oracle_for(definition)
     rng = random.Random(99)
@@ -1079,8 +1082,19 @@ def test_hop_tier_agrees_with_oracle():
     cd, co = lines_to_csr(want_lines)
     om3, oc3 = orc.extract_batch(cd, co, nthreads=8)
     assert np.array_equal(m3, om3) and np.array_equal(c3, oc3)
-    # lines of 50-2000 bytes through the rounds of the tile kernel
-    d2, o2, _ = W.syslog_lines(meta, 3000, seed=43, min_len=50, max_len=2000)
-    m4, c4 = gorp.extract_batch(d2, o2, kernel=N.GX_KERNEL_HOPS)
+    # lines of 50-2000 bytes: through the rounds of the tile kernel, and through the hop slice kernel (the default for them)
+    d2, o2, _ = W.syslog_lines(meta, 30000, seed=43, min_len=50, max_len=2000)
     om4, oc4 = orc.extract_batch(d2, o2, nthreads=8)
-    assert np.array_equal(m4, om4) and np.array_equal(c4, oc4)
+    for kernel in (N.GX_KERNEL_HOPS, N.GX_KERNEL_HOP_SLICES, N.GX_KERNEL_AUTO):
+        m4, c4 = gorp.extract_batch(d2, o2, kernel=kernel)
+        assert np.array_equal(m4, om4) and np.array_equal(c4, oc4), kernel
+    rows, over = gorp.extract_batch(d2, o2, kernel=N.GX_KERNEL_HOP_SLICES, compact=True)
+    cm, cc = G.unpack_rows(rows)
+    assert over == 0 and np.array_equal(cm, om4) and np.array_equal(cc, oc4)
+    m5, c5 = gorp.extract_batch(np.frombuffer(raw, np.uint8), off, strip_eol=True, kernel=N.GX_KERNEL_HOP_SLICES)
+    assert np.array_equal(m5, om3) and np.array_equal(c5, oc3)
+    for ls in (lines, lines[:1], lines[:65]):   # the corrupted lines again, few and many lanes busy
+        dd, oo = lines_to_csr(ls)
+        m6, c6 = gorp.extract_batch(dd, oo, kernel=N.GX_KERNEL_HOP_SLICES)
+        om6, oc6 = orc.extract_batch(dd, oo)
+        assert np.array_equal(m6, om6) and np.array_equal(c6, oc6)

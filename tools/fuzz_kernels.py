@@ -29,7 +29,8 @@ variants = [(0, 0, False), (N.GX_CREATE_TIER_L2, 0, False), (0, N.GX_KERNEL_SLIC
             # the hop tier (run + chain records over dense rows in global memory; the tile kernel on class ids), where the
             # definition is within its limits (else the handle's other tables answer); 2 = u8 result rows
             (N.GX_CREATE_TIER_HOP, N.GX_KERNEL_HOPS, False), (N.GX_CREATE_TIER_HOP, N.GX_KERNEL_HOPS, True), (N.GX_CREATE_TIER_HOP, N.GX_KERNEL_HOPS, 2),
-            (N.GX_CREATE_TIER_HOP | N.GX_CREATE_TIER_L2, N.GX_KERNEL_HOPS, False), (0, 0, 2), (N.GX_CREATE_TIER_RECORDS, 0, 2)]
+            (N.GX_CREATE_TIER_HOP | N.GX_CREATE_TIER_L2, N.GX_KERNEL_HOPS, False), (0, 0, 2), (N.GX_CREATE_TIER_RECORDS, 0, 2),
+            (N.GX_CREATE_TIER_HOP, N.GX_KERNEL_HOP_SLICES, False), (N.GX_CREATE_TIER_HOP, N.GX_KERNEL_HOP_SLICES, True), (N.GX_CREATE_TIER_HOP, N.GX_KERNEL_HOP_SLICES, 2)]
 done = bad = 0
 while done < n_defs:
     exts = [FlattenedExtraction("e%d" % i, TC.gen_pieces(rng)) for i in range(rng.randint(1, 5))]
