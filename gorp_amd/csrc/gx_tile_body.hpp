@@ -218,9 +218,9 @@ __device__ __forceinline__ void tile_commit(const TileInfo& t, uint32_t lane, co
 // KCH: 16-byte chunks per lane that cover the staging area (stage_bytes <= KCH * 1024).  A tile's span is
 // fetched into KCH*4 VGPRs per lane one tile AHEAD: the loads are issued before the current tile is walked
 // and land while the wave computes out of LDS, so HBM latency is hidden without a second LDS buffer.
-// PACKED: results leave as compact rows (gx_batch_opts.compact_results) -- a kernel of its own, so that profiles tell
+// PACKED: 1 = results leave as compact u16 rows, 2 = as u8 rows (gx_batch_opts.compact_results) -- kernels of their own, so that profiles tell
 // the two result formats apart.
-template <typename OFF, int KCH, int TIER, int MODE, bool PACKED>
+template <typename OFF, int KCH, int TIER, int MODE, int PACKED>
 __global__ void __launch_bounds__(KCH > 13 ? 512 : 768) __attribute__((amdgpu_waves_per_eu(1, KCH > 13 ? 2 : 3)))
 k_extract_tile(GxLds L, TileIO io) {
     // ---- prologue: table image -> LDS (the only access through the __shared__ symbol; its address is 0) ----
@@ -434,7 +434,7 @@ k_extract_tile(GxLds L, TileIO io) {
             if (PACKED) {
                 // u16 rows (int16 id + u16 offsets), or -- io.narrow, wave-uniform -- u8 rows (int8 id + u8 offsets, an offset
                 // above 254 stored as 254 and counted).  A staged line is shorter than 65 535 bytes, so u16 rows never clamp here.
-                const bool narrow = io.narrow != 0;
+                constexpr bool narrow = PACKED == 2;
                 const uint32_t row_b = narrow ? 1u + slots : 2u + 2u * slots;
                 uint8_t* out_rows = reinterpret_cast<uint8_t*>(io.packed) + (cur.i - lane) * static_cast<uint64_t>(row_b);
                 const bool rows_aligned = (reinterpret_cast<uintptr_t>(io.packed) & 15u) == 0u;  // (64 rows are a multiple of 16 bytes)
@@ -532,7 +532,7 @@ k_extract_tile(GxLds L, TileIO io) {
 #endif
 }
 
-template <typename OFF, int KCH, int TIER, int MODE, bool PACKED>
+template <typename OFF, int KCH, int TIER, int MODE, int PACKED>
 hipError_t launch_tile_p(const GxLds& lds, const TileIO& io, dim3 grid, dim3 block, hipStream_t stream) {
     hipError_t e = allow_full_lds(&k_extract_tile<OFF, KCH, TIER, MODE, PACKED>);
     if (e != hipSuccess) return e;
@@ -541,8 +541,9 @@ hipError_t launch_tile_p(const GxLds& lds, const TileIO& io, dim3 grid, dim3 blo
 }
 template <typename OFF, int KCH, int TIER, int MODE>
 hipError_t launch_tile_t(const GxLds& lds, const TileIO& io, dim3 grid, dim3 block, hipStream_t stream) {
-    if (MODE != 0 && io.packed) return launch_tile_p<OFF, KCH, TIER, MODE, MODE != 0>(lds, io, grid, block, stream);
-    return launch_tile_p<OFF, KCH, TIER, MODE, false>(lds, io, grid, block, stream);
+    if (MODE != 0 && io.packed && io.narrow) return launch_tile_p<OFF, KCH, TIER, MODE, MODE != 0 ? 2 : 0>(lds, io, grid, block, stream);
+    if (MODE != 0 && io.packed) return launch_tile_p<OFF, KCH, TIER, MODE, MODE != 0 ? 1 : 0>(lds, io, grid, block, stream);
+    return launch_tile_p<OFF, KCH, TIER, MODE, 0>(lds, io, grid, block, stream);
 }
 template <typename OFF, int TIER, int MODE>
 hipError_t launch_tile_k(const GxLds& lds, const TileIO& io, dim3 grid, dim3 block, hipStream_t stream) {

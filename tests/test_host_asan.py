@@ -36,7 +36,7 @@ def _golden_definitions():
 def test_host_compiler_under_asan_ubsan(tmp_path):
     exe = str(tmp_path / "asan_driver")
     srcs = [os.path.join(ROOT, "tests", "cpp", "asan_driver.cpp")] + [os.path.join(CSRC, f) for f in
-                                                                        ("gx_regex.cpp", "gx_compile.cpp", "gx_host.cpp", "gx_dsl.cpp")]
+                                                                        ("gx_regex.cpp", "gx_compile.cpp", "gx_host.cpp", "gx_dsl.cpp", "gx_json.cpp", "gx_hop.cpp")]
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-I", CSRC, "-I",
            os.path.join(ROOT, "include")] + srcs + ["-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)

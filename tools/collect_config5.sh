@@ -1,7 +1,7 @@
 #!/bin/bash
 # Developer tool, run ON THE GPU BOX from the repo root:   bash tools/collect_config5.sh r02
 # BASELINE.json configs[4] (512 extractions, lines of 50-2000 bytes): L2 hit rate and instruction mix of the lane kernel on
-# length-sorted tiles (separate rocprofv3 --pmc passes of tools/bench_config3.py 512 2000000 50 2000, --kernel-trace only).
+# length-sorted tiles (match-only batches) and of the hop slice kernel (captures) (separate rocprofv3 --pmc passes of tools/bench_config3.py 512 2000000 50 2000, --kernel-trace only).
 set -eo pipefail
 tag=${1:-r02}
 root=$(pwd)
@@ -24,7 +24,10 @@ out = sys.argv[1]
 acc = collections.defaultdict(list)
 for path in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(path)):
-        if "k_extract_lanes" in r["Kernel_Name"]:
+        if "k_extract_hop_slices" in r["Kernel_Name"]:
+            variant = "hop slices"
+            acc[(variant, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        elif "k_extract_lanes" in r["Kernel_Name"]:
             variant = "captures" if ", true, true, " in r["Kernel_Name"] or ", true, false, " in r["Kernel_Name"] else "match only"
             acc[(variant, r["Counter_Name"])].append(float(r["Counter_Value"]))
 with open(os.path.join(out, "pmc.txt"), "w") as f:

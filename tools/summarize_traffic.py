@@ -6,8 +6,8 @@ stream on gfx950 and is doubled; the copy kernel in the same run is the calibrat
 import csv, json, os, sys
 
 tag, fetch_csv, write_csv = sys.argv[1], sys.argv[2], sys.argv[3]
-fmt = sys.argv[4] if len(sys.argv) > 4 else "compact"   # result format of the profiled launches
-row_bytes = {"compact": 18, "dense": 36, "match_only": 4}[fmt]
+fmt = sys.argv[4] if len(sys.argv) > 4 else "narrow"   # result format of the profiled launches
+row_bytes = {"narrow": 9, "compact": 18, "dense": 36, "match_only": 4}[fmt]
 out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 
 
