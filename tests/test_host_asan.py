@@ -1,4 +1,4 @@
-"""The host-side compiler (definition language -> regexps -> automata -> table blob; no HIP involved) built with
+"""The host-side compiler (definition language -> regexps -> automata -> table blob -> hop tier tables; no HIP involved) built with
 AddressSanitizer + UndefinedBehaviorSanitizer and run over the golden definitions and mutated copies of them.
 (GPU AddressSanitizer is not available on the GPU pool: sanitizers run on the CPU build only.)"""
 import json
@@ -70,3 +70,6 @@ def test_host_compiler_under_asan_ubsan(tmp_path):
     assert "asan driver: " in out
     compiled = int(out.split("asan driver: ")[1].split()[0])
     assert compiled >= len(defs)   # every golden definition compiles
+    # the hop tier's tables (gx_hop.cpp), walked on the host as the kernel walks them, agree with the dense automaton
+    hop_defs, hop_lines = [int(x) for x in out.split("hop tier: ")[1].replace(" definitions,", "").split()[:2]]
+    assert hop_defs >= len(defs) // 2 and hop_lines >= 400 * hop_defs
