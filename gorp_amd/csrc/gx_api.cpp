@@ -646,7 +646,8 @@ bool plan_tile_layout(GxLds L, uint32_t line_bytes_hint, GxLds* out) {
     L.stage_bytes = (64u * line_bytes_hint + 64u + 15u) & ~15u;  // + slack: the walk reads ahead of the line
     if (L.stage_bytes > 16384u) L.stage_bytes = 16384u;  // the kernel prefetches a tile into <= 64 VGPRs per lane;
                                                           // longer lines go in several rounds or to the per-line kernel
-    const uint32_t fixed = L.regs_wave_bytes + GX_BITMAP_WAVE_BYTES;
+    const uint32_t bitmap_bytes = L.tier == 4 ? 0u : GX_BITMAP_WAVE_BYTES;   // (the hop tier has no chunk bitmap)
+    const uint32_t fixed = L.regs_wave_bytes + bitmap_bytes;
     if (L.table_bytes + 4 * (L.stage_bytes + fixed) > LDS_BYTES) return false;
     uint32_t nw = (LDS_BYTES - L.table_bytes) / (L.stage_bytes + fixed);
     if (nw > 12) nw = 12;  // 768 threads: leaves 170 VGPRs per lane for the prefetch registers
@@ -666,7 +667,7 @@ bool plan_tile_layout(GxLds L, uint32_t line_bytes_hint, GxLds* out) {
     L.nwaves = nw;
     L.regs = L.table_bytes;
     L.bitmap = L.regs + nw * L.regs_wave_bytes;
-    L.counter = L.bitmap + nw * GX_BITMAP_WAVE_BYTES;
+    L.counter = L.bitmap + nw * bitmap_bytes;
     L.stage = (L.counter + 16u + 15u) & ~15u;
     L.total_bytes = L.stage + nw * L.stage_bytes;
     if (L.total_bytes > LDS_BYTES) { L.stage_bytes -= 16u; L.total_bytes = L.stage + nw * L.stage_bytes; }
@@ -803,6 +804,7 @@ void choose_tile_image(gx_handle* h) {
         L.tier = 4;
         L.rec = HOP_AT;
         L.rec_indexed = h->hop.n_hot;
+        L.sort_chunk = h->hop.n_reachable_hot;  // (hop tier: the states well-formed lines reach; rec_indexed of them are in LDS)
         L.acc_tab = h->hop.info_lds;   // int16 info words of the hot states
         L.at = h->hop.fin_lds;         // final records in LDS (0: in the global image at fin_tags)
         L.hot_lo4 = 0;
@@ -1139,6 +1141,7 @@ int64_t gx_stat(const gx_handle* h, int32_t which) {
     case 16: return h->hop_ok ? static_cast<int64_t>(h->hop.n_reachable_hot) : 0;  // ... that well-formed lines reach
     case 17: return h->hop_ok ? static_cast<int64_t>(h->hop.n_chains) : 0;         // ... that have a chain
     case 18: { GxLds L; return plan_hop_launch(h, 0, &L) ? static_cast<int64_t>(L.nwaves) : 0; }  // hop tier: waves per CU
+    case 20: return h->hop_ok ? static_cast<int64_t>(h->hop.n_lds_rows) : 0;       // ... whose dense row is in LDS too (branching states)
     case 19: { GxLds L; return plan_hop_slice_launch(h, &L) ? static_cast<int64_t>(L.nwaves) : 0; }  // ... of the hop slice kernel
     case 9: return !h->tile_ok ? 0 : !h->has_mo ? gx_stat(h, 7) : h->lds_mo.tier == 3 ? 4 : h->lds_mo.tier == 2 ? 3 : h->lds_mo.tier == 1 ? 2 : 1;
     default: return -1;

@@ -240,7 +240,7 @@ bool build_hop_image(const Tables& T, uint32_t hot_budget_bytes, HopImage& out) 
         uint32_t run_lo = 0, run_k = 0x80;  // none: every byte fails the test
         if (run[s].hi >= run[s].lo && s != dead) { run_lo = static_cast<uint32_t>(run[s].lo); run_k = 0x7Fu - static_cast<uint32_t>(run[s].hi); ++out.n_runs; }
         r[0] = run_lo | run_k << 8 | static_cast<uint32_t>(ch.klen) << 16 | ch.off[0] << 20 | ch.off[1] << 23;
-        r[1] = perm[ch.klen ? ch.target : static_cast<uint32_t>(s)] | ch.col[0] << 16 | ch.col[1] << 24;
+        r[1] = (ch.klen ? perm[ch.target] : 0u) | ch.col[0] << 16 | ch.col[1] << 24;   // (no chain: the field is the LDS row's address / 4, below)
         uint8_t el[HOP_CHAIN], ns[HOP_CHAIN];
         for (uint32_t k = 0; k < HOP_CHAIN; ++k) {
             if (static_cast<int>(k) < ch.klen) { el[k] = static_cast<uint8_t>(0x80u - ch.lo[k]); ns[k] = static_cast<uint8_t>(0x7Fu - ch.span[k]); }
@@ -299,6 +299,29 @@ bool build_hop_image(const Tables& T, uint32_t hot_budget_bytes, HopImage& out) 
         out.lds.push_back(static_cast<uint8_t>((v >> 8) & 0xFF));
     }
     while (out.lds.size() % 16) out.lds.push_back(0);
+    // the dense rows of the first hot branching states: an exact step there is an LDS read
+    {
+        // (compact: u16 successors [ncls, padded to a dword], then u8 register columns [ncls, padded])
+        const uint32_t row_budget = 8192u, succ_bytes = (2u * ncls + 3u) & ~3u, row_lds_bytes = succ_bytes + ((ncls + 3u) & ~3u);
+        for (uint32_t s = 0; s < out.n_hot && (out.n_lds_rows + 1) * row_lds_bytes <= row_budget; ++s) {
+            const uint32_t orig = order[s];
+            if (chain[orig].klen != 0 || plausible_targets[orig].size() < 2) continue;
+            const uint32_t at = static_cast<uint32_t>(out.lds.size());
+            if ((at >> 2) > 0xFFFFu) break;
+            out.lds.resize(at + row_lds_bytes, 0);
+            for (int cc = 0; cc < ncls; ++cc) {
+                const uint32_t e = rows[static_cast<size_t>(s) * cols + cc];
+                out.lds[at + 2 * cc] = static_cast<uint8_t>(e & 0xFFu);
+                out.lds[at + 2 * cc + 1] = static_cast<uint8_t>((e >> 8) & 0xFFu);
+                out.lds[at + succ_bytes + cc] = static_cast<uint8_t>(e >> 16);
+            }
+            hops[static_cast<size_t>(s) * (HOP_REC_BYTES / 4) + 1] |= at >> 2;
+            ++out.n_lds_rows;
+        }
+        while (out.lds.size() % 16) out.lds.push_back(0);
+        // (the records were copied into the image above: again, with the row addresses)
+        memcpy(&out.lds[HOP_AT], hops.data(), static_cast<size_t>(out.n_hot) * HOP_REC_BYTES);
+    }
     if (fin_rec.size() * 2 <= 8192u) {  // the final records beside them: a line's result then needs no global read
         out.fin_lds = static_cast<uint32_t>(out.lds.size());
         const uint8_t* fl = reinterpret_cast<const uint8_t*>(fin_rec.data());

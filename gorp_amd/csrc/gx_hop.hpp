@@ -17,7 +17,9 @@
 //          host follows the state's one plausible exit (and its successor's, ...) through the dense rows and records
 //          where that path ends (target) and the (at most two) capture programs on it with their offsets.  When the bytes
 //          do not match, the walk takes ONE exact step through the state's dense row instead (global memory / L2), so the
-//          result never depends on which chains exist: a chain is a fact about the dense rows.
+//          result never depends on which chains exist: a chain is a fact about the dense rows.  The branching nodes of the
+//          literal trie (no chain, several plausible exits) are the states every well-formed line steps through exactly:
+//          the first of them keep a copy of their dense row in LDS (their record's target field holds its address / 4).
 // States are renumbered "hot first" (breadth-first over chain targets and plausible exits from the start state): the
 // records of the first n_hot states are copied into LDS by every workgroup, the others are read from global memory.
 #pragma once
@@ -47,6 +49,7 @@ struct HopImage {
     uint32_t ncls = 0, row_bytes = 0, n_states = 0, n_hot = 0;
     uint32_t hops_off = 0, fin_off = 0;  // byte offsets in `global`
     uint32_t info_lds = 0, fin_lds = 0;  // LDS addresses
+    uint32_t n_lds_rows = 0;             // hot branching states (no chain, several plausible exits) whose dense row is in LDS too
     uint32_t start = 0, dead = 0;        // state indexes (renumbered)
     uint32_t n_regs = 0;
     // diagnostics (gx_stat)

@@ -28,6 +28,7 @@ struct HopTab {
     uint32_t row_bytes;
     uint32_t info_off;     // byte offset of the info column in a row
     uint32_t n_hot;        // states [0, n_hot) have their records in LDS at HOP_LDS_AT
+    uint32_t lrow_cols;    // a dense row's copy in LDS: u16 successors, and at this byte offset its u8 register columns
 };
 
 // two / one dwords at a 4-byte aligned LDS address (ds_read2_b32 / ds_read_b32)
@@ -75,17 +76,33 @@ __device__ __forceinline__ uint32_t run_flags(uint32_t x, uint32_t lo4, uint32_t
 // at `e` (run lengths are cut there); it iterates while p < limit (limit = e when the line ends at e, else 24 bytes
 // before it, so that a whole window and a whole chain are staged); a chain must end at or before e_chain (the end of the
 // LINE; no constraint when the line goes on beyond the staged piece); a capture program's position is its LDS address minus p0.
+// ALL_HOT: every state that a chain or a plausible exact step leads to has its record in LDS (the usual case: a few hundred
+// states).  A lane then leaves the hot set only by an exact step on a byte the definition does not expect there; it takes
+// exact steps -- inside that branch -- until it is back in the hot set or its line is over, and the loop proper never looks
+// for a record in global memory.
+template <bool ALL_HOT>
 __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, uint32_t e, uint32_t limit, uint32_t e_chain, uint32_t p0,
                                                   uint32_t s, uint32_t dead, uint32_t regs) {
     const uint32_t dummy_col = regs - 128u;
     const uint32_t last_hot = H.n_hot - 1u;
+    // one exact step of this lane from state s on the class id c at LDS address q: the dense row (lrow: its copy in LDS, 0: none)
+    auto exact_step = [&](uint32_t lrow, uint32_t c, uint32_t q) {
+        uint32_t xe;
+        if (lrow) xe = lds_ld<uint16_t>(lrow + (c << 1)) | static_cast<uint32_t>(lds_ld<uint8_t>(lrow + H.lrow_cols + c)) << 16;  // (u16 successors, then u8 columns)
+        else xe = *reinterpret_cast<const uint32_t*>(H.rows + (static_cast<uint64_t>(s) * H.row_bytes + (c << 2)));
+        lds_st<uint16_t>(dummy_col + ((xe >> 16) << 7), static_cast<uint16_t>(q - p0));
+        s = xe & 0xFFFFu;
+        p = s == dead ? max(limit, q + 1u) : q + 1u;  // (nothing leaves the dead state: the line is over)
+    };
+    if (ALL_HOT && __builtin_amdgcn_ballot_w64(s > last_hot) != 0ull)   // (the slice kernel: a lane may come back off the path)
+        while (s > last_hot && p < limit) exact_step(0u, lds_ld<uint8_t>(p), p);
     for (;;) {
         const uint64_t unfinished = __builtin_amdgcn_ballot_w64(p < limit);
         if (unfinished == 0ull) break;
         // ---- 1. the state's record ----
-        const uint32_t la = __umul24(min(s, last_hot), HOP_REC_B) + HOP_LDS_AT;
+        const uint32_t la = __umul24(min(s, last_hot), HOP_REC_B) + HOP_LDS_AT;  // (a lane that is done may sit in any state)
         u32x2 h0 = lds_ld<u32x2>(la), h1 = lds_ld<u32x2>(la + 8u), h2 = lds_ld<u32x2>(la + 16u);
-        if ((__builtin_amdgcn_ballot_w64(s > last_hot) & unfinished) != 0ull) {
+        if (!ALL_HOT && (__builtin_amdgcn_ballot_w64(s > last_hot) & unfinished) != 0ull) {
             if (s > last_hot && p < limit) {
                 const u32x2* g = reinterpret_cast<const u32x2*>(H.hops + static_cast<uint64_t>(s) * HOP_REC_B);
                 h0 = g[0]; h1 = g[1]; h2 = g[2];
@@ -133,10 +150,10 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
         const uint64_t m_exact = m_step & ~m_chain;
         if (m_exact != 0ull) {
             if (stepping && !chained) {
-                const uint32_t xe = *reinterpret_cast<const uint32_t*>(H.rows + (static_cast<uint64_t>(s) * H.row_bytes + ((v0 & 0xFFu) << 2)));
-                lds_st<uint16_t>(dummy_col + ((xe >> 16) << 7), static_cast<uint16_t>(rel));
-                s = xe & 0xFFFFu;
-                p = s == dead ? max(limit, q + 1u) : q + 1u;  // (nothing leaves the dead state: the line is over)
+                // a state without a chain keeps the LDS address / 4 of its dense row's copy in the target field (0: none)
+                exact_step(((h0.x >> 16) & 0xFu) == 0u ? (h0.y & 0xFFFFu) << 2 : 0u, v0 & 0xFFu, q);
+                if (ALL_HOT)
+                    while (s > last_hot && p < limit) exact_step(0u, lds_ld<uint8_t>(p), p);   // (off the expected path: rare, and short)
             }
         }
     }
@@ -144,11 +161,12 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
 }
 
 // The tile kernel's case: the whole line [start, end) is staged.
-__device__ __forceinline__ uint32_t walk_hop(const HopTab& H, uint32_t stage, uint32_t s, uint32_t start, uint32_t end, bool on,
+__device__ __forceinline__ uint32_t walk_hop(const HopTab& H, bool all_hot, uint32_t stage, uint32_t s, uint32_t start, uint32_t end, bool on,
                                              uint32_t dead, uint32_t regs) {
     const uint32_t p0 = stage + start, e = stage + end;
     uint32_t p = on ? p0 : e;
-    return walk_hop_span(H, p, e, e, e, p0, s, dead, regs);
+    if (all_hot) return walk_hop_span<true>(H, p, e, e, e, p0, s, dead, regs);
+    return walk_hop_span<false>(H, p, e, e, e, p0, s, dead, regs);
 }
 
 }  // namespace gx

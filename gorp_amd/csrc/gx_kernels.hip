@@ -413,6 +413,7 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
     H.row_bytes = L.row_bytes;
     H.info_off = L.ncls * 4u;
     H.n_hot = L.rec_indexed;
+    H.lrow_cols = (2u * L.ncls + 3u) & ~3u;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t slice = L.stage + wave * L.stage_bytes;
@@ -508,7 +509,8 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
             const uint32_t e = my + (whole ? left : HOP_SLICE);
             const uint32_t limit = whole ? e : e - HOP_SLICE_KEEP;
             uint32_t p = my;
-            row = walk_hop_span(H, p, e, limit, whole ? e : 0xFFFFFFF0u, my - pos, row, dead_row, regs);
+            if (L.rec_indexed >= L.sort_chunk) row = walk_hop_span<true>(H, p, e, limit, whole ? e : 0xFFFFFFF0u, my - pos, row, dead_row, regs);
+            else row = walk_hop_span<false>(H, p, e, limit, whole ? e : 0xFFFFFFF0u, my - pos, row, dead_row, regs);
             pos += p - my;
         }
         // the slice buffer is rewritten by the next iteration

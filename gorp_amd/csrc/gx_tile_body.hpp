@@ -241,6 +241,7 @@ k_extract_tile(GxLds L, TileIO io) {
     H.row_bytes = L.row_bytes;
     H.info_off = L.ncls * 4u;
     H.n_hot = L.rec_indexed;
+    H.lrow_cols = (2u * L.ncls + 3u) & ~3u;
     const uint8_t* __restrict__ data = io.data;
     const OFF* __restrict__ off = static_cast<const OFF*>(io.off);
     const uint64_t n = io.n;
@@ -396,7 +397,7 @@ k_extract_tile(GxLds L, TileIO io) {
             int32_t info;  // of the state the line's walk ended in: -1 null, -2-k ExtractionException, else its final record
             if (HOP) {
                 // ---- fused pass on the hop records: a run and a chain per iteration (gx_hop_dev.hpp) ----
-                const uint32_t urow = walk_hop(H, stage, L.u_start, start, end, true, L.u_dead, regs);
+                const uint32_t urow = walk_hop(H, L.rec_indexed >= L.sort_chunk, stage, L.u_start, start, end, true, L.u_dead, regs);
                 // the final state's info word: int16 in LDS for the hot states (offset / 16, or -1 / -2-k), else its dense row's last column
                 const int32_t hot_info = static_cast<int16_t>(lds_ld<uint16_t>(L.acc_tab + 2u * min(urow, H.n_hot - 1u)));
                 info = hot_info >= 0 ? hot_info * 16 : hot_info;
