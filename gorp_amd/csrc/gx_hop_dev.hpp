@@ -54,13 +54,20 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
 // (the compiler turns __any into a select, a compare and a scalar test; the ballot is the scalar test alone)
 __device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
 
-// byte -> class id for the 16 bytes of one staged chunk (class map: u8[256] at LDS address 0)
-__device__ __forceinline__ uint32_t hop_map4(uint32_t d) {
-    const uint32_t c0 = lds_ld<uint8_t>(d & 0xFFu), c1 = lds_ld<uint8_t>((d >> 8) & 0xFFu);
-    const uint32_t c2 = lds_ld<uint8_t>((d >> 16) & 0xFFu), c3 = lds_ld<uint8_t>(d >> 24);
-    return c0 | c1 << 8 | c2 << 16 | c3 << 24;
+// byte -> class id for the 16 bytes of one staged chunk (class map: u8[256] at LDS address 0).  All 16 lookups are issued
+// before the first of them is used (the scheduling barrier keeps the compiler from pairing each with its use: it would then
+// wait out an LDS round trip per dword, 52 of them per tile).
+__device__ __forceinline__ u32x4 hop_map16(const u32x4& v) {
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+    uint32_t c[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) c[j] = lds_ld<uint8_t>((d[j >> 2] >> ((j & 3) * 8)) & 0xFFu);
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = c[4 * q] | c[4 * q + 1] << 8 | c[4 * q + 2] << 16 | c[4 * q + 3] << 24;
+    return u32x4{o[0], o[1], o[2], o[3]};
 }
-__device__ __forceinline__ u32x4 hop_map16(const u32x4& v) { return u32x4{hop_map4(v.x), hop_map4(v.y), hop_map4(v.z), hop_map4(v.w)}; }
 
 // Walks the line [start, end) of the wave's staging area (class ids) from state `s`; returns the final state.  regs = LDS
 // address of this lane's slot in register column 0 (the write-only dummy column sits 128 bytes before it).
