@@ -51,16 +51,35 @@ def host_cores():
     return min(cores, 64)
 
 
-def reference_jvm_probe():
-    """the preferred CPU baseline is the reference itself on a JVM.  It needs `java` and a classpath
-    holding gorp-core, dk.brics.automaton 1.11-8 and jackson-jr 2.8.2 (GORP_REFERENCE_CLASSPATH).  Neither exists in
-    this image; say so instead of pretending."""
-    java = shutil.which("java")
+def reference_jvm_baseline(definition_text, lines, cores, budget_s=60.0):
+    """the preferred CPU baseline is the reference itself on a JVM -- tools/RefBench.java, T threads over
+    Gorp.extract (README.md:63-79).  It needs `java`, `javac` and a classpath holding gorp-core, dk.brics.automaton 1.11-8
+    and jackson-jr 2.8.2 (GORP_REFERENCE_CLASSPATH).  None of them exists in this image: then this says so and nothing runs.
+    Compiles and runs in child processes; returns a dict (RefBench's JSON line) or a string saying why not."""
+    import subprocess
+    import tempfile
+    java, javac = shutil.which("java"), shutil.which("javac")
     cp = os.environ.get("GORP_REFERENCE_CLASSPATH")
-    if java and cp:
-        return "found (java at %s, classpath given) but no Java driver ships with this repo: not run" % java
-    missing = [w for w, ok in (("java on PATH", java), ("GORP_REFERENCE_CLASSPATH", cp)) if not ok]
-    return "unavailable (no %s)" % ", no ".join(missing)
+    missing = [w for w, ok in (("java on PATH", java), ("javac on PATH", javac), ("GORP_REFERENCE_CLASSPATH", cp)) if not ok]
+    if missing:
+        return "unavailable (no %s)" % ", no ".join(missing)
+    if definition_text is None:
+        return "not run (this workload's definition has no .grp text)"
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            r = subprocess.run([javac, "-cp", cp, "-d", d, os.path.join(ROOT, "tools", "RefBench.java")], capture_output=True, text=True, timeout=120)
+            if r.returncode != 0:
+                return "javac failed: " + r.stderr[-300:]
+            open(os.path.join(d, "def.grp"), "w", encoding="utf-8").write(definition_text)
+            with open(os.path.join(d, "lines.txt"), "wb") as f:
+                f.write(b"\n".join(lines) + b"\n")
+            r = subprocess.run([java, "-cp", d + os.pathsep + cp, "RefBench", os.path.join(d, "def.grp"), os.path.join(d, "lines.txt"), str(cores)],
+                               capture_output=True, text=True, timeout=budget_s + 120)
+            if r.returncode != 0:
+                return "RefBench failed: " + r.stderr[-300:]
+            return json.loads(r.stdout.strip().splitlines()[-1])
+    except (OSError, ValueError, subprocess.TimeoutExpired) as e:
+        return "RefBench did not finish: %s" % e
 
 
 def cpu_baseline(definition, data_cpu, offsets_cpu, budget_s=20.0):
@@ -88,8 +107,7 @@ def cpu_baseline(definition, data_cpu, offsets_cpu, budget_s=20.0):
     return {"value": n / dt, "unit": "lines/s", "cores": cores, "kind": "port",
             "sample": "first %d lines of the rank-0 shard, %d threads, %.1f s; C++ restatement of "
                       "PolyMatcher.match + java.util.regex capture (oracle/), not the JVM" % (n, cores, dt),
-            "single_thread_value": n1 / dt1, "single_thread_sample": "first %d lines, 1 thread, %.1f s" % (n1, dt1),
-            "reference_jvm": reference_jvm_probe()}, mid, caps, n
+            "single_thread_value": n1 / dt1, "single_thread_sample": "first %d lines, 1 thread, %.1f s" % (n1, dt1)}, mid, caps, n
 
 
 def self_launch(n_ranks):
@@ -357,7 +375,10 @@ def main():
                        "results": fmt_desc[headline], "max_line_bytes": max_line,
                        "match_dfa_states": int(gorp.stat(0)), "char_classes": int(gorp.stat(1)),
                        "capture_states": int(gorp.stat(2)), "table_blob_bytes": int(gorp.stat(4)),
-                       "table_tier": {0: "per-line kernel", 1: "LDS (dense rows)", 2: "L2 (dense rows)", 3: "LDS (range records)", 4: "L2 (range records)"}.get(int(gorp.stat(7)), str(gorp.stat(7))),
+                       "table_tier": ("hop tier: run + chain records, %d of %d states' records in LDS (%d of them reachable by well-formed lines), dense rows in global memory"
+                                      % (int(gorp.stat(15)), int(gorp.stat(14)), int(gorp.stat(16)))) if int(gorp.stat(14)) > 0 else
+                                     {0: "per-line kernel", 1: "LDS (dense rows)", 2: "L2 (dense rows)", 3: "LDS (range records)", 4: "L2 (range records)"}.get(int(gorp.stat(7)), str(gorp.stat(7))),
+                       "kernel": "hop slice kernel" if int(gorp.stat(14)) > 0 and (hint > 255) else "tile kernel" if (int(gorp.stat(14)) > 0 or int(gorp.stat(7)) in (1, 2)) else "lane kernel",
                        "parallelism": "lines sharded by rank (dp%d), no collective in a step" % world},
             "gb_per_s_scanned": total_bytes * world * steps / elapsed / 1e9,
             "kernel_ms": {"avg": k_avg, "min": k_sorted[0], "median": k_sorted[len(k_sorted) // 2]},
@@ -391,6 +412,18 @@ def main():
                 same = same and np.array_equal(nm, omid) and np.array_equal(nc, ocaps)
             if not same:
                 raise SystemExit("bench: GPU results differ from the oracle on the baseline sample")
+            # the reference itself, where a JVM and its jars exist (config 2 only: it has a definition text)
+            n_ref = min(ns, 2_000_000)
+            ref_lines = [bytes(d_cpu[int(o_cpu[i]):int(o_cpu[i + 1])]) for i in range(n_ref)] if shutil.which("java") and config == 2 else []
+            from gorp_amd import workloads as W
+            base["reference_jvm"] = reference_jvm_baseline(W.README3_DEFINITION_TEXT if config == 2 else None, ref_lines, base["cores"])
+            if isinstance(base["reference_jvm"], dict):   # the reference ran: it IS the baseline, the port stays beside it
+                port = dict(base)
+                port.pop("reference_jvm")
+                ref = base["reference_jvm"]
+                base = {"value": ref["value"], "unit": "lines/s", "cores": ref["cores"], "kind": "reference",
+                        "sample": "first %d lines of the rank-0 shard, %d threads over Gorp.extract on JVM %s (tools/RefBench.java), %.1f s"
+                                  % (ref["lines"], ref["cores"], ref["java"], ref["seconds"]), "port": port}
             out["cpu_baseline"] = base
         print(json.dumps(out), flush=True)
     if distributed:

@@ -60,6 +60,16 @@ def readme3_definition():
     return [rule("PutRequest", T("PUT")), rule("GetRequest", T("GET")), rule("OtherRequest", WORD)]
 
 
+# the same definition as the reference's README writes it (README.md:114-135), for front ends that take .grp text
+README3_DEFINITION_TEXT = (
+    "pattern %num \\d+\npattern %word \\w+\npattern %phrase \\S+\n\n"
+    "extract PutRequest {\n   template [$timestamp(%num)]: $verb(PUT) $timeTakenInMsec(%num)ms $path(%phrase)\n"
+    "   append { \"marker\" : \"EXTRACTED\" }\n}\n"
+    "extract GetRequest {\n   template [$timestamp(%num)]: $verb(GET) $timeTakenInMsec(%num)ms $path(%phrase)\n"
+    "   append { \"marker\" : \"EXTRACTED\" }\n}\n"
+    "extract OtherRequest {\n   template [$timestamp(%num)]: $verb(%word) $timeTakenInMsec(%num)ms $path(%phrase)\n"
+    "   append { \"marker\" : \"EXTRACTED\" }\n}\n")
+
 README3_VERBS = ["GET", "PUT", "POST", "DELETE", "HEAD", "PATCH"]
 LINE_BYTES = 200
 

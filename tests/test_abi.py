@@ -60,3 +60,19 @@ def test_release_library_reads_no_environment_variables():
     assert not names, names
     syms = subprocess.run(["nm", "-D", "--undefined-only", gbuild.LIB], capture_output=True, text=True).stdout
     assert "getenv" not in syms
+
+
+def test_reference_jvm_baseline_driver_is_source_only_and_says_so_here():
+    """tools/RefBench.java is the reference-as-baseline driver: it uses nothing but the reference's public API
+    (README.md:63-79), ships as source, and bench.py reports "unavailable" where there is no JDK -- as in this image."""
+    import shutil
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    src = open(os.path.join(ROOT, "tools", "RefBench.java")).read()
+    imports = [ln.split()[1].rstrip(";") for ln in src.splitlines() if ln.startswith("import com.salesforce")]
+    assert sorted(imports) == ["com.salesforce.gorp.DefinitionReader", "com.salesforce.gorp.ExtractionException",
+                               "com.salesforce.gorp.ExtractionResult", "com.salesforce.gorp.Gorp"]
+    assert "DefinitionReader.reader(new File(" in src and ".read()" in src and "gorp.extract(" in src
+    if not (shutil.which("java") and shutil.which("javac") and os.environ.get("GORP_REFERENCE_CLASSPATH")):
+        assert bench.reference_jvm_baseline("extract a {\n template x\n}\n", [b"x"], 1).startswith("unavailable (no ")
