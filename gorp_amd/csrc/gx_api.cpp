@@ -77,9 +77,10 @@ struct gx_handle {
     // hop tier (gx_hop.hpp): a further image of the fused automaton for capture batches of definitions whose dense rows do
     // not fit LDS -- hop records (hot ones in LDS) over dense rows in global memory, walked by the tile kernel
     bool hop_ok = false;
-    GxLds lds_hop{};
+    GxLds lds_hop{}, lds_hop_small{};
     HopImage hop;
     void* d_lds_image_hop = nullptr;
+    void* d_lds_image_hop_small = nullptr;
     void* d_hop_global = nullptr;
     int num_cus = 256;
     std::vector<dsl::Extraction> meta;  // names / extractor names / append (from definition text or gx_set_extraction_meta)
@@ -734,8 +735,8 @@ bool plan_slice_launch(const gx_handle* h, GxLds* out, bool match_only = false) 
 // Layout for the hop slice kernel: the hop tier's tables, per wave a register block and a [64][144]-byte piece buffer.
 bool plan_hop_slice_launch(const gx_handle* h, GxLds* out) {
     if (!h->hop_ok) return false;
-    GxLds L = h->lds_hop;
-    L.stage_bytes = 64u * 144u + 16u;  // (+ 16: a window read at a row's last bytes runs a few bytes past it)
+    GxLds L = h->lds_hop_small;
+    L.stage_bytes = 64u * (GX_HOP_SLICE_BYTES + 16u) + 16u;  // (+ 16: a window read at a row's last bytes runs a few bytes past it)
     const uint32_t per_wave = L.stage_bytes + L.regs_wave_bytes;
     if (L.table_bytes + 4u * per_wave > LDS_BYTES) return false;
     uint32_t nw = (LDS_BYTES - L.table_bytes) / per_wave;
@@ -790,7 +791,11 @@ void choose_tile_image(gx_handle* h) {
     h->hop_ok = false;
     const bool forced = force_l2 || force_rec || force_recg;  // (a caller that names a tier gets that tier's kernels)
     const bool want_hop = (h->create_flags & GX_CREATE_TIER_HOP) != 0 || (ok && !forced && (h->lds.tier != 0 || h->tile_global));
-    if (!no_tiles && want_hop && h->T.has_capture && !(h->create_flags & GX_CREATE_NO_FUSED) && build_hop_image(h->T, 48u * 1024u, h->hop)) {
+    uint32_t hot_budget = 48u * 1024u;
+#ifdef GX_DEV
+    if (getenv("GX_DEV_HOT_BUDGET")) hot_budget = static_cast<uint32_t>(atoi(getenv("GX_DEV_HOT_BUDGET")));
+#endif
+    if (!no_tiles && want_hop && h->T.has_capture && !(h->create_flags & GX_CREATE_NO_FUSED) && build_hop_image(h->T, hot_budget, 12u * 1024u, h->hop)) {
         GxLds L{};
         L.ncls = h->hop.ncls;
         L.row_bytes = h->hop.row_bytes;
@@ -799,20 +804,26 @@ void choose_tile_image(gx_handle* h) {
         L.u_start = h->hop.start;
         L.u_dead = h->hop.dead;
         L.fin_tags = h->hop.fin_off;
-        L.table_bytes = static_cast<uint32_t>(h->hop.lds.size());
+        L.table_bytes = static_cast<uint32_t>(h->hop.full.bytes.size());
         L.simple_ops = 1;
         L.tier = 4;
         L.rec = HOP_AT;
-        L.rec_indexed = h->hop.n_hot;
+        L.rec_indexed = h->hop.full.n_hot;
         L.sort_chunk = h->hop.n_reachable_hot;  // (hop tier: the states well-formed lines reach; rec_indexed of them are in LDS)
-        L.acc_tab = h->hop.info_lds;   // int16 info words of the hot states
-        L.at = h->hop.fin_lds;         // final records in LDS (0: in the global image at fin_tags)
+        L.acc_tab = h->hop.full.info_lds;   // int16 info words of the hot states
+        L.at = h->hop.full.fin_lds;         // final records in LDS (0: in the global image at fin_tags)
         L.hot_lo4 = 0;
         L.hot_k4 = 0x80808080u;
         L.regs_wave_bytes = static_cast<uint32_t>(((h->hop.n_regs + 1) * 64 * 2 + 15) & ~15u);
         h->lds_hop = L;
+        // the slice kernel's image (fewer hot records, more waves: gx_hop.cpp), same global tables
+        L.table_bytes = static_cast<uint32_t>(h->hop.small.bytes.size());
+        L.rec_indexed = h->hop.small.n_hot;
+        L.acc_tab = h->hop.small.info_lds;
+        L.at = h->hop.small.fin_lds;
+        h->lds_hop_small = L;
         GxLds P;
-        h->hop_ok = plan_tile_layout(L, 200, &P);
+        h->hop_ok = plan_tile_layout(h->lds_hop, 200, &P);
     }
 }
 
@@ -902,8 +913,10 @@ void upload(gx_handle* h) {
             GX_HIP(hipMemcpy(h->d_l2_image, h->l2_image.data(), h->l2_image.size(), hipMemcpyHostToDevice));
         }
         if (h->hop_ok) {
-            GX_HIP(hipMalloc(&h->d_lds_image_hop, h->hop.lds.size()));
-            GX_HIP(hipMemcpy(h->d_lds_image_hop, h->hop.lds.data(), h->hop.lds.size(), hipMemcpyHostToDevice));
+            GX_HIP(hipMalloc(&h->d_lds_image_hop, h->hop.full.bytes.size()));
+            GX_HIP(hipMemcpy(h->d_lds_image_hop, h->hop.full.bytes.data(), h->hop.full.bytes.size(), hipMemcpyHostToDevice));
+            GX_HIP(hipMalloc(&h->d_lds_image_hop_small, h->hop.small.bytes.size()));
+            GX_HIP(hipMemcpy(h->d_lds_image_hop_small, h->hop.small.bytes.data(), h->hop.small.bytes.size(), hipMemcpyHostToDevice));
             GX_HIP(hipMalloc(&h->d_hop_global, h->hop.global.size()));
             GX_HIP(hipMemcpy(h->d_hop_global, h->hop.global.data(), h->hop.global.size(), hipMemcpyHostToDevice));
         }
@@ -944,7 +957,7 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
     // ... and for long or uneven lines the hop slice kernel: a piece of every lane's own line at a time, lanes refilled
     const bool hop_slices = h->hop_ok && !mo && !b.wide && (kernel == GX_KERNEL_HOP_SLICES || (kernel == GX_KERNEL_AUTO && (long_lines || uneven)));
     if (batchable && hop_slices && plan_hop_slice_launch(h, &L)) {
-        GX_HIP(launch_extract_hop_slices(h->dev, L, static_cast<const uint8_t*>(h->d_lds_image_hop), static_cast<const uint8_t*>(h->d_hop_global), h->num_cus, b, stream));
+        GX_HIP(launch_extract_hop_slices(h->dev, L, static_cast<const uint8_t*>(h->d_lds_image_hop_small), static_cast<const uint8_t*>(h->d_hop_global), h->num_cus, b, stream));
         return;
     }
     const bool hops = h->hop_ok && !mo && !b.wide && (kernel == GX_KERNEL_HOPS || (kernel == GX_KERNEL_AUTO && !long_lines && !uneven));
@@ -1097,6 +1110,7 @@ void gx_destroy(gx_handle* h) {
     if (h->d_lds_image_mo) (void)hipFree(h->d_lds_image_mo);
     if (h->d_l2_image) (void)hipFree(h->d_l2_image);
     if (h->d_lds_image_hop) (void)hipFree(h->d_lds_image_hop);
+    if (h->d_lds_image_hop_small) (void)hipFree(h->d_lds_image_hop_small);
     if (h->d_hop_global) (void)hipFree(h->d_hop_global);
     if (h->hint_probe) { (void)hipHostFree(h->hint_probe); (void)hipEventDestroy(h->hint_event); }
     for (auto& sl : h->host_slot) {
@@ -1137,11 +1151,12 @@ int64_t gx_stat(const gx_handle* h, int32_t which) {
     case 12: return h->tile_ok ? static_cast<int64_t>(h->lds.table_bytes) : 0;
     case 13: return h->tile_ok ? static_cast<int64_t>(h->lds.regs_wave_bytes) : 0;
     case 14: return h->hop_ok ? static_cast<int64_t>(h->hop.n_states) : 0;         // hop tier: states (0: no hop image)
-    case 15: return h->hop_ok ? static_cast<int64_t>(h->hop.n_hot) : 0;            // ... whose records live in LDS
+    case 15: return h->hop_ok ? static_cast<int64_t>(h->hop.full.n_hot) : 0;       // ... whose records live in LDS (tile kernel)
+    case 21: return h->hop_ok ? static_cast<int64_t>(h->hop.small.n_hot) : 0;      // ... (hop slice kernel)
     case 16: return h->hop_ok ? static_cast<int64_t>(h->hop.n_reachable_hot) : 0;  // ... that well-formed lines reach
     case 17: return h->hop_ok ? static_cast<int64_t>(h->hop.n_chains) : 0;         // ... that have a chain
     case 18: { GxLds L; return plan_hop_launch(h, 0, &L) ? static_cast<int64_t>(L.nwaves) : 0; }  // hop tier: waves per CU
-    case 20: return h->hop_ok ? static_cast<int64_t>(h->hop.n_lds_rows) : 0;       // ... whose dense row is in LDS too (branching states)
+    case 20: return h->hop_ok ? static_cast<int64_t>(h->hop.full.n_lds_rows) : 0;       // ... whose dense row is in LDS too (branching states)
     case 19: { GxLds L; return plan_hop_slice_launch(h, &L) ? static_cast<int64_t>(L.nwaves) : 0; }  // ... of the hop slice kernel
     case 9: return !h->tile_ok ? 0 : !h->has_mo ? gx_stat(h, 7) : h->lds_mo.tier == 3 ? 4 : h->lds_mo.tier == 2 ? 3 : h->lds_mo.tier == 1 ? 2 : 1;
     default: return -1;

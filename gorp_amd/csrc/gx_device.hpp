@@ -154,8 +154,11 @@ hipError_t launch_extract_lanes(const GxDev& dev, const GxLds& lds, const uint8_
 hipError_t launch_extract_slices(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
                                  const GxBatch& b, hipStream_t stream);
 
-// Hop slice kernel: the hop tier's tables (GxLds::tier 4), lines staged 128 bytes at a time from each lane's own position
-// (GxLds::stage_bytes = 64 * 144 + 16); captures only.
+// Hop slice kernel: the hop tier's tables (GxLds::tier 4), lines staged GX_HOP_SLICE_BYTES at a time from each lane's own
+// position (GxLds::stage_bytes = 64 * (GX_HOP_SLICE_BYTES + 16) + 16); captures only.
+#ifndef GX_HOP_SLICE_BYTES
+#define GX_HOP_SLICE_BYTES 128u   // (a power of two times 16, at most 1024: one piece is loaded by 64 / (bytes / 16) ... lanes per line)
+#endif
 hipError_t launch_extract_hop_slices(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
                                      const GxBatch& b, hipStream_t stream);
 

@@ -58,7 +58,7 @@ std::vector<int> order_classes(const std::map<ClassSet, uint64_t>& weight, int n
     return new_id;
 }
 
-bool build_hop_image(const Tables& T, uint32_t hot_budget_bytes, HopImage& out) {
+bool build_hop_image(const Tables& T, uint32_t hot_budget_bytes, uint32_t small_budget_bytes, HopImage& out) {
     out = HopImage{};
     if (!T.union_ok || !T.has_capture) return false;
     const RuleTables& U = T.uni;
@@ -286,48 +286,58 @@ bool build_hop_image(const Tables& T, uint32_t hot_budget_bytes, HopImage& out) 
     out.start = perm[0];
     out.dead = perm[dead];
     out.n_regs = static_cast<uint32_t>(U.n_regs);
-    out.lds.assign(HOP_AT, 0);
-    for (int b = 0; b < 256; ++b) out.lds[b] = static_cast<uint8_t>(new_id[T.cls256[b]]);
     const uint8_t* hb = reinterpret_cast<const uint8_t*>(hops.data());
-    out.lds.insert(out.lds.end(), hb, hb + static_cast<size_t>(out.n_hot) * HOP_REC_BYTES);
-    while (out.lds.size() % 16) out.lds.push_back(0);
-    out.info_lds = static_cast<uint32_t>(out.lds.size());
-    for (uint32_t s = 0; s < out.n_hot; ++s) {
-        const int32_t info = static_cast<int32_t>(rows[static_cast<size_t>(s) * cols + ncls]);
-        const int16_t v = static_cast<int16_t>(info >= 0 ? info / 16 : info);
-        out.lds.push_back(static_cast<uint8_t>(v & 0xFF));
-        out.lds.push_back(static_cast<uint8_t>((v >> 8) & 0xFF));
-    }
-    while (out.lds.size() % 16) out.lds.push_back(0);
-    // the dense rows of the first hot branching states: an exact step there is an LDS read
-    {
+    // One LDS image per hot budget (the state order does not depend on it, so the global image serves both).  The records
+    // in the global image keep a zero row address: a state that is hot under one budget is read from there under the other.
+    auto make_lds = [&](uint32_t n_hot) {
+        HopLds L;
+        L.n_hot = n_hot;
+        L.bytes.assign(HOP_AT, 0);
+        for (int b = 0; b < 256; ++b) L.bytes[b] = static_cast<uint8_t>(new_id[T.cls256[b]]);
+        L.bytes.insert(L.bytes.end(), hb, hb + static_cast<size_t>(n_hot) * HOP_REC_BYTES);
+        while (L.bytes.size() % 16) L.bytes.push_back(0);
+        L.info_lds = static_cast<uint32_t>(L.bytes.size());
+        for (uint32_t s = 0; s < n_hot; ++s) {
+            const int32_t info = static_cast<int32_t>(rows[static_cast<size_t>(s) * cols + ncls]);
+            const int16_t v = static_cast<int16_t>(info >= 0 ? info / 16 : info);
+            L.bytes.push_back(static_cast<uint8_t>(v & 0xFF));
+            L.bytes.push_back(static_cast<uint8_t>((v >> 8) & 0xFF));
+        }
+        while (L.bytes.size() % 16) L.bytes.push_back(0);
+        // the dense rows of the first hot branching states: an exact step there is an LDS read
         // (compact: u16 successors [ncls, padded to a dword], then u8 register columns [ncls, padded])
         const uint32_t row_budget = 8192u, succ_bytes = (2u * ncls + 3u) & ~3u, row_lds_bytes = succ_bytes + ((ncls + 3u) & ~3u);
-        for (uint32_t s = 0; s < out.n_hot && (out.n_lds_rows + 1) * row_lds_bytes <= row_budget; ++s) {
+        for (uint32_t s = 0; s < n_hot && (L.n_lds_rows + 1) * row_lds_bytes <= row_budget; ++s) {
             const uint32_t orig = order[s];
             if (chain[orig].klen != 0 || plausible_targets[orig].size() < 2) continue;
-            const uint32_t at = static_cast<uint32_t>(out.lds.size());
+            const uint32_t at = static_cast<uint32_t>(L.bytes.size());
             if ((at >> 2) > 0xFFFFu) break;
-            out.lds.resize(at + row_lds_bytes, 0);
+            L.bytes.resize(at + row_lds_bytes, 0);
             for (int cc = 0; cc < ncls; ++cc) {
                 const uint32_t e = rows[static_cast<size_t>(s) * cols + cc];
-                out.lds[at + 2 * cc] = static_cast<uint8_t>(e & 0xFFu);
-                out.lds[at + 2 * cc + 1] = static_cast<uint8_t>((e >> 8) & 0xFFu);
-                out.lds[at + succ_bytes + cc] = static_cast<uint8_t>(e >> 16);
+                L.bytes[at + 2 * cc] = static_cast<uint8_t>(e & 0xFFu);
+                L.bytes[at + 2 * cc + 1] = static_cast<uint8_t>((e >> 8) & 0xFFu);
+                L.bytes[at + succ_bytes + cc] = static_cast<uint8_t>(e >> 16);
             }
-            hops[static_cast<size_t>(s) * (HOP_REC_BYTES / 4) + 1] |= at >> 2;
-            ++out.n_lds_rows;
+            uint32_t w1;   // the record's copy in THIS image gets the row's address / 4 in its (unused) target field
+            memcpy(&w1, &L.bytes[HOP_AT + static_cast<size_t>(s) * HOP_REC_BYTES + 4], 4);
+            w1 |= at >> 2;
+            memcpy(&L.bytes[HOP_AT + static_cast<size_t>(s) * HOP_REC_BYTES + 4], &w1, 4);
+            ++L.n_lds_rows;
         }
-        while (out.lds.size() % 16) out.lds.push_back(0);
-        // (the records were copied into the image above: again, with the row addresses)
-        memcpy(&out.lds[HOP_AT], hops.data(), static_cast<size_t>(out.n_hot) * HOP_REC_BYTES);
-    }
-    if (fin_rec.size() * 2 <= 8192u) {  // the final records beside them: a line's result then needs no global read
-        out.fin_lds = static_cast<uint32_t>(out.lds.size());
-        const uint8_t* fl = reinterpret_cast<const uint8_t*>(fin_rec.data());
-        out.lds.insert(out.lds.end(), fl, fl + fin_rec.size() * 2);
-        while (out.lds.size() % 16) out.lds.push_back(0);
-    }
+        while (L.bytes.size() % 16) L.bytes.push_back(0);
+        if (fin_rec.size() * 2 <= 8192u) {  // the final records beside them: a line's result then needs no global read
+            L.fin_lds = static_cast<uint32_t>(L.bytes.size());
+            const uint8_t* fl = reinterpret_cast<const uint8_t*>(fin_rec.data());
+            L.bytes.insert(L.bytes.end(), fl, fl + fin_rec.size() * 2);
+            while (L.bytes.size() % 16) L.bytes.push_back(0);
+        }
+        return L;
+    };
+    out.full = make_lds(out.n_hot);
+    // the slice kernel's image: when not every reachable state fits anyway, fewer records and more waves (measured on
+    // BASELINE configs[4], 2 M lines: 48 KB of records 1.57 ms, 24 KB 1.39, 12 KB 1.26, 6 KB 1.27, 3 KB 1.28)
+    out.small = out.n_hot < out.n_reachable_hot ? make_lds(std::min<uint32_t>(out.n_hot, small_budget_bytes / HOP_REC_BYTES)) : out.full;
     const uint8_t* rb = reinterpret_cast<const uint8_t*>(rows.data());
     out.global.assign(rb, rb + rows.size() * 4);
     while (out.global.size() % 16) out.global.push_back(0);

@@ -40,16 +40,22 @@ constexpr uint32_t HOP_REC_BYTES = 24;
 constexpr uint32_t HOP_AT = 272;          // LDS address of the hot records (behind the u8[256] class map)
 constexpr uint32_t HOP_CHAIN = 8;         // elements per chain
 
+// what a workgroup copies into LDS: [0, 256): byte -> class id; [HOP_AT, ...): hop records of the states [0, n_hot); their
+// info words as int16 (final record offset / 16, or -1 / -2-k) at info_lds; the dense rows of the first hot branching states
+// (no chain, several plausible exits; compact: u16 successors, u8 columns); the final records, when they are small, at
+// fin_lds (0: read them from the global image)
+struct HopLds {
+    std::vector<uint8_t> bytes;
+    uint32_t n_hot = 0, info_lds = 0, fin_lds = 0, n_lds_rows = 0;
+};
+
 struct HopImage {
     bool ok = false;
-    std::vector<uint8_t> lds;      // [0, 256): byte -> class id; [HOP_AT, ...): hop records of the states [0, n_hot); then their
-                                   // info words as int16 (final record offset / 16, or -1 / -2-k) at info_lds; then, when they
-                                   // are small, the final records at fin_lds (0: read them from `global`)
+    HopLds full;                   // as many reachable states as the hot budget holds (the tile kernel)
+    HopLds small;                  // the slice kernel's: fewer records, more waves -- the same as `full` when that holds them all
     std::vector<uint8_t> global;   // dense rows u32[n_states][ncls + 1] | hop records of ALL states | final records
     uint32_t ncls = 0, row_bytes = 0, n_states = 0, n_hot = 0;
     uint32_t hops_off = 0, fin_off = 0;  // byte offsets in `global`
-    uint32_t info_lds = 0, fin_lds = 0;  // LDS addresses
-    uint32_t n_lds_rows = 0;             // hot branching states (no chain, several plausible exits) whose dense row is in LDS too
     uint32_t start = 0, dead = 0;        // state indexes (renumbered)
     uint32_t n_regs = 0;
     // diagnostics (gx_stat)
@@ -58,6 +64,6 @@ struct HopImage {
 
 // hot_budget_bytes: LDS bytes the hot records may take.  Returns false (out.ok stays false) when the definition is
 // outside the tier's limits: no fused automaton, general capture programs, more than 127 classes, 65 536 states, 254 registers.
-bool build_hop_image(const Tables& T, uint32_t hot_budget_bytes, HopImage& out);
+bool build_hop_image(const Tables& T, uint32_t hot_budget_bytes, uint32_t small_budget_bytes, HopImage& out);
 
 }  // namespace gx

@@ -394,7 +394,7 @@ hipError_t launch_slices_t(const GxDev& dev, const GxLds& lds, const uint8_t* ld
 // and comes back for the next piece 24 bytes before the end of what is staged (a whole window and a whole chain are
 // always there); a lane whose line has ended writes its result and takes the wave's next line.  A line's padding, fields
 // and literals cost iterations, not bytes, so lanes of a wave stay roughly level however long their lines are.
-constexpr uint32_t HOP_SLICE = 128, HOP_SLICE_ROW = 144, HOP_SLICE_KEEP = 24;
+constexpr uint32_t HOP_SLICE = GX_HOP_SLICE_BYTES, HOP_SLICE_ROW = GX_HOP_SLICE_BYTES + 16u, HOP_SLICE_KEEP = 24;
 
 template <typename OFF>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4)))
@@ -479,13 +479,15 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
         // ---- stage the next piece of every lane's line, from the lane's own position: lane l fetches 16 bytes (l & 7) of the
         // line of lane (l >> 3) + 8 r, as class ids ----
         const bool walking = has_line && pos < len && row != dead_row;
+        // (HOP_SLICE / 16 lanes per line: 8 for 128 bytes)
+        constexpr uint32_t LPL = HOP_SLICE / 16u, LINES_PER_LOAD = 64u / LPL;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int q = static_cast<int>(lane >> 3) + 8 * r;
+        for (uint32_t r = 0; r < LPL; ++r) {
+            const int q = static_cast<int>(lane / LPL + LINES_PER_LOAD * r);
             const uint64_t oq = __shfl(static_cast<unsigned long long>(o0), q);
             const uint32_t pq = static_cast<uint32_t>(__shfl(static_cast<int>(pos), q));
             const uint32_t lq = static_cast<uint32_t>(__shfl(static_cast<int>(walking ? len : 0u), q));
-            const uint32_t at_byte = pq + (lane & 7u) * 16u;
+            const uint32_t at_byte = pq + (lane % LPL) * 16u;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (at_byte < lq) {
                 const uint8_t* src = data + oq + at_byte;
@@ -497,7 +499,7 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
                     v = u32x4{w[0], w[1], w[2], w[3]};
                 }
             }
-            lds_st<u32x4>(slice + static_cast<uint32_t>(q) * HOP_SLICE_ROW + (lane & 7u) * 16u, hop_map16(v));
+            lds_st<u32x4>(slice + static_cast<uint32_t>(q) * HOP_SLICE_ROW + (lane % LPL) * 16u, hop_map16(v));
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -49,7 +49,7 @@ Outcome hop_outcome(const Tables& T, const HopImage& H, const std::vector<uint8_
     const uint32_t cols = H.row_bytes / 4;
     const uint8_t* hops = H.global.data() + H.hops_off;
     std::vector<uint8_t> cls(line.size() + 32, 0);
-    for (size_t i = 0; i < line.size(); ++i) cls[i] = H.lds[line[i]];
+    for (size_t i = 0; i < line.size(); ++i) cls[i] = H.full.bytes[line[i]];
     std::vector<int> col(static_cast<size_t>(H.n_regs) + 2, -1);   // register columns (0 = the dummy)
     uint32_t s = H.start;
     size_t p = 0;
@@ -105,7 +105,8 @@ size_t check_hop_tier(const Tables& T, uint64_t seed) {
     size_t checked = 0, iterations = 0, bytes = 0;
     for (uint32_t budget : {48u * 1024u, 3u * HOP_REC_BYTES}) {   // (a tiny LDS budget: another state order)
         HopImage H;
-        if (!build_hop_image(T, budget, H)) return 0;
+        if (!build_hop_image(T, budget, 2u * HOP_REC_BYTES, H)) return 0;
+        if (H.small.bytes.size() > H.full.bytes.size() || memcmp(H.small.bytes.data(), H.full.bytes.data(), 256) != 0) throw std::runtime_error("hop tier: the two LDS images disagree");
         uint64_t rng = seed * 0x9E3779B97F4A7C15ull + budget;
         auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
         std::vector<std::vector<uint8_t>> of_class(T.ncls);

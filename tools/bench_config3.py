@@ -6,6 +6,9 @@ Usage: bench_config3.py [rules] [lines] [min_len max_len]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from gorp_amd import _native as N
+if os.environ.get("GX_BENCH_DEV_LIB"):   # the developer build (libgorp_hip_dev.so: GX_DEV_* experiment hooks)
+    N.LIB_PATH = os.path.join(os.path.dirname(N.LIB_PATH), "libgorp_hip_dev.so")
 from gorp_amd import workloads as W
 from gorp_amd.gorp import Gorp
 
