@@ -95,7 +95,11 @@ int32_t gx_max_groups(const gx_handle* h);
  * 2 = rows in global memory / L2, 3 = sparse range records in LDS, 4 = range records in global memory, 0 = per-line
  * generic kernel), 9 = the same for match-only batches (a large definition keeps a second, smaller table image for them),
  * 8 = 1 when the handle has capture regexps, 10 / 11 = waves per workgroup of the lane kernel (captures with compact rows /
- * match only; 0 where it does not apply), 12 = bytes of the batch kernels' table image, 13 = bytes of a wave's register block */
+ * match only; 0 where it does not apply), 12 = bytes of the batch kernels' table image, 13 = bytes of a wave's register block;
+ * the hop tier (run + chain records for capture batches of definitions whose dense rows do not fit LDS): 14 = its states
+ * (0: the handle has no hop tables), 15 / 21 = states whose records are in LDS under the tile kernel / the hop slice kernel,
+ * 16 = states that well-formed lines reach, 17 = states that have a chain, 18 / 19 = waves per workgroup of the tile kernel on
+ * these tables / of the hop slice kernel, 20 = branching states whose dense row is in LDS too */
 int64_t gx_stat(const gx_handle* h, int32_t which);
 
 typedef struct gx_batch_opts {
