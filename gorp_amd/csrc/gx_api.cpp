@@ -933,6 +933,34 @@ void upload(gx_handle* h) {
 // per-line kernel otherwise.  kernel: gx_batch_opts.kernel (0 = choose).
 void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t kernel, hipStream_t stream, bool uneven = false) {
     GxLds L;
+    if (b.wide && !b.state_out && b.match_only >= 0 && kernel != GX_KERNEL_PER_LINE && b.n > 0) {
+        // UTF-16 code units: their low bytes through the byte kernels, then the lines that hold a unit above 0xFF again through
+        // the per-line walk (gx_kernels.hip: k_narrow_units).  The copy is n units long -- the one thing this path has to
+        // know on the host, so it reads the two ends of the offsets (a small synchronous copy) -- and lives in
+        // stream-ordered memory for the length of the call.
+        const size_t off_w = b.offsets64 ? 8 : 4;
+        uint64_t first = 0, last = 0;
+        GX_HIP(hipMemcpyAsync(&first, b.offsets, off_w, hipMemcpyDeviceToHost, stream));
+        GX_HIP(hipMemcpyAsync(&last, static_cast<const uint8_t*>(b.offsets) + b.n * off_w, off_w, hipMemcpyDeviceToHost, stream));
+        GX_HIP(hipStreamSynchronize(stream));
+        const uint64_t units = last >= first ? last - first : 0;
+        void* tmp = nullptr;
+        GX_HIP(hipMallocAsync(&tmp, units + b.n + 64, stream));
+        uint8_t* bytes = static_cast<uint8_t*>(tmp);
+        uint8_t* flags = bytes + ((units + 15) & ~15ull);
+        hipError_t e = launch_narrow_units(b, bytes, flags, stream);
+        if (e == hipSuccess) {
+            GxBatch nb = b;
+            nb.wide = 0;
+            nb.data = bytes - first;   // (addressed like the units: line i at data + offsets[i])
+            try { launch_batch(h, nb, line_bytes_hint, kernel, stream, uneven); }
+            catch (...) { (void)hipFreeAsync(tmp, stream); throw; }
+            e = launch_extract_flagged(h->dev, b, flags, stream);
+        }
+        (void)hipFreeAsync(tmp, stream);
+        GX_HIP(e);
+        return;
+    }
     const bool batchable = !b.wide && !b.state_out && b.match_only >= 0 && kernel != GX_KERNEL_PER_LINE;
     // Which kernel (gx_batch_opts.kernel 0), by the tables and the mean line length.  Measured, one device (ms; captures /
     // match only):

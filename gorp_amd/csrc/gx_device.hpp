@@ -134,6 +134,11 @@ inline hipError_t allow_full_lds(K kernel) {
 // Generic kernel: any table size, any line length, bytes or UTF-16.
 hipError_t launch_extract_generic(const GxDev& dev, const GxBatch& b, hipStream_t stream);
 
+// UTF-16 batches: the units' low bytes -> `bytes_at_first_unit` (room for offsets[n] - offsets[0] bytes), flags[i] = 1 for a line
+// with a unit above 0xFF; launch_extract_flagged takes those lines again on the code units (per-line walk).
+hipError_t launch_narrow_units(const GxBatch& b, uint8_t* bytes_at_first_unit, uint8_t* flags, hipStream_t stream);
+hipError_t launch_extract_flagged(const GxDev& dev, const GxBatch& b, const uint8_t* flags, hipStream_t stream);
+
 // Tile kernel (gx_tile.hip): 64-line tiles staged through LDS with coalesced loads, self-loop runs skipped by SWAR
 // tests and a per-chunk bitmap.  Byte input only.  `lds_image` is the device copy of the table image.
 // at_global != nullptr selects the L2 tier: automaton rows are read from that global-memory table (row =

@@ -151,6 +151,62 @@ k_extract_generic(GxDev T, const CH* __restrict__ data, const OFF* __restrict__ 
     }
 }
 
+// ---- UTF-16 batches (gx_batch_opts.utf16: the code units of Java Strings) ----
+// Log text is Latin-1 almost always, and then a code unit IS the byte the batch kernels walk.  k_narrow_units copies the
+// units' low bytes into a byte buffer (16 bytes in, 8 out per lane) and flags the line of every unit above 0xFF; the byte
+// kernels then run on the copy with the same offsets, and k_extract_flagged takes the flagged lines again, on the code
+// units, with the per-line kernel's walk (classes of units above 0xFF by binary search).
+template <typename OFF>
+__global__ void __launch_bounds__(256)
+k_narrow_units(const uint16_t* __restrict__ units, const OFF* __restrict__ off, uint64_t n, uint8_t* __restrict__ bytes, uint8_t* __restrict__ flags) {
+    const uint64_t first = off[0], total = static_cast<uint64_t>(off[n]) - first;
+    const uint16_t* src = units + first;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x * 8u;
+    for (uint64_t i = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 8u; i < total; i += stride) {
+        uint32_t wide = 0;
+        if (total - i >= 8u) {
+            // eight units in one (unaligned) 16-byte load, their low bytes in one aligned 8-byte store
+            const u32x4 v = reinterpret_cast<const UnalignedWindow*>(src + i)->v;
+            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (d[q] & 0xFF00FF00u) wide |= ((d[q] & 0x0000FF00u) ? 1u : 0u) << (2 * q) | ((d[q] & 0xFF000000u) ? 2u : 0u) << (2 * q);
+                const uint32_t two = (d[q] & 0xFFu) | ((d[q] >> 8) & 0xFF00u);
+                if (q < 2) lo |= two << (16 * q); else hi |= two << (16 * (q - 2));
+            }
+            *reinterpret_cast<u32x2*>(bytes + i) = u32x2{lo, hi};
+        } else {
+            for (uint32_t q = 0; q < static_cast<uint32_t>(total - i); ++q) {
+                const uint16_t u = src[i + q];
+                bytes[i + q] = static_cast<uint8_t>(u);
+                if (u > 0xFFu) wide |= 1u << q;
+            }
+        }
+        while (wide) {   // (rare) the line of unit first + i + q: the last offset at or below it
+            const uint32_t q = static_cast<uint32_t>(__ffs(static_cast<int>(wide)) - 1);
+            wide &= wide - 1u;
+            const uint64_t pos = first + i + q;
+            uint64_t lo = 0, hi = n;   // off[lo] <= pos < off[hi]
+            while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (static_cast<uint64_t>(off[mid]) <= pos) lo = mid; else hi = mid; }
+            flags[lo] = 1;
+        }
+    }
+}
+template <typename OFF, typename MS>
+__global__ void __launch_bounds__(256)
+k_extract_flagged(GxDev T, const uint16_t* __restrict__ units, const OFF* __restrict__ off, uint64_t n, const uint8_t* __restrict__ flags,
+                  LineOut out, int match_only, const MS* __restrict__ m_next, int strip_eol) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (!flags[i]) continue;
+        const uint64_t b = off[i], e = off[i + 1];
+        int64_t len = static_cast<int64_t>(e - b);
+        if (strip_eol) len = trim_eol(units + b, len);
+        extract_line_global<uint16_t, MS>(T, m_next, units + b, len, i, out, nullptr, match_only);
+    }
+}
+
 // Follow-up of the tile kernel: the lines it could not stage (one line longer than its staging area, rare) are
 // taken here, one lane per line.  The tile kernel announces that there are any by storing the launch's sequence
 // number into *flag; without it every wave leaves at once.  The predicate is the tile kernel's own (make_round).
@@ -542,6 +598,28 @@ hipError_t launch_extract_hop_slices(const GxDev& dev, const GxLds& lds, const u
         hipLaunchKernelGGL((k_extract_hop_slices<uint32_t>), grid, block, lds.total_bytes, stream, dev, lds, lds_image, at_global,
                            static_cast<const uint8_t*>(b.data), static_cast<const uint32_t*>(b.offsets), b.n, line_out(dev, b), b.strip_eol);
     }
+    return hipGetLastError();
+}
+
+// b: the UTF-16 batch (data = code units, offsets in units).  bytes: room for the batch's units as bytes, addressed like the
+// units (bytes[offsets[i]] is line i's first); flags: n bytes, zeroed here.
+hipError_t launch_narrow_units(const GxBatch& b, uint8_t* bytes_at_first_unit, uint8_t* flags, hipStream_t stream) {
+    if (b.n == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(flags, 0, b.n, stream);
+    if (e != hipSuccess) return e;
+    const dim3 grid(256u * 16u), block(256);
+    if (b.offsets64) hipLaunchKernelGGL((k_narrow_units<uint64_t>), grid, block, 0, stream, static_cast<const uint16_t*>(b.data), static_cast<const uint64_t*>(b.offsets), b.n, bytes_at_first_unit, flags);
+    else hipLaunchKernelGGL((k_narrow_units<uint32_t>), grid, block, 0, stream, static_cast<const uint16_t*>(b.data), static_cast<const uint32_t*>(b.offsets), b.n, bytes_at_first_unit, flags);
+    return hipGetLastError();
+}
+hipError_t launch_extract_flagged(const GxDev& dev, const GxBatch& b, const uint8_t* flags, hipStream_t stream) {
+    if (b.n == 0) return hipSuccess;
+    const dim3 grid(256u * 4u), block(256);
+    const uint16_t* units = static_cast<const uint16_t*>(b.data);
+#define GX_FLAGGED(OFF, MS, NEXT) hipLaunchKernelGGL((k_extract_flagged<OFF, MS>), grid, block, 0, stream, dev, units, static_cast<const OFF*>(b.offsets), b.n, flags, line_out(dev, b), b.match_only, NEXT, b.strip_eol)
+    if (b.offsets64) { if (dev.m_next16) GX_FLAGGED(uint64_t, uint16_t, dev.m_next16); else GX_FLAGGED(uint64_t, uint32_t, dev.m_next32); }
+    else { if (dev.m_next16) GX_FLAGGED(uint32_t, uint16_t, dev.m_next16); else GX_FLAGGED(uint32_t, uint32_t, dev.m_next32); }
+#undef GX_FLAGGED
     return hipGetLastError();
 }
 

@@ -120,9 +120,10 @@ typedef struct gx_batch_opts {
                                   model) and bytes >= 0x80 leave as two-byte UTF-8; 1: copy them unchanged (the
                                   input was UTF-8 all along and the patterns only look at its ASCII structure) */
     uint32_t utf16;            /* gx_extract_batch only.  1: `bytes` holds UTF-16 code units (uint16_t, host byte order), exactly
-                                  the chars of the Java Strings, and offsets count code units.  For the lines that
-                                  gx_split_lines flags as non-ASCII once the caller has decoded them.  Runs on the
-                                  per-line kernel (no LDS staging). */
+                                  the chars of the Java Strings, and offsets count code units.  The units' low bytes go
+                                  through the byte kernels (a copy pass on the device: 16 bytes in, 8 out per lane) and only
+                                  the lines that hold a unit above 0xFF are walked again, per line, on the code units; the
+                                  call reads the two ends of the offsets (one small synchronous copy) to size the copy. */
     uint32_t kernel;           /* gx_extract_batch only: GX_KERNEL_AUTO (0) or one of the kernels below, for measurements and
                                   tests; results never depend on it.  (New fields are only ever appended: a caller compiled
                                   against an older, shorter layout passes its own struct_size and keeps working.) */

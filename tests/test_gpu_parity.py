@@ -519,6 +519,72 @@ def test_config1_from_definition_text(tmp_path):
     assert r.getId() == "sampleMatch" and r.asMap()["authStatus"] == "Accepted"
 
 
+def test_utf16_batches_take_the_byte_kernels():
+    """gx_batch_opts.utf16 at scale: the code units' low bytes go through the byte kernels, the lines that hold a unit above
+    0xFF again through the per-line walk (k_narrow_units / k_extract_flagged) -- mixed batches, every result format,
+    terminators, 64-bit offsets, a definition with the hop tier's tables; all against the oracle on the Strings."""
+    rng = random.Random(31)
+    definition = W.readme3_definition()
+    gorp, orc = Gorp.construct(definition), oracle_for(definition)
+    lines = []
+    for k in range(5000):
+        body = "".join(rng.choice("abc/-_.=?&%09") for _ in range(rng.randrange(1, 180)))
+        if k % 7 == 0:
+            body += rng.choice(["\u4e2d\u6587", "\u00e9\u0142", "\U0001F600", "\u0100"])   # units above 0xFF (and a surrogate pair)
+        if k % 11 == 0:
+            body = "\u00e9\u00ff" + body                                                 # Latin-1 above 0x7F: still a byte
+        lines.append(rng.choice(["[%09d]: GET %dms /%s", "[%09d]: PUT %dms /%s", "[%09d]: HEAD %dms /%s"]) % (rng.randrange(10 ** 9), rng.randrange(9999), body)
+                     if k % 13 else body)
+    lines += ["", "\u4e2d", "[1]: GET 5ms /" + "x" * 70000, "[1]: GET 5ms /\u4e2d" + "y" * 20000]
+    units = [np.frombuffer(s.encode("utf-16-le", "surrogatepass"), dtype=np.uint16) for s in lines]
+    data = np.concatenate([u for u in units if len(u)])
+    offsets = np.zeros(len(lines) + 1, np.uint32)
+    offsets[1:] = np.cumsum([len(u) for u in units])
+    want = [orc.extract(s) for s in lines]
+    G_ = gorp.max_groups
+    omid = np.array([w[0] for w in want], np.int32)
+    ocaps = np.full((len(lines), 2 * G_), -1, np.int32)
+    for i, w in enumerate(want):
+        for g, span in enumerate(w[1]):
+            if span is not None:
+                ocaps[i, 2 * g], ocaps[i, 2 * g + 1] = span
+    for kernel in (N.GX_KERNEL_AUTO, N.GX_KERNEL_TILES, N.GX_KERNEL_SLICES, N.GX_KERNEL_LANES, N.GX_KERNEL_PER_LINE):
+        mid, caps = gorp.extract_batch(data, offsets, kernel=kernel)
+        assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps), kernel
+    m64, c64 = gorp.extract_batch(data, offsets.astype(np.uint64))
+    assert np.array_equal(m64, omid) and np.array_equal(c64, ocaps)
+    rows, over = gorp.extract_batch(data, offsets, compact=True)
+    cm, cc = G.unpack_rows(rows)
+    big = ocaps > 65534
+    assert over == int(big.sum()) and np.array_equal(cm, omid) and np.array_equal(cc, np.where(big, 65534, ocaps))
+    mo, _ = gorp.extract_batch(data, offsets, match_only=True)
+    assert np.array_equal(mo, np.where(omid <= -2, -2 - omid, omid))
+    # terminated text, as UTF-16
+    term = [s + rng.choice(["\n", "\r\n", "\r"]) for s in lines[:600]]
+    tu = [np.frombuffer(s.encode("utf-16-le", "surrogatepass"), dtype=np.uint16) for s in term]
+    td = np.concatenate(tu)
+    to = np.zeros(len(term) + 1, np.uint32)
+    to[1:] = np.cumsum([len(u) for u in tu])
+    m3, c3 = gorp.extract_batch(td, to, strip_eol=True)
+    assert np.array_equal(m3, omid[:600]) and np.array_equal(c3, ocaps[:600])
+    # the 64-extraction definition: the narrowed copy goes through the hop tier
+    rules, meta = W.syslog_definition(64, seed=3)
+    big_g, big_o = Gorp.construct(rules), oracle_for(rules)
+    d8, o8, _ = W.syslog_lines(meta, 3000, seed=77)
+    sl = [bytes(d8[o8[i]:o8[i + 1]]).decode("latin-1") for i in range(3000)]
+    for i in range(0, 3000, 9):
+        sl[i] = sl[i][:40] + "\u4e2d" + sl[i][41:]
+    su = [np.frombuffer(s.encode("utf-16-le"), dtype=np.uint16) for s in sl]
+    sd, so = np.concatenate(su), np.zeros(3001, np.uint32)
+    so[1:] = np.cumsum([len(u) for u in su])
+    m8, c8 = big_g.extract_batch(sd, so)
+    w8 = [big_o.extract(s) for s in sl]
+    assert m8.tolist() == [w[0] for w in w8]
+    for i in (0, 1, 9, 10, 2999):
+        flat = [v for g in w8[i][1] for v in (g if g is not None else (-1, -1))]
+        assert c8[i].tolist()[:len(flat)] == flat
+
+
 @pytest.mark.parametrize("tier", [1, 2, 3, 4, 5, 6])
 def test_mixed_lengths_take_several_rounds_per_group(tier, monkeypatch):
     """Lines of 0-3000 bytes against a staging area sized for the mean: groups are walked in several rounds of
