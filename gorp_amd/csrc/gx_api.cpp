@@ -985,7 +985,16 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
     // ... and for long or uneven lines the hop slice kernel: a piece of every lane's own line at a time, lanes refilled
     const bool hop_slices = h->hop_ok && !mo && !b.wide && (kernel == GX_KERNEL_HOP_SLICES || (kernel == GX_KERNEL_AUTO && (long_lines || uneven)));
     if (batchable && hop_slices && plan_hop_slice_launch(h, &L)) {
+        std::lock_guard<std::mutex> lock(h->slot_mu);
+        b.seq = h->next_seq++;
+        if (h->next_seq == 0) h->next_seq = 1;
+        const int slot = static_cast<int>(b.seq % gx_handle::N_SLOTS);
+        if (h->slot_used[slot]) GX_HIP(hipStreamWaitEvent(stream, h->slot_event[slot], 0));
+        h->slot_used[slot] = true;
+        b.oversize_flag = h->d_slots + slot;
         GX_HIP(launch_extract_hop_slices(h->dev, L, static_cast<const uint8_t*>(h->d_lds_image_hop_small), static_cast<const uint8_t*>(h->d_hop_global), h->num_cus, b, stream));
+        GX_HIP(launch_extract_oversize(h->dev, b, 65535u + 48u, stream));   // (lines beyond the 16-bit positions, if the kernel met any)
+        GX_HIP(hipEventRecord(h->slot_event[slot], stream));
         return;
     }
     const bool hops = h->hop_ok && !mo && !b.wide && (kernel == GX_KERNEL_HOPS || (kernel == GX_KERNEL_AUTO && !long_lines && !uneven));

@@ -455,7 +455,8 @@ constexpr uint32_t HOP_SLICE = GX_HOP_SLICE_BYTES, HOP_SLICE_ROW = GX_HOP_SLICE_
 template <typename OFF>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4)))
 k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const uint8_t* __restrict__ at_global,
-                     const uint8_t* __restrict__ data, const OFF* __restrict__ off, uint64_t n, LineOut out, int strip_eol) {
+                     const uint8_t* __restrict__ data, const OFF* __restrict__ off, uint64_t n, LineOut out, int strip_eol,
+                     uint32_t* __restrict__ oversize_flag, uint32_t seq) {
     {
         extern __shared__ __attribute__((aligned(16))) uint8_t gx_smem[];
         const uint4* src = reinterpret_cast<const uint4*>(lds_image);
@@ -516,9 +517,9 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
                 int64_t len64 = static_cast<int64_t>(static_cast<uint64_t>(off[i + 1]) - o0);
                 if (strip_eol) len64 = trim_eol(data + o0, len64);
                 if (len64 > 65535) {
-                    // positions are 16-bit in the register block: such a line takes the per-lane path, whole
-                    if (T.m_next16) extract_line_global<uint8_t, uint16_t>(T, T.m_next16, data + o0, len64, i, out, nullptr, 0);
-                    else extract_line_global<uint8_t, uint32_t>(T, T.m_next32, data + o0, len64, i, out, nullptr, 0);
+                    // positions are 16-bit in the register block: such a line is left to the follow-up launch of the per-line
+                    // kernel (not walked here: its 96 capture registers would give every lane of this kernel a scratch frame)
+                    __hip_atomic_store(oversize_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
                     has_line = true;
                     len = static_cast<uint32_t>(len64);
@@ -530,7 +531,7 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
         }
         if (!__any(has_line)) {
             if (next >= range_hi) break;
-            continue;  // (only lines for the per-lane path were handed out: hand out more)
+            continue;  // (only lines for the follow-up launch were handed out: hand out more)
         }
         // ---- stage the next piece of every lane's line, from the lane's own position: lane l fetches 16 bytes (l & 7) of the
         // line of lane (l >> 3) + 8 r, as class ids ----
@@ -591,12 +592,12 @@ hipError_t launch_extract_hop_slices(const GxDev& dev, const GxLds& lds, const u
         hipError_t e = allow_full_lds(&k_extract_hop_slices<uint64_t>);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_extract_hop_slices<uint64_t>), grid, block, lds.total_bytes, stream, dev, lds, lds_image, at_global,
-                           static_cast<const uint8_t*>(b.data), static_cast<const uint64_t*>(b.offsets), b.n, line_out(dev, b), b.strip_eol);
+                           static_cast<const uint8_t*>(b.data), static_cast<const uint64_t*>(b.offsets), b.n, line_out(dev, b), b.strip_eol, b.oversize_flag, b.seq);
     } else {
         hipError_t e = allow_full_lds(&k_extract_hop_slices<uint32_t>);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_extract_hop_slices<uint32_t>), grid, block, lds.total_bytes, stream, dev, lds, lds_image, at_global,
-                           static_cast<const uint8_t*>(b.data), static_cast<const uint32_t*>(b.offsets), b.n, line_out(dev, b), b.strip_eol);
+                           static_cast<const uint8_t*>(b.data), static_cast<const uint32_t*>(b.offsets), b.n, line_out(dev, b), b.strip_eol, b.oversize_flag, b.seq);
     }
     return hipGetLastError();
 }

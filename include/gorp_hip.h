@@ -123,7 +123,9 @@ typedef struct gx_batch_opts {
                                   the chars of the Java Strings, and offsets count code units.  The units' low bytes go
                                   through the byte kernels (a copy pass on the device: 16 bytes in, 8 out per lane) and only
                                   the lines that hold a unit above 0xFF are walked again, per line, on the code units; the
-                                  call reads the two ends of the offsets (one small synchronous copy) to size the copy. */
+                                  call reads the two ends of the offsets (one small synchronous copy) to size the copy.
+                                  (With compact rows, an offset that does not fit is counted once per walk: a line with a
+                                  unit above 0xFF is walked twice.) */
     uint32_t kernel;           /* gx_extract_batch only: GX_KERNEL_AUTO (0) or one of the kernels below, for measurements and
                                   tests; results never depend on it.  (New fields are only ever appended: a caller compiled
                                   against an older, shorter layout passes its own struct_size and keeps working.) */
