@@ -76,3 +76,17 @@ def test_reference_jvm_baseline_driver_is_source_only_and_says_so_here():
     assert "DefinitionReader.reader(new File(" in src and ".read()" in src and "gorp.extract(" in src
     if not (shutil.which("java") and shutil.which("javac") and os.environ.get("GORP_REFERENCE_CLASSPATH")):
         assert bench.reference_jvm_baseline("extract a {\n template x\n}\n", [b"x"], 1).startswith("unavailable (no ")
+
+
+def test_unpack_rows_on_the_host():
+    """gorp.unpack_rows: u16 rows (int16 id, 0xFFFF = unset) and u8 rows (int8 id, 0xFF = unset) back to int32."""
+    import numpy as np
+    from gorp_amd.gorp import unpack_rows
+    r16 = np.array([[1, 0, 65534, 0xFFFF, 0xFFFF], [0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF], [0xFFFE - 5, 3, 4, 5, 6]], np.uint16)
+    m, c = unpack_rows(r16)
+    assert m.tolist() == [1, -1, -7] and c.tolist() == [[0, 65534, -1, -1], [-1, -1, -1, -1], [3, 4, 5, 6]]
+    m, c = unpack_rows(r16.view(np.int16))
+    assert m.tolist() == [1, -1, -7] and c[0].tolist() == [0, 65534, -1, -1]
+    r8 = np.array([[127, 0, 254, 0xFF, 0xFF], [0xFF, 0xFF, 0xFF, 0xFF, 0xFF], [0x80, 1, 2, 3, 4]], np.uint8)
+    m, c = unpack_rows(r8)
+    assert m.tolist() == [127, -1, -128] and c.tolist() == [[0, 254, -1, -1], [-1, -1, -1, -1], [1, 2, 3, 4]]
