@@ -81,6 +81,12 @@ struct gx_handle {
     HopImage hop;
     void* d_lds_image_hop = nullptr;
     void* d_lds_image_hop_small = nullptr;
+    bool hop_mo_ok = false;             // the same for the match automaton alone (match-only batches)
+    GxLds lds_hop_mo{}, lds_hop_mo_small{};
+    HopImage hop_mo;
+    void* d_lds_image_hop_mo = nullptr;
+    void* d_lds_image_hop_mo_small = nullptr;
+    void* d_hop_mo_global = nullptr;
     void* d_hop_global = nullptr;
     int num_cus = 256;
     std::vector<dsl::Extraction> meta;  // names / extractor names / append (from definition text or gx_set_extraction_meta)
@@ -638,7 +644,8 @@ bool plan_tile_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out, 
     return plan_tile_layout(match_only && h->has_mo ? h->lds_mo : h->lds, line_bytes_hint, out);
 }
 // the hop tier's layout: the same kernel, its own tables
-bool plan_hop_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out) {
+bool plan_hop_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out, bool match_only = false) {
+    if (match_only) return h->hop_mo_ok && plan_tile_layout(h->lds_hop_mo, line_bytes_hint, out);
     return h->hop_ok && plan_tile_layout(h->lds_hop, line_bytes_hint, out);
 }
 bool plan_tile_layout(GxLds L, uint32_t line_bytes_hint, GxLds* out) {
@@ -733,9 +740,9 @@ bool plan_slice_launch(const gx_handle* h, GxLds* out, bool match_only = false) 
 }
 
 // Layout for the hop slice kernel: the hop tier's tables, per wave a register block and a [64][144]-byte piece buffer.
-bool plan_hop_slice_launch(const gx_handle* h, GxLds* out) {
-    if (!h->hop_ok) return false;
-    GxLds L = h->lds_hop_small;
+bool plan_hop_slice_launch(const gx_handle* h, GxLds* out, bool match_only = false) {
+    if (!(match_only ? h->hop_mo_ok : h->hop_ok)) return false;
+    GxLds L = match_only ? h->lds_hop_mo_small : h->lds_hop_small;
     L.stage_bytes = 64u * (GX_HOP_SLICE_BYTES + 16u) + 16u;  // (+ 16: a window read at a row's last bytes runs a few bytes past it)
     const uint32_t per_wave = L.stage_bytes + L.regs_wave_bytes;
     if (L.table_bytes + 4u * per_wave > LDS_BYTES) return false;
@@ -795,35 +802,44 @@ void choose_tile_image(gx_handle* h) {
 #ifdef GX_DEV
     if (getenv("GX_DEV_HOT_BUDGET")) hot_budget = static_cast<uint32_t>(atoi(getenv("GX_DEV_HOT_BUDGET")));
 #endif
-    if (!no_tiles && want_hop && h->T.has_capture && !(h->create_flags & GX_CREATE_NO_FUSED) && build_hop_image(h->T, hot_budget, 12u * 1024u, h->hop)) {
+    // layouts of one hop image: the tile kernel's (full) and the hop slice kernel's (small: fewer hot records, more waves)
+    auto layouts = [&](const HopImage& I, GxLds* full, GxLds* small) {
         GxLds L{};
-        L.ncls = h->hop.ncls;
-        L.row_bytes = h->hop.row_bytes;
-        L.c_base = h->hop.hops_off;
-        L.m_start = L.m_dead = 0;
-        L.u_start = h->hop.start;
-        L.u_dead = h->hop.dead;
-        L.fin_tags = h->hop.fin_off;
-        L.table_bytes = static_cast<uint32_t>(h->hop.full.bytes.size());
+        L.ncls = I.ncls;
+        L.row_bytes = I.row_bytes;
+        L.c_base = I.hops_off;
+        L.m_start = I.match_automaton ? I.start : 0u;
+        L.m_dead = I.match_automaton ? I.dead : 0u;
+        L.u_start = I.match_automaton ? 0xFFFFFFFFu : I.start;
+        L.u_dead = I.match_automaton ? 0xFFFFFFFFu : I.dead;
+        L.fin_tags = I.fin_off;
         L.simple_ops = 1;
         L.tier = 4;
         L.rec = HOP_AT;
-        L.rec_indexed = h->hop.full.n_hot;
-        L.sort_chunk = h->hop.n_reachable_hot;  // (hop tier: the states well-formed lines reach; rec_indexed of them are in LDS)
-        L.acc_tab = h->hop.full.info_lds;   // int16 info words of the hot states
-        L.at = h->hop.full.fin_lds;         // final records in LDS (0: in the global image at fin_tags)
+        L.sort_chunk = I.n_reachable_hot;  // (hop tier: the states well-formed lines reach; rec_indexed of them are in LDS)
         L.hot_lo4 = 0;
         L.hot_k4 = 0x80808080u;
-        L.regs_wave_bytes = static_cast<uint32_t>(((h->hop.n_regs + 1) * 64 * 2 + 15) & ~15u);
-        h->lds_hop = L;
-        // the slice kernel's image (fewer hot records, more waves: gx_hop.cpp), same global tables
-        L.table_bytes = static_cast<uint32_t>(h->hop.small.bytes.size());
-        L.rec_indexed = h->hop.small.n_hot;
-        L.acc_tab = h->hop.small.info_lds;
-        L.at = h->hop.small.fin_lds;
-        h->lds_hop_small = L;
+        L.regs_wave_bytes = static_cast<uint32_t>(((I.n_regs + 1) * 64 * 2 + 15) & ~15u);
+        for (int q = 0; q < 2; ++q) {
+            const HopLds& P = q ? I.small : I.full;
+            L.table_bytes = static_cast<uint32_t>(P.bytes.size());
+            L.rec_indexed = P.n_hot;
+            L.acc_tab = P.info_lds;   // int16 info words of the hot states
+            L.at = P.fin_lds;         // final records in LDS (0: in the global image at fin_tags)
+            *(q ? small : full) = L;
+        }
+    };
+    if (!no_tiles && want_hop && h->T.has_capture && !(h->create_flags & GX_CREATE_NO_FUSED) && build_hop_image(h->T, false, hot_budget, 12u * 1024u, h->hop)) {
+        layouts(h->hop, &h->lds_hop, &h->lds_hop_small);
         GxLds P;
         h->hop_ok = plan_tile_layout(h->lds_hop, 200, &P);
+    }
+    // ... and of the match automaton alone, for match-only batches (PolyMatcher.match over a batch)
+    h->hop_mo_ok = false;
+    if (!no_tiles && want_hop && build_hop_image(h->T, true, hot_budget, 12u * 1024u, h->hop_mo)) {
+        layouts(h->hop_mo, &h->lds_hop_mo, &h->lds_hop_mo_small);
+        GxLds P;
+        h->hop_mo_ok = plan_tile_layout(h->lds_hop_mo, 200, &P);
     }
 }
 
@@ -920,6 +936,14 @@ void upload(gx_handle* h) {
             GX_HIP(hipMalloc(&h->d_hop_global, h->hop.global.size()));
             GX_HIP(hipMemcpy(h->d_hop_global, h->hop.global.data(), h->hop.global.size(), hipMemcpyHostToDevice));
         }
+        if (h->hop_mo_ok) {
+            GX_HIP(hipMalloc(&h->d_lds_image_hop_mo, h->hop_mo.full.bytes.size()));
+            GX_HIP(hipMemcpy(h->d_lds_image_hop_mo, h->hop_mo.full.bytes.data(), h->hop_mo.full.bytes.size(), hipMemcpyHostToDevice));
+            GX_HIP(hipMalloc(&h->d_lds_image_hop_mo_small, h->hop_mo.small.bytes.size()));
+            GX_HIP(hipMemcpy(h->d_lds_image_hop_mo_small, h->hop_mo.small.bytes.data(), h->hop_mo.small.bytes.size(), hipMemcpyHostToDevice));
+            GX_HIP(hipMalloc(&h->d_hop_mo_global, h->hop_mo.global.size()));
+            GX_HIP(hipMemcpy(h->d_hop_mo_global, h->hop_mo.global.data(), h->hop_mo.global.size(), hipMemcpyHostToDevice));
+        }
         GX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_slots), 2 * gx_handle::N_SLOTS * sizeof(uint32_t)));
         GX_HIP(hipMemset(h->d_slots, 0, 2 * gx_handle::N_SLOTS * sizeof(uint32_t)));
         for (int q = 0; q < gx_handle::N_SLOTS; ++q) GX_HIP(hipEventCreateWithFlags(&h->slot_event[q], hipEventDisableTiming));
@@ -983,8 +1007,12 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
     // hop tier: capture batches of definitions whose dense rows do not fit LDS, lines of ordinary length and evenness (the
     // tile kernel wants a tile's lines to be neighbours in memory and about as long as each other)
     // ... and for long or uneven lines the hop slice kernel: a piece of every lane's own line at a time, lanes refilled
-    const bool hop_slices = h->hop_ok && !mo && !b.wide && (kernel == GX_KERNEL_HOP_SLICES || (kernel == GX_KERNEL_AUTO && (long_lines || uneven)));
-    if (batchable && hop_slices && plan_hop_slice_launch(h, &L)) {
+    const bool have_hop = mo ? h->hop_mo_ok : h->hop_ok;
+    const uint8_t* hop_image = static_cast<const uint8_t*>(mo ? h->d_lds_image_hop_mo : h->d_lds_image_hop);
+    const uint8_t* hop_image_small = static_cast<const uint8_t*>(mo ? h->d_lds_image_hop_mo_small : h->d_lds_image_hop_small);
+    const uint8_t* hop_global = static_cast<const uint8_t*>(mo ? h->d_hop_mo_global : h->d_hop_global);
+    const bool hop_slices = have_hop && !b.wide && (kernel == GX_KERNEL_HOP_SLICES || (kernel == GX_KERNEL_AUTO && (long_lines || uneven)));
+    if (batchable && hop_slices && plan_hop_slice_launch(h, &L, mo)) {
         std::lock_guard<std::mutex> lock(h->slot_mu);
         b.seq = h->next_seq++;
         if (h->next_seq == 0) h->next_seq = 1;
@@ -992,13 +1020,13 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
         if (h->slot_used[slot]) GX_HIP(hipStreamWaitEvent(stream, h->slot_event[slot], 0));
         h->slot_used[slot] = true;
         b.oversize_flag = h->d_slots + slot;
-        GX_HIP(launch_extract_hop_slices(h->dev, L, static_cast<const uint8_t*>(h->d_lds_image_hop_small), static_cast<const uint8_t*>(h->d_hop_global), h->num_cus, b, stream));
+        GX_HIP(launch_extract_hop_slices(h->dev, L, hop_image_small, hop_global, h->num_cus, b, stream));
         GX_HIP(launch_extract_oversize(h->dev, b, 65535u + 48u, stream));   // (lines beyond the 16-bit positions, if the kernel met any)
         GX_HIP(hipEventRecord(h->slot_event[slot], stream));
         return;
     }
-    const bool hops = h->hop_ok && !mo && !b.wide && (kernel == GX_KERNEL_HOPS || (kernel == GX_KERNEL_AUTO && !long_lines && !uneven));
-    if (batchable && hops && plan_hop_launch(h, line_bytes_hint, &L)) {
+    const bool hops = have_hop && !b.wide && (kernel == GX_KERNEL_HOPS || (kernel == GX_KERNEL_AUTO && !long_lines && !uneven));
+    if (batchable && hops && plan_hop_launch(h, line_bytes_hint, &L, mo)) {
         std::lock_guard<std::mutex> lock(h->slot_mu);
         b.seq = h->next_seq++;
         if (h->next_seq == 0) h->next_seq = 1;
@@ -1010,7 +1038,7 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
 #ifdef GX_DEV
         stamps = h->dev_stamps;
 #endif
-        GX_HIP(launch_extract_tile(h->dev, L, static_cast<const uint8_t*>(h->d_lds_image_hop), static_cast<const uint8_t*>(h->d_hop_global), h->num_cus, b, stream, stamps));
+        GX_HIP(launch_extract_tile(h->dev, L, hop_image, hop_global, h->num_cus, b, stream, stamps));
         GX_HIP(launch_extract_oversize(h->dev, b, L.stage_bytes, stream));
         GX_HIP(hipEventRecord(h->slot_event[slot], stream));
         return;
@@ -1148,6 +1176,7 @@ void gx_destroy(gx_handle* h) {
     if (h->d_l2_image) (void)hipFree(h->d_l2_image);
     if (h->d_lds_image_hop) (void)hipFree(h->d_lds_image_hop);
     if (h->d_lds_image_hop_small) (void)hipFree(h->d_lds_image_hop_small);
+    for (void* q : {h->d_lds_image_hop_mo, h->d_lds_image_hop_mo_small, h->d_hop_mo_global}) if (q) (void)hipFree(q);
     if (h->d_hop_global) (void)hipFree(h->d_hop_global);
     if (h->hint_probe) { (void)hipHostFree(h->hint_probe); (void)hipEventDestroy(h->hint_event); }
     for (auto& sl : h->host_slot) {
@@ -1194,6 +1223,8 @@ int64_t gx_stat(const gx_handle* h, int32_t which) {
     case 17: return h->hop_ok ? static_cast<int64_t>(h->hop.n_chains) : 0;         // ... that have a chain
     case 18: { GxLds L; return plan_hop_launch(h, 0, &L) ? static_cast<int64_t>(L.nwaves) : 0; }  // hop tier: waves per CU
     case 20: return h->hop_ok ? static_cast<int64_t>(h->hop.full.n_lds_rows) : 0;       // ... whose dense row is in LDS too (branching states)
+    case 22: return h->hop_mo_ok ? static_cast<int64_t>(h->hop_mo.n_states) : 0;   // hop tier of the match automaton alone (match-only batches): states
+    case 23: return h->hop_mo_ok ? static_cast<int64_t>(h->hop_mo.full.n_hot) : 0; // ... whose records are in LDS
     case 19: { GxLds L; return plan_hop_slice_launch(h, &L) ? static_cast<int64_t>(L.nwaves) : 0; }  // ... of the hop slice kernel
     case 9: return !h->tile_ok ? 0 : !h->has_mo ? gx_stat(h, 7) : h->lds_mo.tier == 3 ? 4 : h->lds_mo.tier == 2 ? 3 : h->lds_mo.tier == 1 ? 2 : 1;
     default: return -1;

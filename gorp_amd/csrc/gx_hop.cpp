@@ -58,18 +58,20 @@ std::vector<int> order_classes(const std::map<ClassSet, uint64_t>& weight, int n
     return new_id;
 }
 
-bool build_hop_image(const Tables& T, uint32_t hot_budget_bytes, uint32_t small_budget_bytes, HopImage& out) {
+bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_bytes, uint32_t small_budget_bytes, HopImage& out) {
     out = HopImage{};
-    if (!T.union_ok || !T.has_capture) return false;
-    const RuleTables& U = T.uni;
+    if (!match_automaton && (!T.union_ok || !T.has_capture)) return false;
+    const RuleTables& U = T.uni;   // (the fused automaton; not looked at for the match automaton)
     const int ncls = T.ncls;
-    const size_t S = static_cast<size_t>(U.n_states);
-    if (ncls < 1 || ncls > 127 || S < 2 || S > 65536u || U.n_regs > 253) return false;
-    const uint32_t dead = static_cast<uint32_t>(U.dead);
+    const size_t S = static_cast<size_t>(match_automaton ? T.m_states : U.n_states);
+    const uint32_t n_regs = match_automaton ? 0u : static_cast<uint32_t>(U.n_regs);
+    if (ncls < 1 || ncls > 127 || S < 2 || S > 65536u || n_regs > 253u) return false;
+    const uint32_t dead = static_cast<uint32_t>(match_automaton ? T.m_dead : U.dead);
 
     // entry(s, c) = successor | register column << 16 (0: no program); every program must be one "register := position"
     std::vector<uint32_t> ent(S * ncls);
     for (size_t i = 0; i < ent.size(); ++i) {
+        if (match_automaton) { ent[i] = T.m_next[i]; continue; }
         const uint32_t w = U.trans[i], op = w >> 16;
         uint32_t col = 0;
         if (op) {
@@ -228,7 +230,9 @@ bool build_hop_image(const Tables& T, uint32_t hot_budget_bytes, uint32_t small_
             const uint32_t e = ent[s * ncls + c];
             row[new_id[c]] = perm[e & 0xFFFFu] | (e & 0xFFFF0000u);
         }
-        row[ncls] = U.fin[s] >= 0 ? fin_record(U.fin[s]) : static_cast<uint32_t>(U.fin[s]);
+        // info word: the match automaton's first accepting extraction (or -1); the fused automaton's final record (or -1 / -2-k)
+        if (match_automaton) row[ncls] = static_cast<uint32_t>(T.m_accept_first[s]);
+        else row[ncls] = U.fin[s] >= 0 ? fin_record(U.fin[s]) : static_cast<uint32_t>(U.fin[s]);
     }
     if (fin_rec.size() * 2 > 0x7FFFu * 16u || T.n_rules > 32000) return false;  // (a hot state's info word is an int16: offset / 16, or -2-k)
 
@@ -285,7 +289,8 @@ bool build_hop_image(const Tables& T, uint32_t hot_budget_bytes, uint32_t small_
     out.n_states = static_cast<uint32_t>(S);
     out.start = perm[0];
     out.dead = perm[dead];
-    out.n_regs = static_cast<uint32_t>(U.n_regs);
+    out.n_regs = n_regs;
+    out.match_automaton = match_automaton;
     const uint8_t* hb = reinterpret_cast<const uint8_t*>(hops.data());
     // One LDS image per hot budget (the state order does not depend on it, so the global image serves both).  The records
     // in the global image keep a zero row address: a state that is hot under one budget is read from there under the other.
@@ -299,7 +304,7 @@ bool build_hop_image(const Tables& T, uint32_t hot_budget_bytes, uint32_t small_
         L.info_lds = static_cast<uint32_t>(L.bytes.size());
         for (uint32_t s = 0; s < n_hot; ++s) {
             const int32_t info = static_cast<int32_t>(rows[static_cast<size_t>(s) * cols + ncls]);
-            const int16_t v = static_cast<int16_t>(info >= 0 ? info / 16 : info);
+            const int16_t v = static_cast<int16_t>(info >= 0 && !match_automaton ? info / 16 : info);   // (an extraction index as it is)
             L.bytes.push_back(static_cast<uint8_t>(v & 0xFF));
             L.bytes.push_back(static_cast<uint8_t>((v >> 8) & 0xFF));
         }
@@ -326,7 +331,7 @@ bool build_hop_image(const Tables& T, uint32_t hot_budget_bytes, uint32_t small_
             ++L.n_lds_rows;
         }
         while (L.bytes.size() % 16) L.bytes.push_back(0);
-        if (fin_rec.size() * 2 <= 8192u) {  // the final records beside them: a line's result then needs no global read
+        if (!match_automaton && fin_rec.size() * 2 <= 8192u) {  // the final records beside them: a line's result then needs no global read
             L.fin_lds = static_cast<uint32_t>(L.bytes.size());
             const uint8_t* fl = reinterpret_cast<const uint8_t*>(fin_rec.data());
             L.bytes.insert(L.bytes.end(), fl, fl + fin_rec.size() * 2);

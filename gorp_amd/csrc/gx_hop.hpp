@@ -58,12 +58,15 @@ struct HopImage {
     uint32_t hops_off = 0, fin_off = 0;  // byte offsets in `global`
     uint32_t start = 0, dead = 0;        // state indexes (renumbered)
     uint32_t n_regs = 0;
+    bool match_automaton = false;        // built from the match automaton (PolyMatcher.match batches): an info word is the first
+                                         // accepting extraction or -1, there are no programs and no final records
     // diagnostics (gx_stat)
     uint32_t n_reachable_hot = 0, n_chains = 0, n_runs = 0;
 };
 
 // hot_budget_bytes: LDS bytes the hot records may take.  Returns false (out.ok stays false) when the definition is
 // outside the tier's limits: no fused automaton, general capture programs, more than 127 classes, 65 536 states, 254 registers.
-bool build_hop_image(const Tables& T, uint32_t hot_budget_bytes, uint32_t small_budget_bytes, HopImage& out);
+// match_automaton: the tables of the match automaton alone (match-only batches) instead of the fused automaton's.
+bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_bytes, uint32_t small_budget_bytes, HopImage& out);
 
 }  // namespace gx

@@ -455,7 +455,7 @@ constexpr uint32_t HOP_SLICE = GX_HOP_SLICE_BYTES, HOP_SLICE_ROW = GX_HOP_SLICE_
 template <typename OFF>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4)))
 k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const uint8_t* __restrict__ at_global,
-                     const uint8_t* __restrict__ data, const OFF* __restrict__ off, uint64_t n, LineOut out, int strip_eol,
+                     const uint8_t* __restrict__ data, const OFF* __restrict__ off, uint64_t n, LineOut out, int match_only, int strip_eol,
                      uint32_t* __restrict__ oversize_flag, uint32_t seq) {
     {
         extern __shared__ __attribute__((aligned(16))) uint8_t gx_smem[];
@@ -476,7 +476,8 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
     const uint32_t slice = L.stage + wave * L.stage_bytes;
     const uint32_t regs = L.regs + wave * L.regs_wave_bytes + 128u + lane * 2u;
     const uint8_t* data_end = data + static_cast<uint64_t>(off[n]);
-    const uint32_t row0 = L.u_start, dead_row = L.u_dead;
+    // (match only: the tables are the match automaton's, a state's info word is its first accepting extraction)
+    const uint32_t row0 = match_only ? L.m_start : L.u_start, dead_row = match_only ? L.m_dead : L.u_dead;
     const uint8_t* fin_g = L.at != 0u ? nullptr : at_global + L.fin_tags;
     const uint32_t fin_lds = L.at;
 
@@ -498,9 +499,10 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
         const bool service = idle >= 16u || !__any(has_line && !finished);
         if (service && finished) {
             const int32_t hot_info = static_cast<int16_t>(lds_ld<uint16_t>(L.acc_tab + 2u * min(row, H.n_hot - 1u)));
-            int32_t info = hot_info >= 0 ? hot_info * 16 : hot_info;
+            int32_t info = hot_info >= 0 && !match_only ? hot_info * 16 : hot_info;
             if (row >= H.n_hot) info = *reinterpret_cast<const int32_t*>(H.rows + (static_cast<uint64_t>(row) * H.row_bytes + H.info_off));
-            out.id(i, line_result<TIER_HOP>(info, fin_lds, fin_g, regs, len, T.max_groups, [&](int g, int32_t pb, int32_t pe) {
+            if (match_only) out.id(i, info);
+            else out.id(i, line_result<TIER_HOP>(info, fin_lds, fin_g, regs, len, T.max_groups, [&](int g, int32_t pb, int32_t pe) {
                 out.cap(i, 2 * g, pb);
                 out.cap(i, 2 * g + 1, pe);
             }));
@@ -592,12 +594,12 @@ hipError_t launch_extract_hop_slices(const GxDev& dev, const GxLds& lds, const u
         hipError_t e = allow_full_lds(&k_extract_hop_slices<uint64_t>);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_extract_hop_slices<uint64_t>), grid, block, lds.total_bytes, stream, dev, lds, lds_image, at_global,
-                           static_cast<const uint8_t*>(b.data), static_cast<const uint64_t*>(b.offsets), b.n, line_out(dev, b), b.strip_eol, b.oversize_flag, b.seq);
+                           static_cast<const uint8_t*>(b.data), static_cast<const uint64_t*>(b.offsets), b.n, line_out(dev, b), (b.match_only != 0 || !dev.has_capture) ? 1 : 0, b.strip_eol, b.oversize_flag, b.seq);
     } else {
         hipError_t e = allow_full_lds(&k_extract_hop_slices<uint32_t>);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_extract_hop_slices<uint32_t>), grid, block, lds.total_bytes, stream, dev, lds, lds_image, at_global,
-                           static_cast<const uint8_t*>(b.data), static_cast<const uint32_t*>(b.offsets), b.n, line_out(dev, b), b.strip_eol, b.oversize_flag, b.seq);
+                           static_cast<const uint8_t*>(b.data), static_cast<const uint32_t*>(b.offsets), b.n, line_out(dev, b), (b.match_only != 0 || !dev.has_capture) ? 1 : 0, b.strip_eol, b.oversize_flag, b.seq);
     }
     return hipGetLastError();
 }

@@ -11,7 +11,7 @@ hipError_t launch_tile_lds(int mode, bool off64, const GxLds& lds, const void* i
 hipError_t launch_tile_l2(int mode, bool off64, const GxLds& lds, const void* io, dim3 grid, dim3 block, hipStream_t stream);
 hipError_t launch_tile_rec(int mode, bool off64, const GxLds& lds, const void* io, dim3 grid, dim3 block, hipStream_t stream);
 hipError_t launch_tile_recg(int mode, bool off64, const GxLds& lds, const void* io, dim3 grid, dim3 block, hipStream_t stream);
-hipError_t launch_tile_hop(bool off64, const GxLds& lds, const void* io, dim3 grid, dim3 block, hipStream_t stream);
+hipError_t launch_tile_hop(int mode, bool off64, const GxLds& lds, const void* io, dim3 grid, dim3 block, hipStream_t stream);
 
 hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
                                const GxBatch& b, hipStream_t stream, unsigned long long* dev_stamps) {
@@ -48,7 +48,7 @@ hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t
     const bool want_caps = b.match_only == 0 && dev.has_capture;
     const int mode = !want_caps ? 0 : (lds.u_start != 0xFFFFFFFFu && lds.simple_ops) ? 1 : 2;
     const bool off64 = b.offsets64 != 0;
-    if (lds.tier == 4) return (at_global && mode == 1) ? launch_tile_hop(off64, lds, &io, grid, block, stream) : hipErrorInvalidValue;
+    if (lds.tier == 4) return (at_global && mode != 2) ? launch_tile_hop(mode, off64, lds, &io, grid, block, stream) : hipErrorInvalidValue;
     if (at_global && lds.tier == 3) return launch_tile_recg(mode, off64, lds, &io, grid, block, stream);
     if (at_global) return launch_tile_l2(mode, off64, lds, &io, grid, block, stream);
     if (lds.tier == 2) return launch_tile_rec(mode, off64, lds, &io, grid, block, stream);

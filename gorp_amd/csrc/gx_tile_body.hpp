@@ -388,6 +388,15 @@ k_extract_tile(GxLds L, TileIO io) {
         if (cur.mode == 2) {
             // one line that does not fit the staging area: the per-line kernel takes it in a follow-up launch
             if (lane == cur.a) __hip_atomic_store(io.oversize_flag, io.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (MODE == 0 && HOP) {
+            // ---- hot loop #1 alone on the match automaton's hop records: a state's info word is its first accepting extraction ----
+            const uint32_t mrow = walk_hop(H, L.rec_indexed >= L.sort_chunk, stage, L.m_start, start, end, true, L.m_dead, regs);
+            int32_t first = static_cast<int16_t>(lds_ld<uint16_t>(L.acc_tab + 2u * min(mrow, H.n_hot - 1u)));
+            if (wave_any(mrow >= H.n_hot)) {
+                if (mrow >= H.n_hot) first = *reinterpret_cast<const int32_t*>(H.rows + (static_cast<uint64_t>(mrow) * H.row_bytes + H.info_off));
+            }
+            if (valid) io.match_id[i] = first;
+            GX_STAMP(2);
         } else if (MODE == 0) {
             // ---- hot loop #1 alone: PolyMatcher.match ----
             const uint32_t mrow = walk<TIER, false, false>(Wm, stage, bitmap, use_map, L.m_start, start, end, true, L.m_dead, regs);

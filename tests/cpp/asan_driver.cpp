@@ -84,6 +84,7 @@ Outcome hop_outcome(const Tables& T, const HopImage& H, const std::vector<uint8_
     }
     const int32_t info = static_cast<int32_t>(rows[static_cast<size_t>(s) * cols + H.ncls]);
     Outcome o{info < 0 ? info : 0, {}};
+    if (H.match_automaton) { o.id = info; return o; }   // (the first accepting extraction, or -1)
     if (info < 0) return o;
     const uint16_t* rec = reinterpret_cast<const uint16_t*>(H.global.data() + H.fin_off + info);
     const size_t tag_slots = 8 * static_cast<size_t>((T.max_groups + 3) / 4);
@@ -100,12 +101,20 @@ Outcome hop_outcome(const Tables& T, const HopImage& H, const std::vector<uint8_
     return o;
 }
 
+// PolyMatcher.match on the dense match automaton: the first accepting extraction of the final state, or -1
+Outcome dense_match(const Tables& T, const std::vector<uint8_t>& line) {
+    uint32_t s = 0;
+    for (uint8_t b : line) s = T.m_next[static_cast<size_t>(s) * T.ncls + T.cls256[b]];
+    return Outcome{T.m_accept_first[s], {}};
+}
+
 // returns the number of lines checked (0: the definition is outside the hop tier's limits); throws on a difference
 size_t check_hop_tier(const Tables& T, uint64_t seed) {
     size_t checked = 0, iterations = 0, bytes = 0;
     for (uint32_t budget : {48u * 1024u, 3u * HOP_REC_BYTES}) {   // (a tiny LDS budget: another state order)
-        HopImage H;
-        if (!build_hop_image(T, budget, 2u * HOP_REC_BYTES, H)) return 0;
+        HopImage H, M;
+        if (!build_hop_image(T, false, budget, 2u * HOP_REC_BYTES, H)) return 0;
+        if (!build_hop_image(T, true, budget, 2u * HOP_REC_BYTES, M)) return 0;   // the match automaton alone
         if (H.small.bytes.size() > H.full.bytes.size() || memcmp(H.small.bytes.data(), H.full.bytes.data(), 256) != 0) throw std::runtime_error("hop tier: the two LDS images disagree");
         uint64_t rng = seed * 0x9E3779B97F4A7C15ull + budget;
         auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
@@ -137,6 +146,8 @@ size_t check_hop_tier(const Tables& T, uint64_t seed) {
             }
             if (!(dense_outcome(T, line) == hop_outcome(T, H, line, &iterations)))
                 throw std::runtime_error("hop tier and dense automaton disagree on a line of " + std::to_string(line.size()) + " bytes");
+            if (!(dense_match(T, line) == hop_outcome(T, M, line, &iterations)))
+                throw std::runtime_error("hop tier and dense match automaton disagree on a line of " + std::to_string(line.size()) + " bytes");
             ++checked;
             bytes += line.size();
         }
