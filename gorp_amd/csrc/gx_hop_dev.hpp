@@ -87,7 +87,8 @@ __device__ __forceinline__ uint32_t run_flags(uint32_t x, uint32_t lo4, uint32_t
 // states).  A lane then leaves the hot set only by an exact step on a byte the definition does not expect there; it takes
 // exact steps -- inside that branch -- until it is back in the hot set or its line is over, and the loop proper never looks
 // for a record in global memory.
-template <bool ALL_HOT>
+// CAPTURE false: the match automaton's tables (no programs anywhere): the register writes are left out.
+template <bool ALL_HOT, bool CAPTURE>
 __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, uint32_t e, uint32_t limit, uint32_t e_chain, uint32_t p0,
                                                   uint32_t s, uint32_t dead, uint32_t regs) {
     const uint32_t dummy_col = regs - 128u;
@@ -97,7 +98,7 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
         uint32_t xe;
         if (lrow) xe = lds_ld<uint16_t>(lrow + (c << 1)) | static_cast<uint32_t>(lds_ld<uint8_t>(lrow + H.lrow_cols + c)) << 16;  // (u16 successors, then u8 columns)
         else xe = *reinterpret_cast<const uint32_t*>(H.rows + (static_cast<uint64_t>(s) * H.row_bytes + (c << 2)));
-        lds_st<uint16_t>(dummy_col + ((xe >> 16) << 7), static_cast<uint16_t>(q - p0));
+        if (CAPTURE) lds_st<uint16_t>(dummy_col + ((xe >> 16) << 7), static_cast<uint16_t>(q - p0));
         s = xe & 0xFFFFu;
         p = s == dead ? max(limit, q + 1u) : q + 1u;  // (nothing leaves the dead state: the line is over)
     };
@@ -149,8 +150,10 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
         const uint32_t c0 = chained ? h0.x : 0u, c1 = chained ? h0.y : s;
         // ---- capture programs of the chain: register column := position (column 0 is the write-only dummy) ----
         const uint32_t rel = q - p0;  // (the position in the line)
-        lds_st<uint16_t>(dummy_col + (((c1 >> 16) & 0xFFu) << 7), static_cast<uint16_t>(rel + ((c0 >> 20) & 7u)));
-        lds_st<uint16_t>(dummy_col + ((c1 >> 24) << 7), static_cast<uint16_t>(rel + ((c0 >> 23) & 7u)));
+        if (CAPTURE) {
+            lds_st<uint16_t>(dummy_col + (((c1 >> 16) & 0xFFu) << 7), static_cast<uint16_t>(rel + ((c0 >> 20) & 7u)));
+            lds_st<uint16_t>(dummy_col + ((c1 >> 24) << 7), static_cast<uint16_t>(rel + ((c0 >> 23) & 7u)));
+        }
         p = p < limit ? q + ((c0 >> 16) & 0xFu) : p;
         s = c1 & 0xFFFFu;
         // ---- 4. one exact step where the chain does not apply ----
@@ -168,12 +171,13 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
 }
 
 // The tile kernel's case: the whole line [start, end) is staged.
+template <bool CAPTURE>
 __device__ __forceinline__ uint32_t walk_hop(const HopTab& H, bool all_hot, uint32_t stage, uint32_t s, uint32_t start, uint32_t end, bool on,
                                              uint32_t dead, uint32_t regs) {
     const uint32_t p0 = stage + start, e = stage + end;
     uint32_t p = on ? p0 : e;
-    if (all_hot) return walk_hop_span<true>(H, p, e, e, e, p0, s, dead, regs);
-    return walk_hop_span<false>(H, p, e, e, e, p0, s, dead, regs);
+    if (all_hot) return walk_hop_span<true, CAPTURE>(H, p, e, e, e, p0, s, dead, regs);
+    return walk_hop_span<false, CAPTURE>(H, p, e, e, e, p0, s, dead, regs);
 }
 
 }  // namespace gx

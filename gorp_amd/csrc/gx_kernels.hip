@@ -570,8 +570,12 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
             const uint32_t e = my + (whole ? left : HOP_SLICE);
             const uint32_t limit = whole ? e : e - HOP_SLICE_KEEP;
             uint32_t p = my;
-            if (L.rec_indexed >= L.sort_chunk) row = walk_hop_span<true>(H, p, e, limit, whole ? e : 0xFFFFFFF0u, my - pos, row, dead_row, regs);
-            else row = walk_hop_span<false>(H, p, e, limit, whole ? e : 0xFFFFFFF0u, my - pos, row, dead_row, regs);
+            const uint32_t e_chain = whole ? e : 0xFFFFFFF0u;
+            const bool all_hot = L.rec_indexed >= L.sort_chunk;
+            if (match_only) row = all_hot ? walk_hop_span<true, false>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs)
+                                          : walk_hop_span<false, false>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs);
+            else row = all_hot ? walk_hop_span<true, true>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs)
+                               : walk_hop_span<false, true>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs);
             pos += p - my;
         }
         // the slice buffer is rewritten by the next iteration

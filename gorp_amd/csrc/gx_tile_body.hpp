@@ -390,7 +390,7 @@ k_extract_tile(GxLds L, TileIO io) {
             if (lane == cur.a) __hip_atomic_store(io.oversize_flag, io.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (MODE == 0 && HOP) {
             // ---- hot loop #1 alone on the match automaton's hop records: a state's info word is its first accepting extraction ----
-            const uint32_t mrow = walk_hop(H, L.rec_indexed >= L.sort_chunk, stage, L.m_start, start, end, true, L.m_dead, regs);
+            const uint32_t mrow = walk_hop<false>(H, L.rec_indexed >= L.sort_chunk, stage, L.m_start, start, end, true, L.m_dead, regs);
             int32_t first = static_cast<int16_t>(lds_ld<uint16_t>(L.acc_tab + 2u * min(mrow, H.n_hot - 1u)));
             if (wave_any(mrow >= H.n_hot)) {
                 if (mrow >= H.n_hot) first = *reinterpret_cast<const int32_t*>(H.rows + (static_cast<uint64_t>(mrow) * H.row_bytes + H.info_off));
@@ -406,7 +406,7 @@ k_extract_tile(GxLds L, TileIO io) {
             int32_t info;  // of the state the line's walk ended in: -1 null, -2-k ExtractionException, else its final record
             if (HOP) {
                 // ---- fused pass on the hop records: a run and a chain per iteration (gx_hop_dev.hpp) ----
-                const uint32_t urow = walk_hop(H, L.rec_indexed >= L.sort_chunk, stage, L.u_start, start, end, true, L.u_dead, regs);
+                const uint32_t urow = walk_hop<true>(H, L.rec_indexed >= L.sort_chunk, stage, L.u_start, start, end, true, L.u_dead, regs);
                 // the final state's info word: int16 in LDS for the hot states (offset / 16, or -1 / -2-k), else its dense row's last column
                 const int32_t hot_info = static_cast<int16_t>(lds_ld<uint16_t>(L.acc_tab + 2u * min(urow, H.n_hot - 1u)));
                 info = hot_info >= 0 ? hot_info * 16 : hot_info;
