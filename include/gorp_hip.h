@@ -99,7 +99,8 @@ int32_t gx_max_groups(const gx_handle* h);
  * the hop tier (run + chain records for capture batches of definitions whose dense rows do not fit LDS): 14 = its states
  * (0: the handle has no hop tables), 15 / 21 = states whose records are in LDS under the tile kernel / the hop slice kernel,
  * 16 = states that well-formed lines reach, 17 = states that have a chain, 18 / 19 = waves per workgroup of the tile kernel on
- * these tables / of the hop slice kernel, 20 = branching states whose dense row is in LDS too */
+ * these tables / of the hop slice kernel, 20 = branching states whose dense row is in LDS too, 22 / 23 = states / states with
+ * their records in LDS of the second hop image, built from the match automaton alone for match-only batches */
 int64_t gx_stat(const gx_handle* h, int32_t which);
 
 typedef struct gx_batch_opts {
