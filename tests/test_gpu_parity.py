@@ -1164,3 +1164,30 @@ def test_hop_tier_agrees_with_oracle():
         m6, c6 = gorp.extract_batch(dd, oo, kernel=N.GX_KERNEL_HOP_SLICES)
         om6, oc6 = orc.extract_batch(dd, oo)
         assert np.array_equal(m6, om6) and np.array_equal(c6, oc6)
+
+
+def test_hop_tier_class_limit():
+    """The hop tier keeps class ids in seven bits: a definition of up to 127 character classes has it, one more and the handle
+    goes without (the other tables answer) -- both bit-exact."""
+    def definition(n_literals):
+        # every literal byte is a class of its own: n_literals extractions "<byte>=<digits>" over distinct bytes
+        chars = [chr(c) for c in range(0x21, 0x21 + 200) if chr(c) not in "0123456789" and chr(c).encode("latin-1")[0] not in (0x7F, 0xAD)][:n_literals]
+        return [FlattenedExtraction("r%d" % i, [["text", ch + "="], ["extractor", "v", [["pattern", "\\d+"]]]]) for i, ch in enumerate(chars)], chars
+    for n_lit, want_hop in ((100, True), (140, False)):
+        rules, chars = definition(n_lit)
+        gorp, orc = Gorp.construct(rules, flags=N.GX_CREATE_TIER_HOP), oracle_for(rules)
+        assert (gorp.stat(14) > 0) == want_hop, (n_lit, gorp.stat(1), gorp.stat(14))
+        rng = random.Random(n_lit)
+        lines = []
+        for _ in range(3000):
+            ch = rng.choice(chars + ["?", "\x7f"])
+            lines.append(ch + rng.choice(["=", "==", ""]) + "".join(rng.choice("0123456789x") for _ in range(rng.randint(0, 12))))
+        raw = [ln.encode("latin-1") for ln in lines]
+        data, offsets = lines_to_csr(raw)
+        omid, ocaps = orc.extract_batch(data, offsets, nthreads=8)
+        assert (omid >= 0).sum() > 300
+        for kernel in (N.GX_KERNEL_AUTO, N.GX_KERNEL_HOPS, N.GX_KERNEL_HOP_SLICES):
+            mid, caps = gorp.extract_batch(data, offsets, kernel=kernel)
+            assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps), (n_lit, kernel)
+            mo, _ = gorp.extract_batch(data, offsets, kernel=kernel, match_only=True)
+            assert np.array_equal(mo, np.where(omid <= -2, -2 - omid, omid))
