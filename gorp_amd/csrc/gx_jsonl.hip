@@ -316,37 +316,52 @@ __device__ __forceinline__ uint64_t esc_bytes(uint32_t b, bool passthrough, uint
 }
 
 // global -> LDS copy of the span [lo, hi) of `data`, 16 bytes per lane, skewed so that LDS and global addresses
-// agree modulo 16; chunks that stick out of [data, data_end) are read byte by byte.  All of a lane's loads (up to 16: the
-// staging area is at most 16 KB) are issued before the first store waits for one: a wave of these kernels has its
-// SIMD to itself, and a load-store-load-store chain costs a trip to memory per chunk.
-__device__ __forceinline__ void stage_in(const uint8_t* __restrict__ data, const uint8_t* data_end, uint64_t lo, uint64_t hi, uint8_t* stage,
-                                         uint32_t lane, uint32_t threads = 64u) {  // lane: 0 .. threads - 1
+// agree modulo 16; chunks that stick out of [data, data_end) are read byte by byte.  In two halves: stage_fetch issues all
+// of a lane's loads (NQ of them: the staging area is at most 16 KB = 64 lanes x 16 chunks), stage_put stores them -- a
+// load-store-load-store chain costs a trip to memory per chunk, and the tile kernels fetch the NEXT tile's bytes while the
+// lanes work on this one.  Returns the number of chunks.
+template <int NQ>
+__device__ __forceinline__ uint32_t stage_fetch(const uint8_t* __restrict__ data, const uint8_t* data_end, uint64_t lo, uint64_t hi, uint32_t lane,
+                                                uint32_t threads, uint4 (&v)[NQ]) {  // lane: 0 .. threads - 1; threads * NQ >= 1024
     const uint8_t* g_lo = data + lo;
     const uint32_t skew = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(g_lo) & 15u);
     const uint8_t* g_al = g_lo - skew;
     const uint32_t nch = static_cast<uint32_t>(((hi - lo) + skew + 15u) >> 4);
-    for (uint32_t c0 = 0; c0 < nch; c0 += threads * 16u) {
-        uint4 v[16];
+    if (g_al >= data && g_al + (static_cast<uint64_t>(nch) << 4) <= data_end) {
+        // every tile but the batch's first and last: nothing sticks out, the loads are one straight run (no value of theirs
+        // is merged with another path's, so nothing waits for one before the next is issued)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const uint32_t c = c0 + threads * q + lane;
+        for (int q = 0; q < NQ; ++q) {
+            const uint32_t c = threads * q + lane;
             v[q] = make_uint4(0u, 0u, 0u, 0u);
-            if (c < nch) {
-                const uint8_t* src = g_al + (static_cast<uint64_t>(c) << 4);
-                if (src >= data && src + 16 <= data_end) v[q] = *reinterpret_cast<const uint4*>(src);
-                else {
-                    uint32_t w[4] = {0, 0, 0, 0};
-                    for (int r = 0; r < 16; ++r)
-                        if (src + r >= data && src + r < data_end) w[r >> 2] |= static_cast<uint32_t>(src[r]) << ((r & 3) * 8);
-                    v[q] = make_uint4(w[0], w[1], w[2], w[3]);
-                }
+            if (c < nch) v[q] = *reinterpret_cast<const uint4*>(g_al + (static_cast<uint64_t>(c) << 4));
+        }
+        return nch;
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const uint32_t c = threads * q + lane;
+        uint4 x = make_uint4(0u, 0u, 0u, 0u);
+        if (c < nch) {
+            const uint8_t* src = g_al + (static_cast<uint64_t>(c) << 4);
+            if (src >= data && src + 16 <= data_end) x = *reinterpret_cast<const uint4*>(src);
+            else {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (int r = 0; r < 16; ++r)
+                    if (src + r >= data && src + r < data_end) w[r >> 2] |= static_cast<uint32_t>(src[r]) << ((r & 3) * 8);
+                x = make_uint4(w[0], w[1], w[2], w[3]);
             }
         }
+        v[q] = x;
+    }
+    return nch;
+}
+template <int NQ>
+__device__ __forceinline__ void stage_put(uint8_t* stage, uint32_t nch, uint32_t lane, uint32_t threads, const uint4 (&v)[NQ]) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const uint32_t c = c0 + threads * q + lane;
-            if (c < nch) *reinterpret_cast<uint4*>(stage + (c << 4)) = v[q];
-        }
+    for (int q = 0; q < NQ; ++q) {
+        const uint32_t c = threads * q + lane;
+        if (c < nch) *reinterpret_cast<uint4*>(stage + (c << 4)) = v[q];
     }
 }
 
@@ -371,11 +386,14 @@ __device__ __forceinline__ void stage_words(const int32_t* __restrict__ src, uin
 // offsets, near the middle of the line's text; the sizes pass leaves the exact number of bytes before it in split[].
 // With a wave per tile the write pass fits 4 waves per CU (13 + 21 KB of staging each), one per SIMD, and a lone wave
 // is bound by its own issue rate; pairs make that 8 waves, each with half the text of a line to write.
-template <typename OFF, bool WRITE, int PAIR>
-__global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTileCfg cfg, const uint8_t* __restrict__ data, const OFF* __restrict__ off,
+// FAST: the template arrays, the literals and the tile's capture rows are all in LDS (plan_jsonl_tile: nearly every definition) --
+// the lanes read them with ds_read.  (Without it each access is a flat load through a pointer that is LDS or global, which waits
+// for every load in flight: the next tile's bytes among them.)
+template <typename OFF, bool WRITE, int PAIR, bool FAST>
+__global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates tm, JsonlTileCfg cfg, const uint8_t* __restrict__ data, const OFF* __restrict__ off,
                                                    uint64_t n, const int32_t* __restrict__ match_id, const int32_t* __restrict__ caps, int slots,
                                                    int passthrough, uint32_t* __restrict__ sizes, const uint64_t* __restrict__ out_off,
-                                                   uint8_t* __restrict__ out, uint32_t* __restrict__ split) {
+                                                   uint8_t* __restrict__ out, uint32_t* __restrict__ split, uint32_t* __restrict__ split_at, uint32_t* __restrict__ tile_flags) {
     const bool pt = passthrough != 0;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_in_block = uni(threadIdx.x >> 6);
@@ -429,14 +447,93 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
     const uint8_t* data_end = data + static_cast<uint64_t>(off[n]);
     const uint64_t tiles = (n + 63) >> 6;
     const uint64_t wstride = static_cast<uint64_t>(gridDim.x) * (cfg.waves / PAIR);
-    for (uint64_t tile = static_cast<uint64_t>(blockIdx.x) * (cfg.waves / PAIR) + wave; tile < tiles; tile += wstride) {
+    // ---- the pipeline: while the lanes work on a tile, the NEXT tile's line bytes and capture rows are already on their way
+    // into registers (pf, pfc), its per-lane offsets too (nx_*), and the bounds of the tile after that (bd_*: what the
+    // fetch needs to know its span).  Only for a tile that goes in one round (the common case: the staging areas are sized
+    // for 64 mean lines and more); any other tile stages inside its rounds as before.  The write pass only: it runs two waves per
+    // SIMD; the sizes pass has three and registers for neither the 64 bytes x 16 of a tile nor a fourth wave's worth of latency to hide
+    // (measured: 1.17 ms with the fetch, 1.08 without) -- it fetches the per-lane offsets ahead and nothing else. ----
+    constexpr int NQ = 16 / PAIR;   // 16-byte chunks of line bytes per lane (in_bytes <= 16 KB)
+    constexpr int NC = 4;           // 16-byte chunks of capture rows per lane
+    const uint32_t threads = 64u * PAIR;
+    uint4 pf[NQ], pfc[NC];
+    bool pf_valid = false;          // uniform
+    uint32_t pf_nch = 0u, pf_cch = 0u;
+    uint64_t nx_o0 = 0, nx_o1 = 0, nx_oo0 = 0, nx_oo1 = 0, bd_lo = 0, bd_hi = 0, bd_olo = 0, bd_ohi = 0;
+    int32_t nx_k = -1;
+    uint32_t nx_split = 0u;         // write pass, second wave of a pair: the bytes of the line's text before its split point
+    uint32_t nx_at = 0xFFFF0000u;   // write pass: the split point (segment - first segment) << 16 | characters / 16; 0xFFFF....: none
+    uint32_t bd_flag = 0u, nx_flag = 0u;  // write pass: tile_flags of the tile after next / of the next tile
+    auto fetch_lane_offsets = [&](uint64_t t) {
+        const uint64_t i = (t << 6) + lane;
+        const bool valid = i < n;
+        nx_o0 = off[valid ? i : n]; nx_o1 = off[valid ? i + 1 : n];
+        nx_k = valid ? match_id[i] : -1;
+        if (WRITE) { nx_oo0 = out_off[valid ? i : n]; nx_oo1 = out_off[valid ? i + 1 : n]; }
+        if (WRITE && PAIR == 2) {
+            nx_split = (valid && part == 1u) ? split[i] : 0u;
+            nx_at = valid ? split_at[i] : 0xFFFF0000u;
+        }
+    };
+    auto fetch_bounds = [&](uint64_t t) {  // (uniform addresses)
+        if (t >= tiles) return;
+        const uint64_t e0 = t << 6, e1 = min(n, e0 + 64u);
+        bd_lo = off[e0]; bd_hi = off[e1];
+        if (WRITE) { bd_olo = out_off[e0]; bd_ohi = out_off[e1]; bd_flag = tile_flags[t]; }
+    };
+    const uint64_t tile0 = static_cast<uint64_t>(blockIdx.x) * (cfg.waves / PAIR) + wave;
+    if (tile0 < tiles) {
+        fetch_lane_offsets(tile0);
+        if (WRITE) nx_flag = tile_flags[tile0];
+        fetch_bounds(tile0 + wstride);
+    }
+    for (uint64_t tile = tile0; tile < tiles; tile += wstride) {
         const uint64_t i = (tile << 6) + lane;
         const bool valid = i < n;
-        const uint64_t o0 = off[valid ? i : n], o1 = off[valid ? i + 1 : n];
-        const int32_t k = valid ? match_id[i] : -1;
-        uint64_t oo0 = 0, oo1 = 0;
-        if (WRITE) { oo0 = out_off[valid ? i : n]; oo1 = out_off[valid ? i + 1 : n]; }
+        const uint64_t o0 = nx_o0, o1 = nx_o1;
+        const int32_t k = nx_k;
+        const uint64_t oo0 = nx_oo0, oo1 = nx_oo1;
+        const uint32_t split_bytes = nx_split, split_point = nx_at;
+        const bool clean = WRITE && uni(nx_flag) != 0u;  // no character of the tile's captures takes an escape: they are copied as they are
+        uint32_t tile_dirty = 0u;                           // sizes pass: what becomes tile_flags[tile]
         const uint32_t group_lines = static_cast<uint32_t>(min(static_cast<uint64_t>(64), n - (tile << 6)));
+        // this tile's bytes, when they were fetched ahead: registers -> LDS (the staging areas are free: the barrier that ends a round)
+        const bool staged = pf_valid;
+        if (staged) {
+            stage_put<NQ>(in_stage, pf_nch, ptid, threads, pf);
+            if (cfg.caps_bytes) stage_put<NC>(caps_stage, pf_cch, ptid, threads, pfc);
+        }
+        // the next tile
+        pf_valid = false;
+        {
+            const uint64_t t1 = tile + wstride;
+            if (t1 < tiles) {
+                fetch_lane_offsets(t1);
+                const uint64_t n_lo = uni(bd_lo), n_hi = uni(bd_hi), n_olo = uni(bd_olo), n_ohi = uni(bd_ohi);
+                nx_flag = bd_flag;
+                const uint32_t lines1 = static_cast<uint32_t>(min(static_cast<uint64_t>(64), n - (t1 << 6)));
+                const uint32_t words = lines1 * static_cast<uint32_t>(slots);
+                bool one_round = WRITE && (n_hi - n_lo) + static_cast<uint32_t>(reinterpret_cast<uintptr_t>(data + n_lo) & 15u) <= cfg.in_bytes;
+                if (WRITE) one_round = one_round && (n_ohi - n_olo) + static_cast<uint32_t>(reinterpret_cast<uintptr_t>(out + n_olo) & 15u) <= cfg.out_bytes;
+                if (cfg.caps_bytes)
+                    one_round = one_round && (words & 3u) == 0u && (words >> 2) <= threads * NC && (reinterpret_cast<uintptr_t>(caps) & 15u) == 0u;
+                if (one_round) {
+                    pf_nch = stage_fetch<NQ>(data, data_end, n_lo, n_hi, ptid, threads, pf);
+                    if (cfg.caps_bytes) {
+                        const uint4* rows = reinterpret_cast<const uint4*>(caps + (t1 << 6) * static_cast<uint64_t>(slots));
+                        pf_cch = words >> 2;
+#pragma unroll
+                        for (int q = 0; q < NC; ++q) {
+                            const uint32_t c = threads * q + ptid;
+                            pfc[q] = make_uint4(0u, 0u, 0u, 0u);
+                            if (c < pf_cch) pfc[q] = rows[c];
+                        }
+                    }
+                    pf_valid = true;
+                }
+                fetch_bounds(t1 + wstride);
+            }
+        }
         uint32_t a = 0;
         while (a < group_lines) {
             // ---- the round: lanes [a, b) whose input (and output) fit the staging areas ----
@@ -458,21 +555,34 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
                 else {
                     const uint32_t t = line_size_wave(tm, data, lo, ia, match_id, caps, slots, pt, lane);
                     if (lane == 0) sizes[ia] = t;
+                    tile_dirty = 1u;  // (its lines are written by line_write_wave either way; the flag only has to be safe)
                 }
                 a += 1;
                 continue;
             }
             const uint32_t b = a + cnt;
             const uint64_t hi = uni(static_cast<uint64_t>(__shfl(static_cast<unsigned long long>(o1), static_cast<int>(b - 1u))));
-            stage_in(data, data_end, lo, hi, in_stage, ptid, 64u * PAIR);
+            const bool in_lds = staged && a == 0u;  // fetched ahead: the whole tile is this one round (b == group_lines)
+            if (!in_lds) {
+                uint4 v[NQ];
+                const uint32_t nch = stage_fetch<NQ>(data, data_end, lo, hi, ptid, threads, v);
+                stage_put<NQ>(in_stage, nch, ptid, threads, v);
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see below
+            }
             if (!cfg.caps_bytes) pair_barrier();
             const bool active = lane >= a && lane < b;
             if (cfg.caps_bytes) {
                 // the round's capture rows are contiguous: stage them with coalesced 16-byte loads
-                const uint64_t row0 = ((tile << 6) + a) * static_cast<uint64_t>(slots);     // in int32 units
-                const uint32_t words = (b - a) * static_cast<uint32_t>(slots);
-                const int32_t* src = caps + row0;
-                stage_words(src, words, reinterpret_cast<int32_t*>(caps_stage), ptid, 64u * PAIR);
+                if (!in_lds) {
+                    const uint64_t row0 = ((tile << 6) + a) * static_cast<uint64_t>(slots);     // in int32 units
+                    const uint32_t words = (b - a) * static_cast<uint32_t>(slots);
+                    const int32_t* src = caps + row0;
+                    stage_words(src, words, reinterpret_cast<int32_t*>(caps_stage), ptid, 64u * PAIR);
+                    // (a load whose store was predicated off is never waited for: without this the compiler has to assume, where
+                    // this path and the fetched-ahead one meet, that a register of the work below is still a load's target, and
+                    // waits for every load in flight there -- the next tile's among them)
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                }
                 pair_barrier();
             }
             // ---- lane = line ----
@@ -482,9 +592,10 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
             // lane before, or the other wave of the pair) with zeros, and those are written by that writer's byte stores
             // after the barrier below, later than every first store of the round.
             uint32_t wp = 0u, wp0 = 0u, head0 = 0u, carry = 0u, pend = 0u;
+            bool lane_dirty = false;
             if (active) {
                 const uint32_t line = lds_addr(in_stage) + skew + static_cast<uint32_t>(o0 - lo);  // LDS byte addresses
-                uint32_t total = 0;
+                uint32_t total = 0, unescaped = 0;  // sizes pass: the text's bytes, and what they would be without escapes
                 auto put_4 = [&](uint32_t e) {  // four bytes
                     const uint64_t t = static_cast<uint64_t>(e) << (8u * pend);
                     *(JX_LDS uint32_t*)(uintptr_t)wp = carry | static_cast<uint32_t>(t);
@@ -508,47 +619,62 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
                 if (k >= 0) {
                     const int32_t* cp_g = caps + i * static_cast<uint64_t>(slots);
                     const int32_t* cp_l = reinterpret_cast<const int32_t*>(caps_stage) + (lane - a) * static_cast<uint32_t>(slots);
-                    auto cap = [&](int idx) { return cfg.caps_bytes ? cp_l[idx] : cp_g[idx]; };
-                    auto t_seg_off = [&](uint32_t x) { return cfg.tm_lds != 0xFFFFFFFFu ? tl_seg_off[x] : tm.seg_off[x]; };
-                    auto t_fixed = [&](uint32_t x) { return cfg.tm_lds != 0xFFFFFFFFu ? tl_fixed[x] : tm.fixed_len[x]; };
-                    auto t_lit_off = [&](uint32_t x) { return cfg.tm_lds != 0xFFFFFFFFu ? tl_lit_off[x] : tm.lit_off[x]; };
-                    auto t_lit_len = [&](uint32_t x) { return cfg.tm_lds != 0xFFFFFFFFu ? tl_lit_len[x] : tm.lit_len[x]; };
-                    auto t_group = [&](uint32_t x) { return cfg.tm_lds != 0xFFFFFFFFu ? tl_group[x] : tm.group[x]; };
+                    const uint32_t caps_row = lds_addr(caps_stage) + (lane - a) * static_cast<uint32_t>(slots) * 4u;
+                    const uint32_t tmb = smem0 + cfg.tm_lds;   // FAST: seg_off | fixed_len | lit_off | lit_len | group
+                    const uint32_t tm_fixed = tmb + (cfg.n_rules + 1u) * 4u, tm_lit_off = tm_fixed + cfg.n_rules * 4u, tm_lit_len = tm_lit_off + cfg.n_segs * 4u,
+                                   tm_group = tm_lit_len + cfg.n_segs * 4u;
+                    auto cap = [&](int idx) -> int32_t {
+                        if (FAST) return static_cast<int32_t>(lds_w(caps_row + static_cast<uint32_t>(idx) * 4u));
+                        return cfg.caps_bytes ? cp_l[idx] : cp_g[idx];
+                    };
+                    auto t_seg_off = [&](uint32_t x) -> uint32_t { if (FAST) return lds_w(tmb + x * 4u); return cfg.tm_lds != 0xFFFFFFFFu ? tl_seg_off[x] : tm.seg_off[x]; };
+                    auto t_fixed = [&](uint32_t x) -> uint32_t { if (FAST) return lds_w(tm_fixed + x * 4u); return cfg.tm_lds != 0xFFFFFFFFu ? tl_fixed[x] : tm.fixed_len[x]; };
+                    auto t_lit_off = [&](uint32_t x) -> uint32_t { if (FAST) return lds_w(tm_lit_off + x * 4u); return cfg.tm_lds != 0xFFFFFFFFu ? tl_lit_off[x] : tm.lit_off[x]; };
+                    auto t_lit_len = [&](uint32_t x) -> uint32_t { if (FAST) return lds_w(tm_lit_len + x * 4u); return cfg.tm_lds != 0xFFFFFFFFu ? tl_lit_len[x] : tm.lit_len[x]; };
+                    auto t_group = [&](uint32_t x) -> int32_t {
+                        if (FAST) return static_cast<int32_t>(lds_w(tm_group + x * 4u));
+                        return cfg.tm_lds != 0xFFFFFFFFu ? tl_group[x] : tm.group[x];
+                    };
                     const uint32_t s0 = t_seg_off(k), s1 = t_seg_off(k + 1);
                     // ---- the split point (m, q): part 0 writes the segments before m, m's literal and -- m has a capture that
                     // is not null -- the opening quote and q characters of it (q a multiple of 16); part 1 the rest.  From the
                     // unescaped sizes: the first place at or past the middle of the text.  m == s1: no split. ----
                     uint32_t sp_m = s1, sp_q = 0u;
-                    const bool want_split = WRITE ? PAIR == 2 : split != nullptr;
-                    if (want_split) {
+                    if (WRITE) {
+                        // (the sizes pass left it in split_at)
+                        if (PAIR == 2 && (split_point >> 16) != 0xFFFFu) { sp_m = s0 + (split_point >> 16); sp_q = (split_point & 0xFFFFu) << 4; }
+                    } else if (split != nullptr) {
                         uint32_t est_total = 0;
                         for (uint32_t s = s0; s < s1; ++s) {
                             const int32_t g = t_group(s);
                             est_total += t_lit_len(s) + (g < 0 ? 0u : (cap(2 * g) < 0 ? 4u : static_cast<uint32_t>(cap(2 * g + 1) - cap(2 * g)) + 2u));
                         }
+                        unescaped = est_total;
                         const uint32_t half = est_total / 2u;
                         uint32_t cum = 0;
-                        for (uint32_t s = s0; s < s1; ++s) {
-                            const int32_t g = t_group(s);
-                            const uint32_t ll = t_lit_len(s);
-                            const bool text = g >= 0 && cap(2 * g) >= 0;
-                            const uint32_t len = text ? static_cast<uint32_t>(cap(2 * g + 1) - cap(2 * g)) : 0u;
-                            const uint32_t e = ll + (g < 0 ? 0u : (text ? len + 2u : 4u));
-                            if (sp_m == s1 && cum + e > half) {
-                                sp_m = s;
-                                const uint32_t at = cum + ll + 1u;  // where the capture's characters begin
-                                sp_q = (text && half > at) ? ((half - at) & ~15u) : 0u;
-                                if (sp_q > (len & ~15u)) sp_q = len & ~15u;
+                        if (s1 - s0 < 0xFFFFu)
+                            for (uint32_t s = s0; s < s1; ++s) {
+                                const int32_t g = t_group(s);
+                                const uint32_t ll = t_lit_len(s);
+                                const bool text = g >= 0 && cap(2 * g) >= 0;
+                                const uint32_t len = text ? static_cast<uint32_t>(cap(2 * g + 1) - cap(2 * g)) : 0u;
+                                const uint32_t e = ll + (g < 0 ? 0u : (text ? len + 2u : 4u));
+                                if (sp_m == s1 && cum + e > half) {
+                                    sp_m = s;
+                                    const uint32_t at = cum + ll + 1u;  // where the capture's characters begin
+                                    sp_q = (text && half > at) ? ((half - at) & ~15u) : 0u;
+                                    if (sp_q > (len & ~15u)) sp_q = len & ~15u;
+                                }
+                                cum += e;
                             }
-                            cum += e;
-                        }
+                        split_at[i] = sp_m < s1 ? ((sp_m - s0) << 16 | (sp_q >> 4)) : 0xFFFF0000u;
                     }
                     uint32_t s_from = s0, s_to = s1;
                     if (WRITE && PAIR == 2) {
                         if (part == 0u) s_to = sp_m < s1 ? sp_m + 1u : s1;
                         else s_from = sp_m;   // (sp_m == s1: nothing)
                     }
-                    const uint32_t dst0 = WRITE ? lds_addr(out_stage) + oskew + static_cast<uint32_t>(oo0 - olo) + ((PAIR == 2 && part == 1u) ? split[i] : 0u) : 0u;
+                    const uint32_t dst0 = WRITE ? lds_addr(out_stage) + oskew + static_cast<uint32_t>(oo0 - olo) + ((PAIR == 2 && part == 1u) ? split_bytes : 0u) : 0u;
                     wp = wp0 = dst0 & ~3u;
                     pend = head0 = dst0 & 3u;
                     uint32_t lit_cum = 0u, before = 0u;  // sizes pass: literal bytes so far, bytes before the split point
@@ -558,7 +684,7 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
                         const bool skip_literal = at_split && part == 1u;   // part 1 enters segment m behind its literal and quote
                         if (WRITE && !skip_literal) {
                             const uint32_t ll = t_lit_len(s), lo_l = t_lit_off(s);
-                            if (cfg.lits_lds != 0xFFFFFFFFu) {
+                            if (FAST || cfg.lits_lds != 0xFFFFFFFFu) {
                                 const uint32_t lit = smem0 + cfg.lits_lds + lo_l;
                                 uint32_t q = 0;
                                 for (; q + 16u <= ll; q += 16u) {  // four words per LDS round trip (the host aligns every literal to 4 bytes)
@@ -614,28 +740,55 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
                                 put_4(__builtin_amdgcn_perm(0x5C5C5C5Cu, w, s_lo));
                                 put_n(__builtin_amdgcn_perm(0x5C5C5C5Cu, w, s_hi), __popc(idx));
                             };
+                            // the last one to three characters of a capture: the same expansion over a word filled up with plain
+                            // characters, cut to the bytes that count
+                            auto put_tail = [&](uint32_t w, uint32_t rem) {
+                                const uint32_t keep = (1u << (8u * rem)) - 1u;
+                                const uint32_t wf = (w & keep) | (0x41414141u & ~keep);
+                                const uint32_t t7 = (wf & 0x7F7F7F7Fu) + 0x60606060u;
+                                if ((~t7 | wf) & 0x80808080u) {
+                                    for (uint32_t q = 0; q < rem; ++q) put1((w >> (8u * q)) & 0xFFu);
+                                    return;
+                                }
+                                const uint32_t x = wf ^ 0x22222222u, y = wf ^ 0x5C5C5C5Cu;
+                                const uint32_t zq = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+                                const uint32_t zb = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
+                                const uint32_t m = (zq | zb) >> 7;
+                                const uint32_t t = m | (m >> 7);
+                                const uint32_t idx = (t | (t >> 14)) & 15u;
+                                const uint32_t sel = perm_tab + idx * 8u;
+                                const uint32_t s_lo = *(JX_LDS const uint32_t*)(uintptr_t)sel, s_hi = *(JX_LDS const uint32_t*)(uintptr_t)(sel + 4u);
+                                const uint32_t cnt = rem + __popc(idx);  // 1..6 bytes
+                                const uint64_t e = (static_cast<uint64_t>(__builtin_amdgcn_perm(0x5C5C5C5Cu, wf, s_hi)) << 32 | __builtin_amdgcn_perm(0x5C5C5C5Cu, wf, s_lo)) &
+                                                   ((1ull << (8u * cnt)) - 1ull);
+                                put_n(static_cast<uint32_t>(e), cnt < 4u ? cnt : 4u);
+                                put_n(static_cast<uint32_t>(e >> 32), cnt > 4u ? cnt - 4u : 0u);
+                            };
                             // the capture's bytes: aligned 32-bit reads (one off its alignment is replayed too) joined by v_alignbyte
-                            int32_t p = c_from;
-                            uint32_t ap = (line + static_cast<uint32_t>(c_from)) & ~3u;
-                            const uint32_t mis = (line + static_cast<uint32_t>(c_from)) & 3u;
-                            uint32_t prev = lds_w(ap);
-                            for (; p + 16 <= c_to; p += 16, ap += 16u) {  // four words per LDS round trip
-                                const uint32_t d0 = lds_w(ap + 4u), d1 = lds_w(ap + 8u), d2 = lds_w(ap + 12u), d3 = lds_w(ap + 16u);
-                                put4(__builtin_amdgcn_alignbyte(d0, prev, mis));
-                                put4(__builtin_amdgcn_alignbyte(d1, d0, mis));
-                                put4(__builtin_amdgcn_alignbyte(d2, d1, mis));
-                                put4(__builtin_amdgcn_alignbyte(d3, d2, mis));
-                                prev = d3;
-                            }
-                            for (; p + 4 <= c_to; p += 4, ap += 4u) {
-                                const uint32_t d = lds_w(ap + 4u);
-                                put4(__builtin_amdgcn_alignbyte(d, prev, mis));
-                                prev = d;
-                            }
-                            if (p < c_to) {
-                                uint32_t w = __builtin_amdgcn_alignbyte(lds_w(ap + 4u), prev, mis);  // (may read past the line: LDS)
-                                for (; p < c_to; ++p, w >>= 8) put1(w & 0xFFu);
-                            }
+                            auto sweep = [&](auto&& on_word, auto&& on_tail) {
+                                int32_t p = c_from;
+                                uint32_t ap = (line + static_cast<uint32_t>(c_from)) & ~3u;
+                                const uint32_t mis = (line + static_cast<uint32_t>(c_from)) & 3u;
+                                uint32_t prev = lds_w(ap);
+                                for (; p + 16 <= c_to; p += 16, ap += 16u) {  // four words per LDS round trip
+                                    const uint32_t d0 = lds_w(ap + 4u), d1 = lds_w(ap + 8u), d2 = lds_w(ap + 12u), d3 = lds_w(ap + 16u);
+                                    on_word(__builtin_amdgcn_alignbyte(d0, prev, mis));
+                                    on_word(__builtin_amdgcn_alignbyte(d1, d0, mis));
+                                    on_word(__builtin_amdgcn_alignbyte(d2, d1, mis));
+                                    on_word(__builtin_amdgcn_alignbyte(d3, d2, mis));
+                                    prev = d3;
+                                }
+                                for (; p + 4 <= c_to; p += 4, ap += 4u) {
+                                    const uint32_t d = lds_w(ap + 4u);
+                                    on_word(__builtin_amdgcn_alignbyte(d, prev, mis));
+                                    prev = d;
+                                }
+                                if (p < c_to) on_tail(__builtin_amdgcn_alignbyte(lds_w(ap + 4u), prev, mis), static_cast<uint32_t>(c_to - p));  // (may read past the line: LDS)
+                            };
+                            if (clean)   // the sizes pass found nothing to escape in this tile: the characters as they are
+                                sweep([&](uint32_t w) { put_4(w); }, [&](uint32_t w, uint32_t rem) { put_n(w & ((1u << (8u * rem)) - 1u), rem); });
+                            else
+                                sweep(put4, put_tail);
                             if (!(at_split && part == 0u)) put_n(0x22u, 1u);
                         } else {
                             // four characters at a time: 4 + one per quote / backslash (+ one per byte >= 0x80 that becomes
@@ -676,9 +829,10 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
                                 count4(__builtin_amdgcn_alignbyte(d, prev, mis));
                                 prev = d;
                             }
-                            if (p < ce) {
-                                uint32_t w = __builtin_amdgcn_alignbyte(lds_w(ap + 4u), prev, mis);
-                                for (; p < ce; ++p, w >>= 8) t += esc_len(w & 0xFFu, pt);
+                            if (p < ce) {  // the last one to three characters: a word filled up with plain ones
+                                const uint32_t rem = static_cast<uint32_t>(ce - p), keep = (1u << (8u * rem)) - 1u;
+                                count4((__builtin_amdgcn_alignbyte(lds_w(ap + 4u), prev, mis) & keep) | (0x41414141u & ~keep));
+                                t -= 4u - rem;
                             }
                             total += t;
                         }
@@ -686,7 +840,9 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
                     if (!WRITE && split != nullptr) split[i] = sp_m < s1 ? before : total;
                 }
                 if (!WRITE) sizes[i] = total;
+                lane_dirty = total != unescaped;
             }
+            if (!WRITE && __ballot(lane_dirty) != 0ull) tile_dirty = 1u;
             if (WRITE) {
                 // the bytes still waiting in the carries: byte stores (the rest of such a dword is the next writer's), once every
                 // writer of the round has done its dword stores.  (A writer that wrote no dword leaves the bytes before its text alone.)
@@ -714,6 +870,7 @@ __global__ void __launch_bounds__(768) k_jsonl_tile(JsonlTemplates tm, JsonlTile
             pair_barrier();
             a = b;
         }
+        if (!WRITE && tile_flags != nullptr && lane == 0u) tile_flags[tile] = tile_dirty ? 0u : 1u;
     }
 }
 
@@ -906,13 +1063,14 @@ hipError_t launch_count_outcomes(const int32_t* match_id, uint64_t n, unsigned l
     return hipGetLastError();
 }
 
-// workspace: u32 sizes[n] | u64 block_sums[nblocks + 2] | u32 split[n] (bytes of a line's text before its split point)
+// workspace: u32 sizes[n] | u64 block_sums[nblocks + 2] | u32 split[n] (bytes of a line's text before its split point) |
+// u32 split_at[n] (the split point itself) | u32 tile_flags[tiles] (1: no captured character of the tile takes an escape)
 static uint64_t jsonl_ws_sums(uint64_t n) { return (n * 4 + 15) & ~static_cast<uint64_t>(15); }
 static uint64_t jsonl_ws_split(uint64_t n) {
     const uint64_t nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     return jsonl_ws_sums(n) + (((nblocks + 2) * 8 + 15) & ~static_cast<uint64_t>(15));
 }
-size_t jsonl_workspace_bytes(uint64_t n) { return static_cast<size_t>(jsonl_ws_split(n) + n * 4 + 64); }
+size_t jsonl_workspace_bytes(uint64_t n) { return static_cast<size_t>(jsonl_ws_split(n) + n * 8 + ((n + 63) >> 6) * 4 + 64); }
 
 namespace {
 // LDS plan of the tile kernels for lines of mean_in bytes producing mean_out bytes of text (0: sizes pass).
@@ -937,9 +1095,30 @@ bool plan_jsonl_tile(const GxJsonl& tm, int slots, uint32_t mean_in, uint32_t me
     const uint32_t per_wave = c.in_bytes + c.out_bytes + c.caps_bytes;
     uint32_t w = (LDS - used) / per_wave;
     if (w < 1) return false;
-    c.waves = std::min<uint32_t>(w, 12u);
+    c.waves = std::min<uint32_t>(w, 12u);   // (the sizes pass: launch bounds of k_jsonl_tile; the write pass runs pairs)
     *cfg = c;
     return true;
+}
+
+// one instantiation of the tile kernel: offsets width, pass, and whether everything the lanes look up sits in LDS
+template <bool WRITE, int PAIR>
+hipError_t launch_jsonl_tile(const JsonlTemplates& t, const JsonlTileCfg& cfg, const GxBatch& b, int slots, int passthrough, unsigned blocks, unsigned threads,
+                             uint32_t lds, uint32_t* sizes, const uint64_t* line_out_off, uint8_t* out, uint32_t* split, uint32_t* split_at, uint32_t* tile_flags,
+                             hipStream_t stream) {
+    const bool fast = cfg.tm_lds != 0xFFFFFFFFu && cfg.lits_lds != 0xFFFFFFFFu && cfg.caps_bytes != 0u;
+    auto go = [&](auto kernel, auto offsets) -> hipError_t {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds, stream, t, cfg, static_cast<const uint8_t*>(b.data), offsets, b.n, b.match_id, b.caps, slots,
+                           passthrough, sizes, line_out_off, out, split, split_at, tile_flags);
+        return hipGetLastError();
+    };
+    if (b.offsets64) {
+        const uint64_t* o = static_cast<const uint64_t*>(b.offsets);
+        return fast ? go(&k_jsonl_tile<uint64_t, WRITE, PAIR, true>, o) : go(&k_jsonl_tile<uint64_t, WRITE, PAIR, false>, o);
+    }
+    const uint32_t* o = static_cast<const uint32_t*>(b.offsets);
+    return fast ? go(&k_jsonl_tile<uint32_t, WRITE, PAIR, true>, o) : go(&k_jsonl_tile<uint32_t, WRITE, PAIR, false>, o);
 }
 }  // namespace
 
@@ -952,6 +1131,8 @@ hipError_t launch_jsonl_sizes(const GxJsonl& tm, const GxBatch& b, int slots, in
     uint32_t* sizes = static_cast<uint32_t*>(workspace);
     uint64_t* block_sums = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(workspace) + jsonl_ws_sums(b.n));
     uint32_t* split = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(workspace) + jsonl_ws_split(b.n));
+    uint32_t* split_at = split + b.n;
+    uint32_t* tile_flags = split_at + b.n;
     JsonlTemplates t{tm.seg_off, tm.lit_off, tm.lit_len, tm.group, tm.fixed_len, tm.lits};
     JsonlTileCfg cfg;
     if (!plan_jsonl_tile(tm, slots, mean_in, 0, &cfg)) return hipErrorInvalidValue;
@@ -959,20 +1140,9 @@ hipError_t launch_jsonl_sizes(const GxJsonl& tm, const GxBatch& b, int slots, in
         const uint32_t lds = cfg.stage0 + cfg.waves * (cfg.in_bytes + cfg.out_bytes + cfg.caps_bytes);
         const uint64_t tiles = (b.n + 63) >> 6;
         uint64_t blocks = std::min<uint64_t>((tiles + cfg.waves - 1) / cfg.waves, 256u * 4u);
-        hipError_t e;
-        if (b.offsets64) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jsonl_tile<uint64_t, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((k_jsonl_tile<uint64_t, false, 1>), dim3(static_cast<unsigned>(blocks)), dim3(cfg.waves * 64), lds, stream, t, cfg,
-                               static_cast<const uint8_t*>(b.data), static_cast<const uint64_t*>(b.offsets), b.n, b.match_id, b.caps, slots, passthrough,
-                               sizes, nullptr, nullptr, split);
-        } else {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jsonl_tile<uint32_t, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((k_jsonl_tile<uint32_t, false, 1>), dim3(static_cast<unsigned>(blocks)), dim3(cfg.waves * 64), lds, stream, t, cfg,
-                               static_cast<const uint8_t*>(b.data), static_cast<const uint32_t*>(b.offsets), b.n, b.match_id, b.caps, slots, passthrough,
-                               sizes, nullptr, nullptr, split);
-        }
+        const hipError_t e = launch_jsonl_tile<false, 1>(t, cfg, b, slots, passthrough, static_cast<unsigned>(blocks), cfg.waves * 64u, lds, sizes, nullptr, nullptr,
+                                                         split, split_at, tile_flags, stream);
+        if (e != hipSuccess) return e;
     }
     if (nblocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_scan_block_sums, dim3(static_cast<unsigned>(nblocks)), dim3(SCAN_THREADS), 0, stream, sizes, b.n, block_sums);
@@ -992,24 +1162,12 @@ hipError_t launch_jsonl_write(const GxJsonl& tm, const GxBatch& b, int slots, in
     // in the workspace the sizes pass of this batch used
     cfg.waves = 2;
     uint32_t* split = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(workspace) + jsonl_ws_split(b.n));
+    uint32_t* split_at = split + b.n;
+    uint32_t* tile_flags = split_at + b.n;
     const uint32_t lds = cfg.stage0 + cfg.in_bytes + cfg.out_bytes + cfg.caps_bytes;
     const uint64_t tiles = (b.n + 63) >> 6;
     const uint64_t blocks = std::min<uint64_t>(tiles, 256u * 16u);
-    hipError_t e;
-    if (b.offsets64) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jsonl_tile<uint64_t, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_jsonl_tile<uint64_t, true, 2>), dim3(static_cast<unsigned>(blocks)), dim3(128), lds, stream, t, cfg,
-                           static_cast<const uint8_t*>(b.data), static_cast<const uint64_t*>(b.offsets), b.n, b.match_id, b.caps, slots, passthrough,
-                           nullptr, line_out_off, out, split);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jsonl_tile<uint32_t, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_jsonl_tile<uint32_t, true, 2>), dim3(static_cast<unsigned>(blocks)), dim3(128), lds, stream, t, cfg,
-                           static_cast<const uint8_t*>(b.data), static_cast<const uint32_t*>(b.offsets), b.n, b.match_id, b.caps, slots, passthrough,
-                           nullptr, line_out_off, out, split);
-    }
-    return hipGetLastError();
+    return launch_jsonl_tile<true, 2>(t, cfg, b, slots, passthrough, static_cast<unsigned>(blocks), 128u, lds, nullptr, line_out_off, out, split, split_at, tile_flags, stream);
 }
 
 }  // namespace gx

@@ -226,3 +226,33 @@ def test_text_to_jsonl_short_lines_need_a_second_split():
     assert text.count(b"\n") == n_matched
     first = next(ln for ln in lines if ln != b"?").decode()
     assert text.split(b"\n")[0] == ('{"k":"%s","v":"%s"}' % (first[0], first[2])).encode()
+
+
+def test_tiles_with_nothing_to_escape_are_copied_verbatim():
+    """The sizes pass marks a 64-line tile whose captures hold no character that JSON escapes; the write pass copies such a
+    tile's captures as they are.  A batch that mixes both kinds of tile (and lines of every length, so that captures start and end at
+    every alignment), with the escapes that make a tile the other kind placed in its first line, its last line, or one in
+    the middle: quotes, backslashes, control characters and bytes >= 0x80 (an escape only without utf8_passthrough)."""
+    gorp = Gorp.construct(W.readme3_definition())
+    rng = random.Random(12)
+    plain = "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789/._-~?=&%+:;,!*'()[]{}<>|^`@#$ "
+    plain = plain.replace(" ", "")   # (the path is \S+)
+    lines, kinds = [], []
+    for tile in range(400):
+        kind = rng.choice(["clean", "clean", "quote", "backslash", "control", "high"])
+        kinds.append(kind)
+        where = rng.choice([0, 63, rng.randrange(64)])
+        for j in range(64):
+            verb = rng.choice(["GET", "PUT", "HEAD", "G#T"])
+            path = "".join(rng.choice(plain) for _ in range(rng.randrange(0, 190)))
+            if kind != "clean" and j == where:
+                ch = {"quote": '"', "backslash": "\\", "control": "\x07", "high": "\xe9"}[kind]
+                at = rng.randrange(len(path) + 1)
+                path = path[:at] + ch + path[at:]
+            lines.append(("[%09d]: %s %dms /%s" % (rng.randrange(10 ** 9), verb, rng.randrange(10000), path)).encode("latin-1"))
+    assert kinds.count("clean") > 100 and kinds.count("high") > 30
+    raw, mid, caps, text = run(gorp, lines, id_as="id")
+    assert (mid >= 0).sum() > 15000
+    run(gorp, lines, id_as=None, utf8_passthrough=True)   # the tiles of kind "high" are verbatim ones now
+    # every line of the batch clean, and the last tile a partial one
+    run(gorp, [ln for ln, k in zip(lines, [k for k in kinds for _ in range(64)]) if k == "clean"][:64 * 50 + 17], id_as="id")

@@ -11,7 +11,7 @@ for path in glob.glob(os.path.join(out, "sq*", "**", "*counter_collection.csv"),
             continue
         short = k.split("(")[0].split("::")[-1][:60]
         if "k_jsonl_tile" in k:
-            short = "k_jsonl_tile<write>" if "k_jsonl_tile<unsigned int, true>" in k or "k_jsonl_tile<unsigned long, true>" in k else "k_jsonl_tile<sizes>"
+            short = "k_jsonl_tile<write>" if "k_jsonl_tile<unsigned int, true" in k or "k_jsonl_tile<unsigned long, true" in k else "k_jsonl_tile<sizes>"
         acc[(short, r["Counter_Name"])].append(float(r["Counter_Value"]))
 for (k, c), v in sorted(acc.items()):
     print("%-62s %-26s %16.0f  (n=%d)" % (k, c, sum(v) / len(v), len(v)))
