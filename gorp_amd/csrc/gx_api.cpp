@@ -126,6 +126,11 @@ struct gx_handle {
     // A slot is reused only after the follow-up kernel of its previous user has run (event).
     static const int N_SLOTS = 32;
     uint32_t* d_slots = nullptr;          // [N_SLOTS] oversize flags, then [N_SLOTS] chunk counters of the lane kernel
+    // device scratch of gx_results_to_jsonl / gx_text_to_jsonl (sizes, split points, line offsets), kept between calls and grown as
+    // batches ask: a hipMalloc + hipFree pair per call cost more than the scan kernels.  Used under `mu` only, and every call that
+    // uses it ends with a stream synchronisation.
+    void* scratch[2] = {nullptr, nullptr};
+    size_t scratch_cap[2] = {0, 0};
     uint32_t chunk_tickets[N_SLOTS] = {};  // what each chunk counter will read when the next launch on its slot begins
     hipEvent_t slot_event[N_SLOTS] = {};
     bool slot_used[N_SLOTS] = {};
@@ -1119,6 +1124,17 @@ struct DevBuf {
     void alloc(size_t bytes) { GX_HIP(hipMalloc(&p, bytes ? bytes : 16)); }
 };
 
+// the handle's scratch buffer `which`, at least `bytes` long (the caller holds h->mu)
+void* handle_scratch(gx_handle* h, int which, size_t bytes) {
+    if (h->scratch_cap[which] < bytes) {
+        if (h->scratch[which]) { (void)hipFree(h->scratch[which]); h->scratch[which] = nullptr; h->scratch_cap[which] = 0; }
+        const size_t cap = bytes + bytes / 8 + 256;
+        GX_HIP(hipMalloc(&h->scratch[which], cap));
+        h->scratch_cap[which] = cap;
+    }
+    return h->scratch[which];
+}
+
 }  // namespace
 
 extern "C" {
@@ -1188,6 +1204,7 @@ void gx_destroy(gx_handle* h) {
         for (int q = 0; q < gx_handle::N_SLOTS; ++q) if (h->slot_event[q]) (void)hipEventDestroy(h->slot_event[q]);
     }
     for (auto& e : h->jsonl) if (e.second.d) (void)hipFree(e.second.d);
+    for (void* q : h->scratch) if (q) (void)hipFree(q);
     if (h->one_dev) (void)hipFree(h->one_dev);
     if (h->one_host) (void)hipHostFree(h->one_host);
     delete h;
@@ -1370,25 +1387,25 @@ int gx_results_to_jsonl(gx_handle* h, const uint8_t* bytes, const void* offsets,
         const GxJsonl& tm = jsonl_templates(h, id_as);
         hipStream_t stream = static_cast<hipStream_t>(o.stream);
         const size_t off_w = o.offsets64 ? 8 : 4;
-        DevBuf ws, d_bytes, d_off, d_mid, d_caps, d_loff, d_out;
-        ws.alloc(jsonl_workspace_bytes(n));
+        DevBuf d_bytes, d_off, d_mid, d_caps, d_out;
+        void* ws = handle_scratch(h, 0, jsonl_workspace_bytes(n));
         GxBatch b{};
         b.n = n;
         b.offsets64 = o.offsets64 ? 1 : 0;
         uint64_t* loff = line_out_offsets;
         if (o.device_pointers) {
             b.data = bytes; b.offsets = offsets; b.match_id = const_cast<int32_t*>(match_id); b.caps = const_cast<int32_t*>(caps);
-            if (!loff) { d_loff.alloc((n + 1) * 8); loff = static_cast<uint64_t*>(d_loff.p); }
+            if (!loff) loff = static_cast<uint64_t*>(handle_scratch(h, 1, (n + 1) * 8));
         } else {
             uint64_t total_in = 0;
             if (n) total_in = o.offsets64 ? static_cast<const uint64_t*>(offsets)[n] : static_cast<const uint32_t*>(offsets)[n];
-            d_bytes.alloc(total_in); d_off.alloc((n + 1) * off_w); d_mid.alloc(n * 4); d_caps.alloc(n * slots * 4); d_loff.alloc((n + 1) * 8);
+            d_bytes.alloc(total_in); d_off.alloc((n + 1) * off_w); d_mid.alloc(n * 4); d_caps.alloc(n * slots * 4);
             if (total_in) GX_HIP(hipMemcpyAsync(d_bytes.p, bytes, total_in, hipMemcpyHostToDevice, stream));
             GX_HIP(hipMemcpyAsync(d_off.p, offsets, (n + 1) * off_w, hipMemcpyHostToDevice, stream));
             if (n) GX_HIP(hipMemcpyAsync(d_mid.p, match_id, n * 4, hipMemcpyHostToDevice, stream));
             if (n && slots) GX_HIP(hipMemcpyAsync(d_caps.p, caps, n * slots * 4, hipMemcpyHostToDevice, stream));
             b.data = d_bytes.p; b.offsets = d_off.p; b.match_id = static_cast<int32_t*>(d_mid.p); b.caps = static_cast<int32_t*>(d_caps.p);
-            loff = static_cast<uint64_t*>(d_loff.p);
+            loff = static_cast<uint64_t*>(handle_scratch(h, 1, (n + 1) * 8));
         }
         // mean line length, for the LDS staging of the kernels (device pointers: from the two ends of the offsets array)
         uint64_t first_off = 0, last_off = 0;
@@ -1403,7 +1420,7 @@ int gx_results_to_jsonl(gx_handle* h, const uint8_t* bytes, const void* offsets,
             }
         }
         const uint32_t mean_in = n ? static_cast<uint32_t>(std::min<uint64_t>((last_off - first_off + n - 1) / n, 1u << 20)) : 1u;
-        GX_HIP(launch_jsonl_sizes(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, mean_in, loff, ws.p, stream));
+        GX_HIP(launch_jsonl_sizes(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, mean_in, loff, ws, stream));
         uint64_t total = 0;
         GX_HIP(hipMemcpyAsync(&total, loff + n, 8, hipMemcpyDeviceToHost, stream));
         GX_HIP(hipStreamSynchronize(stream));
@@ -1414,7 +1431,7 @@ int gx_results_to_jsonl(gx_handle* h, const uint8_t* bytes, const void* offsets,
         uint8_t* dst = out;
         if (!o.device_pointers) { d_out.alloc(total); dst = static_cast<uint8_t*>(d_out.p); }
         const uint32_t mean_out = n ? static_cast<uint32_t>(std::min<uint64_t>((total + n - 1) / n, 1u << 20)) : 1u;
-        GX_HIP(launch_jsonl_write(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, mean_in, mean_out, loff, dst, ws.p, stream));
+        GX_HIP(launch_jsonl_write(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, mean_in, mean_out, loff, dst, ws, stream));
         if (!o.device_pointers && total) GX_HIP(hipMemcpyAsync(out, dst, total, hipMemcpyDeviceToHost, stream));
         GX_HIP(hipStreamSynchronize(stream));
         return GX_OK;
@@ -1437,7 +1454,7 @@ int gx_text_to_jsonl(gx_handle* h, const uint8_t* text, uint64_t size, const cha
         std::lock_guard<std::mutex> lock(h->mu);
         const GxJsonl& tm = jsonl_templates(h, id_as);
         hipStream_t stream = static_cast<hipStream_t>(o.stream);
-        DevBuf d_text, ws_split, d_mid, d_caps, ws_json, d_loff, d_counts, d_out;
+        DevBuf d_text, ws_split, d_mid, d_caps, d_counts, d_out;
         const uint8_t* src = text;
         if (!o.device_pointers) {
             d_text.alloc(size);
@@ -1477,10 +1494,9 @@ int gx_text_to_jsonl(gx_handle* h, const uint8_t* text, uint64_t size, const cha
         d_counts.alloc(16);
         GX_HIP(launch_count_outcomes(b.match_id, n, static_cast<unsigned long long*>(d_counts.p), stream));
         // 3. the text
-        ws_json.alloc(jsonl_workspace_bytes(n));
-        d_loff.alloc((n + 1) * 8);
-        uint64_t* loff = static_cast<uint64_t*>(d_loff.p);
-        GX_HIP(launch_jsonl_sizes(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, mean_in, loff, ws_json.p, stream));
+        void* ws_json = handle_scratch(h, 0, jsonl_workspace_bytes(n));
+        uint64_t* loff = static_cast<uint64_t*>(handle_scratch(h, 1, (n + 1) * 8));
+        GX_HIP(launch_jsonl_sizes(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, mean_in, loff, ws_json, stream));
         uint64_t total = 0;
         unsigned long long counts[2] = {0, 0};
         GX_HIP(hipMemcpyAsync(&total, loff + n, 8, hipMemcpyDeviceToHost, stream));
@@ -1495,7 +1511,7 @@ int gx_text_to_jsonl(gx_handle* h, const uint8_t* text, uint64_t size, const cha
         uint8_t* dst = out;
         if (!o.device_pointers) { d_out.alloc(total); dst = static_cast<uint8_t*>(d_out.p); }
         const uint32_t mean_out = n ? static_cast<uint32_t>(std::min<uint64_t>((total + n - 1) / n, 1u << 20)) : 1u;
-        GX_HIP(launch_jsonl_write(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, mean_in, mean_out, loff, dst, ws_json.p, stream));
+        GX_HIP(launch_jsonl_write(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, mean_in, mean_out, loff, dst, ws_json, stream));
         if (!o.device_pointers && total) GX_HIP(hipMemcpyAsync(out, dst, total, hipMemcpyDeviceToHost, stream));
         GX_HIP(hipStreamSynchronize(stream));
         return GX_OK;

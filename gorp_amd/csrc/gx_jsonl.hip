@@ -616,6 +616,21 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                         pend = np;
                     }
                 };
+                auto put_e = [&](uint32_t e_lo, uint32_t e_hi, uint32_t count) {  // the low `count` (4..8) bytes of e_hi:e_lo; the others are zero
+                    const uint64_t t = (static_cast<uint64_t>(e_hi) << 32 | e_lo) << (8u * pend);
+                    const uint32_t t2 = (e_hi >> 8) >> (24u - 8u * pend);  // what the shift pushed out of the 64 bits
+                    *(JX_LDS uint32_t*)(uintptr_t)wp = carry | static_cast<uint32_t>(t);
+                    const uint32_t np = pend + count;
+                    if (np >= 8u) {
+                        *(JX_LDS uint32_t*)(uintptr_t)(wp + 4u) = static_cast<uint32_t>(t >> 32);
+                        wp += 8u;
+                        carry = t2;
+                    } else {
+                        wp += 4u;
+                        carry = static_cast<uint32_t>(t >> 32);
+                    }
+                    pend = np & 3u;
+                };
                 if (k >= 0) {
                     const int32_t* cp_g = caps + i * static_cast<uint64_t>(slots);
                     const int32_t* cp_l = reinterpret_cast<const int32_t*>(caps_stage) + (lane - a) * static_cast<uint32_t>(slots);
@@ -729,16 +744,14 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                                     for (int q = 0; q < 4; ++q) put1((w >> (8 * q)) & 0xFFu);
                                     return;
                                 }
-                                const uint32_t x = w ^ 0x22222222u, y = w ^ 0x5C5C5C5Cu;
-                                const uint32_t zq = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
-                                const uint32_t zb = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
-                                const uint32_t m = (zq | zb) >> 7;           // bit 8 j: character j takes a backslash
+                                // (every byte is in 0x20..0x7F now: v + 0x7F sets bit 7 of a byte exactly when v != 0, nothing carries)
+                                const uint32_t nq = (w ^ 0x22222222u) + 0x7F7F7F7Fu, nb = (w ^ 0x5C5C5C5Cu) + 0x7F7F7F7Fu;
+                                const uint32_t m = (~(nq & nb) & 0x80808080u) >> 7;  // bit 8 j: character j takes a backslash
                                 const uint32_t t = m | (m >> 7);
                                 const uint32_t idx = (t | (t >> 14)) & 15u;  // bit j: character j
                                 const uint32_t sel = perm_tab + idx * 8u;
                                 const uint32_t s_lo = *(JX_LDS const uint32_t*)(uintptr_t)sel, s_hi = *(JX_LDS const uint32_t*)(uintptr_t)(sel + 4u);
-                                put_4(__builtin_amdgcn_perm(0x5C5C5C5Cu, w, s_lo));
-                                put_n(__builtin_amdgcn_perm(0x5C5C5C5Cu, w, s_hi), __popc(idx));
+                                put_e(__builtin_amdgcn_perm(0x5C5C5C5Cu, w, s_lo), __builtin_amdgcn_perm(0x5C5C5C5Cu, w, s_hi), 4u + __popc(idx));
                             };
                             // the last one to three characters of a capture: the same expansion over a word filled up with plain
                             // characters, cut to the bytes that count
@@ -750,10 +763,8 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                                     for (uint32_t q = 0; q < rem; ++q) put1((w >> (8u * q)) & 0xFFu);
                                     return;
                                 }
-                                const uint32_t x = wf ^ 0x22222222u, y = wf ^ 0x5C5C5C5Cu;
-                                const uint32_t zq = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
-                                const uint32_t zb = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
-                                const uint32_t m = (zq | zb) >> 7;
+                                const uint32_t nq = (wf ^ 0x22222222u) + 0x7F7F7F7Fu, nb = (wf ^ 0x5C5C5C5Cu) + 0x7F7F7F7Fu;
+                                const uint32_t m = (~(nq & nb) & 0x80808080u) >> 7;
                                 const uint32_t t = m | (m >> 7);
                                 const uint32_t idx = (t | (t >> 14)) & 15u;
                                 const uint32_t sel = perm_tab + idx * 8u;
@@ -805,10 +816,11 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                                 if ((~(tt | w)) & 0x80808080u) {  // some byte < 0x20
                                     for (int q = 0; q < 4; ++q) t += esc_len((w >> (8 * q)) & 0xFFu, pt);
                                 } else {
-                                    const uint32_t x = w ^ 0x22222222u, y = w ^ 0x5C5C5C5Cu;
-                                    const uint32_t zq = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
-                                    const uint32_t zb = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
-                                    t += 4u + __popc(zq | zb) + (pt ? 0u : __popc(w & 0x80808080u));
+                                    // (on the low seven bits of every byte, where v + 0x7F sets bit 7 exactly when v != 0 and nothing
+                                    // carries; a byte >= 0x80 is no quote whatever its low bits say)
+                                    const uint32_t w7 = w & 0x7F7F7F7Fu;
+                                    const uint32_t nq = (w7 ^ 0x22222222u) + 0x7F7F7F7Fu, nb = (w7 ^ 0x5C5C5C5Cu) + 0x7F7F7F7Fu;
+                                    t += 4u + __popc(~(nq & nb) & ~w & 0x80808080u) + (pt ? 0u : __popc(w & 0x80808080u));
                                 }
                             };
                             // bytes before the split point: the literals so far, the captures before this one, the opening quote and
