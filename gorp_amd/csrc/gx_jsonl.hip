@@ -591,37 +591,37 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
             // bytes wait in `carry`; the first store of a writer also covers the last bytes of the text before it (the
             // lane before, or the other wave of the pair) with zeros, and those are written by that writer's byte stores
             // after the barrier below, later than every first store of the round.
-            uint32_t wp = 0u, wp0 = 0u, head0 = 0u, carry = 0u, pend = 0u;
+            uint32_t wp = 0u, wp0 = 0u, head0 = 0u, carry = 0u, pend8 = 0u;  // pend8: BITS waiting in carry (0, 8, 16, 24)
             bool lane_dirty = false;
             if (active) {
                 const uint32_t line = lds_addr(in_stage) + skew + static_cast<uint32_t>(o0 - lo);  // LDS byte addresses
                 uint32_t total = 0, unescaped = 0;  // sizes pass: the text's bytes, and what they would be without escapes
                 auto put_4 = [&](uint32_t e) {  // four bytes
-                    const uint64_t t = static_cast<uint64_t>(e) << (8u * pend);
+                    const uint64_t t = static_cast<uint64_t>(e) << pend8;
                     *(JX_LDS uint32_t*)(uintptr_t)wp = carry | static_cast<uint32_t>(t);
                     wp += 4u;
                     carry = static_cast<uint32_t>(t >> 32);
                 };
                 auto put_n = [&](uint32_t e, uint32_t count) {  // the low `count` (0..4) bytes of e; its other bytes are zero
-                    const uint64_t t = static_cast<uint64_t>(e) << (8u * pend);
+                    const uint64_t t = static_cast<uint64_t>(e) << pend8;
                     const uint32_t acc = carry | static_cast<uint32_t>(t);
-                    const uint32_t np = pend + count;
-                    if (np >= 4u) {
+                    const uint32_t np8 = pend8 + 8u * count;
+                    if (np8 >= 32u) {
                         *(JX_LDS uint32_t*)(uintptr_t)wp = acc;
                         wp += 4u;
                         carry = static_cast<uint32_t>(t >> 32);
-                        pend = np - 4u;
+                        pend8 = np8 - 32u;
                     } else {
                         carry = acc;
-                        pend = np;
+                        pend8 = np8;
                     }
                 };
-                auto put_e = [&](uint32_t e_lo, uint32_t e_hi, uint32_t count) {  // the low `count` (4..8) bytes of e_hi:e_lo; the others are zero
-                    const uint64_t t = (static_cast<uint64_t>(e_hi) << 32 | e_lo) << (8u * pend);
-                    const uint32_t t2 = (e_hi >> 8) >> (24u - 8u * pend);  // what the shift pushed out of the 64 bits
+                auto put_e = [&](uint32_t e_lo, uint32_t e_hi, uint32_t extra) {  // the low 4 + extra (0..4) bytes of e_hi:e_lo; the others are zero
+                    const uint64_t t = (static_cast<uint64_t>(e_hi) << 32 | e_lo) << pend8;
+                    const uint32_t t2 = (e_hi >> 8) >> (24u - pend8);  // what the shift pushed out of the 64 bits
                     *(JX_LDS uint32_t*)(uintptr_t)wp = carry | static_cast<uint32_t>(t);
-                    const uint32_t np = pend + count;
-                    if (np >= 8u) {
+                    const uint32_t np8 = pend8 + 32u + 8u * extra;
+                    if (np8 >= 64u) {
                         *(JX_LDS uint32_t*)(uintptr_t)(wp + 4u) = static_cast<uint32_t>(t >> 32);
                         wp += 8u;
                         carry = t2;
@@ -629,7 +629,7 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                         wp += 4u;
                         carry = static_cast<uint32_t>(t >> 32);
                     }
-                    pend = np & 3u;
+                    pend8 = np8 & 24u;
                 };
                 if (k >= 0) {
                     const int32_t* cp_g = caps + i * static_cast<uint64_t>(slots);
@@ -658,32 +658,13 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                     if (WRITE) {
                         // (the sizes pass left it in split_at)
                         if (PAIR == 2 && (split_point >> 16) != 0xFFFFu) { sp_m = s0 + (split_point >> 16); sp_q = (split_point & 0xFFFFu) << 4; }
-                    } else if (split != nullptr) {
-                        uint32_t est_total = 0;
-                        for (uint32_t s = s0; s < s1; ++s) {
-                            const int32_t g = t_group(s);
-                            est_total += t_lit_len(s) + (g < 0 ? 0u : (cap(2 * g) < 0 ? 4u : static_cast<uint32_t>(cap(2 * g + 1) - cap(2 * g)) + 2u));
-                        }
-                        unescaped = est_total;
-                        const uint32_t half = est_total / 2u;
-                        uint32_t cum = 0;
-                        if (s1 - s0 < 0xFFFFu)
-                            for (uint32_t s = s0; s < s1; ++s) {
-                                const int32_t g = t_group(s);
-                                const uint32_t ll = t_lit_len(s);
-                                const bool text = g >= 0 && cap(2 * g) >= 0;
-                                const uint32_t len = text ? static_cast<uint32_t>(cap(2 * g + 1) - cap(2 * g)) : 0u;
-                                const uint32_t e = ll + (g < 0 ? 0u : (text ? len + 2u : 4u));
-                                if (sp_m == s1 && cum + e > half) {
-                                    sp_m = s;
-                                    const uint32_t at = cum + ll + 1u;  // where the capture's characters begin
-                                    sp_q = (text && half > at) ? ((half - at) & ~15u) : 0u;
-                                    if (sp_q > (len & ~15u)) sp_q = len & ~15u;
-                                }
-                                cum += e;
-                            }
-                        split_at[i] = sp_m < s1 ? ((sp_m - s0) << 16 | (sp_q >> 4)) : 0xFFFF0000u;
                     }
+                    // (the sizes pass chooses it inside its one loop over the segments, below: the first place at or past `half` of the
+                    // unescaped text -- half of an ESTIMATE of its size, literals + line, so that no loop has to run ahead to add the
+                    // captures up; the split only balances the two waves, any point is a correct one)
+                    const uint32_t half = (WRITE || split == nullptr) ? 0u : (t_fixed(k) + static_cast<uint32_t>(o1 - o0)) / 2u;
+                    const bool splittable = !WRITE && split != nullptr && s1 - s0 < 0xFFFFu;
+                    uint32_t cum = 0u;  // sizes pass: the unescaped bytes of the segments so far
                     uint32_t s_from = s0, s_to = s1;
                     if (WRITE && PAIR == 2) {
                         if (part == 0u) s_to = sp_m < s1 ? sp_m + 1u : s1;
@@ -691,7 +672,8 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                     }
                     const uint32_t dst0 = WRITE ? lds_addr(out_stage) + oskew + static_cast<uint32_t>(oo0 - olo) + ((PAIR == 2 && part == 1u) ? split_bytes : 0u) : 0u;
                     wp = wp0 = dst0 & ~3u;
-                    pend = head0 = dst0 & 3u;
+                    head0 = dst0 & 3u;
+                    pend8 = head0 * 8u;
                     uint32_t lit_cum = 0u, before = 0u;  // sizes pass: literal bytes so far, bytes before the split point
                     if (!WRITE) total = t_fixed(k);
                     for (uint32_t s = s_from; s < s_to; ++s) {
@@ -713,10 +695,24 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                                 for (uint32_t q = 0; q < ll; ++q) put_n(lit[q], 1u);
                             }
                         }
-                        if (!WRITE && split != nullptr) lit_cum += t_lit_len(s);
                         const int32_t g = t_group(s);
+                        int32_t cb = -1, ce = -1;
+                        if (g >= 0) { cb = cap(2 * g); ce = cap(2 * g + 1); }
+                        if (!WRITE && split != nullptr) {
+                            const uint32_t ll = t_lit_len(s);
+                            lit_cum += ll;
+                            const bool text = g >= 0 && cb >= 0;
+                            const uint32_t len = text ? static_cast<uint32_t>(ce - cb) : 0u;
+                            const uint32_t e = ll + (g < 0 ? 0u : (text ? len + 2u : 4u));
+                            if (splittable && sp_m == s1 && cum + e > half) {
+                                sp_m = s;
+                                const uint32_t at = cum + ll + 1u;  // where the capture's characters begin
+                                sp_q = (text && half > at) ? ((half - at) & ~15u) : 0u;
+                                if (sp_q > (len & ~15u)) sp_q = len & ~15u;
+                            }
+                            cum += e;
+                        }
                         if (g < 0) { if (!WRITE && s == sp_m) before = lit_cum + (total - t_fixed(k)); continue; }
-                        const int32_t cb = cap(2 * g), ce = cap(2 * g + 1);
                         if (cb < 0) {
                             if (WRITE) { if (!skip_literal) put_4(0x6C6C756Eu); }  // null (part 0's, with the literal)
                             else { total += 4u; if (s == sp_m) before = lit_cum + (total - t_fixed(k)); }
@@ -738,20 +734,29 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                                 put_n(static_cast<uint32_t>(e), cnt < 4u ? cnt : 4u);
                                 if (cnt > 4u) put_n(static_cast<uint32_t>(e >> 32), cnt - 4u);
                             };
-                            auto put4 = [&](uint32_t w) {
-                                const uint32_t t7 = (w & 0x7F7F7F7Fu) + 0x60606060u;
-                                if ((~t7 | w) & 0x80808080u) {  // a control character or a byte >= 0x80
-                                    for (int q = 0; q < 4; ++q) put1((w >> (8 * q)) & 0xFFu);
-                                    return;
-                                }
-                                // (every byte is in 0x20..0x7F now: v + 0x7F sets bit 7 of a byte exactly when v != 0, nothing carries)
+                            auto put4_plain = [&](uint32_t w) {  // every byte in 0x20..0x7F
+                                // (v + 0x7F sets bit 7 of such a byte exactly when v != 0, and nothing carries)
                                 const uint32_t nq = (w ^ 0x22222222u) + 0x7F7F7F7Fu, nb = (w ^ 0x5C5C5C5Cu) + 0x7F7F7F7Fu;
                                 const uint32_t m = (~(nq & nb) & 0x80808080u) >> 7;  // bit 8 j: character j takes a backslash
                                 const uint32_t t = m | (m >> 7);
                                 const uint32_t idx = (t | (t >> 14)) & 15u;  // bit j: character j
                                 const uint32_t sel = perm_tab + idx * 8u;
                                 const uint32_t s_lo = *(JX_LDS const uint32_t*)(uintptr_t)sel, s_hi = *(JX_LDS const uint32_t*)(uintptr_t)(sel + 4u);
-                                put_e(__builtin_amdgcn_perm(0x5C5C5C5Cu, w, s_lo), __builtin_amdgcn_perm(0x5C5C5C5Cu, w, s_hi), 4u + __popc(idx));
+                                put_e(__builtin_amdgcn_perm(0x5C5C5C5Cu, w, s_lo), __builtin_amdgcn_perm(0x5C5C5C5Cu, w, s_hi), __popc(idx));
+                            };
+                            auto odd = [&](uint32_t w) {  // bit 7 of a byte: a control character or a byte >= 0x80
+                                return ~((w & 0x7F7F7F7Fu) + 0x60606060u) | w;
+                            };
+                            auto put4 = [&](uint32_t w) {
+                                if (odd(w) & 0x80808080u) {
+                                    for (int q = 0; q < 4; ++q) put1((w >> (8 * q)) & 0xFFu);
+                                    return;
+                                }
+                                put4_plain(w);
+                            };
+                            auto put16 = [&](uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {  // one test for the sixteen
+                                if ((odd(w0) | odd(w1) | odd(w2) | odd(w3)) & 0x80808080u) { put4(w0); put4(w1); put4(w2); put4(w3); }
+                                else { put4_plain(w0); put4_plain(w1); put4_plain(w2); put4_plain(w3); }
                             };
                             // the last one to three characters of a capture: the same expansion over a word filled up with plain
                             // characters, cut to the bytes that count
@@ -776,17 +781,15 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                                 put_n(static_cast<uint32_t>(e >> 32), cnt > 4u ? cnt - 4u : 0u);
                             };
                             // the capture's bytes: aligned 32-bit reads (one off its alignment is replayed too) joined by v_alignbyte
-                            auto sweep = [&](auto&& on_word, auto&& on_tail) {
+                            auto sweep = [&](auto&& on_chunk, auto&& on_word, auto&& on_tail) {
                                 int32_t p = c_from;
                                 uint32_t ap = (line + static_cast<uint32_t>(c_from)) & ~3u;
                                 const uint32_t mis = (line + static_cast<uint32_t>(c_from)) & 3u;
                                 uint32_t prev = lds_w(ap);
                                 for (; p + 16 <= c_to; p += 16, ap += 16u) {  // four words per LDS round trip
                                     const uint32_t d0 = lds_w(ap + 4u), d1 = lds_w(ap + 8u), d2 = lds_w(ap + 12u), d3 = lds_w(ap + 16u);
-                                    on_word(__builtin_amdgcn_alignbyte(d0, prev, mis));
-                                    on_word(__builtin_amdgcn_alignbyte(d1, d0, mis));
-                                    on_word(__builtin_amdgcn_alignbyte(d2, d1, mis));
-                                    on_word(__builtin_amdgcn_alignbyte(d3, d2, mis));
+                                    on_chunk(__builtin_amdgcn_alignbyte(d0, prev, mis), __builtin_amdgcn_alignbyte(d1, d0, mis), __builtin_amdgcn_alignbyte(d2, d1, mis),
+                                             __builtin_amdgcn_alignbyte(d3, d2, mis));
                                     prev = d3;
                                 }
                                 for (; p + 4 <= c_to; p += 4, ap += 4u) {
@@ -797,9 +800,10 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                                 if (p < c_to) on_tail(__builtin_amdgcn_alignbyte(lds_w(ap + 4u), prev, mis), static_cast<uint32_t>(c_to - p));  // (may read past the line: LDS)
                             };
                             if (clean)   // the sizes pass found nothing to escape in this tile: the characters as they are
-                                sweep([&](uint32_t w) { put_4(w); }, [&](uint32_t w, uint32_t rem) { put_n(w & ((1u << (8u * rem)) - 1u), rem); });
+                                sweep([&](uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) { put_4(w0); put_4(w1); put_4(w2); put_4(w3); }, [&](uint32_t w) { put_4(w); },
+                                      [&](uint32_t w, uint32_t rem) { put_n(w & ((1u << (8u * rem)) - 1u), rem); });
                             else
-                                sweep(put4, put_tail);
+                                sweep(put16, put4, put_tail);
                             if (!(at_split && part == 0u)) put_n(0x22u, 1u);
                         } else {
                             // four characters at a time: 4 + one per quote / backslash (+ one per byte >= 0x80 that becomes
@@ -849,7 +853,11 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                             total += t;
                         }
                     }
-                    if (!WRITE && split != nullptr) split[i] = sp_m < s1 ? before : total;
+                    if (!WRITE && split != nullptr) {
+                        split[i] = sp_m < s1 ? before : total;
+                        split_at[i] = sp_m < s1 ? ((sp_m - s0) << 16 | (sp_q >> 4)) : 0xFFFF0000u;
+                        unescaped = cum;
+                    }
                 }
                 if (!WRITE) sizes[i] = total;
                 lane_dirty = total != unescaped;
@@ -860,7 +868,7 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                 // writer of the round has done its dword stores.  (A writer that wrote no dword leaves the bytes before its text alone.)
                 pair_barrier();
                 if (active && k >= 0)
-                    for (uint32_t q = (wp == wp0 ? head0 : 0u); q < pend; ++q) lds_put_u8(wp + q, (carry >> (8u * q)) & 0xFFu);
+                    for (uint32_t q = (wp == wp0 ? head0 : 0u); q < (pend8 >> 3); ++q) lds_put_u8(wp + q, (carry >> (8u * q)) & 0xFFu);
             }
             if (WRITE) {
                 // ---- flush: the round's text is the contiguous span [olo, ohi) of the output ----
