@@ -2081,6 +2081,9 @@ int gx_definition_to_json(const char* definition_text, const char* source_ref, c
 // Developer build only (libgorp_hip_dev.so, `python -m gorp_amd.build --dev`): the tile kernel adds up the cycles
 // each wave spends in its four phases (stage, prefetch issue, walk, results) into this device buffer,
 // 4 x uint64 per wave of the grid (256 workgroups x 12 waves at most).  Not part of the product ABI.
+namespace gx { hipError_t jsonl_dev_phases(unsigned long long* out16, int reset); }
+// cycles per phase of the JSONL tile kernels summed over their waves since the last reset: [0..5] sizes pass, [8..13] write pass
+extern "C" int gx_dev_jsonl_phases(unsigned long long* out16, int reset) { return gx::jsonl_dev_phases(out16, reset) == hipSuccess ? GX_OK : GX_E_DEVICE; }
 extern "C" int gx_dev_set_stamps(gx_handle* h, void* device_buffer) {
     if (!h) return GX_E_ARG;
     h->dev_stamps = static_cast<unsigned long long*>(device_buffer);

@@ -259,6 +259,14 @@ __device__ void line_write_wave(const JsonlTemplates& tm, const uint8_t* __restr
 // single line that does not fit goes through line_size_wave / line_write_wave.
 extern __shared__ __attribute__((aligned(16))) uint8_t jx_smem[];
 
+#ifdef GX_DEV
+// developer build: cycles per phase of the tile kernels, summed over the waves (tools/jsonl_phases.py)
+__device__ unsigned long long jx_phase[16];
+#define JX_STAMP(slot) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[slot] += now_ - ph_t; ph_t = now_; } while (0)
+#else
+#define JX_STAMP(slot) do { } while (0)
+#endif
+
 struct JsonlTileCfg {
     uint32_t lits_lds;    // LDS offset of a copy of tm.lits, or 0xFFFFFFFF: read them from global memory
     uint32_t lits_bytes;
@@ -409,11 +417,11 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
         }
     };
     // LDS copies of the template arrays, when they are small enough (plan_jsonl_tile)
+    // (seg_off[n_rules + 1] | fixed_len[n_rules] | up to the next 16 bytes | one uint4 per segment: lit_off, lit_len, group, 0)
     uint32_t* tl_seg_off = reinterpret_cast<uint32_t*>(jx_smem + (cfg.tm_lds == 0xFFFFFFFFu ? 0u : cfg.tm_lds));
     uint32_t* tl_fixed = tl_seg_off + (cfg.n_rules + 1u);
-    uint32_t* tl_lit_off = tl_fixed + cfg.n_rules;
-    uint32_t* tl_lit_len = tl_lit_off + cfg.n_segs;
-    int32_t* tl_group = reinterpret_cast<int32_t*>(tl_lit_len + cfg.n_segs);
+    const uint32_t tm_seg_rel = ((2u * cfg.n_rules + 1u) * 4u + 15u) & ~15u;
+    uint4* tl_seg = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(tl_seg_off) + tm_seg_rel);
     const uint32_t smem0 = lds_addr(jx_smem);
     const uint32_t perm_tab = smem0 + cfg.perm_lds;
     if (WRITE && threadIdx.x < 16u) {
@@ -433,13 +441,12 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
     if (cfg.tm_lds != 0xFFFFFFFFu) {
         for (uint32_t q = threadIdx.x; q <= cfg.n_rules; q += blockDim.x) tl_seg_off[q] = tm.seg_off[q];
         for (uint32_t q = threadIdx.x; q < cfg.n_rules; q += blockDim.x) tl_fixed[q] = tm.fixed_len[q];
-        for (uint32_t q = threadIdx.x; q < cfg.n_segs; q += blockDim.x) {
-            tl_lit_off[q] = tm.lit_off[q];
-            tl_lit_len[q] = tm.lit_len[q];
-            tl_group[q] = tm.group[q];
-        }
+        for (uint32_t q = threadIdx.x; q < cfg.n_segs; q += blockDim.x) tl_seg[q] = make_uint4(tm.lit_off[q], tm.lit_len[q], static_cast<uint32_t>(tm.group[q]), 0u);
     }
     __syncthreads();
+#ifdef GX_DEV
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
+#endif
     const uint32_t per_wave = cfg.in_bytes + cfg.out_bytes + cfg.caps_bytes;
     uint8_t* in_stage = jx_smem + cfg.stage0 + wave * per_wave;
     uint8_t* out_stage = in_stage + cfg.in_bytes;
@@ -475,8 +482,17 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
             nx_at = valid ? split_at[i] : 0xFFFF0000u;
         }
     };
-    auto fetch_bounds = [&](uint64_t t) {  // (uniform addresses)
-        if (t >= tiles) return;
+    // (uniform addresses, but the loads must be VECTOR loads: scalar ones land in SGPRs, of which the kernel has none to spare -- the
+    // compiler parks them in VGPR lanes at once, and for that waits for them where they are issued: a trip to memory per tile)
+    auto in_vgpr = [&](uint64_t v) -> uint64_t {
+        uint32_t lo, hi;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(lo) : "s"(static_cast<uint32_t>(v)));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(hi) : "s"(static_cast<uint32_t>(v >> 32)));
+        return static_cast<uint64_t>(hi) << 32 | lo;
+    };
+    auto fetch_bounds = [&](uint64_t t_uniform) {
+        if (t_uniform >= tiles) return;
+        const uint64_t t = in_vgpr(t_uniform);
         const uint64_t e0 = t << 6, e1 = min(n, e0 + 64u);
         bd_lo = off[e0]; bd_hi = off[e1];
         if (WRITE) { bd_olo = out_off[e0]; bd_ohi = out_off[e1]; bd_flag = tile_flags[t]; }
@@ -508,9 +524,12 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
         {
             const uint64_t t1 = tile + wstride;
             if (t1 < tiles) {
-                fetch_lane_offsets(t1);
+                // (everything that is read here arrived long ago; it is read BEFORE the first new load is issued, or the wait for it
+                // -- the counter of loads in flight cannot tell old from new -- would be a wait for the new loads: a trip to memory per tile)
                 const uint64_t n_lo = uni(bd_lo), n_hi = uni(bd_hi), n_olo = uni(bd_olo), n_ohi = uni(bd_ohi);
-                nx_flag = bd_flag;
+                nx_flag = uni(bd_flag);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch_lane_offsets(t1);
                 const uint32_t lines1 = static_cast<uint32_t>(min(static_cast<uint64_t>(64), n - (t1 << 6)));
                 const uint32_t words = lines1 * static_cast<uint32_t>(slots);
                 bool one_round = WRITE && (n_hi - n_lo) + static_cast<uint32_t>(reinterpret_cast<uintptr_t>(data + n_lo) & 15u) <= cfg.in_bytes;
@@ -534,6 +553,7 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                 fetch_bounds(t1 + wstride);
             }
         }
+        JX_STAMP(0);  // registers -> LDS of this tile (waits for its loads), loads of the next one issued
         uint32_t a = 0;
         while (a < group_lines) {
             // ---- the round: lanes [a, b) whose input (and output) fit the staging areas ----
@@ -585,6 +605,7 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                 }
                 pair_barrier();
             }
+            JX_STAMP(1);  // staging inside the round + the barrier that ends staging
             // ---- lane = line ----
             // The write pass: a lane's text leaves through ALIGNED 32-bit stores (a 32-bit LDS store off its alignment is
             // replayed at 64 cycles, measured: SQ_LDS_UNALIGNED_STALL was 88 % of the LDS-active cycles).  Up to three
@@ -631,26 +652,44 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                     }
                     pend8 = np8 & 24u;
                 };
+                // The same without a branch, for text that more text of the same writer follows (at least four bytes that it stores
+                // itself): the second dword is stored whether it is complete or not -- an incomplete one is what waits in `carry`, zeros
+                // above it, and the writer's next store, at that very address, puts the whole dword there.  (Never the last store of a
+                // writer: the zeros would land on the first bytes of the text behind it, whose writer stored them long before.)
+                // Straight-line code: the four words of sixteen characters make one basic block, and their four table reads one
+                // LDS round trip instead of four.
+                auto put_e_fast = [&](uint32_t e_lo, uint32_t e_hi, uint32_t extra) {
+                    const uint64_t t = (static_cast<uint64_t>(e_hi) << 32 | e_lo) << pend8;
+                    const uint32_t t2 = (e_hi >> 8) >> (24u - pend8);
+                    *(JX_LDS uint32_t*)(uintptr_t)wp = carry | static_cast<uint32_t>(t);
+                    *(JX_LDS uint32_t*)(uintptr_t)(wp + 4u) = static_cast<uint32_t>(t >> 32);
+                    const uint32_t np8 = pend8 + 32u + 8u * extra;   // 32 .. 88
+                    carry = np8 >= 64u ? t2 : static_cast<uint32_t>(t >> 32);
+                    wp += 4u + ((np8 >> 4) & 4u);
+                    pend8 = np8 & 24u;
+                };
                 if (k >= 0) {
                     const int32_t* cp_g = caps + i * static_cast<uint64_t>(slots);
                     const int32_t* cp_l = reinterpret_cast<const int32_t*>(caps_stage) + (lane - a) * static_cast<uint32_t>(slots);
                     const uint32_t caps_row = lds_addr(caps_stage) + (lane - a) * static_cast<uint32_t>(slots) * 4u;
-                    const uint32_t tmb = smem0 + cfg.tm_lds;   // FAST: seg_off | fixed_len | lit_off | lit_len | group
-                    const uint32_t tm_fixed = tmb + (cfg.n_rules + 1u) * 4u, tm_lit_off = tm_fixed + cfg.n_rules * 4u, tm_lit_len = tm_lit_off + cfg.n_segs * 4u,
-                                   tm_group = tm_lit_len + cfg.n_segs * 4u;
+                    const uint32_t tmb = smem0 + cfg.tm_lds;   // FAST: the template arrays' LDS copy (see tl_seg)
+                    const uint32_t tm_fixed = tmb + (cfg.n_rules + 1u) * 4u, tm_seg = tmb + tm_seg_rel;
                     auto cap = [&](int idx) -> int32_t {
                         if (FAST) return static_cast<int32_t>(lds_w(caps_row + static_cast<uint32_t>(idx) * 4u));
                         return cfg.caps_bytes ? cp_l[idx] : cp_g[idx];
                     };
                     auto t_seg_off = [&](uint32_t x) -> uint32_t { if (FAST) return lds_w(tmb + x * 4u); return cfg.tm_lds != 0xFFFFFFFFu ? tl_seg_off[x] : tm.seg_off[x]; };
                     auto t_fixed = [&](uint32_t x) -> uint32_t { if (FAST) return lds_w(tm_fixed + x * 4u); return cfg.tm_lds != 0xFFFFFFFFu ? tl_fixed[x] : tm.fixed_len[x]; };
-                    auto t_lit_off = [&](uint32_t x) -> uint32_t { if (FAST) return lds_w(tm_lit_off + x * 4u); return cfg.tm_lds != 0xFFFFFFFFu ? tl_lit_off[x] : tm.lit_off[x]; };
-                    auto t_lit_len = [&](uint32_t x) -> uint32_t { if (FAST) return lds_w(tm_lit_len + x * 4u); return cfg.tm_lds != 0xFFFFFFFFu ? tl_lit_len[x] : tm.lit_len[x]; };
-                    auto t_group = [&](uint32_t x) -> int32_t {
-                        if (FAST) return static_cast<int32_t>(lds_w(tm_group + x * 4u));
-                        return cfg.tm_lds != 0xFFFFFFFFu ? tl_group[x] : tm.group[x];
+                    auto seg_rec = [&](uint32_t x) -> uint4 {  // lit_off, lit_len, group of segment x
+                        if (FAST) {  // one ds_read_b128
+                            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                            const u32x4 r = *(JX_LDS const u32x4*)(uintptr_t)(tm_seg + x * 16u);
+                            return make_uint4(r.x, r.y, r.z, r.w);
+                        }
+                        if (cfg.tm_lds != 0xFFFFFFFFu) return tl_seg[x];
+                        return make_uint4(tm.lit_off[x], tm.lit_len[x], static_cast<uint32_t>(tm.group[x]), 0u);
                     };
-                    const uint32_t s0 = t_seg_off(k), s1 = t_seg_off(k + 1);
+                    const uint32_t s0 = t_seg_off(k), s1 = t_seg_off(k + 1), fixed_k = t_fixed(k);
                     // ---- the split point (m, q): part 0 writes the segments before m, m's literal and -- m has a capture that
                     // is not null -- the opening quote and q characters of it (q a multiple of 16); part 1 the rest.  From the
                     // unescaped sizes: the first place at or past the middle of the text.  m == s1: no split. ----
@@ -662,7 +701,10 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                     // (the sizes pass chooses it inside its one loop over the segments, below: the first place at or past `half` of the
                     // unescaped text -- half of an ESTIMATE of its size, literals + line, so that no loop has to run ahead to add the
                     // captures up; the split only balances the two waves, any point is a correct one)
-                    const uint32_t half = (WRITE || split == nullptr) ? 0u : (t_fixed(k) + static_cast<uint32_t>(o1 - o0)) / 2u;
+                    #ifndef JX_SPLIT_256
+#define JX_SPLIT_256 112   // 0.44: the first wave of a pair has the many short segments, measured best of 96..160
+#endif
+                    const uint32_t half = (WRITE || split == nullptr) ? 0u : ((fixed_k + static_cast<uint32_t>(o1 - o0)) * JX_SPLIT_256) >> 8;
                     const bool splittable = !WRITE && split != nullptr && s1 - s0 < 0xFFFFu;
                     uint32_t cum = 0u;  // sizes pass: the unescaped bytes of the segments so far
                     uint32_t s_from = s0, s_to = s1;
@@ -675,12 +717,27 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                     head0 = dst0 & 3u;
                     pend8 = head0 * 8u;
                     uint32_t lit_cum = 0u, before = 0u;  // sizes pass: literal bytes so far, bytes before the split point
-                    if (!WRITE) total = t_fixed(k);
+                    if (!WRITE) total = fixed_k;
+                    // The loop over the segments looks nothing up that it then waits for: a segment's record arrives while the segment
+                    // two before it is written, its capture offsets (which need the record's group) during the one before it.
+                    uint4 rec_n = make_uint4(0u, 0u, 0xFFFFFFFFu, 0u), rec_nn = rec_n;
+                    int32_t cb_n = -1, ce_n = -1;
+                    if (s_from < s_to) {
+                        rec_n = seg_rec(s_from);
+                        if (s_from + 1u < s_to) rec_nn = seg_rec(s_from + 1u);
+                        if (static_cast<int32_t>(rec_n.z) >= 0) { cb_n = cap(2 * static_cast<int32_t>(rec_n.z)); ce_n = cap(2 * static_cast<int32_t>(rec_n.z) + 1); }
+                    }
                     for (uint32_t s = s_from; s < s_to; ++s) {
+                        const uint4 rec = rec_n;
+                        const int32_t cb = cb_n, ce = ce_n;
+                        rec_n = rec_nn;
+                        cb_n = ce_n = -1;
+                        if (s + 1u < s_to && static_cast<int32_t>(rec_n.z) >= 0) { cb_n = cap(2 * static_cast<int32_t>(rec_n.z)); ce_n = cap(2 * static_cast<int32_t>(rec_n.z) + 1); }
+                        if (s + 2u < s_to) rec_nn = seg_rec(s + 2u);
                         const bool at_split = WRITE && PAIR == 2 && s == sp_m;
                         const bool skip_literal = at_split && part == 1u;   // part 1 enters segment m behind its literal and quote
                         if (WRITE && !skip_literal) {
-                            const uint32_t ll = t_lit_len(s), lo_l = t_lit_off(s);
+                            const uint32_t ll = rec.y, lo_l = rec.x;
                             if (FAST || cfg.lits_lds != 0xFFFFFFFFu) {
                                 const uint32_t lit = smem0 + cfg.lits_lds + lo_l;
                                 uint32_t q = 0;
@@ -695,11 +752,9 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                                 for (uint32_t q = 0; q < ll; ++q) put_n(lit[q], 1u);
                             }
                         }
-                        const int32_t g = t_group(s);
-                        int32_t cb = -1, ce = -1;
-                        if (g >= 0) { cb = cap(2 * g); ce = cap(2 * g + 1); }
+                        const int32_t g = static_cast<int32_t>(rec.z);
                         if (!WRITE && split != nullptr) {
-                            const uint32_t ll = t_lit_len(s);
+                            const uint32_t ll = rec.y;
                             lit_cum += ll;
                             const bool text = g >= 0 && cb >= 0;
                             const uint32_t len = text ? static_cast<uint32_t>(ce - cb) : 0u;
@@ -712,10 +767,10 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                             }
                             cum += e;
                         }
-                        if (g < 0) { if (!WRITE && s == sp_m) before = lit_cum + (total - t_fixed(k)); continue; }
+                        if (g < 0) { if (!WRITE && s == sp_m) before = lit_cum + (total - fixed_k); continue; }
                         if (cb < 0) {
                             if (WRITE) { if (!skip_literal) put_4(0x6C6C756Eu); }  // null (part 0's, with the literal)
-                            else { total += 4u; if (s == sp_m) before = lit_cum + (total - t_fixed(k)); }
+                            else { total += 4u; if (s == sp_m) before = lit_cum + (total - fixed_k); }
                             continue;
                         }
                         // the characters [c_from, c_to) of the capture
@@ -758,6 +813,23 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                                 if ((odd(w0) | odd(w1) | odd(w2) | odd(w3)) & 0x80808080u) { put4(w0); put4(w1); put4(w2); put4(w3); }
                                 else { put4_plain(w0); put4_plain(w1); put4_plain(w2); put4_plain(w3); }
                             };
+                            auto esc_index = [&](uint32_t w) {  // bit j: character j of the word (all in 0x20..0x7F) takes a backslash
+                                const uint32_t nq = (w ^ 0x22222222u) + 0x7F7F7F7Fu, nb = (w ^ 0x5C5C5C5Cu) + 0x7F7F7F7Fu;
+                                const uint32_t m = (~(nq & nb) & 0x80808080u) >> 7;
+                                const uint32_t t = m | (m >> 7);
+                                return (t | (t >> 14)) & 15u;
+                            };
+                            auto put16_fast = [&](uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {  // sixteen characters that more follow
+                                if ((odd(w0) | odd(w1) | odd(w2) | odd(w3)) & 0x80808080u) { put4(w0); put4(w1); put4(w2); put4(w3); return; }
+                                const uint32_t i0 = esc_index(w0), i1 = esc_index(w1), i2 = esc_index(w2), i3 = esc_index(w3);
+                                const uint32_t a0 = perm_tab + i0 * 8u, a1 = perm_tab + i1 * 8u, a2 = perm_tab + i2 * 8u, a3 = perm_tab + i3 * 8u;
+                                const uint32_t l0 = lds_w(a0), h0 = lds_w(a0 + 4u), l1 = lds_w(a1), h1 = lds_w(a1 + 4u), l2 = lds_w(a2), h2 = lds_w(a2 + 4u),
+                                               l3 = lds_w(a3), h3 = lds_w(a3 + 4u);
+                                put_e_fast(__builtin_amdgcn_perm(0x5C5C5C5Cu, w0, l0), __builtin_amdgcn_perm(0x5C5C5C5Cu, w0, h0), __popc(i0));
+                                put_e_fast(__builtin_amdgcn_perm(0x5C5C5C5Cu, w1, l1), __builtin_amdgcn_perm(0x5C5C5C5Cu, w1, h1), __popc(i1));
+                                put_e_fast(__builtin_amdgcn_perm(0x5C5C5C5Cu, w2, l2), __builtin_amdgcn_perm(0x5C5C5C5Cu, w2, h2), __popc(i2));
+                                put_e_fast(__builtin_amdgcn_perm(0x5C5C5C5Cu, w3, l3), __builtin_amdgcn_perm(0x5C5C5C5Cu, w3, h3), __popc(i3));
+                            };
                             // the last one to three characters of a capture: the same expansion over a word filled up with plain
                             // characters, cut to the bytes that count
                             auto put_tail = [&](uint32_t w, uint32_t rem) {
@@ -781,11 +853,17 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                                 put_n(static_cast<uint32_t>(e >> 32), cnt > 4u ? cnt - 4u : 0u);
                             };
                             // the capture's bytes: aligned 32-bit reads (one off its alignment is replayed too) joined by v_alignbyte
-                            auto sweep = [&](auto&& on_chunk, auto&& on_word, auto&& on_tail) {
+                            auto sweep = [&](auto&& on_chunk_more, auto&& on_chunk, auto&& on_word, auto&& on_tail) {
                                 int32_t p = c_from;
                                 uint32_t ap = (line + static_cast<uint32_t>(c_from)) & ~3u;
                                 const uint32_t mis = (line + static_cast<uint32_t>(c_from)) & 3u;
                                 uint32_t prev = lds_w(ap);
+                                for (; p + 32 <= c_to; p += 16, ap += 16u) {  // sixteen characters that sixteen more follow
+                                    const uint32_t d0 = lds_w(ap + 4u), d1 = lds_w(ap + 8u), d2 = lds_w(ap + 12u), d3 = lds_w(ap + 16u);
+                                    on_chunk_more(__builtin_amdgcn_alignbyte(d0, prev, mis), __builtin_amdgcn_alignbyte(d1, d0, mis), __builtin_amdgcn_alignbyte(d2, d1, mis),
+                                                  __builtin_amdgcn_alignbyte(d3, d2, mis));
+                                    prev = d3;
+                                }
                                 for (; p + 16 <= c_to; p += 16, ap += 16u) {  // four words per LDS round trip
                                     const uint32_t d0 = lds_w(ap + 4u), d1 = lds_w(ap + 8u), d2 = lds_w(ap + 12u), d3 = lds_w(ap + 16u);
                                     on_chunk(__builtin_amdgcn_alignbyte(d0, prev, mis), __builtin_amdgcn_alignbyte(d1, d0, mis), __builtin_amdgcn_alignbyte(d2, d1, mis),
@@ -800,10 +878,11 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                                 if (p < c_to) on_tail(__builtin_amdgcn_alignbyte(lds_w(ap + 4u), prev, mis), static_cast<uint32_t>(c_to - p));  // (may read past the line: LDS)
                             };
                             if (clean)   // the sizes pass found nothing to escape in this tile: the characters as they are
-                                sweep([&](uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) { put_4(w0); put_4(w1); put_4(w2); put_4(w3); }, [&](uint32_t w) { put_4(w); },
-                                      [&](uint32_t w, uint32_t rem) { put_n(w & ((1u << (8u * rem)) - 1u), rem); });
-                            else
-                                sweep(put16, put4, put_tail);
+                            {
+                                auto copy16 = [&](uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) { put_4(w0); put_4(w1); put_4(w2); put_4(w3); };
+                                sweep(copy16, copy16, [&](uint32_t w) { put_4(w); }, [&](uint32_t w, uint32_t rem) { put_n(w & ((1u << (8u * rem)) - 1u), rem); });
+                            } else
+                                sweep(put16_fast, put16, put4, put_tail);
                             if (!(at_split && part == 0u)) put_n(0x22u, 1u);
                         } else {
                             // four characters at a time: 4 + one per quote / backslash (+ one per byte >= 0x80 that becomes
@@ -829,7 +908,7 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                             };
                             // bytes before the split point: the literals so far, the captures before this one, the opening quote and
                             // the characters before p_split (t counts both quotes: t - 1)
-                            auto mark = [&]() { before = lit_cum + (total - t_fixed(k)) + t - 1u; };
+                            auto mark = [&]() { before = lit_cum + (total - fixed_k) + t - 1u; };
                             for (; p + 16 <= ce; p += 16, ap += 16u) {  // four aligned words per LDS round trip
                                 if (is_m && p == p_split) mark();
                                 const uint32_t d0 = lds_w(ap + 4u), d1 = lds_w(ap + 8u), d2 = lds_w(ap + 12u), d3 = lds_w(ap + 16u);
@@ -863,35 +942,69 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                 lane_dirty = total != unescaped;
             }
             if (!WRITE && __ballot(lane_dirty) != 0ull) tile_dirty = 1u;
+            JX_STAMP(2);  // the lanes' work
             if (WRITE) {
                 // the bytes still waiting in the carries: byte stores (the rest of such a dword is the next writer's), once every
                 // writer of the round has done its dword stores.  (A writer that wrote no dword leaves the bytes before its text alone.)
                 pair_barrier();
+                JX_STAMP(3);  // waiting for the other wave of the pair
                 if (active && k >= 0)
                     for (uint32_t q = (wp == wp0 ? head0 : 0u); q < (pend8 >> 3); ++q) lds_put_u8(wp + q, (carry >> (8u * q)) & 0xFFu);
             }
             if (WRITE) {
                 // ---- flush: the round's text is the contiguous span [olo, ohi) of the output ----
                 pair_barrier();
+                JX_STAMP(4);  // carries + barrier
                 const uint64_t ohi = uni(static_cast<uint64_t>(__shfl(static_cast<unsigned long long>(oo1), static_cast<int>(b - 1u))));
                 const uint32_t span = static_cast<uint32_t>(ohi - olo);
                 uint8_t* g_al = out + olo - oskew;  // 16-byte aligned
                 const uint32_t nch = (span + oskew + 15u) >> 4;
-                for (uint32_t c = ptid; c < nch; c += 64u * PAIR) {
-                    const uint32_t first = c << 4;
-                    if (first >= oskew && first + 16u <= oskew + span)
-                        *reinterpret_cast<uint4*>(g_al + first) = *reinterpret_cast<const uint4*>(out_stage + first);
-                    else
-                        for (uint32_t q = first; q < first + 16u; ++q)
-                            if (q >= oskew && q < oskew + span) g_al[q] = out_stage[q];
+                // four chunks per lane and LDS round trip; the two chunks at the ends of the span (the neighbouring bytes are another
+                // tile's) leave as dwords and bytes out of the registers -- no load-store chain per byte
+                const uint32_t lds_out = lds_addr(out_stage);
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                for (uint32_t c0 = 0; c0 < nch; c0 += 4u * threads) {
+                    u32x4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t c = c0 + threads * q + ptid;
+                        if (c < nch) v[q] = *(JX_LDS const u32x4*)(uintptr_t)(lds_out + (c << 4));
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t c = c0 + threads * q + ptid;
+                        if (c >= nch) continue;
+                        const uint32_t first = c << 4;
+                        if (first >= oskew && first + 16u <= oskew + span) {
+                            *reinterpret_cast<uint4*>(g_al + first) = make_uint4(v[q].x, v[q].y, v[q].z, v[q].w);
+                        } else {
+                            const uint32_t from = max(first, oskew), to = min(first + 16u, oskew + span);   // the bytes of the chunk that are text
+                            const uint32_t w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) {
+                                const uint32_t b0 = first + 4u * d;
+                                if (from <= b0 && b0 + 4u <= to) *reinterpret_cast<uint32_t*>(g_al + b0) = w[d];
+                                else {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r)
+                                        if (b0 + r >= from && b0 + r < to) g_al[b0 + r] = static_cast<uint8_t>(w[d] >> (8 * r));
+                                }
+                            }
+                        }
+                    }
                 }
             }
             // the staging areas are reused by the next round
             pair_barrier();
+            JX_STAMP(5);  // flush + barrier
             a = b;
         }
         if (!WRITE && tile_flags != nullptr && lane == 0u) tile_flags[tile] = tile_dirty ? 0u : 1u;
     }
+#ifdef GX_DEV
+    if (lane == 0u)
+        for (int q = 0; q < 6; ++q) atomicAdd(&jx_phase[(WRITE ? 8 : 0) + q], ph[q]);
+#endif
 }
 
 // ---- exclusive scan u32[n] -> u64[n + 1] (out[n] = total): block sums, one-workgroup scan, block scans ----
@@ -1104,8 +1217,8 @@ bool plan_jsonl_tile(const GxJsonl& tm, int slots, uint32_t mean_in, uint32_t me
     c.n_rules = tm.n_rules;
     c.n_segs = tm.n_segs;
     if (tm.lits_bytes <= 24u * 1024u) { c.lits_lds = 0; used = (tm.lits_bytes + 15u) & ~15u; }
-    const uint32_t tm_bytes = (2u * tm.n_rules + 1u + 3u * tm.n_segs) * 4u;
-    if (tm_bytes <= 16u * 1024u) { c.tm_lds = used; used += (tm_bytes + 15u) & ~15u; }
+    const uint32_t tm_bytes = (((2u * tm.n_rules + 1u) * 4u + 15u) & ~15u) + 16u * tm.n_segs;  // (k_jsonl_tile: tl_seg)
+    if (tm_bytes <= 20u * 1024u) { c.tm_lds = used; used += (tm_bytes + 15u) & ~15u; }
     c.perm_lds = used;
     used += 128u;
     c.caps_bytes = slots > 0 && slots <= 32 ? 64u * static_cast<uint32_t>(slots) * 4u : 0u;
@@ -1189,5 +1302,16 @@ hipError_t launch_jsonl_write(const GxJsonl& tm, const GxBatch& b, int slots, in
     const uint64_t blocks = std::min<uint64_t>(tiles, 256u * 16u);
     return launch_jsonl_tile<true, 2>(t, cfg, b, slots, passthrough, static_cast<unsigned>(blocks), 128u, lds, nullptr, line_out_off, out, split, split_at, tile_flags, stream);
 }
+
+#ifdef GX_DEV
+hipError_t jsonl_dev_phases(unsigned long long* out16, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(jx_phase), sizeof(unsigned long long) * 16);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(jx_phase), z, sizeof(z));
+    }
+    return e;
+}
+#endif
 
 }  // namespace gx
