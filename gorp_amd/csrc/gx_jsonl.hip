@@ -7,9 +7,12 @@
 // into one template per extraction (gx_api.cpp: build_jsonl_templates): a list of segments, each a literal byte
 // string followed by an optional capture group.
 //
-// One wave per line, one lane per byte: pass 1 sums the escaped lengths, an exclusive scan turns the sizes into
-// output offsets, pass 2 writes.  Bytes are Latin-1 code units
-// (the batch path's input model) and leave as UTF-8; with utf8_passthrough the bytes >= 0x80 are copied as they are (input that was UTF-8 all along).
+// Two passes of one kernel (k_jsonl_tile, below: a wave per 64 consecutive lines staged in LDS, a lane per line): the sizes pass
+// sums the escaped lengths -- and leaves, per line, the point where the write pass's two waves divide its text, and per tile whether
+// anything in it needs an escape at all --, an exclusive scan turns the sizes into output offsets, the write pass assembles each
+// tile's text in LDS and flushes it.  A line that does not fit the staging areas is taken by a whole wave, a lane per byte
+// (line_size_wave / line_write_wave).  Bytes are Latin-1 code units (the batch path's input model) and leave as UTF-8; with
+// utf8_passthrough the bytes >= 0x80 are copied as they are (input that was UTF-8 all along).  DESIGN.md section 9.
 #include <algorithm>
 #include <cstdint>
 #include <hip/hip_runtime.h>
