@@ -469,7 +469,10 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
     uint4 pf[NQ], pfc[NC];
     bool pf_valid = false;          // uniform
     uint32_t pf_nch = 0u, pf_cch = 0u;
-    uint64_t nx_o0 = 0, nx_o1 = 0, nx_oo0 = 0, nx_oo1 = 0, bd_lo = 0, bd_hi = 0, bd_olo = 0, bd_ohi = 0;
+    // (what a load fetches ahead keeps the type it is loaded with: widening a 32-bit offset to 64 bits is an instruction on the
+    // loaded value, placed right behind the load -- a wait for the load that was meant to fly during the whole tile)
+    OFF nx_o0 = 0, nx_o1 = 0, bd_lo = 0, bd_hi = 0;
+    uint64_t nx_oo0 = 0, nx_oo1 = 0, bd_olo = 0, bd_ohi = 0;
     int32_t nx_k = -1;
     uint32_t nx_split = 0u;         // write pass, second wave of a pair: the bytes of the line's text before its split point
     uint32_t nx_at = 0xFFFF0000u;   // write pass: the split point (segment - first segment) << 16 | characters / 16; 0xFFFF....: none
@@ -529,7 +532,7 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
             if (t1 < tiles) {
                 // (everything that is read here arrived long ago; it is read BEFORE the first new load is issued, or the wait for it
                 // -- the counter of loads in flight cannot tell old from new -- would be a wait for the new loads: a trip to memory per tile)
-                const uint64_t n_lo = uni(bd_lo), n_hi = uni(bd_hi), n_olo = uni(bd_olo), n_ohi = uni(bd_ohi);
+                const uint64_t n_lo = uni(static_cast<uint64_t>(bd_lo)), n_hi = uni(static_cast<uint64_t>(bd_hi)), n_olo = uni(bd_olo), n_ohi = uni(bd_ohi);
                 nx_flag = uni(bd_flag);
                 __builtin_amdgcn_sched_barrier(0);
                 fetch_lane_offsets(t1);
@@ -617,6 +620,7 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
             // after the barrier below, later than every first store of the round.
             uint32_t wp = 0u, wp0 = 0u, head0 = 0u, carry = 0u, pend8 = 0u;  // pend8: BITS waiting in carry (0, 8, 16, 24)
             bool lane_dirty = false;
+            uint32_t r_total = 0u, r_split = 0u, r_at = 0xFFFF0000u;  // sizes pass: what the lane stores for its line
             if (active) {
                 const uint32_t line = lds_addr(in_stage) + skew + static_cast<uint32_t>(o0 - lo);  // LDS byte addresses
                 uint32_t total = 0, unescaped = 0;  // sizes pass: the text's bytes, and what they would be without escapes
@@ -936,15 +940,25 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                         }
                     }
                     if (!WRITE && split != nullptr) {
-                        split[i] = sp_m < s1 ? before : total;
-                        split_at[i] = sp_m < s1 ? ((sp_m - s0) << 16 | (sp_q >> 4)) : 0xFFFF0000u;
+                        r_split = sp_m < s1 ? before : total;
+                        r_at = sp_m < s1 ? ((sp_m - s0) << 16 | (sp_q >> 4)) : 0xFFFF0000u;
                         unescaped = cum;
                     }
                 }
-                if (!WRITE) sizes[i] = total;
+                r_total = total;
                 lane_dirty = total != unescaped;
             }
-            if (!WRITE && __ballot(lane_dirty) != 0ull) tile_dirty = 1u;
+            if (!WRITE) {
+                // The next tile's offsets (loaded while this one was staged) have long arrived.  Said HERE, before this tile's stores
+                // are issued: the counter of memory operations in flight is one for loads and stores, in order, so at the top of the
+                // next tile "the offsets are there" would read "nothing is in flight" -- a wait for these stores to be acknowledged.
+                asm volatile("" : : "v"(nx_o0), "v"(nx_o1), "v"(nx_k));
+                if (active) {
+                    sizes[i] = r_total;
+                    if (split != nullptr && k >= 0) { split[i] = r_split; split_at[i] = r_at; }
+                }
+                if (__ballot(lane_dirty) != 0ull) tile_dirty = 1u;
+            }
             JX_STAMP(2);  // the lanes' work
             if (WRITE) {
                 // the bytes still waiting in the carries: byte stores (the rest of such a dword is the next writer's), once every
