@@ -15,6 +15,10 @@
 // relaxed atomics, wave-wide look-back) took 1.30 ms with 32 KiB blocks and 3.7 ms with 128 KiB blocks -- the polling
 // of the predecessors' words goes to the memory side of the XCDs' L2s and competes with the text stream; and pass 1
 // spilling its 16-bit chunk masks for pass 3 (text read once, 2-byte stores) took 1.02 ms.  Neither was kept.
+// Round 3 (per kernel: count 328 us = 6.1 TB/s, scan 95 us, write 546 us): the scan now takes 4096 counts per step and one barrier
+// (50 us); classifying a block's eight chunks per thread up front -- all loads in flight, the byte behind a chunk from the
+// neighbouring lane / wave through a shuffle / LDS, one barrier instead of sixteen in the write pass -- was built and measured:
+// count 404 us, write 565 us.  Slower: the passes are bound by the memory pipeline, which the simple loop keeps fuller.
 #include <cstdint>
 #include <hip/hip_runtime.h>
 
@@ -101,32 +105,41 @@ __global__ void __launch_bounds__(SPLIT_THREADS) k_split_count(const uint8_t* __
     }
 }
 
-// pass 2: exclusive scan of the block counts (one workgroup), total -> *total_ends
+// pass 2: exclusive scan of the block counts (one workgroup), total -> *total_ends; 4096 counts per step of the loop
 __global__ void __launch_bounds__(1024) k_split_scan(const uint32_t* __restrict__ counts, uint64_t* __restrict__ prefix, uint64_t nblocks,
                                                     uint64_t* __restrict__ total_ends) {
-    __shared__ uint64_t wsum[16];
-    __shared__ uint64_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
+    __shared__ uint64_t wsum[2][16];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint64_t b0 = 0; b0 < nblocks; b0 += 1024) {
-        const uint64_t b = b0 + threadIdx.x;
-        const uint64_t v = b < nblocks ? counts[b] : 0;
-        uint64_t inc = v;
+    uint64_t carry = 0;   // (every thread keeps it)
+    uint32_t flip = 0;
+    for (uint64_t b0 = 0; b0 < nblocks; b0 += 4096, flip ^= 1u) {
+        const uint64_t b = b0 + 4ull * threadIdx.x;
+        uint32_t v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = b + q < nblocks ? counts[b + q] : 0u;
+        const uint64_t mine = static_cast<uint64_t>(v[0]) + v[1] + v[2] + v[3];
+        uint64_t inc = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint64_t o = __shfl_up(static_cast<unsigned long long>(inc), d);
             if (lane >= static_cast<uint32_t>(d)) inc += o;
         }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        uint64_t wbase = 0;
-        for (uint32_t w = 0; w < wave; ++w) wbase += wsum[w];
-        const uint64_t c = carry;
-        if (b < nblocks) prefix[b] = c + wbase + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = c + wbase + inc;
-        __syncthreads();
+        if (lane == 63) wsum[flip][wave] = inc;
+        __syncthreads();   // (one barrier per step: the sums alternate between two rows)
+        uint64_t wbase = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; ++w) {
+            const uint64_t t = wsum[flip][w];
+            if (w < wave) wbase += t;
+            total += t;
+        }
+        uint64_t run = carry + wbase + inc - mine;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (b + q < nblocks) prefix[b + q] = run;
+            run += v[q];
+        }
+        carry += total;
     }
     if (threadIdx.x == 0) *total_ends = carry;
 }
