@@ -129,8 +129,8 @@ struct gx_handle {
     // device scratch of gx_results_to_jsonl / gx_text_to_jsonl (sizes, split points, line offsets), kept between calls and grown as
     // batches ask: a hipMalloc + hipFree pair per call cost more than the scan kernels.  Used under `mu` only, and every call that
     // uses it ends with a stream synchronisation.
-    void* scratch[2] = {nullptr, nullptr};
-    size_t scratch_cap[2] = {0, 0};
+    void* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // stream-ordered memory of the UTF-16 batch path (the narrowed copy of a batch): a pool of the handle's own that keeps what a
     // batch frees for the next one (the device's default pool gives everything back at the next synchronisation: an allocation of
     // gigabytes per call, 0.6 of that path's 2.4 ms per 10 M lines)
@@ -1469,7 +1469,7 @@ int gx_text_to_jsonl(gx_handle* h, const uint8_t* text, uint64_t size, const cha
         std::lock_guard<std::mutex> lock(h->mu);
         const GxJsonl& tm = jsonl_templates(h, id_as);
         hipStream_t stream = static_cast<hipStream_t>(o.stream);
-        DevBuf d_text, ws_split, d_mid, d_caps, d_counts, d_out;
+        DevBuf d_text, d_out;   // (host buffers only; everything between lives in the handle's scratch: 2 split workspace, 3 offsets, 4 ids, 5 captures, 6 counts)
         const uint8_t* src = text;
         if (!o.device_pointers) {
             d_text.alloc(size);
@@ -1479,35 +1479,32 @@ int gx_text_to_jsonl(gx_handle* h, const uint8_t* text, uint64_t size, const cha
             return fail(GX_E_ARG, "gx_text_to_jsonl: device text must be 16-byte aligned");
         }
         // 1. lines: offsets for the guess "64 bytes or more per line"; a text with shorter lines is split a second time
-        ws_split.alloc(split_workspace_bytes(size));
+        void* ws_split = handle_scratch(h, 2, split_workspace_bytes(size));
         uint64_t cap = size / 64 + 4096;
-        DevBuf d_off2;
-        d_off2.alloc((cap + 1) * 4);
+        void* d_off2 = handle_scratch(h, 3, (cap + 1) * 4);
         uint64_t* d_n = nullptr;
-        GX_HIP(launch_split_lines(src, size, d_off2.p, 0, cap, nullptr, ws_split.p, &d_n, stream));
+        GX_HIP(launch_split_lines(src, size, d_off2, 0, cap, nullptr, ws_split, &d_n, stream));
         uint64_t n = 0;
         GX_HIP(hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, stream));
         GX_HIP(hipStreamSynchronize(stream));
         if (n > cap) {
-            (void)hipFree(d_off2.p);
-            d_off2.p = nullptr;
-            d_off2.alloc((n + 1) * 4);
-            GX_HIP(launch_split_lines(src, size, d_off2.p, 0, n, nullptr, ws_split.p, &d_n, stream));
+            d_off2 = handle_scratch(h, 3, (n + 1) * 4);
+            GX_HIP(launch_split_lines(src, size, d_off2, 0, n, nullptr, ws_split, &d_n, stream));
         }
         // 2. the path
-        d_mid.alloc(n * 4);
-        d_caps.alloc(n * slots * 4);
+        void* d_mid = handle_scratch(h, 4, n * 4 + 16);
+        void* d_caps = handle_scratch(h, 5, n * slots * 4 + 16);
         GxBatch b{};
-        b.data = src; b.offsets = d_off2.p; b.n = n; b.match_id = static_cast<int32_t*>(d_mid.p);
-        b.caps = h->T.has_capture ? static_cast<int32_t*>(d_caps.p) : nullptr;
+        b.data = src; b.offsets = d_off2; b.n = n; b.match_id = static_cast<int32_t*>(d_mid);
+        b.caps = h->T.has_capture ? static_cast<int32_t*>(d_caps) : nullptr;
         b.match_only = h->T.has_capture ? 0 : 1;
         b.strip_eol = 1;
         const uint32_t mean_in = n ? static_cast<uint32_t>(std::min<uint64_t>((size + n - 1) / n, 1u << 20)) : 1u;
         launch_batch(h, b, mean_in, GX_KERNEL_AUTO, stream);
-        if (!h->T.has_capture && n && slots) GX_HIP(hipMemsetAsync(d_caps.p, 0xFF, n * slots * 4, stream));
-        b.caps = static_cast<int32_t*>(d_caps.p);
-        d_counts.alloc(16);
-        GX_HIP(launch_count_outcomes(b.match_id, n, static_cast<unsigned long long*>(d_counts.p), stream));
+        if (!h->T.has_capture && n && slots) GX_HIP(hipMemsetAsync(d_caps, 0xFF, n * slots * 4, stream));
+        b.caps = static_cast<int32_t*>(d_caps);
+        void* d_counts = handle_scratch(h, 6, 16);
+        GX_HIP(launch_count_outcomes(b.match_id, n, static_cast<unsigned long long*>(d_counts), stream));
         // 3. the text
         void* ws_json = handle_scratch(h, 0, jsonl_workspace_bytes(n));
         uint64_t* loff = static_cast<uint64_t*>(handle_scratch(h, 1, (n + 1) * 8));
@@ -1515,7 +1512,7 @@ int gx_text_to_jsonl(gx_handle* h, const uint8_t* text, uint64_t size, const cha
         uint64_t total = 0;
         unsigned long long counts[2] = {0, 0};
         GX_HIP(hipMemcpyAsync(&total, loff + n, 8, hipMemcpyDeviceToHost, stream));
-        GX_HIP(hipMemcpyAsync(counts, d_counts.p, 16, hipMemcpyDeviceToHost, stream));
+        GX_HIP(hipMemcpyAsync(counts, d_counts, 16, hipMemcpyDeviceToHost, stream));
         GX_HIP(hipStreamSynchronize(stream));
         *out_size = total;
         if (n_lines) *n_lines = n;
