@@ -184,7 +184,10 @@ int gx_split_lines(const uint8_t* bytes, uint64_t size, void* offsets, uint64_t 
  * of gx_extract_batch.  line_out_offsets (optional, n + 1 entries) receives where each line's text starts
  * (equal neighbours = no text).  *out_size receives the total; out == NULL only asks for the size; GX_E_LIMIT
  * when out_cap is too small.  With opts->device_pointers = 1 every buffer except out_size is a device pointer.
- * Needs the extraction names: a handle from gx_create_from_definition, or gx_set_extraction_meta first. */
+ * Needs the extraction names: a handle from gx_create_from_definition, or gx_set_extraction_meta first.
+ * The call's device workspace (sizes, line offsets; for gx_text_to_jsonl also the lines' offsets, ids and capture rows) stays
+ * allocated on the handle and is reused by later calls (it grows to what the largest batch asked for; gx_destroy frees it);
+ * likewise the narrowed copy of a utf16 batch (a memory pool of the handle's own). */
 int gx_results_to_jsonl(gx_handle* h, const uint8_t* bytes, const void* offsets, uint64_t n, const int32_t* match_id,
                         const int32_t* caps, const char* id_as, uint8_t* out, uint64_t out_cap, uint64_t* out_size,
                         uint64_t* line_out_offsets, const gx_batch_opts* opts);
