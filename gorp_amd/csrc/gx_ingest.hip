@@ -15,10 +15,10 @@
 // relaxed atomics, wave-wide look-back) took 1.30 ms with 32 KiB blocks and 3.7 ms with 128 KiB blocks -- the polling
 // of the predecessors' words goes to the memory side of the XCDs' L2s and competes with the text stream; and pass 1
 // spilling its 16-bit chunk masks for pass 3 (text read once, 2-byte stores) took 1.02 ms.  Neither was kept.
-// Round 3 (per kernel: count 328 us = 6.1 TB/s, scan 95 us, write 546 us): the scan now takes 4096 counts per step and one barrier
-// (50 us); classifying a block's eight chunks per thread up front -- all loads in flight, the byte behind a chunk from the
-// neighbouring lane / wave through a shuffle / LDS, one barrier instead of sixteen in the write pass -- was built and measured:
-// count 404 us, write 565 us.  Slower: the passes are bound by the memory pipeline, which the simple loop keeps fuller.
+// Round 3 (per kernel before: count 328 us = 6.1 TB/s, scan 95 us, write 546 us): the scan takes 4096 counts per step and one barrier
+// (52 us); the write pass classifies a thread's eight chunks first -- sixteen loads in flight, as in the counting pass -- and needs
+// one barrier per block instead of sixteen; the wave scans run on DPP, not through LDS (491 us).  Measured and not kept: the byte
+// behind a chunk taken from the neighbouring lane / wave (shuffle, LDS) instead of loaded: count 404 us, write 565 us.
 #include <cstdint>
 #include <hip/hip_runtime.h>
 
@@ -75,12 +75,15 @@ __device__ __forceinline__ Chunk classify(const uint8_t* __restrict__ data, uint
     return c;
 }
 
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(v, d);
-        if (lane >= static_cast<uint32_t>(d)) v += o;
-    }
+// inclusive sum over the wave's lanes, on the vector unit alone (DPP: shifts within rows of 16 lanes, then the last lane of a row
+// broadcast to the rows after it); `lane` is unused
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t) {
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xF, 0xF, true));   // row_shr:1
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xF, 0xF, true));   // row_shr:2
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xF, 0xF, true));   // row_shr:4
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118, 0xF, 0xF, true));   // row_shr:8
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1 and 3
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xC, 0xF, false));  // row_bcast:31 into rows 2 and 3
     return v;
 }
 
@@ -148,27 +151,40 @@ __global__ void __launch_bounds__(1024) k_split_scan(const uint32_t* __restrict_
 template <typename OFF>
 __global__ void __launch_bounds__(SPLIT_THREADS) k_split_write(const uint8_t* __restrict__ data, uint64_t size, const uint64_t* __restrict__ prefix,
                                                                OFF* __restrict__ offsets, uint64_t cap_lines, uint8_t* __restrict__ flags) {
-    __shared__ uint32_t wsum[SPLIT_THREADS / 64];
-    __shared__ uint32_t running;
+    constexpr int WAVES = SPLIT_THREADS / 64;
+    __shared__ uint32_t wsum[SPLIT_ITERS][WAVES];
     const uint64_t base = static_cast<uint64_t>(blockIdx.x) * SPLIT_BLOCK_BYTES;
     const uint64_t block_rank = prefix[blockIdx.x];
-    if (threadIdx.x == 0) running = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) offsets[0] = 0;
-    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // all of a thread's chunks first (sixteen loads in flight, as in the counting pass), their masks kept in registers; the waves leave
+    // their sums per iteration in LDS, and after one barrier every thread knows the rank of each of its chunks
+    Chunk c[SPLIT_ITERS];
+#pragma unroll
+    for (int it = 0; it < SPLIT_ITERS; ++it) c[it] = classify(data, base + (static_cast<uint64_t>(it) * SPLIT_THREADS + threadIdx.x) * 16, size);
+    uint32_t before[SPLIT_ITERS];   // line ends in the wave's chunks of the iteration before this thread's
+#pragma unroll
     for (int it = 0; it < SPLIT_ITERS; ++it) {
-        const uint64_t pos = base + (static_cast<uint64_t>(it) * SPLIT_THREADS + threadIdx.x) * 16;
-        const Chunk c = classify(data, pos, size);
-        const uint32_t cnt = __popc(c.ends);
+        const uint32_t cnt = __popc(c[it].ends);
         const uint32_t inc = wave_inclusive_sum(cnt, lane);
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        uint32_t wbase = 0;
-        for (uint32_t w = 0; w < wave; ++w) wbase += wsum[w];
-        const uint32_t r0 = running;
+        if (lane == 63) wsum[it][wave] = inc;
+        before[it] = inc - cnt;
+    }
+    __syncthreads();
+    uint32_t running = 0;   // line ends of the block before the iteration
+#pragma unroll
+    for (int it = 0; it < SPLIT_ITERS; ++it) {
+        uint32_t wbase = 0, total = 0;
+#pragma unroll
+        for (int q = 0; q < WAVES; ++q) {
+            const uint32_t t = wsum[it][q];
+            if (static_cast<uint32_t>(q) < wave) wbase += t;
+            total += t;
+        }
+        const uint64_t pos = base + (static_cast<uint64_t>(it) * SPLIT_THREADS + threadIdx.x) * 16;
         // number of line ends before this thread's first byte = index of the line that byte belongs to
-        const uint64_t rank = block_rank + r0 + wbase + inc - cnt;
-        uint32_t e = c.ends;
+        const uint64_t rank = block_rank + running + wbase + before[it];
+        uint32_t e = c[it].ends;
         uint64_t k = rank;
         while (e) {
             const uint32_t j = __ffs(e) - 1u;
@@ -177,17 +193,15 @@ __global__ void __launch_bounds__(SPLIT_THREADS) k_split_write(const uint8_t* __
             if (k <= cap_lines) offsets[k] = static_cast<OFF>(pos + j + 1);
         }
         if (flags) {
-            uint32_t hb = c.high;
+            uint32_t hb = c[it].high;
             while (hb) {
                 const uint32_t j = __ffs(hb) - 1u;
                 hb &= hb - 1u;
-                const uint64_t line = rank + __popc(c.ends & ((1u << j) - 1u));
+                const uint64_t line = rank + __popc(c[it].ends & ((1u << j) - 1u));
                 if (line < cap_lines) flags[line] = 1;
             }
         }
-        __syncthreads();
-        if (threadIdx.x == SPLIT_THREADS - 1) running = r0 + wbase + inc;
-        __syncthreads();
+        running += total;
     }
 }
 
