@@ -256,3 +256,27 @@ def test_tiles_with_nothing_to_escape_are_copied_verbatim():
     run(gorp, lines, id_as=None, utf8_passthrough=True)   # the tiles of kind "high" are verbatim ones now
     # every line of the batch clean, and the last tile a partial one
     run(gorp, [ln for ln, k in zip(lines, [k for k in kinds for _ in range(64)]) if k == "clean"][:64 * 50 + 17], id_as="id")
+
+
+@pytest.mark.parametrize("n_groups", [16, 17, 32])
+def test_many_capture_groups(n_groups):
+    """16 groups = 32 capture slots is the most whose rows the kernels stage in LDS (and fetch ahead: exactly four 16-byte chunks per lane
+    of a pair); 17 and 32 groups (the most an extraction may have) read their offsets from global memory (the general variant of the kernels)."""
+    rng = random.Random(n_groups)
+    parts = []
+    for g in range(n_groups):
+        parts.append(["text", "%d=" % g])   # (digits and = are no value characters: the fields cannot run into each other)
+        parts.append(["extractor", "v%d" % g, [["pattern", "[a-z\"\\\\]+"]]])
+        parts.append(["text", ";"])
+    gorp = Gorp.construct([FlattenedExtraction("wide", parts)])
+    lines = []
+    for _ in range(3000):
+        if rng.random() < 0.1:
+            lines.append("junk")
+            continue
+        lines.append("".join("%d=%s;" % (g, "".join(rng.choice("abcxyz\"\\") for _ in range(rng.randrange(1, 9)))) for g in range(n_groups)))
+    raw, mid, caps, text = run(gorp, lines, id_as="id")
+    assert (mid == 0).sum() > 2500
+    for t in text.decode("utf-8").split("\n")[:50]:
+        if t:
+            assert len(json.loads(t)) == n_groups + 1
