@@ -417,12 +417,12 @@ Dfa product(const std::vector<Dfa>& parts, int ncls, std::vector<std::vector<int
 // its captures in a single pass.
 const int MAX_TAGS = 64;
 const int TDFA_STATE_LIMIT = 60000;
-const int16_t R_NIL = -1, R_NEW = -2;
+const int16_t R_NIL = -1, R_NEW = -2;   // (while a step is built: R_NEW - k = "the current position", k = the tag's run, see tag_run_)
 
 struct Thread {
     int pc;
     uint64_t pending;
-    std::vector<int16_t> reg;  // per tag of the thread's rule: register id, R_NIL, or (while building) R_NEW
+    std::vector<int16_t> reg;  // per tag of the thread's rule: register id, R_NIL, or (while building) R_NEW - k
     bool operator==(const Thread& o) const { return pc == o.pc && pending == o.pending && reg == o.reg; }
     bool operator<(const Thread& o) const {
         if (pc != o.pc) return pc < o.pc;
@@ -496,6 +496,22 @@ public:
     TdfaBuilder(const MultiProg& p, const Classes& C, OpListPool& ops, std::vector<uint16_t>& fin_tags, const Tables* fused)
         : p_(p), C_(C), ops_(ops), fin_tags_(fin_tags), with_rule_id_(fused != nullptr), fused_(fused) {
         for (int t : p.ntags) if (t > MAX_TAGS) throw GxError(GX_E_LIMIT, "more than 32 capture groups in one extraction");
+        // Tags that are set in one step all receive the current position.  Which of them SHARE the register that receives it is a
+        // matter of the automaton's shape only, and it is decided by the program, not by the line: tags whose TAG instructions
+        // stand in one run ("((", ")(", "))": always set together) share one; any other pair (the two ends of a group that
+        // may match the empty string: set together on one path, apart on another) gets a register each.  With one register for
+        // all, "this group was empty" stayed visible in the state for ever -- as which registers coincide -- and n such
+        // groups made 2^n states (fourteen fields ([^,]*), did not compile).
+        tag_run_.resize(p.ntags.size());
+        for (size_t k = 0; k < p.ntags.size(); ++k) tag_run_[k].assign(static_cast<size_t>(p.ntags[k]), -1);
+        for (size_t pc = 0; pc < p.code.size(); ++pc) {
+            if (p.code[pc].op != Inst::TAG) continue;
+            const int rule = p.rule_of_pc[pc];
+            size_t first = pc;
+            while (first > 0 && p.code[first - 1].op == Inst::TAG && p.rule_of_pc[first - 1] == rule) --first;
+            int& run = tag_run_[static_cast<size_t>(rule)][static_cast<size_t>(p.code[pc].x)];
+            if (run < 0) run = static_cast<int>(first);   // (a tag with several TAG instructions: the first one's run)
+        }
     }
 
     RuleTables build() {
@@ -549,6 +565,7 @@ private:
     std::map<std::vector<std::pair<int, uint64_t>>, std::vector<int>> by_shape_;
     std::vector<uint32_t> trans_;
     std::vector<char> seen_;
+    std::vector<std::vector<int>> tag_run_;   // per rule and tag: the pc that begins the run of TAG instructions the tag's stands in
 
     int ntags_at(int pc) const { return p_.ntags[p_.rule_of_pc[pc]]; }
 
@@ -644,40 +661,63 @@ private:
             if (nd == fused_->m_dead) return DEAD_MARK;  // no extraction can match any more: the line's result is null
         }
         std::vector<Thread> seeds;
+        size_t n_new = 0;   // R_NEW - k, k < n_new: the step's k-th new register
         for (const Thread& t : cur.th) {
             const Inst& in = p_.code[t.pc];
             if (in.op != Inst::CHAR || !C_.set_has(in.x, cls)) continue;
             Thread s;
             s.pc = t.pc + 1; s.pending = 0; s.reg = t.reg;
-            for (size_t g = 0; g < s.reg.size(); ++g) if ((t.pending >> g) & 1) s.reg[g] = R_NEW;
+            if (t.pending) {
+                // the thread's pending tags by run, in program order: the j-th run takes the step's j-th new register (threads of
+                // other extractions that are at the same point of the line share it: one register per distinct live position)
+                const std::vector<int>& runs = tag_run_[static_cast<size_t>(p_.rule_of_pc[t.pc])];
+                std::vector<int> mine;
+                for (size_t g = 0; g < s.reg.size(); ++g)
+                    if (((t.pending >> g) & 1) && std::find(mine.begin(), mine.end(), runs[g]) == mine.end()) mine.push_back(runs[g]);
+                std::sort(mine.begin(), mine.end());
+                for (size_t g = 0; g < s.reg.size(); ++g)
+                    if ((t.pending >> g) & 1) {
+                        const size_t k = static_cast<size_t>(std::find(mine.begin(), mine.end(), runs[g]) - mine.begin());
+                        s.reg[g] = static_cast<int16_t>(R_NEW - static_cast<int>(k));
+                    }
+                n_new = std::max(n_new, mine.size());
+            }
             seeds.push_back(std::move(s));
         }
         std::vector<Thread> nxt;
         if (!seeds.empty()) nxt = close(seeds);
         if (nxt.empty() && !fused_) return DEAD_MARK;
-        // one register receives the current position: the lowest one no surviving thread still reads
-        int new_reg = -1;
+        // registers that receive the current position, one per run of tags that a surviving thread set in this step (the j-th run of
+        // every thread the same one): the lowest ones no surviving thread still reads, handed out in the order of the runs in the
+        // program, so that what a state looks like does not depend on whether two runs were set in one step or in two
+        std::vector<int> new_regs;        // in allocation order
+        std::vector<int> reg_of_run(n_new, -1);
         {
-            bool any_new = false;
-            std::vector<char> busy(static_cast<size_t>(nregs_) + 1, 0);
-            for (auto& t : nxt) for (int16_t r : t.reg) { if (r == R_NEW) any_new = true; else if (r >= 0) busy[r] = 1; }
-            if (any_new) {
-                new_reg = 0;
-                while (new_reg < nregs_ && (busy[new_reg] || new_reg == scratch_)) ++new_reg;
-                if (new_reg >= 0x7FF0) throw GxError(GX_E_LIMIT, "capture automaton needs too many registers");
-                if (new_reg >= nregs_) nregs_ = new_reg + 1;
+            std::vector<char> used(n_new, 0);
+            std::vector<char> busy(static_cast<size_t>(nregs_) + n_new + 1, 0);
+            for (auto& t : nxt) for (int16_t r : t.reg) { if (r <= R_NEW) used[static_cast<size_t>(R_NEW - r)] = 1; else if (r >= 0) busy[static_cast<size_t>(r)] = 1; }
+            int next_free = 0;
+            for (size_t k = 0; k < n_new; ++k) {
+                if (!used[k]) continue;
+                while (next_free < nregs_ && (busy[static_cast<size_t>(next_free)] || next_free == scratch_)) ++next_free;
+                if (next_free >= 0x7FF0) throw GxError(GX_E_LIMIT, "capture automaton needs too many registers");
+                if (next_free >= nregs_) nregs_ = next_free + 1;
+                reg_of_run[k] = next_free;
+                new_regs.push_back(next_free);
+                ++next_free;
             }
         }
+        auto is_new = [&](int r) { return std::find(new_regs.begin(), new_regs.end(), r) != new_regs.end(); };
         TState resolved;
         resolved.d = nd;
         resolved.th = nxt;
-        for (auto& t : resolved.th) for (auto& r : t.reg) if (r == R_NEW) r = static_cast<int16_t>(new_reg);
+        for (auto& t : resolved.th) for (auto& r : t.reg) if (r <= R_NEW) r = static_cast<int16_t>(reg_of_run[static_cast<size_t>(R_NEW - r)]);
         std::vector<std::pair<int, int>> moves;
         auto it = exact_.find(resolved);
         int target = -1;
         if (it != exact_.end()) {
             target = it->second;
-            if (new_reg >= 0) moves.push_back({new_reg, -1});
+            for (int r : new_regs) moves.push_back({r, -1});
         } else {
             // an existing state of the same shape whose registers can be produced from ours by moves?
             auto sh = by_shape_.find(shape_of(resolved));
@@ -696,13 +736,13 @@ private:
                         }
                     if (!ok) continue;
                     target = cand;
-                    for (auto& kv : src_of) moves.push_back({kv.first, kv.second == new_reg ? -1 : kv.second});
+                    for (auto& kv : src_of) moves.push_back({kv.first, is_new(kv.second) ? -1 : kv.second});
                     break;
                 }
             }
             if (target < 0) {
                 target = add_state(resolved);
-                if (new_reg >= 0) moves.push_back({new_reg, -1});
+                for (int r : new_regs) moves.push_back({r, -1});
             }
         }
         if (target > 0xFFFE) throw GxError(GX_E_LIMIT, "capture automaton too large");
