@@ -1191,3 +1191,32 @@ def test_hop_tier_class_limit():
             assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps), (n_lit, kernel)
             mo, _ = gorp.extract_batch(data, offsets, kernel=kernel, match_only=True)
             assert np.array_equal(mo, np.where(omid <= -2, -2 - omid, omid))
+
+
+def test_csv_like_extraction_with_32_optional_fields():
+    """Thirty-two fields that may each be empty (the most groups an extraction may have), every end of a group in a register of its own:
+    multi-operation capture programs through the batch kernels, against the oracle."""
+    pieces = []
+    for k in range(32):
+        pieces.append(["extractor", "f%d" % k, [["pattern", "[^,]*"]]])
+        if k < 31:
+            pieces.append(["text", ","])
+    definition = [FlattenedExtraction("csv", pieces), FlattenedExtraction("comment", [["text", "#"], ["extractor", "rest", [["pattern", ".*"]]]])]
+    gorp, orc = Gorp.construct(definition), oracle_for(definition)
+    rng = random.Random(32)
+    lines = []
+    for _ in range(6000):
+        fields = ["".join(rng.choice("abc12 \"\\") for _ in range(rng.choice([0, 0, 0, 1, 3, 9]))) for _ in range(32)]
+        line = ",".join(fields)
+        r = rng.random()
+        if r < 0.1:
+            line = "#" + line
+        elif r < 0.2:
+            line = line[:rng.randrange(len(line) + 1)]      # fewer than 31 commas: no match
+        elif r < 0.25:
+            line = line + "," + line                         # more: the last field takes none of them -> no match
+        lines.append(line.encode("latin-1"))
+    check_batch(gorp, orc, lines)
+    data, offsets = lines_to_csr(lines)
+    omid, _ = orc.extract_batch(data, offsets, nthreads=8)
+    assert (omid == 0).sum() > 3000 and (omid == -1).sum() > 300   # (a line that begins with # is a csv line too, and csv comes first)
