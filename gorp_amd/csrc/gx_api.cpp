@@ -1040,7 +1040,7 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
         h->slot_used[slot] = true;
         b.oversize_flag = h->d_slots + slot;
         GX_HIP(launch_extract_hop_slices(h->dev, L, hop_image_small, hop_global, h->num_cus, b, stream));
-        GX_HIP(launch_extract_oversize(h->dev, b, 65535u + 48u, stream));   // (lines beyond the 16-bit positions, if the kernel met any)
+        if (!b.no_followup) GX_HIP(launch_extract_oversize(h->dev, b, 65535u + 48u, stream));   // (lines beyond the 16-bit positions, if the kernel met any)
         GX_HIP(hipEventRecord(h->slot_event[slot], stream));
         return;
     }
@@ -1058,7 +1058,7 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
         stamps = h->dev_stamps;
 #endif
         GX_HIP(launch_extract_tile(h->dev, L, hop_image, hop_global, h->num_cus, b, stream, stamps));
-        GX_HIP(launch_extract_oversize(h->dev, b, L.stage_bytes, stream));
+        if (!b.no_followup) GX_HIP(launch_extract_oversize(h->dev, b, L.stage_bytes, stream));
         GX_HIP(hipEventRecord(h->slot_event[slot], stream));
         return;
     }
@@ -1097,7 +1097,7 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
         GX_HIP(launch_extract_lanes(h->dev, L, image, at_global, h->num_cus, b, stream, stamps));
         if (L.sort_chunk) h->chunk_tickets[slot] += lanes_sorted_tickets(b.n, L.sort_chunk, h->num_cus);  // (what the launch will draw)
         // (the lines the lane kernel leaves: longer than its 16-bit positions -- with compact rows, than the 65 534 they can hold)
-        GX_HIP(launch_extract_oversize(h->dev, b, (b.packed ? 65534u : 65535u) + 48u, stream));
+        if (!b.no_followup) GX_HIP(launch_extract_oversize(h->dev, b, (b.packed ? 65534u : 65535u) + 48u, stream));
         GX_HIP(hipEventRecord(h->slot_event[slot], stream));
         return;
     }
@@ -1116,7 +1116,7 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
         stamps = h->dev_stamps;
 #endif
         GX_HIP(launch_extract_tile(h->dev, L, image, at_global, h->num_cus, b, stream, stamps));
-        GX_HIP(launch_extract_oversize(h->dev, b, L.stage_bytes, stream));
+        if (!b.no_followup) GX_HIP(launch_extract_oversize(h->dev, b, L.stage_bytes, stream));
         GX_HIP(hipEventRecord(h->slot_event[slot], stream));
     } else {
         GX_HIP(launch_extract_generic(h->dev, b, stream));
@@ -1938,6 +1938,41 @@ static int one_line(gx_handle* h, const uint16_t* s, int32_t len, int32_t* match
         uint32_t* offs = reinterpret_cast<uint32_t*>(hb);
         offs[0] = 0; offs[1] = static_cast<uint32_t>(len);
         if (len) memcpy(hb + 8, s, static_cast<size_t>(len) * 2);
+        bool latin1 = mode == 0 && len > 0 && len <= 4096 && h->tile_ok;
+        for (int32_t q = 0; latin1 && q < len; ++q) latin1 = s[q] <= 0xFFu;
+        if (latin1) {
+            // Gorp.extract(String) on a Latin-1 line -- nearly every call: the line's BYTES go through the batch kernels as a batch of
+            // one (tables in LDS, the line staged there too: a step costs an LDS round trip, not two trips to L2 as in the per-line
+            // kernel), straight out of the pinned buffer and back into it; the host knows the line fits: no follow-up launch
+            uint8_t* bytes = hb + 8;
+            for (int32_t q = 0; q < len; ++q) bytes[q] = static_cast<uint8_t>(s[q]);   // (in place of the units copied above)
+            GxBatch b{};
+            b.data = bytes; b.offsets = hb; b.n = 1; b.wide = 0; b.offsets64 = 0;
+            b.match_only = h->T.has_capture ? 0 : 1;
+            int32_t* out = reinterpret_cast<int32_t*>(hb + in_bytes);
+            b.match_id = out; b.caps = h->T.has_capture ? out + 2 : nullptr;
+            b.no_followup = 1;
+            launch_batch(h, b, static_cast<uint32_t>(len), GX_KERNEL_AUTO, nullptr);
+            GX_HIP(hipStreamSynchronize(nullptr));
+            if (match_id) *match_id = out[0];
+            if (caps) for (size_t t = 0; t < slots; ++t) caps[t] = h->T.has_capture ? out[2 + t] : -1;
+            return GX_OK;
+        }
+        if (len <= 16384) {
+            // the short way: the kernel reads the units out of the pinned buffer and writes the result words into it (no copy commands)
+            GxBatch b{};
+            b.n = 1; b.wide = 1;
+            b.match_only = mode < 0 ? mode : ((mode == 1 || !h->T.has_capture) ? 1 : 0);
+            int32_t* out = reinterpret_cast<int32_t*>(hb + in_bytes);
+            b.match_id = out; b.state_out = out + 1; b.caps = b.match_only == 1 ? nullptr : out + 2;
+            GX_HIP(launch_extract_one(h->dev, reinterpret_cast<const uint16_t*>(hb + 8), static_cast<uint32_t>(len), b, nullptr));
+            GX_HIP(hipStreamSynchronize(nullptr));
+            const int32_t* host = out;
+            if (match_id) *match_id = host[0];
+            if (state) *state = host[1];
+            if (caps) for (size_t t = 0; t < slots; ++t) caps[t] = b.match_only == 1 ? -1 : host[2 + t];
+            return GX_OK;
+        }
         // (the results area is not initialised: the kernel writes every word that is read back)
         GX_HIP(hipMemcpyAsync(db, hb, in_bytes, hipMemcpyHostToDevice, nullptr));
         GxBatch b{};

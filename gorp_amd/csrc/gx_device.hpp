@@ -115,6 +115,9 @@ struct GxBatch {
     // one ticket per chunk and one more per workgroup)
     uint32_t* chunk_ctr;
     uint32_t chunk_base;
+    // the host knows that no line of the batch is beyond what the chosen kernel stages (the one-line calls: the host has the line):
+    // no follow-up launch of the per-line kernel behind the batch kernel
+    uint32_t no_followup;
 };
 
 // More than 64 KiB of dynamic LDS needs the attribute, once per kernel (= per instantiation of this template) and
@@ -186,6 +189,8 @@ struct GxJsonl {
     uint32_t lits_bytes, n_rules, n_segs;
 };
 size_t jsonl_workspace_bytes(uint64_t n);
+// one line out of / into pinned host memory (gx_kernels.hip: k_extract_one); hipErrorInvalidValue for a line of more than 16 384 code units
+hipError_t launch_extract_one(const GxDev& dev, const uint16_t* units, uint32_t len, const GxBatch& b, hipStream_t stream);
 // mean_in / mean_out: mean bytes per line of input and of output text; they size the LDS staging of the tile kernels
 hipError_t launch_jsonl_sizes(const GxJsonl& tm, const GxBatch& b, int slots, int passthrough, uint32_t mean_in, uint64_t* line_out_off,
                               void* workspace, hipStream_t stream);

@@ -256,6 +256,21 @@ hipError_t launch_generic_t(const GxDev& dev, const GxBatch& b, hipStream_t stre
     return hipGetLastError();
 }
 
+// One line (gx_extract_one_utf16 / gx_match_one_utf16 / the capture-alone call): the call's latency is what counts.  The code units
+// and the result words live in PINNED HOST memory that the device reads and writes directly -- no copy commands either side of the
+// kernel -- so the wave first brings the line into LDS with one coalesced sweep (a walk straight out of host memory would cross the
+// bus once per character), then lane 0 walks it there.
+constexpr uint32_t ONE_LINE_MAX_UNITS = 16384;   // 32 KB of LDS; longer lines take the batch path's kernel on a device copy
+template <typename MS>
+__global__ void __launch_bounds__(64)
+k_extract_one(GxDev T, const uint16_t* __restrict__ units, uint32_t len, LineOut out, int32_t* __restrict__ state_out, int match_only,
+              const MS* __restrict__ m_next) {
+    __shared__ uint16_t line[ONE_LINE_MAX_UNITS];
+    const uint32_t pairs = (len + 1u) >> 1;   // (the buffer is padded to a multiple of 8 bytes)
+    for (uint32_t q = threadIdx.x; q < pairs; q += 64u) reinterpret_cast<uint32_t*>(line)[q] = reinterpret_cast<const uint32_t*>(units)[q];
+    __syncthreads();
+    if (threadIdx.x == 0) extract_line_global<uint16_t, MS>(T, m_next, line, static_cast<int64_t>(len), 0, out, state_out, match_only);
+}
 // ---------------------------------------------------------------------------
 // Slice kernel: lines staged 64 bytes at a time, lanes refilled as their lines end
 // ---------------------------------------------------------------------------
@@ -627,6 +642,15 @@ hipError_t launch_extract_flagged(const GxDev& dev, const GxBatch& b, const uint
     if (b.offsets64) { if (dev.m_next16) GX_FLAGGED(uint64_t, uint16_t, dev.m_next16); else GX_FLAGGED(uint64_t, uint32_t, dev.m_next32); }
     else { if (dev.m_next16) GX_FLAGGED(uint32_t, uint16_t, dev.m_next16); else GX_FLAGGED(uint32_t, uint32_t, dev.m_next32); }
 #undef GX_FLAGGED
+    return hipGetLastError();
+}
+
+hipError_t launch_extract_one(const GxDev& dev, const uint16_t* units, uint32_t len, const GxBatch& b, hipStream_t stream) {
+    if (len > ONE_LINE_MAX_UNITS) return hipErrorInvalidValue;
+    if (dev.m_next16)
+        hipLaunchKernelGGL((k_extract_one<uint16_t>), dim3(1), dim3(64), 0, stream, dev, units, len, line_out(dev, b), b.state_out, b.match_only, dev.m_next16);
+    else
+        hipLaunchKernelGGL((k_extract_one<uint32_t>), dim3(1), dim3(64), 0, stream, dev, units, len, line_out(dev, b), b.state_out, b.match_only, dev.m_next32);
     return hipGetLastError();
 }
 

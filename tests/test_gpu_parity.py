@@ -1220,3 +1220,40 @@ def test_csv_like_extraction_with_32_optional_fields():
     data, offsets = lines_to_csr(lines)
     omid, _ = orc.extract_batch(data, offsets, nthreads=8)
     assert (omid == 0).sum() > 3000 and (omid == -1).sum() > 300   # (a line that begins with # is a csv line too, and csv comes first)
+
+
+def test_one_line_calls_of_every_kind():
+    """gx_extract_one_utf16 (what Gorp.extract(String) binds) takes a Latin-1 line of up to 4 096 characters through the batch kernels as
+    a batch of one, longer lines and lines with a character above U+00FF through the per-line kernel, on the code units; both ways the
+    line and its result never leave pinned host memory.  Lines of every length around the limits, the README definition (tables in LDS)
+    and a 64-extraction definition (the hop tier), against the oracle; exceptions and nulls as the reference raises / returns them."""
+    small = W.readme3_definition()
+    rules, meta = W.syslog_definition(64, seed=11)
+    data, off, _ = W.syslog_lines(meta, 40, seed=11, corrupt_frac=0.2)
+    big_lines = [bytes(data[off[i]:off[i + 1]]).decode("latin-1") for i in range(40)]
+    rng = random.Random(3)
+    for definition, samples in ((small, ["[123456789]: GET 12ms /index.html?x=1&y=2", "[1]: PUT 5ms /\xe9t\xe9", "[7]: HEAD 1ms /h", "nothing", ""]),
+                                (rules, big_lines)):
+        gorp, orc = Gorp.construct(definition), oracle_for(definition)
+        lines = list(samples)
+        base = samples[0]
+        for n in (1, 2, 63, 64, 65, 255, 256, 4095, 4096, 4097, 16384, 16385, 20000):
+            lines.append((base + "x" * n)[:n] if n < len(base) else base + "x" * (n - len(base)))
+        lines += [base + "中", "中" + base, base[:5] + "Ā" + base[5:]]
+        for s in lines:
+            want = orc.extract(s)
+            try:
+                got = gorp.extract(s)
+            except G.ExtractionException:
+                assert want[0] <= -2, s[:60]
+                continue
+            if want[0] == -1:
+                assert got is None, s[:60]
+                continue
+            assert want[0] >= 0, s[:60]
+            spans = [None if sp is None else s[sp[0]:sp[1]] for sp in want[1]]
+            names = gorp.getExtractions()[want[0]]._extractorNames
+            m = got.asMap()
+            for nm, text in zip(names, spans):
+                if list(names).count(nm) == 1:
+                    assert m.get(nm) == text, (s[:60], nm)
