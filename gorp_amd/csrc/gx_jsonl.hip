@@ -270,6 +270,10 @@ __device__ unsigned long long jx_phase[16];
 #define JX_STAMP(slot) do { } while (0)
 #endif
 
+// where the write pass's two waves divide a line's text: at this many 256ths of its estimated size (0.44: the first wave of a pair has
+// the many short segments; measured best of 0.38 .. 0.63)
+constexpr uint32_t SPLIT_AT_256 = 112;
+
 struct JsonlTileCfg {
     uint32_t lits_lds;    // LDS offset of a copy of tm.lits, or 0xFFFFFFFF: read them from global memory
     uint32_t lits_bytes;
@@ -708,10 +712,7 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
                     // (the sizes pass chooses it inside its one loop over the segments, below: the first place at or past `half` of the
                     // unescaped text -- half of an ESTIMATE of its size, literals + line, so that no loop has to run ahead to add the
                     // captures up; the split only balances the two waves, any point is a correct one)
-                    #ifndef JX_SPLIT_256
-#define JX_SPLIT_256 112   // 0.44: the first wave of a pair has the many short segments, measured best of 96..160
-#endif
-                    const uint32_t half = (WRITE || split == nullptr) ? 0u : ((fixed_k + static_cast<uint32_t>(o1 - o0)) * JX_SPLIT_256) >> 8;
+                    const uint32_t half = (WRITE || split == nullptr) ? 0u : ((fixed_k + static_cast<uint32_t>(o1 - o0)) * SPLIT_AT_256) >> 8;
                     const bool splittable = !WRITE && split != nullptr && s1 - s0 < 0xFFFFu;
                     uint32_t cum = 0u;  // sizes pass: the unescaped bytes of the segments so far
                     uint32_t s_from = s0, s_to = s1;
