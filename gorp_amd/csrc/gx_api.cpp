@@ -978,7 +978,9 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
         GX_HIP(hipStreamSynchronize(stream));
         const uint64_t units = last >= first ? last - first : 0;
         void* tmp = nullptr;
-        if (!h->pool) {
+        {
+          std::lock_guard<std::mutex> pool_lock(h->slot_mu);   // (device-pointer batches of several threads come here without h->mu)
+          if (!h->pool) {
             hipMemPoolProps props{};
             props.allocType = hipMemAllocationTypePinned;
             props.handleTypes = hipMemHandleTypeNone;
@@ -987,6 +989,7 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
             GX_HIP(hipMemPoolCreate(&h->pool, &props));
             uint64_t keep = ~0ull;
             GX_HIP(hipMemPoolSetAttribute(h->pool, hipMemPoolAttrReleaseThreshold, &keep));
+          }
         }
         GX_HIP(hipMallocFromPoolAsync(&tmp, units + b.n + 64, h->pool, stream));
         uint8_t* bytes = static_cast<uint8_t*>(tmp);
