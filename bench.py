@@ -425,6 +425,25 @@ def main():
                         "sample": "first %d lines of the rank-0 shard, %d threads over Gorp.extract on JVM %s (tools/RefBench.java), %.1f s"
                                   % (ref["lines"], ref["cores"], ref["java"], ref["seconds"]), "port": port}
             out["cpu_baseline"] = base
+        if world == 1 and config == 2:
+            # beside the batch number: what ONE Gorp.extract(String) costs through the same library (gx_extract_one_utf16, the
+            # drop-in for a caller that does not batch) -- a latency, reported for context, never part of `value`
+            try:
+                import ctypes as _C
+                import time as _time
+                from gorp_amd import _native as _N
+                one = "[123456789]: GET 12ms /index.html?x=1&y=2"
+                u = np.frombuffer(one.encode("utf-16-le"), np.uint16)
+                m1, c1 = _C.c_int32(0), np.zeros(2 * gorp.max_groups, np.int32)
+                call = lambda: _N.lib().gx_extract_one_utf16(gorp._h.ptr, u.ctypes.data, len(u), _C.byref(m1), c1.ctypes.data)
+                for _ in range(50):
+                    call()
+                t_one = _time.perf_counter()
+                for _ in range(1000):
+                    call()
+                out["one_line_latency_us"] = round((_time.perf_counter() - t_one) / 1000 * 1e6, 1)
+            except Exception as e:   # (context only: the bench line does not depend on it)
+                out["one_line_latency_us"] = "unavailable (%s)" % type(e).__name__
         print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()
