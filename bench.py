@@ -168,7 +168,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5], help="BASELINE.md config (0: 2 at one GPU, 4 at several)")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5],
+                    help="BASELINE.md config (0: config 2 per GPU at any N -- the metric's workload, so that the N = 1, 2, 4, 8 values are one "
+                         "weak-scaling curve -- and at N > 1 configs[3], 64 extractions, measured beside it in the same line)")
     ap.add_argument("--lines", type=int, default=0, help="lines per GPU (0: the config's size)")
     ap.add_argument("--results", default="auto", choices=["auto", "narrow", "compact", "dense"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -184,7 +186,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's world size and --gpus must agree" % (args.gpus, world))
-    config = args.config or (2 if world == 1 else 4)
+    config = args.config or 2
+    also_config4 = args.config == 0 and world > 1   # BASELINE.json configs[3]: its hardware run rides along with the scaling curve
 
     import numpy as np
     import torch
@@ -251,9 +254,11 @@ def main():
                                       line_bytes_hint=hint)
 
     def timed(fmt, steps, warmup):
-        """K steps bracketed by barrier + synchronize, max over ranks; per-launch times from events on the launch stream."""
+        """K steps bracketed by barrier + synchronize, max over ranks; per-launch times from events on the launch stream.
+        fmt: a result format of this workload's step(), or any callable that launches one step."""
+        one = fmt if callable(fmt) else (lambda: step(fmt))
         for _ in range(warmup):
-            step(fmt)
+            one()
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
@@ -262,7 +267,7 @@ def main():
         t_start = time.perf_counter()
         ev[0].record()
         for i in range(steps):
-            step(fmt)
+            one()
             ev[i + 1].record()
         torch.cuda.synchronize()
         if distributed:
@@ -322,6 +327,48 @@ def main():
                 assert torch.equal(g8[:n], rows8) and torch.equal(g8[:, 0].view(torch.int8).to(torch.int32), gm)
             del g8
         del gr, gm, gc
+
+    # ---- N > 1: BASELINE.json configs[3] beside the curve -- 64 extractions, 10 M x 200 B lines per GPU (80 M on 8), the tables
+    # compiled on rank 0 and broadcast over RCCL, u8 rows; the same timing protocol, reported as its own object ----
+    config4 = None
+    if also_config4:
+        definition4, data4, offsets4, n4, want4, known4, hint4, desc4 = build_workload(4, args.lines or 10_000_000, rank, dev)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        gorp4, _ = gdist.broadcast_gorp(definition4, dev, src=0)
+        torch.cuda.synchronize()
+        bcast4_ms = (time.perf_counter() - tb) * 1e3
+        G4 = gorp4.max_groups
+        max4 = int((offsets4[1:].to(torch.int64) - offsets4[:-1].to(torch.int64)).max().item())
+        narrow4 = max4 < 255 and len(definition4) <= 126
+        rows4 = torch.empty((n4, 1 + 2 * G4), dtype=torch.uint8 if narrow4 else torch.int16, device=dev)
+        over4 = torch.zeros(1, dtype=torch.int64, device=dev)
+        step4 = lambda: gorp4.extract_batch_device(data4.data_ptr(), offsets4.data_ptr(), n4, None, rows4.data_ptr(), stream=stream, no_sync=True,
+                                                   line_bytes_hint=hint4, compact=2 if narrow4 else True, overflow_ptr=over4.data_ptr())
+        elapsed4, kernel4_ms = timed(step4, args.steps, args.warmup)
+        got4 = (rows4[:, 0].view(torch.int8) if narrow4 else rows4[:, 0]).to(torch.int32)
+        ok4 = (bool(torch.equal(got4, want4)) if known4 is None else bool(torch.equal(got4[known4], want4[known4]))) and int(over4.item()) == 0
+        ok4t = torch.tensor([1 if ok4 else 0], device=dev)
+        dist.all_reduce(ok4t, op=dist.ReduceOp.MIN)
+        if int(ok4t.item()) != 1:
+            raise SystemExit("bench: configs[3]: match ids differ from the generator's expected categories")
+        gather4_ms = None
+        if not args.no_gather:
+            torch.cuda.synchronize()
+            dist.barrier()
+            tg = time.perf_counter()
+            g4 = gdist.gather_rows(rows4, dst=0)
+            torch.cuda.synchronize()
+            gather4_ms = (time.perf_counter() - tg) * 1e3
+            del g4
+        k4 = sum(kernel4_ms) / len(kernel4_ms)
+        bytes4 = int(data4.numel()) + 4 * (n4 + 1)
+        config4 = {"workload": desc4, "baseline_config": 4, "value": n4 * world * args.steps / elapsed4, "unit": "lines/s",
+                   "ms_per_step": elapsed4 * 1e3 / args.steps, "kernel_ms_avg": k4, "lines_per_gpu": n4,
+                   "results": "%s rows, %d B/line" % ("u8" if narrow4 else "u16", (1 + 2 * G4) * (1 if narrow4 else 2)),
+                   "frac_of_hbm_peak_per_gpu": bytes4 / (k4 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "table_bcast_ms": bcast4_ms, "gather_ms": gather4_ms, "table_blob_bytes": int(gorp4.stat(4))}
+        del data4, offsets4, rows4
 
     if rank == 0:
         steps = args.steps
@@ -394,6 +441,8 @@ def main():
             "gather_dense_ms": gather_dense_ms,
             "gather_narrow_ms": gather_narrow_ms,
         }
+        if config4 is not None:
+            out["configs3_64_extractions"] = config4
         if not args.no_cpu_baseline and world == 1:
             sample = min(n, 10_000_000 if config == 2 else 2_000_000)
             end = int(offsets[sample].item())

@@ -715,7 +715,7 @@ def test_bench_two_ranks_self_launched():
     """`python bench.py --gpus 2` with no launcher, as the driver spells the scaling runs: the parent starts the ranks as
     fresh child processes and relays rank 0's line.  Both ranks share the one GPU of the box, so the process group is gloo
     (RCCL refuses two ranks on one device); everything else -- blob broadcast, per-rank shards, the timed steps with
-    barriers and max over ranks, the final gathers -- is config 4's path."""
+    barriers and max over ranks, the final gathers -- is the N > 1 path, for the metric's workload and for configs[3] beside it."""
     import json
     import os
     import subprocess
@@ -729,8 +729,12 @@ def test_bench_two_ranks_self_launched():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["config"]["baseline_config"] == 4 and out["scaling"] == "weak"
+    # the metric's workload (configs[1]) per GPU at every N -- one weak-scaling curve -- and configs[3] measured beside it
+    assert out["n_gpus"] == 2 and out["config"]["baseline_config"] == 2 and out["scaling"] == "weak"
     assert out["table_bcast_ms"] is not None and out["gather_ms"] is not None and out["value"] > 0
+    c4 = out["configs3_64_extractions"]
+    assert c4["baseline_config"] == 4 and c4["value"] > 0 and c4["table_bcast_ms"] is not None and c4["gather_ms"] is not None
+    assert "64 syslog-like extractions" in c4["workload"]
 
 
 def test_utf16_batch_input():
