@@ -242,19 +242,23 @@ def main():
     overflow = torch.zeros(1, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
+    # (the caller knows its longest line -- here from the generator, in a pipeline from gx_split_lines_max -- and says so:
+    # gx_batch_opts.max_line_bytes, a promise the library checks; it spares every step a second, nearly empty launch)
     def step(fmt):
         if fmt == "compact":
             gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, None, rows.data_ptr(), stream=stream, no_sync=True,
-                                      line_bytes_hint=hint, compact=True, overflow_ptr=overflow.data_ptr())
+                                      line_bytes_hint=hint, compact=True, overflow_ptr=overflow.data_ptr(), max_line_bytes=max_line)
         elif fmt == "narrow":
             gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, None, rows8.data_ptr(), stream=stream, no_sync=True,
-                                      line_bytes_hint=hint, compact=2, overflow_ptr=overflow.data_ptr())
+                                      line_bytes_hint=hint, compact=2, overflow_ptr=overflow.data_ptr(), max_line_bytes=max_line)
         else:
             gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=stream, no_sync=True,
-                                      line_bytes_hint=hint)
+                                      line_bytes_hint=hint, max_line_bytes=max_line)
 
-    def timed(fmt, steps, warmup):
-        """K steps bracketed by barrier + synchronize, max over ranks; per-launch times from events on the launch stream.
+    def timed(fmt, steps, warmup, per_step=False):
+        """K steps bracketed by barrier + synchronize, max over ranks, and the launches' average duration from two events on the
+        launch stream, one before the first step and one behind the last (per_step: an event behind every step instead -- the
+        spread of the steps, at the price of a marker between the kernels; never used for the headline).
         fmt: a result format of this workload's step(), or any callable that launches one step."""
         one = fmt if callable(fmt) else (lambda: step(fmt))
         for _ in range(warmup):
@@ -263,12 +267,15 @@ def main():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1 if per_step else 2)]
         t_start = time.perf_counter()
         ev[0].record()
         for i in range(steps):
             one()
-            ev[i + 1].record()
+            if per_step:
+                ev[i + 1].record()
+        if not per_step:
+            ev[1].record()
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
@@ -277,12 +284,15 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         if distributed:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item()), [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+        if per_step:
+            return float(t.item()), [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+        return float(t.item()), [ev[0].elapsed_time(ev[1]) / steps] * steps
 
     runs = {}
     for fmt in [f for f in formats if f != headline]:
         runs[fmt] = timed(fmt, args.steps, args.warmup)                      # the other result formats, same step count, reported beside
     elapsed, kernel_ms = runs[headline] = timed(headline, args.steps, args.warmup)   # THE timed region
+    _, step_ms = timed(headline, args.steps, 1, per_step=True)                       # (afterwards: the spread of single steps)
 
     # ---- correctness of what was timed: the generator knows every (uncorrupted) line's answer ----
     got = {"compact": lambda: rows[:, 0].to(torch.int32), "narrow": lambda: rows8[:, 0].view(torch.int8).to(torch.int32), "dense": lambda: mid}[headline]()
@@ -344,7 +354,8 @@ def main():
         rows4 = torch.empty((n4, 1 + 2 * G4), dtype=torch.uint8 if narrow4 else torch.int16, device=dev)
         over4 = torch.zeros(1, dtype=torch.int64, device=dev)
         step4 = lambda: gorp4.extract_batch_device(data4.data_ptr(), offsets4.data_ptr(), n4, None, rows4.data_ptr(), stream=stream, no_sync=True,
-                                                   line_bytes_hint=hint4, compact=2 if narrow4 else True, overflow_ptr=over4.data_ptr())
+                                                   line_bytes_hint=hint4, compact=2 if narrow4 else True, overflow_ptr=over4.data_ptr(),
+                                                   max_line_bytes=max4)
         elapsed4, kernel4_ms = timed(step4, args.steps, args.warmup)
         got4 = (rows4[:, 0].view(torch.int8) if narrow4 else rows4[:, 0]).to(torch.int32)
         ok4 = (bool(torch.equal(got4, want4)) if known4 is None else bool(torch.equal(got4[known4], want4[known4]))) and int(over4.item()) == 0
@@ -375,7 +386,7 @@ def main():
         ms_per_step = elapsed * 1e3 / steps
         value = n * world * steps / elapsed
         k_avg = sum(kernel_ms) / len(kernel_ms)
-        k_sorted = sorted(kernel_ms)
+        k_sorted = sorted(step_ms)
         algo_read = total_bytes + 4 * (n + 1)            # line bytes + u32 offsets
         write_bytes = {"narrow": n * (1 + 2 * G), "compact": n * (2 + 4 * G), "dense": n * (4 + 8 * G)}
         fmt_desc = {"narrow": "narrow rows (int8 id + uint8 offsets, %d B/line)" % (1 + 2 * G),
@@ -387,7 +398,7 @@ def main():
         # kernel in the same run).  Counters cannot be read from inside this process: the RECORDED figure of the committed
         # summary is reported when its workload and result format match this run, else null.
         traffic, traffic_src = None, None
-        for name in ("r03_traffic.json", "r02_traffic.json"):
+        for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
             try:
                 path = os.path.join(ROOT, "profiles", name)
                 tj = json.load(open(path))
@@ -407,6 +418,7 @@ def main():
         out = {
             "metric": "lines/sec (Gorp.extract: product-DFA match + capture offsets; results as %s)" % fmt_desc[headline],
             "value": value,
+            "value_compact_rows": per_format["compact"]["lines_per_s"],   # the same workload with u16 rows: the format `value` had in round 2 (a stable key for trends)
             "unit": "lines/s",
             "n_gpus": world,
             "steps": steps,
@@ -425,12 +437,17 @@ def main():
                        "table_tier": ("hop tier: run + chain records, %d of %d states' records in LDS (%d of them reachable by well-formed lines), dense rows in global memory"
                                       % (int(gorp.stat(15)), int(gorp.stat(14)), int(gorp.stat(16)))) if int(gorp.stat(14)) > 0 else
                                      {0: "per-line kernel", 1: "LDS (dense rows)", 2: "L2 (dense rows)", 3: "LDS (range records)", 4: "L2 (range records)"}.get(int(gorp.stat(7)), str(gorp.stat(7))),
-                       "kernel": "hop slice kernel" if int(gorp.stat(14)) > 0 and (hint > 255) else "tile kernel" if (int(gorp.stat(14)) > 0 or int(gorp.stat(7)) in (1, 2)) else "lane kernel",
+                       "kernel": {1: "tile kernel", 2: "slice kernel", 3: "per-line kernel", 4: "lane kernel", 5: "tile kernel on the hop tier's tables",
+                                  6: "hop slice kernel"}.get(int(gorp.stat(25)), "?") + " (gx_stat(h, 25): what the library launched)",
                        "parallelism": "lines sharded by rank (dp%d), no collective in a step" % world},
             "gb_per_s_scanned": total_bytes * world * steps / elapsed / 1e9,
-            "kernel_ms": {"avg": k_avg, "min": k_sorted[0], "median": k_sorted[len(k_sorted) // 2]},
+            "kernel_ms": {"avg": k_avg, "clock": "two events on the launch stream around the %d timed steps" % steps,
+                          "single_steps_after": {"min": k_sorted[0], "median": k_sorted[len(k_sorted) // 2], "max": k_sorted[-1],
+                                                 "clock": "an event behind every step, a second run of %d steps" % steps}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "frac_by_wall_clock": algo_read / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,   # (the same bytes over ms_per_step, the host's clock around barrier + synchronize)
+                         "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,
                          "algorithmic_read_bytes": algo_read, "algorithmic_write_bytes": write_bytes[headline],
                          "frac_of_measured_copy_ceiling": achieved / 6290.0},

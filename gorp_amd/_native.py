@@ -38,7 +38,7 @@ SYMBOLS = [
     "gx_extraction_append_count", "gx_extraction_append_key", "gx_extraction_append_value_json",
     "gx_pack_results", "gx_unpack_results", "gx_unpack_results8", "gx_text_to_jsonl", "gx_capture_one_utf16",
     "gx_match_batch", "gx_state_accepts", "gx_set_device", "gx_handle_device", "gx_extract_batch_multi",
-    "gx_host_register", "gx_host_unregister",
+    "gx_host_register", "gx_host_unregister", "gx_split_lines_max",
 ]
 
 
@@ -58,6 +58,7 @@ class gx_batch_opts(C.Structure):
         ("compact_results", C.c_uint32),
         ("uneven_lines", C.c_uint32),
         ("overflow", C.c_void_p),
+        ("max_line_bytes", C.c_uint32),
     ]
 
 
@@ -169,6 +170,9 @@ def lib():
     L.gx_split_lines.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p,
                                  C.POINTER(gx_batch_opts)]
     L.gx_split_lines.restype = C.c_int
+    L.gx_split_lines_max.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p,
+                                     C.POINTER(C.c_uint64), C.POINTER(gx_batch_opts)]
+    L.gx_split_lines_max.restype = C.c_int
     L.gx_results_to_jsonl.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_char_p,
                                       C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(gx_batch_opts)]
     L.gx_results_to_jsonl.restype = C.c_int

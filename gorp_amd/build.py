@@ -54,6 +54,11 @@ def build(force=False, verbose=False, dev=False):
         cmd = [_hipcc()] + common + ["-c", os.path.join(CSRC, src), "-o", obj]
         if src == "gx_api.cpp":
             cmd[1:1] = ["-x", "hip"]
+        if src.startswith("gx_tile_"):
+            # the tile kernel draws its next tile from a counter in global memory a whole walk before it needs the answer; the
+            # compiler's atomic optimizer would rewrite that draw into a wave reduction that WAITS for the answer on the spot --
+            # i.e. for every load of the prefetch issued just before it
+            cmd[1:1] = ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
         jobs.append((cmd, obj))
 
     def run(job):

@@ -124,8 +124,22 @@ struct gx_handle {
     // Tile-kernel launches that are in flight share nothing but these slots: one word each, into which a launch
     // stores its sequence number when it meets a line it cannot stage (gx_device.hpp: GxBatch::oversize_flag).
     // A slot is reused only after the follow-up kernel of its previous user has run (event).
+    // A slot belongs to ONE STREAM for the life of the handle (launches of a stream run in order, so the word is free again
+    // when the stream's next launch begins: nothing to wait for, nothing to record); the last slot is shared by the streams
+    // that come after N_SLOTS - 1 others and is handed over with an event.
     static const int N_SLOTS = 32;
     uint32_t* d_slots = nullptr;          // [N_SLOTS] oversize flags, then [N_SLOTS] chunk counters of the lane kernel
+    hipStream_t slot_stream[N_SLOTS] = {};
+    bool slot_taken[N_SLOTS] = {};
+    // Batches that promise their longest line (gx_batch_opts.max_line_bytes) have no follow-up launch; their flag word is in
+    // pinned host memory (one per slot; the device writes it only if the promise is broken), so that the host can see it.
+    uint32_t* h_broken = nullptr;         // [N_SLOTS], pinned + mapped
+    uint32_t* d_broken = nullptr;         // the device's address of the same words
+    uint32_t* d_steal[N_SLOTS] = {};      // per slot, at its first tile launch: [2][GX_STEAL_MAX * GX_STEAL_STRIDE], the tile kernel's workgroup counters (GxBatch::steal)
+    uint32_t steal_parity[N_SLOTS] = {};  // the row the slot's next tile-kernel launch draws from
+    uint32_t promise_seq[N_SLOTS] = {};   // the sequence number of the slot's last launch under a promise (0: none)
+    std::atomic<uint64_t> promises_broken{0};
+    std::atomic<int> last_kernel{0};      // GX_KERNEL_* of the most recent batch launch (gx_stat(h, 25))
     // device scratch of gx_results_to_jsonl / gx_text_to_jsonl (sizes, split points, line offsets), kept between calls and grown as
     // batches ask: a hipMalloc + hipFree pair per call cost more than the scan kernels.  Used under `mu` only, and every call that
     // uses it ends with a stream synchronisation.
@@ -136,8 +150,8 @@ struct gx_handle {
     // gigabytes per call, 0.6 of that path's 2.4 ms per 10 M lines)
     hipMemPool_t pool = nullptr;
     uint32_t chunk_tickets[N_SLOTS] = {};  // what each chunk counter will read when the next launch on its slot begins
-    hipEvent_t slot_event[N_SLOTS] = {};
-    bool slot_used[N_SLOTS] = {};
+    hipEvent_t shared_event = nullptr;    // the shared slot's "previous user is done"
+    bool shared_used = false;
     uint32_t next_seq = 1;
     std::mutex slot_mu;
 #ifdef GX_DEV
@@ -937,6 +951,8 @@ void upload(gx_handle* h) {
             GX_HIP(hipMalloc(&h->d_l2_image, h->l2_image.size()));
             GX_HIP(hipMemcpy(h->d_l2_image, h->l2_image.data(), h->l2_image.size(), hipMemcpyHostToDevice));
         }
+    }
+    if (h->tile_ok || h->hop_ok || h->hop_mo_ok) {
         if (h->hop_ok) {
             GX_HIP(hipMalloc(&h->d_lds_image_hop, h->hop.full.bytes.size()));
             GX_HIP(hipMemcpy(h->d_lds_image_hop, h->hop.full.bytes.data(), h->hop.full.bytes.size(), hipMemcpyHostToDevice));
@@ -955,7 +971,11 @@ void upload(gx_handle* h) {
         }
         GX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_slots), 2 * gx_handle::N_SLOTS * sizeof(uint32_t)));
         GX_HIP(hipMemset(h->d_slots, 0, 2 * gx_handle::N_SLOTS * sizeof(uint32_t)));
-        for (int q = 0; q < gx_handle::N_SLOTS; ++q) GX_HIP(hipEventCreateWithFlags(&h->slot_event[q], hipEventDisableTiming));
+        GX_HIP(hipEventCreateWithFlags(&h->shared_event, hipEventDisableTiming));
+
+        GX_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_broken), gx_handle::N_SLOTS * sizeof(uint32_t), hipHostMallocMapped));
+        for (int q = 0; q < gx_handle::N_SLOTS; ++q) h->h_broken[q] = 0;
+        GX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_broken), h->h_broken, 0));
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->num_cus = cus;
     }
@@ -964,7 +984,71 @@ void upload(gx_handle* h) {
 
 // One batch on the device: tile kernel (LDS tier when the tables fit LDS, else L2 tier), slice kernel for long lines,
 // per-line kernel otherwise.  kernel: gx_batch_opts.kernel (0 = choose).
-void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t kernel, hipStream_t stream, bool uneven = false) {
+// What a launch leaves for its caller: where a broken max_line_bytes promise would show, and how to make good for it.
+struct Launched {
+    int slot = -1;
+    uint32_t seq = 0;
+    bool promised = false;     // no follow-up launch: the caller said that no line is longer than the kernel takes
+    uint32_t limit = 0;        // launch_extract_oversize's arguments for this launch
+    int by_length = 0;
+};
+
+// The launch's flag word (and the lane kernel's chunk counter): the slot of its stream.  Call under h->slot_mu.
+struct SlotUse { int slot; bool shared; };
+SlotUse take_slot(gx_handle* h, GxBatch& b, hipStream_t stream) {
+    b.seq = h->next_seq++;
+    if (h->next_seq == 0) h->next_seq = 1;
+    int slot = -1;
+    for (int q = 0; q < gx_handle::N_SLOTS - 1 && slot < 0; ++q)
+        if (h->slot_taken[q] && h->slot_stream[q] == stream) slot = q;
+    for (int q = 0; q < gx_handle::N_SLOTS - 1 && slot < 0; ++q)
+        if (!h->slot_taken[q]) { h->slot_taken[q] = true; h->slot_stream[q] = stream; slot = q; }
+    const bool shared = slot < 0;
+    if (shared) {
+        slot = gx_handle::N_SLOTS - 1;
+        if (h->shared_used) GX_HIP(hipStreamWaitEvent(stream, h->shared_event, 0));
+        h->shared_used = true;
+    }
+    // a batch of this stream that promised its longest line, ran without a follow-up launch and met a longer line after all
+    // (no_sync batches: nobody has looked yet)
+    if (h->promise_seq[slot] != 0 && __atomic_load_n(&h->h_broken[slot], __ATOMIC_RELAXED) == h->promise_seq[slot]) {
+        h->promise_seq[slot] = 0;
+        h->promises_broken.fetch_add(1);
+        throw GxError(GX_E_ARG, "an earlier no_sync batch on this stream held a line longer than its gx_batch_opts.max_line_bytes: that line was not "
+                                "processed (its result row is unwritten); this batch was not launched");
+    }
+    b.oversize_flag = h->d_slots + slot;
+    if (!h->d_steal[slot]) {   // (the slot's first launch: 768 KB, zeroed once -- every launch leaves the next one's row zeroed)
+        const size_t bytes = 2 * static_cast<size_t>(GX_STEAL_MAX) * GX_STEAL_STRIDE * sizeof(uint32_t);
+        GX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_steal[slot]), bytes));
+        GX_HIP(hipMemset(h->d_steal[slot], 0, bytes));   // (the null stream's memset: done before any later launch begins? not with non-blocking streams: wait for it)
+        GX_HIP(hipDeviceSynchronize());
+    }
+    b.steal = h->d_steal[slot];
+    b.steal_parity = h->steal_parity[slot];
+    return SlotUse{slot, shared};
+}
+// The follow-up launch for the lines the batch kernel leaves (longer than `limit`: see launch_extract_oversize) -- unless the
+// caller promised that there are none (b.max_line_bytes within `fits`), or the host knows (b.no_followup: the one-line calls).
+// Call before the batch kernel is launched; returns what to launch after it.
+bool plan_followup(gx_handle* h, GxBatch& b, const SlotUse& u, uint32_t fits, Launched* out) {
+    if (out) { out->slot = u.slot; out->seq = b.seq; }
+    if (b.no_followup) return false;
+    if (b.max_line_bytes != 0 && b.max_line_bytes <= fits) {
+        b.no_followup = 1;
+        b.oversize_flag = h->d_broken + u.slot;
+        h->promise_seq[u.slot] = b.seq;
+        if (out) out->promised = true;
+        return false;
+    }
+    h->promise_seq[u.slot] = 0;
+    return true;
+}
+void done_slot(gx_handle* h, const SlotUse& u, hipStream_t stream) {
+    if (u.shared) GX_HIP(hipEventRecord(h->shared_event, stream));
+}
+
+void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t kernel, hipStream_t stream, bool uneven = false, Launched* launched = nullptr) {
     GxLds L;
     if (b.wide && !b.state_out && b.match_only >= 0 && kernel != GX_KERNEL_PER_LINE && b.n > 0) {
         // UTF-16 code units: their low bytes through the byte kernels, then the lines that hold a unit above 0xFF again through
@@ -998,8 +1082,9 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
         if (e == hipSuccess) {
             GxBatch nb = b;
             nb.wide = 0;
+            nb.max_line_bytes = 0;     // (the copy does not outlive this call: its follow-up launch always runs)
             nb.data = bytes - first;   // (addressed like the units: line i at data + offsets[i])
-            try { launch_batch(h, nb, line_bytes_hint, kernel, stream, uneven); }
+            try { launch_batch(h, nb, line_bytes_hint, kernel, stream, uneven, launched); }
             catch (...) { (void)hipFreeAsync(tmp, stream); throw; }
             e = launch_extract_flagged(h->dev, b, flags, stream);
         }
@@ -1036,37 +1121,36 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
     const bool hop_slices = have_hop && !b.wide && (kernel == GX_KERNEL_HOP_SLICES || (kernel == GX_KERNEL_AUTO && (long_lines || uneven)));
     if (batchable && hop_slices && plan_hop_slice_launch(h, &L, mo)) {
         std::lock_guard<std::mutex> lock(h->slot_mu);
-        b.seq = h->next_seq++;
-        if (h->next_seq == 0) h->next_seq = 1;
-        const int slot = static_cast<int>(b.seq % gx_handle::N_SLOTS);
-        if (h->slot_used[slot]) GX_HIP(hipStreamWaitEvent(stream, h->slot_event[slot], 0));
-        h->slot_used[slot] = true;
-        b.oversize_flag = h->d_slots + slot;
+        const SlotUse u = take_slot(h, b, stream);
+        const bool followup = plan_followup(h, b, u, 65535u, launched);
+        if (launched) { launched->limit = 65535u; launched->by_length = 1; }
+        h->last_kernel = GX_KERNEL_HOP_SLICES;
         GX_HIP(launch_extract_hop_slices(h->dev, L, hop_image_small, hop_global, h->num_cus, b, stream));
-        if (!b.no_followup) GX_HIP(launch_extract_oversize(h->dev, b, 65535u + 48u, stream));   // (lines beyond the 16-bit positions, if the kernel met any)
-        GX_HIP(hipEventRecord(h->slot_event[slot], stream));
+        if (followup) GX_HIP(launch_extract_oversize(h->dev, b, 65535u, 1, stream));   // (lines beyond the 16-bit positions, if the kernel met any)
+        done_slot(h, u, stream);
         return;
     }
     const bool hops = have_hop && !b.wide && (kernel == GX_KERNEL_HOPS || (kernel == GX_KERNEL_AUTO && !long_lines && !uneven));
     if (batchable && hops && plan_hop_launch(h, line_bytes_hint, &L, mo)) {
         std::lock_guard<std::mutex> lock(h->slot_mu);
-        b.seq = h->next_seq++;
-        if (h->next_seq == 0) h->next_seq = 1;
-        const int slot = static_cast<int>(b.seq % gx_handle::N_SLOTS);
-        if (h->slot_used[slot]) GX_HIP(hipStreamWaitEvent(stream, h->slot_event[slot], 0));
-        h->slot_used[slot] = true;
-        b.oversize_flag = h->d_slots + slot;
+        const SlotUse u = take_slot(h, b, stream);
+        // (a line fits a wave's staging area when its bytes + the 15 its address may add + the walk's look-ahead do)
+        const bool followup = plan_followup(h, b, u, L.stage_bytes >= 63u ? L.stage_bytes - 63u : 0u, launched);
+        if (launched) { launched->limit = L.stage_bytes; launched->by_length = 0; }
         unsigned long long* stamps = nullptr;
 #ifdef GX_DEV
         stamps = h->dev_stamps;
 #endif
+        h->last_kernel = GX_KERNEL_HOPS;
         GX_HIP(launch_extract_tile(h->dev, L, hop_image, hop_global, h->num_cus, b, stream, stamps));
-        if (!b.no_followup) GX_HIP(launch_extract_oversize(h->dev, b, L.stage_bytes, stream));
-        GX_HIP(hipEventRecord(h->slot_event[slot], stream));
+        h->steal_parity[u.slot] ^= 1u;
+        if (followup) GX_HIP(launch_extract_oversize(h->dev, b, L.stage_bytes, 0, stream));
+        done_slot(h, u, stream);
         return;
     }
     const bool slices = kernel == GX_KERNEL_SLICES || (kernel == GX_KERNEL_AUTO && very_long);
     if (batchable && slices && plan_slice_launch(h, &L, mo)) {
+        h->last_kernel = GX_KERNEL_SLICES;
         GX_HIP(launch_extract_slices(h->dev, L, image, at_global, h->num_cus, b, stream));
         return;
     }
@@ -1077,18 +1161,19 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
     if (lanes_ok && kernel == GX_KERNEL_AUTO && long_lines && L.sort_chunk == 0) {
         GxLds S;
         if (plan_slice_launch(h, &S, mo)) {
+            h->last_kernel = GX_KERNEL_SLICES;
             GX_HIP(launch_extract_slices(h->dev, S, image, at_global, h->num_cus, b, stream));
             return;
         }
     }
     if (lanes_ok) {
         std::lock_guard<std::mutex> lock(h->slot_mu);
-        b.seq = h->next_seq++;
-        if (h->next_seq == 0) h->next_seq = 1;
-        const int slot = static_cast<int>(b.seq % gx_handle::N_SLOTS);
-        if (h->slot_used[slot]) GX_HIP(hipStreamWaitEvent(stream, h->slot_event[slot], 0));
-        h->slot_used[slot] = true;
-        b.oversize_flag = h->d_slots + slot;
+        const SlotUse u = take_slot(h, b, stream);
+        const int slot = u.slot;
+        // (the lines the lane kernel leaves: longer than its 16-bit positions -- with compact rows, than the 65 534 they can hold)
+        const uint32_t lanes_limit = b.packed ? 65534u : 65535u;
+        const bool followup = plan_followup(h, b, u, lanes_limit, launched);
+        if (launched) { launched->limit = lanes_limit; launched->by_length = 1; }
         if (L.sort_chunk) {
             b.chunk_ctr = h->d_slots + gx_handle::N_SLOTS + slot;
             b.chunk_base = h->chunk_tickets[slot];
@@ -1097,31 +1182,31 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
 #ifdef GX_DEV
         stamps = h->dev_stamps;
 #endif
+        h->last_kernel = GX_KERNEL_LANES;
         GX_HIP(launch_extract_lanes(h->dev, L, image, at_global, h->num_cus, b, stream, stamps));
         if (L.sort_chunk) h->chunk_tickets[slot] += lanes_sorted_tickets(b.n, L.sort_chunk, h->num_cus);  // (what the launch will draw)
-        // (the lines the lane kernel leaves: longer than its 16-bit positions -- with compact rows, than the 65 534 they can hold)
-        if (!b.no_followup) GX_HIP(launch_extract_oversize(h->dev, b, (b.packed ? 65534u : 65535u) + 48u, stream));
-        GX_HIP(hipEventRecord(h->slot_event[slot], stream));
+        if (followup) GX_HIP(launch_extract_oversize(h->dev, b, lanes_limit, 1, stream));
+        done_slot(h, u, stream);
         return;
     }
     if (batchable && plan_tile_launch(h, line_bytes_hint, &L, mo)) {
         // a slot for the "lines I could not stage" word of this launch, free again once its follow-up kernel has run
         // (submission of tile launches is serialised per handle; the launches themselves are asynchronous)
         std::lock_guard<std::mutex> lock(h->slot_mu);
-        b.seq = h->next_seq++;
-        if (h->next_seq == 0) h->next_seq = 1;
-        const int slot = static_cast<int>(b.seq % gx_handle::N_SLOTS);
-        if (h->slot_used[slot]) GX_HIP(hipStreamWaitEvent(stream, h->slot_event[slot], 0));
-        h->slot_used[slot] = true;
-        b.oversize_flag = h->d_slots + slot;
+        const SlotUse u = take_slot(h, b, stream);
+        const bool followup = plan_followup(h, b, u, L.stage_bytes >= 63u ? L.stage_bytes - 63u : 0u, launched);
+        if (launched) { launched->limit = L.stage_bytes; launched->by_length = 0; }
         unsigned long long* stamps = nullptr;
 #ifdef GX_DEV
         stamps = h->dev_stamps;
 #endif
+        h->last_kernel = GX_KERNEL_TILES;
         GX_HIP(launch_extract_tile(h->dev, L, image, at_global, h->num_cus, b, stream, stamps));
-        if (!b.no_followup) GX_HIP(launch_extract_oversize(h->dev, b, L.stage_bytes, stream));
-        GX_HIP(hipEventRecord(h->slot_event[slot], stream));
+        h->steal_parity[u.slot] ^= 1u;
+        if (followup) GX_HIP(launch_extract_oversize(h->dev, b, L.stage_bytes, 0, stream));
+        done_slot(h, u, stream);
     } else {
+        h->last_kernel = GX_KERNEL_PER_LINE;
         GX_HIP(launch_extract_generic(h->dev, b, stream));
     }
 }
@@ -1218,7 +1303,9 @@ void gx_destroy(gx_handle* h) {
     }
     if (h->d_slots) {
         (void)hipFree(h->d_slots);
-        for (int q = 0; q < gx_handle::N_SLOTS; ++q) if (h->slot_event[q]) (void)hipEventDestroy(h->slot_event[q]);
+        if (h->shared_event) (void)hipEventDestroy(h->shared_event);
+        if (h->h_broken) (void)hipHostFree(h->h_broken);
+        for (uint32_t* q : h->d_steal) if (q) (void)hipFree(q);
     }
     for (auto& e : h->jsonl) if (e.second.d) (void)hipFree(e.second.d);
     for (void* q : h->scratch) if (q) (void)hipFree(q);
@@ -1259,6 +1346,8 @@ int64_t gx_stat(const gx_handle* h, int32_t which) {
     case 18: { GxLds L; return plan_hop_launch(h, 0, &L) ? static_cast<int64_t>(L.nwaves) : 0; }  // hop tier: waves per CU
     case 20: return h->hop_ok ? static_cast<int64_t>(h->hop.full.n_lds_rows) : 0;       // ... whose dense row is in LDS too (branching states)
     case 22: return h->hop_mo_ok ? static_cast<int64_t>(h->hop_mo.n_states) : 0;   // hop tier of the match automaton alone (match-only batches): states
+    case 24: return static_cast<int64_t>(h->promises_broken.load());
+    case 25: return h->last_kernel.load();
     case 23: return h->hop_mo_ok ? static_cast<int64_t>(h->hop_mo.full.n_hot) : 0; // ... whose records are in LDS
     case 19: { GxLds L; return plan_hop_slice_launch(h, &L) ? static_cast<int64_t>(L.nwaves) : 0; }  // ... of the hop slice kernel
     case 9: return !h->tile_ok ? 0 : !h->has_mo ? gx_stat(h, 7) : h->lds_mo.tier == 3 ? 4 : h->lds_mo.tier == 2 ? 3 : h->lds_mo.tier == 1 ? 2 : 1;
@@ -1278,6 +1367,11 @@ static bool read_opts(const gx_batch_opts* opts, gx_batch_opts* o) {
 
 int gx_split_lines(const uint8_t* bytes, uint64_t size, void* offsets, uint64_t cap_lines, uint64_t* n_lines, uint8_t* line_flags,
                    const gx_batch_opts* opts) {
+    return gx_split_lines_max(bytes, size, offsets, cap_lines, n_lines, line_flags, nullptr, opts);
+}
+
+int gx_split_lines_max(const uint8_t* bytes, uint64_t size, void* offsets, uint64_t cap_lines, uint64_t* n_lines, uint8_t* line_flags,
+                       uint64_t* max_line_bytes, const gx_batch_opts* opts) {
     if (!offsets || !n_lines || (size && !bytes)) return fail(GX_E_ARG, "gx_split_lines: bad argument");
     gx_batch_opts o{};
     if (!read_opts(opts, &o)) return fail(GX_E_ARG, "gx_batch_opts.struct_size mismatch");
@@ -1305,11 +1399,14 @@ int gx_split_lines(const uint8_t* bytes, uint64_t size, void* offsets, uint64_t 
             dst_flags = line_flags ? static_cast<uint8_t*>(d_flags.p) : nullptr;
         }
         uint64_t* d_n = nullptr;
-        GX_HIP(launch_split_lines(src, size, dst_off, o.offsets64 ? 1 : 0, cap_lines, dst_flags, ws.p, &d_n, stream));
-        uint64_t n = 0;
-        GX_HIP(hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, stream));
+        uint64_t* d_max = nullptr;
+        GX_HIP(launch_split_lines(src, size, dst_off, o.offsets64 ? 1 : 0, cap_lines, dst_flags, ws.p, &d_n, stream, max_line_bytes ? &d_max : nullptr));
+        uint64_t n_and_max[2] = {0, 0};   // (n_lines and max_line are neighbours in the workspace)
+        GX_HIP(hipMemcpyAsync(n_and_max, d_n, max_line_bytes ? 16 : 8, hipMemcpyDeviceToHost, stream));
         GX_HIP(hipStreamSynchronize(stream));
+        const uint64_t n = n_and_max[0];
         *n_lines = n;
+        if (max_line_bytes) *max_line_bytes = n_and_max[1];
         if (n > cap_lines) return fail(GX_E_LIMIT, "gx_split_lines: the buffer holds more lines than cap_lines");
         if (!o.device_pointers) {
             GX_HIP(hipMemcpy(offsets, d_off.p, (n + 1) * off_w, hipMemcpyDeviceToHost));
@@ -1798,8 +1895,24 @@ static int extract_batch_impl(gx_handle* h, const uint8_t* bytes, const void* of
                     uneven = lines_are_uneven(sample.data(), m, o.offsets64 != 0);
                 }
             }
-            launch_batch(h, b, hint, o.kernel, stream, uneven);
-            if (!o.no_sync) GX_HIP(hipStreamSynchronize(stream));
+            b.max_line_bytes = o.max_line_bytes;
+            Launched done;
+            launch_batch(h, b, hint, o.kernel, stream, uneven, &done);
+            if (!o.no_sync) {
+                GX_HIP(hipStreamSynchronize(stream));
+                if (done.promised && __atomic_load_n(&h->h_broken[done.slot], __ATOMIC_RELAXED) == done.seq) {
+                    // the promise did not hold: the lines the batch kernel left, now (and the word is clean for the stream's next launch)
+                    {
+                        std::lock_guard<std::mutex> lock(h->slot_mu);
+                        if (h->promise_seq[done.slot] == done.seq) h->promise_seq[done.slot] = 0;
+                    }
+                    h->promises_broken.fetch_add(1);
+                    b.seq = done.seq;
+                    b.oversize_flag = h->d_broken + done.slot;
+                    GX_HIP(launch_extract_oversize(h->dev, b, done.limit, done.by_length, stream));
+                    GX_HIP(hipStreamSynchronize(stream));
+                }
+            }
             return GX_OK;
         }
         // host pointers: the chunked pipeline (gx_handle::host_slot)
@@ -2130,7 +2243,7 @@ int gx_definition_to_json(const char* definition_text, const char* source_ref, c
 #ifdef GX_DEV
 // Developer build only (libgorp_hip_dev.so, `python -m gorp_amd.build --dev`): the tile kernel adds up the cycles
 // each wave spends in its four phases (stage, prefetch issue, walk, results) into this device buffer,
-// 4 x uint64 per wave of the grid (256 workgroups x 12 waves at most).  Not part of the product ABI.
+// 8 x uint64 per wave of the grid (256 workgroups x 12 waves at most; gx_tile_body.hpp: TileIO::stamps).  Not part of the product ABI.
 namespace gx { hipError_t jsonl_dev_phases(unsigned long long* out16, int reset); }
 // cycles per phase of the JSONL tile kernels summed over their waves since the last reset: [0..5] sizes pass, [8..13] write pass
 extern "C" int gx_dev_jsonl_phases(unsigned long long* out16, int reset) { return gx::jsonl_dev_phases(out16, reset) == hipSuccess ? GX_OK : GX_E_DEVICE; }

@@ -87,6 +87,9 @@ struct GxLds {
     uint32_t sort_lds;    // lane kernel, length-sorted mode: LDS address of u16 perm[sort_chunk] + u32 hist[64] + u32 cursor[64]
     uint32_t sort_chunk;  // ... lines per chunk (0: tiles in input order)
 };
+constexpr uint32_t GX_STEAL_MAX = 3072;         // workgroups of a tile-kernel launch at most (256 CUs x 12)
+constexpr uint32_t GX_STEAL_STRIDE = 32;        // u32 words between two workgroups' counters: a cache line each (atomics on ONE line
+                                                // take their turns at 11 ns apiece, whichever words of it they want)
 constexpr uint32_t GX_BITMAP_WAVE_BYTES = 144;  // 16 x u64 (1024 chunks = 16 KB of staging) + one word read ahead
 
 struct GxBatch {
@@ -115,9 +118,15 @@ struct GxBatch {
     // one ticket per chunk and one more per workgroup)
     uint32_t* chunk_ctr;
     uint32_t chunk_base;
-    // the host knows that no line of the batch is beyond what the chosen kernel stages (the one-line calls: the host has the line):
-    // no follow-up launch of the per-line kernel behind the batch kernel
+    // the host knows that no line of the batch is beyond what the chosen kernel stages (the one-line calls: the host has the line;
+    // batches: the caller's promise, gx_batch_opts.max_line_bytes): no follow-up launch of the per-line kernel behind the batch
+    // kernel.  oversize_flag then points to a word in pinned HOST memory: a kernel that meets such a line after all says so there.
     uint32_t no_followup;
+    uint32_t max_line_bytes;   // the promise itself (0: none)
+    // tile kernel: the workgroups' tile counters, u32[2][GX_STEAL_MAX * GX_STEAL_STRIDE] of the launch's stream slot (every GX_STEAL_STRIDE-th word is a counter).  A launch draws from row
+    // steal_parity and zeroes the other row, which the stream's next launch draws from.
+    uint32_t* steal;
+    uint32_t steal_parity;
 };
 
 // More than 64 KiB of dynamic LDS needs the attribute, once per kernel (= per instantiation of this template) and
@@ -150,7 +159,10 @@ hipError_t launch_extract_flagged(const GxDev& dev, const GxBatch& b, const uint
 // takes those lines with the per-line kernel.  dev_stamps: developer builds (-DGX_DEV) only, else ignored.
 hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
                                const GxBatch& b, hipStream_t stream, unsigned long long* dev_stamps);
-hipError_t launch_extract_oversize(const GxDev& dev, const GxBatch& b, uint32_t stage_bytes, hipStream_t stream);
+// by_length 0: the lines for which (bytes in memory) + (address & 15) + 48 > limit (the tile kernel's staging predicate, limit =
+// GxLds::stage_bytes); 1: the lines longer than `limit` bytes without their terminator (lane and hop slice kernels: 65 535, or
+// 65 534 with compact rows under the lane kernel).
+hipError_t launch_extract_oversize(const GxDev& dev, const GxBatch& b, uint32_t limit, int by_length, hipStream_t stream);
 // Lane kernel (gx_lanes.hip): tables in global memory (GxLds::tier 1 or 3), every lane keeps its own line in registers;
 // lds.nwaves waves per workgroup; lds.regs_wave_bytes = the wave's LDS area (register block of lds.stage_bytes bytes + result rows).
 // Lines longer than 65 535 bytes are left to launch_extract_oversize (stage_bytes = 65 535 + 48).
@@ -173,8 +185,9 @@ hipError_t launch_extract_hop_slices(const GxDev& dev, const GxLds& lds, const u
 // Line ingestion (gx_ingest.hip): raw bytes -> CSR offsets of readLine()-style lines, terminators included.
 // `workspace` holds split_workspace_bytes(size) bytes; *d_n_lines receives the device address of the line count.
 size_t split_workspace_bytes(uint64_t size);
+// d_max_line (optional): *d_max_line receives the device address of the longest line's length, terminator included.
 hipError_t launch_split_lines(const uint8_t* data, uint64_t size, void* offsets, int offsets64, uint64_t cap_lines, uint8_t* flags,
-                              void* workspace, uint64_t** d_n_lines, hipStream_t stream);
+                              void* workspace, uint64_t** d_n_lines, hipStream_t stream, uint64_t** d_max_line = nullptr);
 
 
 // Result materialisation (gx_jsonl.hip): per-extraction JSON templates on the device.  A template is a list of

@@ -221,29 +221,46 @@ __global__ void k_split_finish(const uint8_t* __restrict__ data, uint64_t size, 
     *n_lines = n;
 }
 
+// the longest line, terminator included (what gx_batch_opts.max_line_bytes wants to hear): one sweep over the offsets just written
+// (4 bytes per line: 1 % of the text's bytes)
+template <typename OFF>
+__global__ void __launch_bounds__(256) k_split_max(const OFF* __restrict__ offsets, const uint64_t* __restrict__ n_lines, uint64_t cap_lines,
+                                                   unsigned long long* __restrict__ max_line) {
+    const uint64_t n = min(*n_lines, cap_lines);
+    unsigned long long m = 0;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+        m = max(m, static_cast<unsigned long long>(offsets[i + 1]) - static_cast<unsigned long long>(offsets[i]));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63u) == 0 && m) atomicMax(max_line, m);
+}
+
 }  // namespace
 
 size_t split_workspace_bytes(uint64_t size) {
     const uint64_t nblocks = (size + SPLIT_BLOCK_BYTES - 1) / SPLIT_BLOCK_BYTES;
-    return static_cast<size_t>((nblocks + 1) * 4 + (nblocks + 1) * 8 + 64);
+    return static_cast<size_t>((nblocks + 1) * 4 + (nblocks + 2) * 8 + 64);
 }
 
-// workspace: [total_ends u64][n_lines u64][prefix u64 * nblocks][counts u32 * nblocks]
+// workspace: [total_ends u64][n_lines u64][max_line u64][prefix u64 * nblocks][counts u32 * nblocks]
 hipError_t launch_split_lines(const uint8_t* data, uint64_t size, void* offsets, int offsets64, uint64_t cap_lines, uint8_t* flags,
-                              void* workspace, uint64_t** d_n_lines, hipStream_t stream) {
+                              void* workspace, uint64_t** d_n_lines, hipStream_t stream, uint64_t** d_max_line) {
     const uint64_t nblocks = (size + SPLIT_BLOCK_BYTES - 1) / SPLIT_BLOCK_BYTES;
     uint64_t* total_ends = static_cast<uint64_t*>(workspace);
     uint64_t* n_lines = total_ends + 1;
-    uint64_t* prefix = total_ends + 2;
+    uint64_t* max_line = total_ends + 2;
+    uint64_t* prefix = total_ends + 3;
     uint32_t* counts = reinterpret_cast<uint32_t*>(prefix + nblocks + 1);
     *d_n_lines = n_lines;
+    if (d_max_line) *d_max_line = max_line;
     hipError_t e;
     if (flags && cap_lines) {
         e = hipMemsetAsync(flags, 0, cap_lines, stream);
         if (e != hipSuccess) return e;
     }
     if (nblocks == 0) {
-        e = hipMemsetAsync(workspace, 0, 16, stream);  // no ends, no lines
+        e = hipMemsetAsync(workspace, 0, 24, stream);  // no ends, no lines
         if (e != hipSuccess) return e;
         return hipMemsetAsync(offsets, 0, offsets64 ? 8 : 4, stream);
     }
@@ -260,6 +277,16 @@ hipError_t launch_split_lines(const uint8_t* data, uint64_t size, void* offsets,
                            static_cast<uint32_t*>(offsets), cap_lines, flags);
         hipLaunchKernelGGL(k_split_finish<uint32_t>, dim3(1), dim3(1), 0, stream, data, size, total_ends, static_cast<uint32_t*>(offsets), cap_lines,
                            n_lines);
+    }
+    if (d_max_line) {
+        e = hipMemsetAsync(max_line, 0, 8, stream);
+        if (e != hipSuccess) return e;
+        const uint64_t want = (size / 64 + 255) / 256 + 1;   // (a thread per line of 64 bytes: more lines than that, and they take turns)
+        const dim3 grid(static_cast<unsigned>(want < 2048 ? want : 2048));
+        if (offsets64) hipLaunchKernelGGL(k_split_max<uint64_t>, grid, dim3(256), 0, stream, static_cast<const uint64_t*>(offsets), n_lines, cap_lines,
+                                          reinterpret_cast<unsigned long long*>(max_line));
+        else hipLaunchKernelGGL(k_split_max<uint32_t>, grid, dim3(256), 0, stream, static_cast<const uint32_t*>(offsets), n_lines, cap_lines,
+                                reinterpret_cast<unsigned long long*>(max_line));
     }
     return hipGetLastError();
 }

@@ -209,19 +209,28 @@ k_extract_flagged(GxDev T, const uint16_t* __restrict__ units, const OFF* __rest
 
 // Follow-up of the tile kernel: the lines it could not stage (one line longer than its staging area, rare) are
 // taken here, one lane per line.  The tile kernel announces that there are any by storing the launch's sequence
-// number into *flag; without it every wave leaves at once.  The predicate is the tile kernel's own (make_round).
+// number into *flag; without it every wave leaves at once.  The predicate is the batch kernel's own: the tile kernel's
+// make_round (the line, as it lies in memory, against the staging area: by_length 0), or the lane and hop slice kernels' "longer
+// than the 16-bit positions hold" on the line WITHOUT its terminator (by_length 1) -- never a line the batch kernel has
+// already answered (it would be counted twice in *overflow).
 template <typename OFF>
 __global__ void __launch_bounds__(256)
 k_extract_oversize(GxDev T, const uint8_t* __restrict__ data, const OFF* __restrict__ off, uint64_t n, LineOut out, int match_only,
-                   int strip_eol, const uint32_t* __restrict__ flag, uint32_t seq, uint32_t stage_bytes) {
-    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) return;
+                   int strip_eol, const uint32_t* __restrict__ flag, uint32_t seq, uint32_t limit, int by_length) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) return;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint64_t b = off[i], e = off[i + 1];
-        const uint32_t skew = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(data + b) & 15u);
-        if ((e - b) + skew + 48u <= stage_bytes) continue;  // the tile kernel staged this one
         int64_t len = static_cast<int64_t>(e - b);
-        if (strip_eol) len = trim_eol(data + b, len);
+        if (!by_length) {
+            const uint32_t skew = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(data + b) & 15u);
+            if ((e - b) + skew + 48u <= limit) continue;  // the tile kernel staged this one
+            if (strip_eol) len = trim_eol(data + b, len);
+        } else {
+            if (e - b <= limit) continue;                // (no need to look at its last bytes)
+            if (strip_eol) len = trim_eol(data + b, len);
+            if (len <= static_cast<int64_t>(limit)) continue;
+        }
         if (T.m_next16) extract_line_global<uint8_t, uint16_t>(T, T.m_next16, data + b, len, i, out, nullptr, match_only);
         else extract_line_global<uint8_t, uint32_t>(T, T.m_next32, data + b, len, i, out, nullptr, match_only);
     }
@@ -536,7 +545,7 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
                 if (len64 > 65535) {
                     // positions are 16-bit in the register block: such a line is left to the follow-up launch of the per-line
                     // kernel (not walked here: its 96 capture registers would give every lane of this kernel a scratch frame)
-                    __hip_atomic_store(oversize_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(oversize_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 } else {
                     has_line = true;
                     len = static_cast<uint32_t>(len64);
@@ -661,16 +670,16 @@ hipError_t launch_extract_generic(const GxDev& dev, const GxBatch& b, hipStream_
     return b.offsets64 ? launch_generic_t<uint8_t, uint64_t>(dev, b, stream) : launch_generic_t<uint8_t, uint32_t>(dev, b, stream);
 }
 
-hipError_t launch_extract_oversize(const GxDev& dev, const GxBatch& b, uint32_t stage_bytes, hipStream_t stream) {
+hipError_t launch_extract_oversize(const GxDev& dev, const GxBatch& b, uint32_t limit, int by_length, hipStream_t stream) {
     if (b.n == 0) return hipSuccess;
     // a small grid: without the flag every wave leaves at once; with it, the lines in question are few and long
     const dim3 grid(256), block(256);
     if (b.offsets64)
         hipLaunchKernelGGL((k_extract_oversize<uint64_t>), grid, block, 0, stream, dev, static_cast<const uint8_t*>(b.data),
-                           static_cast<const uint64_t*>(b.offsets), b.n, line_out(dev, b), b.match_only, b.strip_eol, b.oversize_flag, b.seq, stage_bytes);
+                           static_cast<const uint64_t*>(b.offsets), b.n, line_out(dev, b), b.match_only, b.strip_eol, b.oversize_flag, b.seq, limit, by_length);
     else
         hipLaunchKernelGGL((k_extract_oversize<uint32_t>), grid, block, 0, stream, dev, static_cast<const uint8_t*>(b.data),
-                           static_cast<const uint32_t*>(b.offsets), b.n, line_out(dev, b), b.match_only, b.strip_eol, b.oversize_flag, b.seq, stage_bytes);
+                           static_cast<const uint32_t*>(b.offsets), b.n, line_out(dev, b), b.match_only, b.strip_eol, b.oversize_flag, b.seq, limit, by_length);
     return hipGetLastError();
 }
 

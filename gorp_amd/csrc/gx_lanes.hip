@@ -172,7 +172,7 @@ k_extract_lanes(GxLds L, LanesIO io) {
             // (include/gorp_hip.h): a line of exactly 65 535 bytes can have such an offset, so it goes the same way (the
             // per-line kernel writes through LineOut, which clamps and counts).
             const bool oversize = valid && len64 > (PACKED ? 65534u : 65535u);
-            if (oversize) __hip_atomic_store(io.oversize_flag, io.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (oversize) __hip_atomic_store(io.oversize_flag, io.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             const uint32_t len = oversize ? 0u : static_cast<uint32_t>(len64);
             const uint8_t* line = data + o0;
 

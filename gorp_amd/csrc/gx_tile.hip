@@ -23,6 +23,8 @@ hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t
     uint64_t blocks = static_cast<uint64_t>(num_cus) * blocks_per_cu;
     const uint64_t need = (tiles + lds.nwaves - 1) / lds.nwaves;
     if (blocks > need) blocks = need;
+    if (blocks > GX_STEAL_MAX) blocks = GX_STEAL_MAX;
+    if (!b.steal) return hipErrorInvalidValue;
     dim3 grid(static_cast<unsigned>(blocks)), block(lds.nwaves * 64);
     TileIO io{};
     io.image = lds_image;
@@ -37,11 +39,15 @@ hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t
     io.narrow = b.narrow;
     io.oversize_flag = b.oversize_flag;
     io.seq = b.seq;
+    io.steal = b.steal;
+    io.steal_parity = b.steal_parity & 1u;
+    io.share64 = 8;   // an eighth: the XCDs of a chip differ by up to a tenth in what they finish (dense results; 3 % with u8 rows)
     io.max_groups = dev.max_groups;
     io.strip_eol = b.strip_eol;
 #ifdef GX_DEV
     io.stamps = dev_stamps;
     io.dev_flags = getenv("GX_DEV_FLAGS") ? static_cast<uint32_t>(atoi(getenv("GX_DEV_FLAGS"))) : 0u;
+    if (getenv("GX_DEV_SHARE64")) io.share64 = static_cast<uint32_t>(atoi(getenv("GX_DEV_SHARE64")));   // (0: nothing shared, 64: everything)
 #else
     (void)dev_stamps;
 #endif

@@ -47,8 +47,11 @@ struct TileIO {
     uint32_t seq;
     int32_t max_groups;
     int32_t strip_eol;
+    uint32_t* steal;             // tile counters of the launch's workgroups, u32[2][GX_STEAL_MAX * GX_STEAL_STRIDE] (gx_device.hpp: GxBatch::steal)
+    uint32_t steal_parity;       // which of the two rows this launch draws from (it zeroes the other one for the next launch)
+    uint32_t share64;            // 64ths of a workgroup's tiles that are handed out through its global counter (other workgroups may take them)
 #ifdef GX_DEV
-    unsigned long long* stamps;  // developer build: per-phase cycle totals, [4] per wave
+    unsigned long long* stamps;  // developer build: [8] per wave -- per-phase cycle totals [0..3], begin / end on the chip's 100 MHz clock, tiles, XCC id
     uint32_t dev_flags;          // developer build: experiments (bit 1: nontemporal result stores;
                                  // bit 2: no result stores)
 #endif
@@ -229,7 +232,10 @@ k_extract_tile(GxLds L, TileIO io) {
         const uint4* src = reinterpret_cast<const uint4*>(io.image);
         uint4* dst = reinterpret_cast<uint4*>(gx_smem);
         for (uint32_t c = threadIdx.x; c < L.table_bytes / 16; c += blockDim.x) dst[c] = src[c];
-        if (threadIdx.x == 0) lds_st<uint32_t>(L.counter, 2u * L.nwaves);  // the workgroup's tile counter (below)
+        // the tile counters of the NEXT launch on this stream (the other row): zero when it begins
+        uint32_t* other = io.steal + (io.steal_parity ^ 1u) * (GX_STEAL_MAX * GX_STEAL_STRIDE);
+        for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < GX_STEAL_MAX; q += gridDim.x * blockDim.x) other[q * GX_STEAL_STRIDE] = 0u;
+        if (threadIdx.x == 0) lds_st<uint32_t>(L.counter, 0u);   // the workgroup's tile counter (below)
     }
     __syncthreads();
 
@@ -317,26 +323,101 @@ k_extract_tile(GxLds L, TileIO io) {
         return t;
     };
 
-    // Tiles are handed out inside the workgroup on demand: workgroup b owns tiles b, b + grid, b + 2 grid, ... (so the
-    // tiles being read at any moment are one dense window of the buffer), and a wave that has finished a tile takes
-    // the workgroup's next one from a counter in LDS.  A static split would leave every wave the same number of tiles,
-    // but the waves of a workgroup do not run at the same speed -- 11 waves sit 3, 3, 3 and 2 to a SIMD -- and the
-    // kernel would end with the slowest.  Each wave looks three tiles ahead (walking / bytes in flight / offsets in
-    // flight), so the counter's answer is never waited for.
-    const uint64_t grid = gridDim.x;
-    auto tile_of = [&](uint32_t j) -> uint64_t { return min(static_cast<uint64_t>(blockIdx.x) + static_cast<uint64_t>(j) * grid, tiles); };
-    auto grab = [&]() -> uint32_t {  // (lane 0's value counts; read with readfirstlane where it is used)
+    // Tiles are handed out on demand.  Workgroup b owns tiles b, b + grid, b + 2 grid, ... (so the tiles being read at any
+    // moment are one dense window of the buffer), and a wave that has finished a tile takes the workgroup's next one from a
+    // counter.  A static split would leave every wave the same number of tiles, but the waves of a workgroup do not run at
+    // the same speed -- 11 waves sit 3, 3, 3 and 2 to a SIMD -- and the kernel would end with the slowest.  Nor do the
+    // workgroups: the XCDs differ (on some boxes of this pool the odd ones finish an equal share 3 % later with u8 result
+    // rows, 10 % later with dense results: profiles/r04_tile_tail.txt).  So a workgroup's tiles come in two parts: the
+    // first (1 - share) from a counter in LDS, as cheap as a draw gets; the last `share` from a counter in GLOBAL memory,
+    // one cache line per workgroup, which the waves of OTHER workgroups draw from as well once their own tiles are gone --
+    // they pick a workgroup that has tiles left at random.  (All tiles from global counters: 8 % slower -- a returning
+    // atomic per tile and wave in a kernel that saturates the memory system; counters that share cache lines: 29 %, atomics
+    // on one line take their turns at 11 ns apiece; a single counter for the grid: 1.8 ms per 10 M lines.
+    // tools/micro/atomic_rate.hip, tools/ab_flags.sh.)  Each wave looks three tiles ahead (walking / bytes in flight /
+    // offsets in flight) and draws a whole walk before it needs the answer, so no draw is waited for until the wave steals,
+    // at the end of the launch.  Exit: counters only grow; a wave leaves when no workgroup has a tile left.
+    const uint32_t grid = gridDim.x;
+    const uint32_t j_base = 2u * L.nwaves;   // (the first two tiles of every wave are fixed: draw j is the workgroup's tile j_base + j)
+    uint32_t* const ctr = io.steal + io.steal_parity * (GX_STEAL_MAX * GX_STEAL_STRIDE);
+    const uint32_t tiles32 = static_cast<uint32_t>(tiles);   // (n < 2^32 lines: at most 2^26 tiles)
+    auto tile_at = [&](uint32_t wg, uint32_t k) -> uint64_t { return min(static_cast<uint64_t>(wg) + static_cast<uint64_t>(k) * grid, tiles); };
+    // workgroup v's draws: `local` from its LDS counter, then `shared` from its global one
+    auto shared_of = [&](uint32_t v, uint32_t& local) -> uint32_t {
+        const uint32_t own = v < tiles32 ? (tiles32 - v + grid - 1u) / grid : 0u;   // tiles v, v + grid, ...
+        const uint32_t avail = own > j_base ? own - j_base : 0u;
+        const uint32_t shared = (avail * io.share64 + 63u) >> 6;
+        local = avail - shared;
+        return shared;
+    };
+    uint32_t local_own;
+    const uint32_t shared_own = shared_of(blockIdx.x, local_own);
+    // The next draw of this workgroup (inc 0: none wanted -- the LDS instruction is issued all the same): lane 0's `j` is the
+    // LDS ticket; a ticket beyond the local part is followed by a draw of the global counter, lane 0's `g`.
+    auto draw_own = [&](uint32_t inc, uint32_t& g, bool& from_shared) -> uint32_t {
         uint32_t j = 0;
-        if (lane == 0) j = __hip_atomic_fetch_add((GX_LDS uint32_t*)(uintptr_t)L.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) j = __hip_atomic_fetch_add((GX_LDS uint32_t*)(uintptr_t)L.counter, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        from_shared = inc != 0u && __builtin_amdgcn_readfirstlane(j) >= local_own;
+        g = 0;
+        if (from_shared) {   // (wave-uniform; the last `share` of the launch only)
+            if (lane == 0) g = __hip_atomic_fetch_add(ctr + blockIdx.x * GX_STEAL_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return j;
     };
-    uint64_t tile = tile_of(wave);
-    uint64_t t1 = tile_of(L.nwaves + wave);   // the group after `tile`: its offsets are loaded one iteration ahead
-    uint32_t j2 = grab();                     // and the one after that
+    // a tile from another workgroup's shared part, or `tiles` when nobody has one left (wave-uniform; waits for its loads)
+    uint32_t steal_salt = (blockIdx.x * L.nwaves + wave) * 2654435761u;
+    auto steal = [&]() -> uint64_t {
+        for (;;) {
+            // workgroups with shared draws left, and how many there are
+            uint32_t cands = 0;
+            for (uint32_t v0 = 0; v0 < grid; v0 += 64u) {
+                const uint32_t v = v0 + lane;
+                bool left = false;
+                if (v < grid) {
+                    uint32_t lv;
+                    left = __hip_atomic_load(ctr + v * GX_STEAL_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < shared_of(v, lv);
+                }
+                cands += static_cast<uint32_t>(__popcll(__ballot(left)));
+            }
+            if (cands == 0u) return tiles;
+            steal_salt = steal_salt * 1664525u + 1013904223u;
+            uint32_t pick = (steal_salt >> 8) % cands, victim = 0xFFFFFFFFu, victim_local = 0;
+            for (uint32_t v0 = 0; v0 < grid && victim == 0xFFFFFFFFu; v0 += 64u) {   // (the counters again: they are close by now)
+                const uint32_t v = v0 + lane;
+                bool left = false;
+                uint32_t lv = 0;
+                if (v < grid) left = __hip_atomic_load(ctr + v * GX_STEAL_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < shared_of(v, lv);
+                const unsigned long long m = __ballot(left);
+                const uint32_t c = static_cast<uint32_t>(__popcll(m));
+                if (pick < c) {
+                    unsigned long long mm = m;
+                    for (uint32_t q = 0; q < pick; ++q) mm &= mm - 1ull;
+                    const uint32_t src = static_cast<uint32_t>(__ffsll(static_cast<long long>(mm)) - 1);
+                    victim = v0 + src;
+                    victim_local = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(lv), static_cast<int>(src)));
+                } else pick -= c;
+            }
+            if (victim == 0xFFFFFFFFu) continue;   // (taken in between: look again)
+            uint32_t g = 0;
+            if (lane == 0) g = __hip_atomic_fetch_add(ctr + victim * GX_STEAL_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g = __builtin_amdgcn_readfirstlane(g);
+            const uint64_t t = tile_at(victim, j_base + victim_local + g);   // (beyond the victim's tiles: `tiles`)
+            if (t < tiles) return t;
+        }
+    };
+    uint64_t tile = tile_at(blockIdx.x, wave);
+    uint64_t t1 = tile_at(blockIdx.x, L.nwaves + wave);   // the group after `tile`: its offsets are loaded one iteration ahead
+    uint64_t t2 = tiles;                        // and the one after that: from the draw (j3, g3), once that has answered (need_t2)
+    uint32_t g3 = 0, jn = 0u, gn = 0u;
+    bool sh3 = false, shn = false;
+    uint32_t j3 = draw_own(1u, g3, sh3);
+    bool need_t2 = true, stealing = false, drew_before = false;   // (wave-uniform)
     if (tile >= tiles) return;
 #ifdef GX_DEV
     unsigned long long phase_cycles[4] = {0, 0, 0, 0};
     unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long dev_begin = __builtin_amdgcn_s_memrealtime();   // (100 MHz, one clock for the whole chip)
+    unsigned long long dev_tiles = 0;
 #endif
     u32x4 pre[KCH];  // the next round's bytes, in flight or landed
     uint64_t no0 = 0, no1 = 0;
@@ -357,7 +438,20 @@ k_extract_tile(GxLds L, TileIO io) {
         const bool same_group = cur.b < group_lines;
         const uint64_t ntile = same_group ? tile : t1;
         const bool has_next = ntile < tiles;
-        const uint64_t t2 = tile_of(__builtin_amdgcn_readfirstlane(j2));
+        if (drew_before) { j3 = jn; g3 = gn; sh3 = shn; }   // (the draw of the round before: it went out behind that round's prefetch, which has landed)
+        if (need_t2) {   // (wave-uniform) the draw that was issued a whole walk ago
+            if (!stealing) {
+                if (!sh3) t2 = tile_at(blockIdx.x, j_base + __builtin_amdgcn_readfirstlane(j3));
+                else {
+                    const uint32_t g = __builtin_amdgcn_readfirstlane(g3);
+                    t2 = g < shared_own ? tile_at(blockIdx.x, j_base + local_own + g) : tiles;
+                }
+                if (t2 >= tiles) stealing = true;   // this workgroup's tiles are all taken: from now on, other workgroups'
+            }
+            if (stealing) t2 = steal();
+        }
+        const bool drew = need_t2 && !stealing;     // ... and the next one goes out behind the prefetch, below
+        need_t2 = false;
         const uint64_t after = same_group ? t1 : t2;  // the group after `ntile`
         // Offsets of the group after the next one first, then the prefetch, and nothing in between that depends on
         // vector memory: both are unconditional (index clamped -- the same values again while the group is
@@ -369,6 +463,8 @@ k_extract_tile(GxLds L, TileIO io) {
                                   has_next && !same_group ? no0 : cur.o0, has_next && !same_group ? no1 : cur.o1);
         if (!has_next) nxt.mode = 3;  // nothing to fetch: the loop ends after this round
         tile_issue_loads<KCH>(nxt, lane, pre, io.image);
+        jn = draw_own(drew ? 1u : 0u, gn, shn);
+        drew_before = drew;
         GX_STAMP(1);
 
         const uint64_t i = cur.i;
@@ -387,7 +483,7 @@ k_extract_tile(GxLds L, TileIO io) {
         }
         if (cur.mode == 2) {
             // one line that does not fit the staging area: the per-line kernel takes it in a follow-up launch
-            if (lane == cur.a) __hip_atomic_store(io.oversize_flag, io.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == cur.a) __hip_atomic_store(io.oversize_flag, io.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         } else if (MODE == 0 && HOP) {
             // ---- hot loop #1 alone on the match automaton's hop records: a state's info word is its first accepting extraction ----
             const uint32_t mrow = walk_hop<false>(H, L.rec_indexed >= L.sort_chunk, stage, L.m_start, start, end, true, L.m_dead, regs);
@@ -493,7 +589,12 @@ k_extract_tile(GxLds L, TileIO io) {
                         rp[0] = static_cast<uint16_t>(result);
                     }
                 }
-                if (narrow && clamped && io.overflow) atomicAdd(io.overflow, static_cast<unsigned long long>(clamped));
+                if (narrow && io.overflow && __any(clamped != 0u)) {   // (one atomic per wave: this file is built without the compiler's atomic optimizer)
+                    uint32_t sum = clamped;
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) sum += static_cast<uint32_t>(__shfl_xor(static_cast<int>(sum), d));
+                    if (lane == 0) atomicAdd(io.overflow, static_cast<unsigned long long>(sum));
+                }
             } else {
                 const uint32_t row_b = slots * 4u;
                 const bool caps_aligned = ((reinterpret_cast<uintptr_t>(io.caps) | reinterpret_cast<uintptr_t>(io.match_id)) & 15u) == 0u;
@@ -524,10 +625,13 @@ k_extract_tile(GxLds L, TileIO io) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         GX_STAMP(3);
+#ifdef GX_DEV
+        ++dev_tiles;
+#endif
         if (!has_next) break;
         if (!same_group) {  // (wave-uniform)
             t1 = t2;
-            j2 = grab();
+            need_t2 = true;
         }
         cur = nxt;
         tile = ntile;
@@ -536,8 +640,14 @@ k_extract_tile(GxLds L, TileIO io) {
     }
 #ifdef GX_DEV
     if (io.stamps && lane == 0) {
-        unsigned long long* s = io.stamps + 4ull * (static_cast<uint64_t>(blockIdx.x) * L.nwaves + wave);
+        unsigned long long* s = io.stamps + 8ull * (static_cast<uint64_t>(blockIdx.x) * L.nwaves + wave);
         for (int q = 0; q < 4; ++q) s[q] = phase_cycles[q];
+        s[4] = dev_begin;
+        s[5] = __builtin_amdgcn_s_memrealtime();
+        s[6] = dev_tiles;
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        s[7] = xcc;
     }
 #endif
 }

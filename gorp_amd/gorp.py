@@ -575,9 +575,10 @@ class Gorp:
 
     def extract_batch_device(self, data_ptr, offsets_ptr, n, match_id_ptr, caps_ptr, offsets64=False, match_only=False,
                              stream=None, no_sync=False, strip_eol=False, line_bytes_hint=0, kernel=0, compact=False,
-                             overflow_ptr=None, uneven=0):
+                             overflow_ptr=None, uneven=0, max_line_bytes=0, utf16=False):
         """Device pointers (ints), e.g. torch tensors' data_ptr(); results stay in HBM.  line_bytes_hint sizes
         the kernel's staging area (0: 200 bytes with no_sync, else the batch's mean line length).
+        max_line_bytes: the caller's promise that no line is longer (gx_batch_opts.max_line_bytes: no follow-up launch).
         compact=True: caps_ptr receives compact rows uint16[n, 1 + 2*max_groups] (match_id_ptr may be None),
         overflow_ptr (device uint64, zeroed by the caller) counts the offsets that did not fit."""
         o = N.gx_batch_opts()
@@ -593,6 +594,8 @@ class Gorp:
         o.compact_results = int(compact)   # 1 / True: u16 rows; 2: u8 rows
         o.overflow = overflow_ptr
         o.uneven_lines = int(uneven)  # 2: lines differ much in length (0 with a hint or no_sync: taken as 1, similar lengths)
+        o.max_line_bytes = int(max_line_bytes)
+        o.utf16 = 1 if utf16 else 0
         _check(N.lib().gx_extract_batch(self._h.ptr, data_ptr, offsets_ptr, n, match_id_ptr, caps_ptr, C.byref(o)))
 
     def results(self, data, offsets, match_id, caps, safe=False):
@@ -688,14 +691,19 @@ def unpack_results_device(packed_ptr, n, slots, match_id_ptr, caps_ptr, stream=N
     _check(fn(packed_ptr, n, slots, match_id_ptr, caps_ptr, C.byref(o)))
 
 
-def split_lines_device(data_ptr, size, offsets_ptr, cap_lines, flags_ptr=None, offsets64=False, stream=None):
-    """gx_split_lines on device buffers (ints, e.g. torch data_ptr()); returns the number of lines."""
+def split_lines_device(data_ptr, size, offsets_ptr, cap_lines, flags_ptr=None, offsets64=False, stream=None, want_max=False):
+    """gx_split_lines on device buffers (ints, e.g. torch data_ptr()); returns the number of lines -- with want_max
+    (gx_split_lines_max) the pair (lines, length of the longest line with its terminator)."""
     o = N.gx_batch_opts()
     o.struct_size = C.sizeof(N.gx_batch_opts)
     o.device_pointers = 1
     o.offsets64 = 1 if offsets64 else 0
     o.stream = stream
     n = C.c_uint64(0)
+    if want_max:
+        m = C.c_uint64(0)
+        _check(N.lib().gx_split_lines_max(data_ptr, size, offsets_ptr, cap_lines, C.byref(n), flags_ptr, C.byref(m), C.byref(o)))
+        return n.value, m.value
     _check(N.lib().gx_split_lines(data_ptr, size, offsets_ptr, cap_lines, C.byref(n), flags_ptr, C.byref(o)))
     return n.value
 

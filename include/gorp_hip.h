@@ -100,7 +100,9 @@ int32_t gx_max_groups(const gx_handle* h);
  * (0: the handle has no hop tables), 15 / 21 = states whose records are in LDS under the tile kernel / the hop slice kernel,
  * 16 = states that well-formed lines reach, 17 = states that have a chain, 18 / 19 = waves per workgroup of the tile kernel on
  * these tables / of the hop slice kernel, 20 = branching states whose dense row is in LDS too, 22 / 23 = states / states with
- * their records in LDS of the second hop image, built from the match automaton alone for match-only batches */
+ * their records in LDS of the second hop image, built from the match automaton alone for match-only batches;
+ * 24 = batches so far that broke their gx_batch_opts.max_line_bytes promise; 25 = the kernel the most recent batch ran on
+ * (a GX_KERNEL_* value; 0: none yet) */
 int64_t gx_stat(const gx_handle* h, int32_t which);
 
 typedef struct gx_batch_opts {
@@ -147,6 +149,16 @@ typedef struct gx_batch_opts {
                                   and assumes 1 elsewhere.  Batches with a mean length above 255 bytes are taken as uneven. */
     void*    overflow;         /* with compact_results: uint64_t counter that the call ADDS to (the caller zeroes it); a device
                                   pointer with device_pointers, else a host pointer.  NULL: not counted. */
+    uint32_t max_line_bytes;   /* gx_extract_batch with device_pointers.  The caller's PROMISE: no line of the batch -- offsets[i+1] -
+                                  offsets[i], terminator included -- is longer than this many code units (0: no promise).
+                                  gx_split_lines_max reports it for free; a log shipper knows its own cap.  Without it every batch
+                                  kernel is followed by a second, nearly empty launch that takes the lines the batch kernel cannot
+                                  stage (longer than a wave's staging area: about 64 x line_bytes_hint bytes; 65 535 for the lane
+                                  and hop slice kernels); with it, and when it is within what the chosen kernel takes, that launch
+                                  is dropped (1-2 % of a 10 M-line batch).  A promise that does not hold is detected, never
+                                  silently wrong: without no_sync the call sees it when it synchronises, runs the follow-up then and
+                                  returns the right results; with no_sync the longer line's result row is left UNWRITTEN, and the next
+                                  gx_extract_batch on the same stream fails with GX_E_ARG (gx_stat(h, 24) counts such batches). */
 } gx_batch_opts;
 
 enum { GX_KERNEL_AUTO = 0, GX_KERNEL_TILES = 1, GX_KERNEL_SLICES = 2, GX_KERNEL_PER_LINE = 3, GX_KERNEL_LANES = 4,
@@ -174,6 +186,10 @@ int gx_extract_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, ui
  * still set, so the caller can retry with a larger offsets array). */
 int gx_split_lines(const uint8_t* bytes, uint64_t size, void* offsets, uint64_t cap_lines, uint64_t* n_lines,
                    uint8_t* line_flags, const gx_batch_opts* opts);
+/* The same, and *max_line_bytes (host, optional) receives the length of the longest line, terminator included: what
+ * gx_batch_opts.max_line_bytes wants to hear (the pass that writes the offsets sees every line end anyway). */
+int gx_split_lines_max(const uint8_t* bytes, uint64_t size, void* offsets, uint64_t cap_lines, uint64_t* n_lines,
+                       uint8_t* line_flags, uint64_t* max_line_bytes, const gx_batch_opts* opts);
 
 /* Result materialisation, the step after the path: ExtractionResult.asMap(idAs)
  * (core/ExtractionResult.java:65-88) for every matched line of a finished batch, written as one JSON object per

@@ -180,6 +180,19 @@ def test_config2_full_size_properties():
     gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, mid2.data_ptr(), caps2.data_ptr(), stream=stream)
     torch.cuda.synchronize()
     assert torch.equal(mid, mid2) and torch.equal(caps, caps2)
+    # the headline's format and launch: u8 rows, no_sync, the longest line promised (no follow-up launch) -- and u16 rows
+    rows8 = torch.empty((n, 9), dtype=torch.uint8, device="cuda")
+    rows16 = torch.empty((n, 9), dtype=torch.int16, device="cuda")
+    over = torch.zeros(1, dtype=torch.int64, device="cuda")
+    gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, None, rows8.data_ptr(), stream=stream, no_sync=True,
+                              line_bytes_hint=W.LINE_BYTES, compact=2, overflow_ptr=over.data_ptr(), max_line_bytes=W.LINE_BYTES)
+    gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, None, rows16.data_ptr(), stream=stream, no_sync=True,
+                              line_bytes_hint=W.LINE_BYTES, compact=True, overflow_ptr=over.data_ptr(), max_line_bytes=W.LINE_BYTES)
+    torch.cuda.synchronize()
+    assert int(over.item()) == 0 and gorp.stat(24) == 0
+    assert torch.equal(rows8[:, 0].view(torch.int8).to(torch.int32), mid) and torch.equal(rows16[:, 0].to(torch.int32), mid)
+    assert torch.equal(rows8[:, 1:].to(torch.int32), torch.where(caps < 0, torch.full_like(caps, 255), caps))
+    assert torch.equal(rows16[:, 1:].to(torch.int32), caps)
     # a strided sample against the oracle
     idx = torch.arange(0, n, 97, device="cuda")[:100000]
     rows = data.view(n, W.LINE_BYTES)[idx].cpu().numpy().reshape(-1)
@@ -443,6 +456,21 @@ def _full_size_properties(gorp, orc, data, offsets, cats, reps, hint, uneven=0):
     torch.cuda.synchronize()
     assert int(over.item()) == 0 and torch.equal(rows[:, 0].to(torch.int32), mid)
     assert torch.equal(rows[:, 1:].to(torch.int32), caps)             # (-1 stays -1 through int16; offsets < 32768 here)
+    if len(gorp.getExtractions()) <= 126:
+        # ... and the u8 rows (the headline's format), launched the way bench.py launches them: no_sync, with the promise
+        # that no line is longer than the longest (no follow-up launch)
+        max_line = int((o[1:].to(torch.int64) - o[:-1].to(torch.int64)).max().item())
+        rows8 = torch.empty((n, 1 + 2 * G_), dtype=torch.uint8, device="cuda")
+        over.zero_()
+        gorp.extract_batch_device(d.data_ptr(), o.data_ptr(), n, None, rows8.data_ptr(), stream=st, line_bytes_hint=hint, compact=2,
+                                  overflow_ptr=over.data_ptr(), uneven=uneven, no_sync=True, max_line_bytes=max_line)
+        torch.cuda.synchronize()
+        assert torch.equal(rows8[:, 0].view(torch.int8).to(torch.int32), mid)
+        c8 = rows8[:, 1:].to(torch.int32)
+        want8 = torch.where(caps < 0, torch.full_like(caps, 255), torch.clamp(caps, max=254))
+        assert torch.equal(c8, want8)
+        assert int(over.item()) == int((caps > 254).sum().item())
+        assert gorp.stat(24) == 0                                     # the promise held
     ok = mid >= 0
     assert bool((caps[~ok] == -1).all())
     assert bool((caps[ok][:, 0] >= 0).all())                          # a matched line has its first group
@@ -1261,3 +1289,91 @@ def test_one_line_calls_of_every_kind():
             for nm, text in zip(names, spans):
                 if list(names).count(nm) == 1:
                     assert m.get(nm) == text, (s[:60], nm)
+
+
+@pytest.mark.parametrize("flags,kernel", [(0, 0), (N.GX_CREATE_TIER_L2, 0), (N.GX_CREATE_TIER_RECORDS, N.GX_KERNEL_LANES), (N.GX_CREATE_TIER_HOP, 0),
+                                          (N.GX_CREATE_TIER_HOP, N.GX_KERNEL_HOP_SLICES)])
+def test_max_line_bytes_promise(flags, kernel):
+    """gx_batch_opts.max_line_bytes: a promise that holds drops the follow-up launch (results unchanged); one that does not is
+    detected -- a synchronous call returns the right results all the same, a no_sync call leaves the longer line's row unwritten and
+    the next batch on that stream fails with GX_E_ARG (gx_stat(h, 24) counts both)."""
+    import torch
+    definition = W.readme3_definition()
+    gorp, orc = Gorp.construct(definition, flags=flags), oracle_for(definition)
+    rng = random.Random(77)
+    lines = ["[123456789]: %s 5ms /%s" % (rng.choice(["GET", "PUT", "HEAD"]), "x" * rng.randrange(1, 150)) for _ in range(5000)]
+    big = 70000 if kernel in (N.GX_KERNEL_LANES, N.GX_KERNEL_HOP_SLICES) else 20000   # beyond what the kernel in question takes
+    long_line = "[123456789]: GET 5ms /" + "y" * big
+    lines[1234] = long_line
+    data, offsets = lines_to_csr(lines)
+    omid, ocaps = orc.extract_batch(data, offsets, nthreads=4)
+    d, o = torch.from_numpy(data).cuda(), torch.from_numpy(offsets).cuda()
+    n = len(lines)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(max_line, no_sync, fill=-7):
+        mid = torch.full((n,), fill, dtype=torch.int32, device="cuda")
+        caps = torch.full((n, 8), fill, dtype=torch.int32, device="cuda")
+        gorp.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=st, line_bytes_hint=200,
+                                  kernel=kernel, max_line_bytes=max_line, no_sync=no_sync)
+        torch.cuda.synchronize()
+        return mid.cpu().numpy(), caps.cpu().numpy()
+
+    # no promise, and a promise that holds (beyond what the kernel stages: the follow-up launch stays; within: it goes)
+    for promise in (0, len(long_line)):
+        mid, caps = run(promise, False)
+        assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+    assert gorp.stat(24) == 0
+    short = [i for i in range(n) if i != 1234]
+    sd, so = lines_to_csr([lines[i] for i in short])
+    d2, o2 = torch.from_numpy(sd).cuda(), torch.from_numpy(so).cuda()
+    m2 = torch.empty(n - 1, dtype=torch.int32, device="cuda")
+    c2 = torch.empty((n - 1, 8), dtype=torch.int32, device="cuda")
+    gorp.extract_batch_device(d2.data_ptr(), o2.data_ptr(), n - 1, m2.data_ptr(), c2.data_ptr(), stream=st, line_bytes_hint=200, kernel=kernel,
+                              max_line_bytes=200, no_sync=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(m2.cpu().numpy(), omid[short]) and np.array_equal(c2.cpu().numpy(), ocaps[short]) and gorp.stat(24) == 0
+    # a broken promise, synchronous call: detected, made good
+    mid, caps = run(200, False)
+    assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+    assert gorp.stat(24) == 1
+    # a broken promise, no_sync: every other line is right, that line's row is unwritten, the next batch on the stream refuses
+    mid, caps = run(200, True)
+    assert np.array_equal(mid[short], omid[short]) and np.array_equal(caps[short], ocaps[short])
+    assert mid[1234] == -7 and (caps[1234] == -7).all()
+    with pytest.raises(G.GorpError, match="max_line_bytes"):
+        run(0, False)
+    assert gorp.stat(24) == 2
+    mid, caps = run(0, False)     # (reported once)
+    assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+
+
+def test_launches_of_many_streams_share_a_handle():
+    """Every stream keeps its own flag word (no event between a stream's launches); the streams after the 31st share one, handed
+    over with an event.  40 streams, interleaved no_sync batches with and without an oversize line."""
+    import torch
+    definition = W.readme3_definition()
+    gorp, orc = Gorp.construct(definition), oracle_for(definition)
+    rng = random.Random(3)
+    batches = []
+    for b in range(40):
+        lines = ["[123456789]: %s 5ms /%s" % (rng.choice(["GET", "PUT", "HEAD"]), "x" * rng.randrange(1, 150)) for _ in range(700)]
+        if b % 3 == 0:
+            lines[rng.randrange(700)] = "[123456789]: PUT 5ms /" + "z" * 30000
+        batches.append(lines_to_csr(lines))
+    streams = [torch.cuda.Stream() for _ in range(40)]
+    outs = []
+    for rep in range(3):
+        for s, (data, offsets) in zip(streams, batches):
+            d, o = torch.from_numpy(data).cuda(), torch.from_numpy(offsets).cuda()
+            n = len(offsets) - 1
+            mid = torch.empty(n, dtype=torch.int32, device="cuda")
+            caps = torch.empty((n, 8), dtype=torch.int32, device="cuda")
+            torch.cuda.current_stream().synchronize()
+            gorp.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=s.cuda_stream, no_sync=True,
+                                      line_bytes_hint=100)
+            outs.append((d, o, mid, caps, data, offsets))
+    torch.cuda.synchronize()
+    for d, o, mid, caps, data, offsets in outs:
+        omid, ocaps = orc.extract_batch(data, offsets, nthreads=4)
+        assert np.array_equal(mid.cpu().numpy(), omid) and np.array_equal(caps.cpu().numpy(), ocaps)

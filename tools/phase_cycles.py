@@ -29,7 +29,7 @@ else:
 L = N.lib()
 L.gx_dev_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
 waves = 256 * 12
-stamps = torch.zeros(waves * 4, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(waves * 8, dtype=torch.int64, device="cuda")
 L.gx_dev_set_stamps(g._h.ptr, stamps.data_ptr())
 mid = torch.empty(n, dtype=torch.int32, device="cuda")
 caps = torch.empty((n, 2 * g.max_groups), dtype=torch.int32, device="cuda")
@@ -43,7 +43,7 @@ for compact in (False, True):
     e0.record()
     g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=st, no_sync=True, line_bytes_hint=200, compact=compact)
     e1.record(); torch.cuda.synchronize()
-    s = stamps.cpu().numpy().reshape(-1, 4)
+    s = stamps.cpu().numpy().reshape(-1, 8)[:, :4]
     s = s[s.sum(axis=1) > 0]
     tiles = (n + 63) // 64
     per_tile = s.sum(axis=0) / tiles
