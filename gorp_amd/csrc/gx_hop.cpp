@@ -65,7 +65,7 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
     const int ncls = T.ncls;
     const size_t S = static_cast<size_t>(match_automaton ? T.m_states : U.n_states);
     const uint32_t n_regs = match_automaton ? 0u : static_cast<uint32_t>(U.n_regs);
-    if (ncls < 1 || ncls > 127 || S < 2 || S > 65536u || n_regs > 253u) return false;
+    if (ncls < 1 || ncls > 256 || S < 2 || S > 65536u || n_regs > 253u) return false;
     const uint32_t dead = static_cast<uint32_t>(match_automaton ? T.m_dead : U.dead);
 
     // entry(s, c) = successor | register column << 16 (0: no program); every program must be one "register := position"
@@ -82,15 +82,24 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
         ent[i] = (w & 0xFFFFu) | (col << 16);
     }
 
-    // how likely text is to take a class: its printable bytes (and the tab)
-    std::vector<long> printable(ncls, 0);
-    for (int b = 0; b < 256; ++b) if ((b >= 0x20 && b < 0x7F) || b == 0x09) ++printable[T.cls256[b]];
-    auto set_weight = [&](const ClassSet& s) { long p = 0; for (int c = 0; c < ncls; ++c) if (has(s, c)) p += printable[c]; return p; };
+    // Everything the walk tests is a BYTE interval (bytes below 0x80 only: a byte with its top bit set always takes the exact
+    // step).  The byte set of a class set; how likely text is to take a byte: printable ones (and the tab)
+    struct ByteSet { uint64_t w[2] = {0, 0}; };
+    auto bytes_of = [&](const ClassSet& cs) {
+        ByteSet m;
+        for (int bt = 0; bt < 128; ++bt) if (has(cs, T.cls256[bt])) m.w[bt >> 6] |= 1ull << (bt & 63);
+        return m;
+    };
+    auto in_set = [](const ByteSet& m, int bt) { return (m.w[bt >> 6] >> (bt & 63)) & 1ull; };
+    auto is_printable = [](int bt) { return (bt >= 0x20 && bt < 0x7F) || bt == 0x09; };
+    auto set_weight = [&](const ClassSet& cs) { const ByteSet m = bytes_of(cs); long p = 0; for (int bt = 0; bt < 128; ++bt) if (in_set(m, bt) && is_printable(bt)) ++p; return p; };
+    // ... and which of a set's intervals to keep when it has several (\w is four: digits, upper case, '_', lower case): log text is
+    // lower case before it is digits before it is upper case
+    auto byte_worth = [&](int bt) { return (bt >= 'a' && bt <= 'z') ? 4 : (bt >= '0' && bt <= '9') ? 3 : (bt >= 'A' && bt <= 'Z') ? 2 : bt == ' ' ? 2 : is_printable(bt) ? 1 : 0; };   // (a blank is a space before it is a tab)
 
     // the groups of every state: entry -> classes (the dead successor is not a group)
     struct Group { uint32_t entry; ClassSet set; long weight; };
     std::vector<std::vector<Group>> groups(S);
-    std::map<ClassSet, uint64_t> weight;
     for (size_t s = 0; s < S; ++s) {
         std::map<uint32_t, ClassSet> by_entry;
         for (int c = 0; c < ncls; ++c) {
@@ -98,26 +107,19 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
             if ((e & 0xFFFFu) == dead) continue;
             put(by_entry[e], c);
         }
-        for (auto& g : by_entry) {
-            groups[s].push_back(Group{g.first, g.second, set_weight(g.second)});
-            ++weight[g.second];
-        }
+        for (auto& g : by_entry) groups[s].push_back(Group{g.first, g.second, set_weight(g.second)});
     }
-    const std::vector<int> new_id = order_classes(weight, ncls);
-    std::vector<long> printable_new(ncls, 0);
-    for (int c = 0; c < ncls; ++c) printable_new[new_id[c]] = printable[c];
 
-    // the heaviest contiguous id range of a class set (ties: the longer one)
+    // the heaviest interval of byte values inside a class set's bytes (ties: the longer one)
     struct Range { int lo = 0, hi = -1; long weight = -1; };
-    auto best_range = [&](const ClassSet& s) {
-        std::vector<char> in(ncls, 0);
-        for (int c = 0; c < ncls; ++c) if (has(s, c)) in[new_id[c]] = 1;
+    auto best_range = [&](const ClassSet& cs) {
+        const ByteSet m = bytes_of(cs);
         Range best;
-        for (int i = 0; i < ncls; ++i) {
-            if (!in[i]) continue;
+        for (int i = 0; i < 128; ++i) {
+            if (!in_set(m, i)) continue;
             int j = i;
             long w = 0;
-            while (j < ncls && in[j]) { w += printable_new[j]; ++j; }
+            while (j < 128 && in_set(m, j)) { w += byte_worth(j); ++j; }
             if (w > best.weight || (w == best.weight && j - i > best.hi - best.lo + 1)) best = Range{i, j - 1, w};
             i = j;
         }
@@ -220,7 +222,7 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
         return static_cast<uint32_t>(at * 2);
     };
 
-    // dense rows (the exact step): u32[S][ncls + 1], successor | column << 16 by NEW state index and NEW class id; the last
+    // dense rows (the exact step): u32[S][ncls + 1], successor | column << 16 by NEW state index and class id; the last
     // column is the state's info word (byte offset of its final record, or -1 / -2-k)
     const uint32_t cols = static_cast<uint32_t>(ncls) + 1u;
     std::vector<uint32_t> rows(S * cols, 0);
@@ -228,7 +230,7 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
         uint32_t* row = &rows[static_cast<size_t>(perm[s]) * cols];
         for (int c = 0; c < ncls; ++c) {
             const uint32_t e = ent[s * ncls + c];
-            row[new_id[c]] = perm[e & 0xFFFFu] | (e & 0xFFFF0000u);
+            row[c] = perm[e & 0xFFFFu] | (e & 0xFFFF0000u);
         }
         // info word: the match automaton's first accepting extraction (or -1); the fused automaton's final record (or -1 / -2-k)
         if (match_automaton) row[ncls] = static_cast<uint32_t>(T.m_accept_first[s]);
@@ -248,7 +250,7 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
         uint8_t el[HOP_CHAIN], ns[HOP_CHAIN];
         for (uint32_t k = 0; k < HOP_CHAIN; ++k) {
             if (static_cast<int>(k) < ch.klen) { el[k] = static_cast<uint8_t>(0x80u - ch.lo[k]); ns[k] = static_cast<uint8_t>(0x7Fu - ch.span[k]); }
-            else { el[k] = 0x80; ns[k] = 0; }             // any class
+            else { el[k] = 0x80; ns[k] = 0; }             // any byte below 0x80
         }
         if (ch.klen == 0) ns[0] = 0x80;                   // no chain: element 0 never matches
         else ++out.n_chains;
@@ -256,14 +258,14 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
         memcpy(&r[4], ns, 8);
     }
 
-    // self-check against the dense rows: every class of a run loops with no program; every class sequence a chain
-    // accepts leads where the chain says, with the chain's programs at the chain's offsets and no others
+    // self-check against the dense rows: every byte of a run loops with no program; every byte sequence a chain accepts
+    // leads where the chain says, with the chain's programs at the chain's offsets and no others
     for (size_t s = 0; s < S; ++s) {
         const uint32_t* r = &hops[s * (HOP_REC_BYTES / 4)];
         const uint32_t run_lo = r[0] & 0xFFu, run_k = (r[0] >> 8) & 0xFFu;
         if (run_k != 0x80u)
-            for (uint32_t c = run_lo; c <= 0x7Fu - run_k; ++c)
-                if (c >= static_cast<uint32_t>(ncls) || rows[s * cols + c] != static_cast<uint32_t>(s)) throw GxError(GX_E_ARG, "internal: hop tier run does not match the dense rows");
+            for (uint32_t bt = run_lo; bt <= 0x7Fu - run_k; ++bt)
+                if (rows[s * cols + T.cls256[bt]] != static_cast<uint32_t>(s)) throw GxError(GX_E_ARG, "internal: hop tier run does not match the dense rows");
         const uint32_t klen = (r[0] >> 16) & 0xFu;
         const uint8_t* el = reinterpret_cast<const uint8_t*>(&r[2]);
         const uint8_t* ns = reinterpret_cast<const uint8_t*>(&r[4]);
@@ -271,9 +273,9 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
         const uint32_t want_col[2] = {(r[1] >> 16) & 0xFFu, r[1] >> 24}, want_off[2] = {(r[0] >> 20) & 7u, (r[0] >> 23) & 7u};
         for (uint32_t k = 0; k < klen; ++k) {
             const uint32_t lo = 0x80u - el[k], hi = lo + (0x7Fu - ns[k]);
-            if (hi >= static_cast<uint32_t>(ncls)) throw GxError(GX_E_ARG, "internal: hop tier chain element out of range");
-            const uint32_t e0 = rows[cur * cols + lo];
-            for (uint32_t c = lo; c <= hi; ++c) if (rows[cur * cols + c] != e0) throw GxError(GX_E_ARG, "internal: hop tier chain element is not one group");
+            if (hi > 0x7Fu) throw GxError(GX_E_ARG, "internal: hop tier chain element out of range");
+            const uint32_t e0 = rows[cur * cols + T.cls256[lo]];
+            for (uint32_t bt = lo; bt <= hi; ++bt) if (rows[cur * cols + T.cls256[bt]] != e0) throw GxError(GX_E_ARG, "internal: hop tier chain element is not one group");
             if (e0 >> 16) {
                 if (nops >= 2 || want_col[nops] != (e0 >> 16) || want_off[nops] != k) throw GxError(GX_E_ARG, "internal: hop tier chain programs");
                 ++nops;
@@ -298,7 +300,7 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
         HopLds L;
         L.n_hot = n_hot;
         L.bytes.assign(HOP_AT, 0);
-        for (int b = 0; b < 256; ++b) L.bytes[b] = static_cast<uint8_t>(new_id[T.cls256[b]]);
+        for (int b = 0; b < 256; ++b) L.bytes[b] = T.cls256[b];   // (the exact step's class id)
         L.bytes.insert(L.bytes.end(), hb, hb + static_cast<size_t>(n_hot) * HOP_REC_BYTES);
         while (L.bytes.size() % 16) L.bytes.push_back(0);
         L.info_lds = static_cast<uint32_t>(L.bytes.size());

@@ -5,14 +5,16 @@
 // over Automata.step core/autom/Automata.java:133-135, with JDKRegexpCookedExtraction.match
 // core/jdkre/JDKRegexpCookedExtraction.java:36-59 fused in.
 //
-// The staging area holds CLASS IDS (the tile kernel maps the bytes while it stages them: hop_map16), every lane walks its
-// own line at its own position:
+// The staging area holds the lines' BYTES as they are (until round 4 it held class ids: 208 LDS lookups per lane and tile
+// to map them, a fifth of the kernel; the tables' intervals are byte intervals now, gx_hop.cpp), every lane walks its own
+// line at its own position:
 //   1. the state's hop record (24 bytes; LDS for the hot states, global memory / L2 for the others);
-//   2. 16 class ids at the lane's position; one SWAR interval test finds how many of them the state's RUN covers;
-//   3. 8 class ids behind the run; one SWAR test against the chain's 8 (lo, span) elements.  Match: the lane is at the
+//   2. 16 bytes at the lane's position; one SWAR interval test finds how many of them the state's RUN covers;
+//   3. 8 bytes behind the run; one SWAR test against the chain's 8 (lo, span) elements.  Match: the lane is at the
 //      chain's target, klen bytes further, and the chain's (at most two) capture programs are written;
-//   4. no match: ONE exact step through the state's dense row (global memory / L2) -- a wave-uniform branch that the waves
-//      of a well-formed log take for the branching nodes of the literal trie only.
+//   4. no match: ONE exact step through the state's dense row (global memory / L2; the byte's class id from the map at LDS
+//      address 0) -- a wave-uniform branch that the waves of a well-formed log take for the branching nodes of the literal
+//      trie only.  A byte with its top bit set fails every interval test: it always takes the exact step.
 // LDS is read in aligned dwords only (an unaligned ds_read stalls the LDS pipe for dozens of cycles on gfx950): a window at
 // byte address p is five (or three) dwords from p & ~3, joined by v_alignbyte.
 #pragma once
@@ -54,32 +56,18 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
 // (the compiler turns __any into a select, a compare and a scalar test; the ballot is the scalar test alone)
 __device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
 
-// byte -> class id for the 16 bytes of one staged chunk (class map: u8[256] at LDS address 0).  All 16 lookups are issued
-// before the first of them is used (the scheduling barrier keeps the compiler from pairing each with its use: it would then
-// wait out an LDS round trip per dword, 52 of them per tile).
-__device__ __forceinline__ u32x4 hop_map16(const u32x4& v) {
-    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-    uint32_t c[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) c[j] = lds_ld<uint8_t>((d[j >> 2] >> ((j & 3) * 8)) & 0xFFu);
-    __builtin_amdgcn_sched_barrier(0);
-    uint32_t o[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = c[4 * q] | c[4 * q + 1] << 8 | c[4 * q + 2] << 16 | c[4 * q + 3] << 24;
-    return u32x4{o[0], o[1], o[2], o[3]};
-}
-
-// Walks the line [start, end) of the wave's staging area (class ids) from state `s`; returns the final state.  regs = LDS
+// Walks the line [start, end) of the wave's staging area from state `s`; returns the final state.  regs = LDS
 // address of this lane's slot in register column 0 (the write-only dummy column sits 128 bytes before it).
 // A lane that is done keeps running the loop with the wave: at the end of its line its position no longer moves (no
 // bytes left), and a lane that steps into the dead state is moved to the end of its line.  Wave-level tests are ANDs of the
 // lane masks of single compares (the compiler turns the ballot of a compound condition into a select and a compare).
 __device__ __forceinline__ uint32_t run_flags(uint32_t x, uint32_t lo4, uint32_t k4) {
-    // bit 7 of a byte of the result is set iff that class id lies outside [lo, hi] (ids are below 0x80, so x itself never
-    // contributes: (x - lo4 | x + k4) & 0x80808080, one v_bitop3); exact for the lowest offending byte, which is all the walk uses
-    return ((x - lo4) | (x + k4)) & HI_BITS;
+    // bit 7 of a byte of the result is set iff that byte lies outside [lo, hi] (hi <= 0x7F: a byte with its top bit set is
+    // outside by itself): (x | x - lo4 | x + k4) & 0x80808080; exact for the lowest offending byte -- borrows and carries only
+    // travel upwards from one -- which is all the walk uses
+    return (x | (x - lo4) | (x + k4)) & HI_BITS;
 }
-// General form (the slice kernel stages a piece of the line at a time): the lane is at LDS address p; staged class ids end
+// General form (the slice kernel stages a piece of the line at a time): the lane is at LDS address p; staged bytes end
 // at `e` (run lengths are cut there); it iterates while p < limit (limit = e when the line ends at e, else 24 bytes
 // before it, so that a whole window and a whole chain are staged); a chain must end at or before e_chain (the end of the
 // LINE; no constraint when the line goes on beyond the staged piece); a capture program's position is its LDS address minus p0.
@@ -93,8 +81,9 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
                                                   uint32_t s, uint32_t dead, uint32_t regs) {
     const uint32_t dummy_col = regs - 128u;
     const uint32_t last_hot = H.n_hot - 1u;
-    // one exact step of this lane from state s on the class id c at LDS address q: the dense row (lrow: its copy in LDS, 0: none)
-    auto exact_step = [&](uint32_t lrow, uint32_t c, uint32_t q) {
+    // one exact step of this lane from state s on the byte `bt` at LDS address q: the dense row (lrow: its copy in LDS, 0: none)
+    auto exact_step = [&](uint32_t lrow, uint32_t bt, uint32_t q) {
+        const uint32_t c = lds_ld<uint8_t>(bt);   // (byte -> class id: u8[256] at LDS address 0)
         uint32_t xe;
         if (lrow) xe = lds_ld<uint16_t>(lrow + (c << 1)) | static_cast<uint32_t>(lds_ld<uint8_t>(lrow + H.lrow_cols + c)) << 16;  // (u16 successors, then u8 columns)
         else xe = *reinterpret_cast<const uint32_t*>(H.rows + (static_cast<uint64_t>(s) * H.row_bytes + (c << 2)));
@@ -142,7 +131,8 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
         // per byte: a = v + (0x80 - lo) has bit 7 set iff v >= lo; t = (a & 0x7F) + (0x7F - span) has bit 7 set iff v - lo > span
         const uint32_t ca0 = v0 + h1.x, ca1 = v1 + h1.y;
         const uint32_t ct0 = (ca0 & LOW7) + h2.x, ct1 = (ca1 & LOW7) + h2.y;
-        const uint32_t ok8 = bfi(ct0, 0u, ca0) & bfi(ct1, 0u, ca1) & HI_BITS;  // byte j: elements j and j + 4 both hold
+        // (a byte with its top bit set fails its element -- and may spoil the sums of the bytes above it, which no longer matters)
+        const uint32_t ok8 = bfi(ct0 | v0, 0u, ca0) & bfi(ct1 | v1, 0u, ca1) & HI_BITS;  // byte j: elements j and j + 4 both hold
         const uint64_t m_chain = m_step & __builtin_amdgcn_ballot_w64(ok8 == HI_BITS) & __builtin_amdgcn_ballot_w64(q + ((h0.x >> 16) & 0xFu) <= e_chain);
         const bool stepping = n < 16u && q < e && p < limit;  // (the same compares, per lane: their masks ARE the select conditions)
         const bool chained = stepping && ok8 == HI_BITS && q + ((h0.x >> 16) & 0xFu) <= e_chain;

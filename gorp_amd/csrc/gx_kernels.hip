@@ -582,7 +582,7 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
                     v = u32x4{w[0], w[1], w[2], w[3]};
                 }
             }
-            lds_st<u32x4>(slice + static_cast<uint32_t>(q) * HOP_SLICE_ROW + (lane % LPL) * 16u, hop_map16(v));
+            lds_st<u32x4>(slice + static_cast<uint32_t>(q) * HOP_SLICE_ROW + (lane % LPL) * 16u, v);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -119,7 +119,7 @@ __device__ __forceinline__ uint32_t walk(const WalkTab& W, uint32_t stage, uint3
 }
 
 // Staging copy for a span that touches the first or last bytes of the buffer: never reads outside [data, data_end).
-template <bool CLASSES>  // TIER_HOP: the staging area holds class ids
+template <bool CLASSES>  // (unused since round 4: every tier stages the bytes as they are)
 __device__ __attribute__((unused)) void stage_span_guarded(const uint8_t* __restrict__ g_al, uint32_t nch, uint32_t stage, uint32_t lane,
                                    const uint8_t* data, const uint8_t* data_end) {
     for (uint32_t c = lane; c < nch; c += 64) {
@@ -128,7 +128,7 @@ __device__ __attribute__((unused)) void stage_span_guarded(const uint8_t* __rest
         for (int q = 0; q < 16; ++q)
             if (src + q >= data && src + q < data_end) w[q >> 2] |= static_cast<uint32_t>(src[q]) << ((q & 3) * 8);
         const u32x4 v = {w[0], w[1], w[2], w[3]};
-        lds_st<u32x4>(stage + (c << 4), CLASSES ? hop_map16(v) : v);
+        lds_st<u32x4>(stage + (c << 4), v);
     }
 }
 
@@ -173,13 +173,13 @@ __device__ __forceinline__ void tile_issue_loads(const TileInfo& t, uint32_t lan
 // Registers -> staging area, and the hot-interval bit of every chunk -> the wave's bitmap (bit 64 k + lane of the
 // map belongs to the chunk lane `lane` holds in pre[k]; a clamped lane describes a chunk beyond the span, which no
 // line of the round reaches).
-template <int KCH, int MAP>  // MAP 0: no bitmap; 1: general hot interval; 2: hot interval ends at 0x7F; 3: no bitmap, class ids (TIER_HOP)
+template <int KCH, int MAP>  // MAP 0: no bitmap; 1: general hot interval; 2: hot interval ends at 0x7F; 3: no bitmap (TIER_HOP)
 __device__ __forceinline__ void commit_chunks(const TileInfo& t, uint32_t lane, const u32x4 (&pre)[KCH], uint32_t stage, uint32_t bitmap,
                                               uint32_t hot_lo4, uint32_t hot_k4) {
     const uint32_t last = stage + ((t.nch - 1u) << 4), mine = stage + (lane << 4);
 #pragma unroll
     for (int k = 0; k < KCH; ++k) {
-        lds_st<u32x4>(min(mine + 1024u * k, last), MAP == 3 ? hop_map16(pre[k]) : pre[k]);
+        lds_st<u32x4>(min(mine + 1024u * k, last), pre[k]);
         if (MAP == 1 || MAP == 2) {
             const unsigned long long m = __ballot(chunk_inside<MAP == 2>(pre[k], hot_lo4, hot_k4));
             if (lane == 0) lds_st<u32x2>(bitmap + 8u * k, u32x2{static_cast<uint32_t>(m), static_cast<uint32_t>(m >> 32)});
@@ -472,14 +472,8 @@ k_extract_tile(GxLds L, TileIO io) {
         const uint32_t start = cur.start;
         uint32_t end = cur.end;
         if (io.strip_eol && cur.mode != 2) {  // the terminator is staged with the line (trim_eol, from LDS)
-            if (HOP) {  // (the staging area holds class ids: the line's last bytes from global memory)
-                const uint8_t* line = data + cur.o0;
-                if (valid && end > start && line[end - start - 1u] == 0x0Au) --end;
-                if (valid && end > start && line[end - start - 1u] == 0x0Du) --end;
-            } else {
-                if (end > start && lds_ld<uint8_t>(stage + end - 1u) == 0x0Au) --end;
-                if (end > start && lds_ld<uint8_t>(stage + end - 1u) == 0x0Du) --end;
-            }
+            if (end > start && lds_ld<uint8_t>(stage + end - 1u) == 0x0Au) --end;
+            if (end > start && lds_ld<uint8_t>(stage + end - 1u) == 0x0Du) --end;
         }
         if (cur.mode == 2) {
             // one line that does not fit the staging area: the per-line kernel takes it in a follow-up launch

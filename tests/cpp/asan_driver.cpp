@@ -48,8 +48,8 @@ Outcome hop_outcome(const Tables& T, const HopImage& H, const std::vector<uint8_
     const uint32_t* rows = reinterpret_cast<const uint32_t*>(H.global.data());
     const uint32_t cols = H.row_bytes / 4;
     const uint8_t* hops = H.global.data() + H.hops_off;
-    std::vector<uint8_t> cls(line.size() + 32, 0);
-    for (size_t i = 0; i < line.size(); ++i) cls[i] = H.full.bytes[line[i]];
+    std::vector<uint8_t> cls(line.size() + 32, 0);   // (the staged bytes, as they are; H.full.bytes[b] = the class id of byte b)
+    for (size_t i = 0; i < line.size(); ++i) cls[i] = line[i];
     std::vector<int> col(static_cast<size_t>(H.n_regs) + 2, -1);   // register columns (0 = the dummy)
     uint32_t s = H.start;
     size_t p = 0;
@@ -60,7 +60,7 @@ Outcome hop_outcome(const Tables& T, const HopImage& H, const std::vector<uint8_
         memcpy(r, hops + static_cast<size_t>(s) * HOP_REC_BYTES, HOP_REC_BYTES);
         const uint32_t run_lo = r[0] & 0xFFu, run_k = (r[0] >> 8) & 0xFFu, klen = (r[0] >> 16) & 0xFu;
         size_t n = 0;
-        while (n < 16 && p + n < e && run_k != 0x80u && cls[p + n] >= run_lo && cls[p + n] <= 0x7Fu - run_k) ++n;
+        while (n < 16 && p + n < e && run_k != 0x80u && cls[p + n] < 0x80u && cls[p + n] >= run_lo && cls[p + n] <= 0x7Fu - run_k) ++n;
         const size_t q = p + n;
         if (n == 16 || q >= e) { p = q; continue; }
         const uint8_t* el = reinterpret_cast<const uint8_t*>(&r[2]);
@@ -68,7 +68,7 @@ Outcome hop_outcome(const Tables& T, const HopImage& H, const std::vector<uint8_
         bool ok = q + klen <= e;
         for (int j = 0; j < 8 && ok; ++j) {
             const uint32_t a = cls[q + j] + el[j], t = (a & 0x7Fu) + ns[j];
-            ok = (a & 0x80u) && !(t & 0x80u);
+            ok = cls[q + j] < 0x80u && (a & 0x80u) && !(t & 0x80u);
         }
         if (ok) {
             col[(r[1] >> 16) & 0xFFu] = static_cast<int>(q + ((r[0] >> 20) & 7u));
@@ -76,7 +76,7 @@ Outcome hop_outcome(const Tables& T, const HopImage& H, const std::vector<uint8_
             p = q + klen;
             s = r[1] & 0xFFFFu;
         } else {
-            const uint32_t x = rows[static_cast<size_t>(s) * cols + cls[q]];
+            const uint32_t x = rows[static_cast<size_t>(s) * cols + H.full.bytes[cls[q]]];
             col[x >> 16] = static_cast<int>(q);
             s = x & 0xFFFFu;
             p = s == H.dead ? e : q + 1;

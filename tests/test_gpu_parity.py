@@ -1199,13 +1199,14 @@ def test_hop_tier_agrees_with_oracle():
 
 
 def test_hop_tier_class_limit():
-    """The hop tier keeps class ids in seven bits: a definition of up to 127 character classes has it, one more and the handle
-    goes without (the other tables answer) -- both bit-exact."""
+    """Until round 4 the hop tier kept class ids in seven bits (127 character classes at most); its intervals are byte intervals
+    now and a definition of any number of classes has it -- 100 and 140 single-byte literals, bytes above 0x7F among them (they
+    take the exact step), both bit-exact."""
     def definition(n_literals):
         # every literal byte is a class of its own: n_literals extractions "<byte>=<digits>" over distinct bytes
         chars = [chr(c) for c in range(0x21, 0x21 + 200) if chr(c) not in "0123456789" and chr(c).encode("latin-1")[0] not in (0x7F, 0xAD)][:n_literals]
         return [FlattenedExtraction("r%d" % i, [["text", ch + "="], ["extractor", "v", [["pattern", "\\d+"]]]]) for i, ch in enumerate(chars)], chars
-    for n_lit, want_hop in ((100, True), (140, False)):
+    for n_lit, want_hop in ((100, True), (140, True)):
         rules, chars = definition(n_lit)
         gorp, orc = Gorp.construct(rules, flags=N.GX_CREATE_TIER_HOP), oracle_for(rules)
         assert (gorp.stat(14) > 0) == want_hop, (n_lit, gorp.stat(1), gorp.stat(14))
