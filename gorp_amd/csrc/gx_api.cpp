@@ -128,7 +128,8 @@ struct gx_handle {
     // when the stream's next launch begins: nothing to wait for, nothing to record); the last slot is shared by the streams
     // that come after N_SLOTS - 1 others and is handed over with an event.
     static const int N_SLOTS = 32;
-    uint32_t* d_slots = nullptr;          // [N_SLOTS] oversize flags, then [N_SLOTS] chunk counters of the lane kernel
+    uint32_t* d_slots = nullptr;          // [N_SLOTS] oversize flags, then [N_SLOTS] chunk counters of the lane kernel, then [N_SLOTS] "a line
+                                          // of this UTF-16 batch holds a unit above 0xFF" words
     hipStream_t slot_stream[N_SLOTS] = {};
     bool slot_taken[N_SLOTS] = {};
     // Batches that promise their longest line (gx_batch_opts.max_line_bytes) have no follow-up launch; their flag word is in
@@ -139,6 +140,8 @@ struct gx_handle {
     uint32_t steal_parity[N_SLOTS] = {};  // the row the slot's next tile-kernel launch draws from
     uint32_t promise_seq[N_SLOTS] = {};   // the sequence number of the slot's last launch under a promise (0: none)
     std::atomic<uint64_t> promises_broken{0};
+    int hop_reason = 4;                   // why capture batches have no hop tables (gx_stat(h, 26); 0: they have)
+    hipStream_t multi_stream = nullptr;   // gx_extract_batch_multi_device: the stream of shards that bring none
     std::atomic<int> last_kernel{0};      // GX_KERNEL_* of the most recent batch launch (gx_stat(h, 25))
     // device scratch of gx_results_to_jsonl / gx_text_to_jsonl (sizes, split points, line offsets), kept between calls and grown as
     // batches ask: a hipMalloc + hipFree pair per call cost more than the scan kernels.  Used under `mu` only, and every call that
@@ -661,28 +664,30 @@ bool build_tile_image(gx_handle* h, int tier, int part = 0) {
 }
 
 // Complete the layout for one batch: staging sized for 64 lines of the hinted length.
-bool plan_tile_layout(GxLds L, uint32_t line_bytes_hint, GxLds* out);
-bool plan_tile_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out, bool match_only = false) {
+// wide: the kernel variant that reads UTF-16 code units (two prefetch registers per staged chunk: 13 KB of staging and 8 waves at most)
+bool plan_tile_layout(GxLds L, uint32_t line_bytes_hint, GxLds* out, bool wide = false);
+bool plan_tile_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out, bool match_only = false, bool wide = false) {
     if (!h->tile_ok) return false;
-    return plan_tile_layout(match_only && h->has_mo ? h->lds_mo : h->lds, line_bytes_hint, out);
+    return plan_tile_layout(match_only && h->has_mo ? h->lds_mo : h->lds, line_bytes_hint, out, wide);
 }
 // the hop tier's layout: the same kernel, its own tables
-bool plan_hop_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out, bool match_only = false) {
-    if (match_only) return h->hop_mo_ok && plan_tile_layout(h->lds_hop_mo, line_bytes_hint, out);
-    return h->hop_ok && plan_tile_layout(h->lds_hop, line_bytes_hint, out);
+bool plan_hop_launch(const gx_handle* h, uint32_t line_bytes_hint, GxLds* out, bool match_only = false, bool wide = false) {
+    if (match_only) return h->hop_mo_ok && plan_tile_layout(h->lds_hop_mo, line_bytes_hint, out, wide);
+    return h->hop_ok && plan_tile_layout(h->lds_hop, line_bytes_hint, out, wide);
 }
-bool plan_tile_layout(GxLds L, uint32_t line_bytes_hint, GxLds* out) {
+bool plan_tile_layout(GxLds L, uint32_t line_bytes_hint, GxLds* out, bool wide) {
     if (line_bytes_hint == 0) line_bytes_hint = 200;
     if (line_bytes_hint > 2000) line_bytes_hint = 2000;
     L.stage_bytes = (64u * line_bytes_hint + 64u + 15u) & ~15u;  // + slack: the walk reads ahead of the line
     if (L.stage_bytes > 16384u) L.stage_bytes = 16384u;  // the kernel prefetches a tile into <= 64 VGPRs per lane;
                                                           // longer lines go in several rounds or to the per-line kernel
+    if (wide && L.stage_bytes > 13u * 1024u) L.stage_bytes = 13u * 1024u;   // (groups of longer lines go in several rounds)
     const uint32_t bitmap_bytes = L.tier == 4 ? 0u : GX_BITMAP_WAVE_BYTES;   // (the hop tier has no chunk bitmap)
     const uint32_t fixed = L.regs_wave_bytes + bitmap_bytes;
     if (L.table_bytes + 4 * (L.stage_bytes + fixed) > LDS_BYTES) return false;
     uint32_t nw = (LDS_BYTES - L.table_bytes) / (L.stage_bytes + fixed);
     if (nw > 12) nw = 12;  // 768 threads: leaves 170 VGPRs per lane for the prefetch registers
-    if (L.stage_bytes > 13u * 1024u && nw > 8) nw = 8;  // the 16 KB variant prefetches 64 VGPRs: 2 waves per SIMD
+    if ((wide || L.stage_bytes > 13u * 1024u) && nw > 8) nw = 8;  // the 16 KB variant prefetches 64 VGPRs, the UTF-16 variant 104: 2 waves per SIMD
 #ifdef GX_DEV
     if (getenv("GX_DEV_NWAVES") && static_cast<uint32_t>(atoi(getenv("GX_DEV_NWAVES"))) < nw) nw = static_cast<uint32_t>(atoi(getenv("GX_DEV_NWAVES")));
 #endif
@@ -690,7 +695,7 @@ bool plan_tile_layout(GxLds L, uint32_t line_bytes_hint, GxLds* out) {
     // that is a few bytes short (mean length, lines of 201 bytes announced as 200) then still stages whole groups.
     {
         const uint32_t kch = (L.stage_bytes + 1023u) / 1024u;
-        const uint32_t cap = (kch <= 4 ? 4u : kch <= 8 ? 8u : kch <= 13 ? 13u : 16u) * 1024u;
+        const uint32_t cap = (wide ? 13u : kch <= 4 ? 4u : kch <= 8 ? 8u : kch <= 13 ? 13u : 16u) * 1024u;
         uint32_t room = ((LDS_BYTES - L.table_bytes - 32u) / nw - fixed) & ~15u;
         if (room > cap) room = cap;
         if (room > L.stage_bytes) L.stage_bytes = room;
@@ -852,11 +857,15 @@ void choose_tile_image(gx_handle* h) {
             *(q ? small : full) = L;
         }
     };
-    if (!no_tiles && want_hop && h->T.has_capture && !(h->create_flags & GX_CREATE_NO_FUSED) && build_hop_image(h->T, false, hot_budget, 12u * 1024u, h->hop)) {
-        layouts(h->hop, &h->lds_hop, &h->lds_hop_small);
-        GxLds P;
-        h->hop_ok = plan_tile_layout(h->lds_hop, 200, &P);
-    }
+    h->hop_reason = 4;   // not built: the dense rows fit LDS (or the caller named another tier)
+    if (!no_tiles && want_hop && h->T.has_capture && !(h->create_flags & GX_CREATE_NO_FUSED)) {
+        if (build_hop_image(h->T, false, hot_budget, 12u * 1024u, h->hop)) {
+            layouts(h->hop, &h->lds_hop, &h->lds_hop_small);
+            GxLds P;
+            h->hop_ok = plan_tile_layout(h->lds_hop, 200, &P);
+            h->hop_reason = h->hop_ok ? 0 : 5;   // (5: the tables leave no room in LDS for a wave)
+        } else h->hop_reason = h->hop.refused;
+    } else if (want_hop && !no_tiles) h->hop_reason = 1;
     // ... and of the match automaton alone, for match-only batches (PolyMatcher.match over a batch)
     h->hop_mo_ok = false;
     if (!no_tiles && want_hop && build_hop_image(h->T, true, hot_budget, 12u * 1024u, h->hop_mo)) {
@@ -969,8 +978,8 @@ void upload(gx_handle* h) {
             GX_HIP(hipMalloc(&h->d_hop_mo_global, h->hop_mo.global.size()));
             GX_HIP(hipMemcpy(h->d_hop_mo_global, h->hop_mo.global.data(), h->hop_mo.global.size(), hipMemcpyHostToDevice));
         }
-        GX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_slots), 2 * gx_handle::N_SLOTS * sizeof(uint32_t)));
-        GX_HIP(hipMemset(h->d_slots, 0, 2 * gx_handle::N_SLOTS * sizeof(uint32_t)));
+        GX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_slots), 3 * gx_handle::N_SLOTS * sizeof(uint32_t)));
+        GX_HIP(hipMemset(h->d_slots, 0, 3 * gx_handle::N_SLOTS * sizeof(uint32_t)));
         GX_HIP(hipEventCreateWithFlags(&h->shared_event, hipEventDisableTiming));
 
         GX_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_broken), gx_handle::N_SLOTS * sizeof(uint32_t), hipHostMallocMapped));
@@ -1050,6 +1059,58 @@ void done_slot(gx_handle* h, const SlotUse& u, hipStream_t stream) {
 
 void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t kernel, hipStream_t stream, bool uneven = false, Launched* launched = nullptr) {
     GxLds L;
+    if (b.wide && !b.state_out && b.match_only >= 0 && b.n > 0 && line_bytes_hint <= 255u && !uneven &&
+        (kernel == GX_KERNEL_AUTO || kernel == GX_KERNEL_TILES || kernel == GX_KERNEL_HOPS)) {
+        // UTF-16 code units, lines of ordinary length, tables that are dense rows in LDS or hop tables: the tile kernel reads the
+        // units itself -- their low bytes are what it stages -- and flags the lines that hold a unit above 0xFF for the per-line
+        // walk (k_extract_flagged, which leaves at once when there is none).  No copy of the batch, no synchronisation.
+        const bool mo = b.match_only != 0 || !h->T.has_capture;
+        const bool have_hop = mo ? h->hop_mo_ok : h->hop_ok;
+        const bool hop = have_hop && kernel != GX_KERNEL_TILES;
+        const uint32_t image_tier = mo && h->has_mo ? h->lds_mo.tier : h->lds.tier;
+        bool direct = hop ? plan_hop_launch(h, line_bytes_hint, &L, mo, true)
+                          : (kernel != GX_KERNEL_HOPS && h->tile_ok && !h->tile_global && image_tier == 0 && plan_tile_launch(h, line_bytes_hint, &L, mo, true));
+        if (direct && hop && !mo && !(h->lds_hop.u_start != 0xFFFFFFFFu)) direct = false;
+        if (direct) {
+            {
+              std::lock_guard<std::mutex> pool_lock(h->slot_mu);
+              if (!h->pool) {
+                hipMemPoolProps props{};
+                props.allocType = hipMemAllocationTypePinned;
+                props.handleTypes = hipMemHandleTypeNone;
+                props.location.type = hipMemLocationTypeDevice;
+                props.location.id = h->device;
+                GX_HIP(hipMemPoolCreate(&h->pool, &props));
+                uint64_t keep = ~0ull;
+                GX_HIP(hipMemPoolSetAttribute(h->pool, hipMemPoolAttrReleaseThreshold, &keep));
+              }
+            }
+            void* flags = nullptr;
+            GX_HIP(hipMallocFromPoolAsync(&flags, b.n + 64, h->pool, stream));
+            hipError_t e = hipSuccess;
+            {
+                std::lock_guard<std::mutex> lock(h->slot_mu);
+                const SlotUse u = take_slot(h, b, stream);
+                const bool followup = plan_followup(h, b, u, L.stage_bytes >= 63u ? L.stage_bytes - 63u : 0u, launched);
+                if (launched) { launched->limit = L.stage_bytes; launched->by_length = 0; }
+                b.wide_flags = static_cast<uint8_t*>(flags);
+                b.wide_any = h->d_slots + 2 * gx_handle::N_SLOTS + u.slot;
+                const uint8_t* image = static_cast<const uint8_t*>(hop ? (mo ? h->d_lds_image_hop_mo : h->d_lds_image_hop) : (mo && h->has_mo ? h->d_lds_image_mo : h->d_lds_image));
+                const uint8_t* at_global = hop ? static_cast<const uint8_t*>(mo ? h->d_hop_mo_global : h->d_hop_global) : nullptr;
+                h->last_kernel = hop ? GX_KERNEL_HOPS : GX_KERNEL_TILES;
+                e = launch_extract_tile(h->dev, L, image, at_global, h->num_cus, b, stream, nullptr);
+                if (e == hipSuccess) {
+                    h->steal_parity[u.slot] ^= 1u;
+                    e = launch_extract_flagged(h->dev, b, static_cast<const uint8_t*>(flags), stream, b.wide_any);
+                }
+                if (e == hipSuccess && followup) e = launch_extract_oversize(h->dev, b, L.stage_bytes, 0, stream);
+                if (e == hipSuccess) done_slot(h, u, stream);
+            }
+            (void)hipFreeAsync(flags, stream);
+            GX_HIP(e);
+            return;
+        }
+    }
     if (b.wide && !b.state_out && b.match_only >= 0 && kernel != GX_KERNEL_PER_LINE && b.n > 0) {
         // UTF-16 code units: their low bytes through the byte kernels, then the lines that hold a unit above 0xFF again through
         // the per-line walk (gx_kernels.hip: k_narrow_units).  The copy is n units long -- the one thing this path has to
@@ -1310,6 +1371,7 @@ void gx_destroy(gx_handle* h) {
     for (auto& e : h->jsonl) if (e.second.d) (void)hipFree(e.second.d);
     for (void* q : h->scratch) if (q) (void)hipFree(q);
     if (h->pool) (void)hipMemPoolDestroy(h->pool);
+    if (h->multi_stream) (void)hipStreamDestroy(h->multi_stream);
     if (h->one_dev) (void)hipFree(h->one_dev);
     if (h->one_host) (void)hipHostFree(h->one_host);
     delete h;
@@ -1348,6 +1410,7 @@ int64_t gx_stat(const gx_handle* h, int32_t which) {
     case 22: return h->hop_mo_ok ? static_cast<int64_t>(h->hop_mo.n_states) : 0;   // hop tier of the match automaton alone (match-only batches): states
     case 24: return static_cast<int64_t>(h->promises_broken.load());
     case 25: return h->last_kernel.load();
+    case 26: return h->hop_reason;
     case 23: return h->hop_mo_ok ? static_cast<int64_t>(h->hop_mo.full.n_hot) : 0; // ... whose records are in LDS
     case 19: { GxLds L; return plan_hop_slice_launch(h, &L) ? static_cast<int64_t>(L.nwaves) : 0; }  // ... of the hop slice kernel
     case 9: return !h->tile_ok ? 0 : !h->has_mo ? gx_stat(h, 7) : h->lds_mo.tier == 3 ? 4 : h->lds_mo.tier == 2 ? 3 : h->lds_mo.tier == 1 ? 2 : 1;
@@ -2016,6 +2079,55 @@ int gx_extract_batch_multi(gx_handle* const* handles, int32_t n_handles, const u
     for (auto& t : pool) t.join();
     for (int32_t k = 0; k < n_handles; ++k) if (rc[k] != GX_OK) return fail(rc[k], msg[k]);
     if (compact && o.overflow) for (uint64_t v : over) *static_cast<uint64_t*>(o.overflow) += v;
+    return GX_OK;
+}
+
+int gx_extract_batch_multi_device(const gx_device_shard* shards, int32_t n_shards, const gx_batch_opts* opts) {
+    if (!shards || n_shards <= 0) return fail(GX_E_ARG, "gx_extract_batch_multi_device: bad argument");
+    gx_batch_opts o{};
+    if (!read_opts(opts, &o)) return fail(GX_E_ARG, "gx_batch_opts.struct_size mismatch");
+    for (int32_t k = 0; k < n_shards; ++k)
+        if (!shards[k].handle || !shards[k].handle->on_device) return fail(GX_E_ARG, "gx_extract_batch_multi_device: NULL or host-only handle");
+    int prev_device = 0;
+    (void)hipGetDevice(&prev_device);
+    int first_rc = GX_OK;
+    std::string first_msg;
+    std::vector<hipStream_t> used(static_cast<size_t>(n_shards), nullptr);
+    // enqueue everything first (asynchronous launches from this one thread), wait afterwards
+    for (int32_t k = 0; k < n_shards; ++k) {
+        const gx_device_shard& sh = shards[k];
+        gx_handle* h = sh.handle;
+        hipStream_t stream = static_cast<hipStream_t>(sh.stream);
+        if (!stream) {
+            std::lock_guard<std::mutex> lock(h->slot_mu);
+            if (!h->multi_stream) {
+                if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->multi_stream, hipStreamNonBlocking) != hipSuccess) {
+                    if (first_rc == GX_OK) { first_rc = GX_E_DEVICE; first_msg = "gx_extract_batch_multi_device: no stream on the shard's device"; }
+                    continue;
+                }
+            }
+            stream = h->multi_stream;
+        }
+        used[k] = stream;
+        gx_batch_opts ok = o;
+        ok.struct_size = sizeof(gx_batch_opts);
+        ok.device_pointers = 1;
+        ok.no_sync = 1;
+        ok.stream = stream;
+        ok.overflow = sh.overflow;
+        const int rc = sh.n ? gx_extract_batch(h, sh.bytes, sh.offsets, sh.n, sh.match_id, sh.caps, &ok) : GX_OK;
+        if (rc != GX_OK && first_rc == GX_OK) { first_rc = rc; first_msg = gx_last_error(); }
+    }
+    if (!o.no_sync) {
+        for (int32_t k = 0; k < n_shards; ++k) {
+            if (!used[k]) continue;
+            if (hipSetDevice(shards[k].handle->device) != hipSuccess || hipStreamSynchronize(used[k]) != hipSuccess) {
+                if (first_rc == GX_OK) { first_rc = GX_E_DEVICE; first_msg = "gx_extract_batch_multi_device: a shard's stream failed"; }
+            }
+        }
+    }
+    (void)hipSetDevice(prev_device);
+    if (first_rc != GX_OK) return fail(first_rc, first_msg);
     return GX_OK;
 }
 

@@ -127,6 +127,10 @@ struct GxBatch {
     // steal_parity and zeroes the other row, which the stream's next launch draws from.
     uint32_t* steal;
     uint32_t steal_parity;
+    // tile kernel on UTF-16 code units (wide = 1): flags[n] (1: the line holds a unit above 0xFF; launch_extract_flagged takes it
+    // again) and the word that receives `seq` when there is any such line
+    uint8_t* wide_flags;
+    uint32_t* wide_any;
 };
 
 // More than 64 KiB of dynamic LDS needs the attribute, once per kernel (= per instantiation of this template) and
@@ -149,7 +153,8 @@ hipError_t launch_extract_generic(const GxDev& dev, const GxBatch& b, hipStream_
 // UTF-16 batches: the units' low bytes -> `bytes_at_first_unit` (room for offsets[n] - offsets[0] bytes), flags[i] = 1 for a line
 // with a unit above 0xFF; launch_extract_flagged takes those lines again on the code units (per-line walk).
 hipError_t launch_narrow_units(const GxBatch& b, uint8_t* bytes_at_first_unit, uint8_t* flags, hipStream_t stream);
-hipError_t launch_extract_flagged(const GxDev& dev, const GxBatch& b, const uint8_t* flags, hipStream_t stream);
+// any_word != nullptr: every wave leaves at once unless *any_word == b.seq (the tile kernel's "there was such a line")
+hipError_t launch_extract_flagged(const GxDev& dev, const GxBatch& b, const uint8_t* flags, hipStream_t stream, const uint32_t* any_word = nullptr);
 
 // Tile kernel (gx_tile.hip): 64-line tiles staged through LDS with coalesced loads, self-loop runs skipped by SWAR
 // tests and a per-chunk bitmap.  Byte input only.  `lds_image` is the device copy of the table image.

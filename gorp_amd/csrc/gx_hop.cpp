@@ -60,12 +60,12 @@ std::vector<int> order_classes(const std::map<ClassSet, uint64_t>& weight, int n
 
 bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_bytes, uint32_t small_budget_bytes, HopImage& out) {
     out = HopImage{};
-    if (!match_automaton && (!T.union_ok || !T.has_capture)) return false;
+    if (!match_automaton && (!T.union_ok || !T.has_capture)) { out.refused = 1; return false; }
     const RuleTables& U = T.uni;   // (the fused automaton; not looked at for the match automaton)
     const int ncls = T.ncls;
     const size_t S = static_cast<size_t>(match_automaton ? T.m_states : U.n_states);
     const uint32_t n_regs = match_automaton ? 0u : static_cast<uint32_t>(U.n_regs);
-    if (ncls < 1 || ncls > 256 || S < 2 || S > 65536u || n_regs > 253u) return false;
+    if (ncls < 1 || ncls > 256 || S < 2 || S > 65536u || n_regs > 253u) { out.refused = 3; return false; }
     const uint32_t dead = static_cast<uint32_t>(match_automaton ? T.m_dead : U.dead);
 
     // entry(s, c) = successor | register column << 16 (0: no program); every program must be one "register := position"
@@ -76,7 +76,7 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
         uint32_t col = 0;
         if (op) {
             const uint32_t b = T.ops_off[op], e = T.ops_off[op + 1];
-            if (e - b != 1 || T.ops[2 * b + 1] != GX_SRC_POS || T.ops[2 * b] >= 254u) return false;
+            if (e - b != 1 || T.ops[2 * b + 1] != GX_SRC_POS || T.ops[2 * b] >= 254u) { out.refused = 2; return false; }
             col = T.ops[2 * b] + 1u;
         }
         ent[i] = (w & 0xFFFFu) | (col << 16);
@@ -236,7 +236,7 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
         if (match_automaton) row[ncls] = static_cast<uint32_t>(T.m_accept_first[s]);
         else row[ncls] = U.fin[s] >= 0 ? fin_record(U.fin[s]) : static_cast<uint32_t>(U.fin[s]);
     }
-    if (fin_rec.size() * 2 > 0x7FFFu * 16u || T.n_rules > 32000) return false;  // (a hot state's info word is an int16: offset / 16, or -2-k)
+    if (fin_rec.size() * 2 > 0x7FFFu * 16u || T.n_rules > 32000) { out.refused = 3; return false; }  // (a hot state's info word is an int16: offset / 16, or -2-k)
 
     // hop records
     std::vector<uint32_t> hops(S * (HOP_REC_BYTES / 4), 0);
@@ -355,7 +355,7 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
     const uint8_t* fr = reinterpret_cast<const uint8_t*>(fin_rec.data());
     out.global.insert(out.global.end(), fr, fr + fin_rec.size() * 2);
     while (out.global.size() % 16) out.global.push_back(0);
-    if (out.global.size() > 0xFFFFFFF0ull) return false;
+    if (out.global.size() > 0xFFFFFFF0ull) { out.refused = 3; return false; }
     out.ok = true;
     return true;
 }

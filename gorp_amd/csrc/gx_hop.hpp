@@ -51,6 +51,8 @@ struct HopLds {
 
 struct HopImage {
     bool ok = false;
+    uint32_t refused = 0;          // why there is no image: 1 no fused automaton (or no captures), 2 capture programs other than one
+                                   // "register := position" per step, 3 beyond a limit of the tier (states, registers, final records)
     HopLds full;                   // as many reachable states as the hot budget holds (the tile kernel)
     HopLds small;                  // the slice kernel's: fewer records, more waves -- the same as `full` when that holds them all
     std::vector<uint8_t> global;   // dense rows u32[n_states][ncls + 1] | hop records of ALL states | final records

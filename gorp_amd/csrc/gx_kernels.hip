@@ -196,7 +196,8 @@ k_narrow_units(const uint16_t* __restrict__ units, const OFF* __restrict__ off, 
 template <typename OFF, typename MS>
 __global__ void __launch_bounds__(256)
 k_extract_flagged(GxDev T, const uint16_t* __restrict__ units, const OFF* __restrict__ off, uint64_t n, const uint8_t* __restrict__ flags,
-                  LineOut out, int match_only, const MS* __restrict__ m_next, int strip_eol) {
+                  LineOut out, int match_only, const MS* __restrict__ m_next, int strip_eol, const uint32_t* __restrict__ any_word, uint32_t seq) {
+    if (any_word && __hip_atomic_load(any_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) return;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
         if (!flags[i]) continue;
@@ -213,9 +214,9 @@ k_extract_flagged(GxDev T, const uint16_t* __restrict__ units, const OFF* __rest
 // make_round (the line, as it lies in memory, against the staging area: by_length 0), or the lane and hop slice kernels' "longer
 // than the 16-bit positions hold" on the line WITHOUT its terminator (by_length 1) -- never a line the batch kernel has
 // already answered (it would be counted twice in *overflow).
-template <typename OFF>
+template <typename OFF, typename CH>
 __global__ void __launch_bounds__(256)
-k_extract_oversize(GxDev T, const uint8_t* __restrict__ data, const OFF* __restrict__ off, uint64_t n, LineOut out, int match_only,
+k_extract_oversize(GxDev T, const CH* __restrict__ data, const OFF* __restrict__ off, uint64_t n, LineOut out, int match_only,
                    int strip_eol, const uint32_t* __restrict__ flag, uint32_t seq, uint32_t limit, int by_length) {
     if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) return;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
@@ -223,7 +224,8 @@ k_extract_oversize(GxDev T, const uint8_t* __restrict__ data, const OFF* __restr
         const uint64_t b = off[i], e = off[i + 1];
         int64_t len = static_cast<int64_t>(e - b);
         if (!by_length) {
-            const uint32_t skew = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(data + b) & 15u);
+            // (code units: a staged chunk is 32 bytes of the buffer, and the skew counts in units)
+            const uint32_t skew = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(data + b) & (sizeof(CH) == 2 ? 31u : 15u)) / static_cast<uint32_t>(sizeof(CH));
             if ((e - b) + skew + 48u <= limit) continue;  // the tile kernel staged this one
             if (strip_eol) len = trim_eol(data + b, len);
         } else {
@@ -231,8 +233,8 @@ k_extract_oversize(GxDev T, const uint8_t* __restrict__ data, const OFF* __restr
             if (strip_eol) len = trim_eol(data + b, len);
             if (len <= static_cast<int64_t>(limit)) continue;
         }
-        if (T.m_next16) extract_line_global<uint8_t, uint16_t>(T, T.m_next16, data + b, len, i, out, nullptr, match_only);
-        else extract_line_global<uint8_t, uint32_t>(T, T.m_next32, data + b, len, i, out, nullptr, match_only);
+        if (T.m_next16) extract_line_global<CH, uint16_t>(T, T.m_next16, data + b, len, i, out, nullptr, match_only);
+        else extract_line_global<CH, uint32_t>(T, T.m_next32, data + b, len, i, out, nullptr, match_only);
     }
 }
 
@@ -643,11 +645,11 @@ hipError_t launch_narrow_units(const GxBatch& b, uint8_t* bytes_at_first_unit, u
     else hipLaunchKernelGGL((k_narrow_units<uint32_t>), grid, block, 0, stream, static_cast<const uint16_t*>(b.data), static_cast<const uint32_t*>(b.offsets), b.n, bytes_at_first_unit, flags);
     return hipGetLastError();
 }
-hipError_t launch_extract_flagged(const GxDev& dev, const GxBatch& b, const uint8_t* flags, hipStream_t stream) {
+hipError_t launch_extract_flagged(const GxDev& dev, const GxBatch& b, const uint8_t* flags, hipStream_t stream, const uint32_t* any_word) {
     if (b.n == 0) return hipSuccess;
     const dim3 grid(256u * 4u), block(256);
     const uint16_t* units = static_cast<const uint16_t*>(b.data);
-#define GX_FLAGGED(OFF, MS, NEXT) hipLaunchKernelGGL((k_extract_flagged<OFF, MS>), grid, block, 0, stream, dev, units, static_cast<const OFF*>(b.offsets), b.n, flags, line_out(dev, b), b.match_only, NEXT, b.strip_eol)
+#define GX_FLAGGED(OFF, MS, NEXT) hipLaunchKernelGGL((k_extract_flagged<OFF, MS>), grid, block, 0, stream, dev, units, static_cast<const OFF*>(b.offsets), b.n, flags, line_out(dev, b), b.match_only, NEXT, b.strip_eol, any_word, b.seq)
     if (b.offsets64) { if (dev.m_next16) GX_FLAGGED(uint64_t, uint16_t, dev.m_next16); else GX_FLAGGED(uint64_t, uint32_t, dev.m_next32); }
     else { if (dev.m_next16) GX_FLAGGED(uint32_t, uint16_t, dev.m_next16); else GX_FLAGGED(uint32_t, uint32_t, dev.m_next32); }
 #undef GX_FLAGGED
@@ -674,12 +676,11 @@ hipError_t launch_extract_oversize(const GxDev& dev, const GxBatch& b, uint32_t 
     if (b.n == 0) return hipSuccess;
     // a small grid: without the flag every wave leaves at once; with it, the lines in question are few and long
     const dim3 grid(256), block(256);
-    if (b.offsets64)
-        hipLaunchKernelGGL((k_extract_oversize<uint64_t>), grid, block, 0, stream, dev, static_cast<const uint8_t*>(b.data),
-                           static_cast<const uint64_t*>(b.offsets), b.n, line_out(dev, b), b.match_only, b.strip_eol, b.oversize_flag, b.seq, limit, by_length);
-    else
-        hipLaunchKernelGGL((k_extract_oversize<uint32_t>), grid, block, 0, stream, dev, static_cast<const uint8_t*>(b.data),
-                           static_cast<const uint32_t*>(b.offsets), b.n, line_out(dev, b), b.match_only, b.strip_eol, b.oversize_flag, b.seq, limit, by_length);
+#define GX_OVERSIZE(OFF, CH) hipLaunchKernelGGL((k_extract_oversize<OFF, CH>), grid, block, 0, stream, dev, static_cast<const CH*>(b.data), \
+                           static_cast<const OFF*>(b.offsets), b.n, line_out(dev, b), b.match_only, b.strip_eol, b.oversize_flag, b.seq, limit, by_length)
+    if (b.wide) { if (b.offsets64) GX_OVERSIZE(uint64_t, uint16_t); else GX_OVERSIZE(uint32_t, uint16_t); }
+    else { if (b.offsets64) GX_OVERSIZE(uint64_t, uint8_t); else GX_OVERSIZE(uint32_t, uint8_t); }
+#undef GX_OVERSIZE
     return hipGetLastError();
 }
 

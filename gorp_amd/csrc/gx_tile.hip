@@ -12,6 +12,8 @@ hipError_t launch_tile_l2(int mode, bool off64, const GxLds& lds, const void* io
 hipError_t launch_tile_rec(int mode, bool off64, const GxLds& lds, const void* io, dim3 grid, dim3 block, hipStream_t stream);
 hipError_t launch_tile_recg(int mode, bool off64, const GxLds& lds, const void* io, dim3 grid, dim3 block, hipStream_t stream);
 hipError_t launch_tile_hop(int mode, bool off64, const GxLds& lds, const void* io, dim3 grid, dim3 block, hipStream_t stream);
+hipError_t launch_tile_lds_w(int mode, bool off64, const GxLds& lds, const void* io, dim3 grid, dim3 block, hipStream_t stream);
+hipError_t launch_tile_hop_w(int mode, bool off64, const GxLds& lds, const void* io, dim3 grid, dim3 block, hipStream_t stream);
 
 hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
                                const GxBatch& b, hipStream_t stream, unsigned long long* dev_stamps) {
@@ -41,6 +43,8 @@ hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t
     io.seq = b.seq;
     io.steal = b.steal;
     io.steal_parity = b.steal_parity & 1u;
+    io.wide_flags = b.wide_flags;
+    io.wide_any = b.wide_any;
     io.share64 = 8;   // an eighth: the XCDs of a chip differ by up to a tenth in what they finish (dense results; 3 % with u8 rows)
     io.max_groups = dev.max_groups;
     io.strip_eol = b.strip_eol;
@@ -54,6 +58,12 @@ hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t
     const bool want_caps = b.match_only == 0 && dev.has_capture;
     const int mode = !want_caps ? 0 : (lds.u_start != 0xFFFFFFFFu && lds.simple_ops) ? 1 : 2;
     const bool off64 = b.offsets64 != 0;
+    if (b.wide) {   // UTF-16 code units: dense rows in LDS, or the hop tier (the other tiers take the narrowed copy: gx_api.cpp)
+        if (!b.wide_flags || !b.wide_any) return hipErrorInvalidValue;
+        if (lds.tier == 4) return (at_global && mode != 2) ? launch_tile_hop_w(mode, off64, lds, &io, grid, block, stream) : hipErrorInvalidValue;
+        if (at_global || lds.tier != 0) return hipErrorInvalidValue;
+        return launch_tile_lds_w(mode, off64, lds, &io, grid, block, stream);
+    }
     if (lds.tier == 4) return (at_global && mode != 2) ? launch_tile_hop(mode, off64, lds, &io, grid, block, stream) : hipErrorInvalidValue;
     if (at_global && lds.tier == 3) return launch_tile_recg(mode, off64, lds, &io, grid, block, stream);
     if (at_global) return launch_tile_l2(mode, off64, lds, &io, grid, block, stream);

@@ -50,6 +50,8 @@ struct TileIO {
     uint32_t* steal;             // tile counters of the launch's workgroups, u32[2][GX_STEAL_MAX * GX_STEAL_STRIDE] (gx_device.hpp: GxBatch::steal)
     uint32_t steal_parity;       // which of the two rows this launch draws from (it zeroes the other one for the next launch)
     uint32_t share64;            // 64ths of a workgroup's tiles that are handed out through its global counter (other workgroups may take them)
+    uint8_t* wide_flags;         // WIDE (UTF-16 code units in `data`): [n], 1 for a line that holds a unit above 0xFF -- the per-line walk takes it again
+    uint32_t* wide_any;          // ... and the launch's sequence number here when there is any such line
 #ifdef GX_DEV
     unsigned long long* stamps;  // developer build: [8] per wave -- per-phase cycle totals [0..3], begin / end on the chip's 100 MHz clock, tiles, XCC id
     uint32_t dev_flags;          // developer build: experiments (bit 1: nontemporal result stores;
@@ -119,14 +121,16 @@ __device__ __forceinline__ uint32_t walk(const WalkTab& W, uint32_t stage, uint3
 }
 
 // Staging copy for a span that touches the first or last bytes of the buffer: never reads outside [data, data_end).
-template <bool CLASSES>  // (unused since round 4: every tier stages the bytes as they are)
+template <bool WIDE>  // WIDE: the buffer holds 16-bit code units; their low bytes are staged (16 of them per chunk, out of 32 bytes)
 __device__ __attribute__((unused)) void stage_span_guarded(const uint8_t* __restrict__ g_al, uint32_t nch, uint32_t stage, uint32_t lane,
                                    const uint8_t* data, const uint8_t* data_end) {
     for (uint32_t c = lane; c < nch; c += 64) {
-        const uint8_t* src = g_al + (static_cast<uint64_t>(c) << 4);
+        const uint8_t* src = g_al + (static_cast<uint64_t>(c) << (WIDE ? 5 : 4));
         uint32_t w[4] = {0, 0, 0, 0};
-        for (int q = 0; q < 16; ++q)
-            if (src + q >= data && src + q < data_end) w[q >> 2] |= static_cast<uint32_t>(src[q]) << ((q & 3) * 8);
+        for (int q = 0; q < 16; ++q) {
+            const uint8_t* at = src + (WIDE ? 2 * q : q);
+            if (at >= data && at < data_end) w[q >> 2] |= static_cast<uint32_t>(*at) << ((q & 3) * 8);
+        }
         const u32x4 v = {w[0], w[1], w[2], w[3]};
         lds_st<u32x4>(stage + (c << 4), v);
     }
@@ -154,53 +158,85 @@ struct TileInfo {
 // Unconditional as well: a round that is not prefetched (mode != 0, or no next round) loads one dummy chunk instead.
 // A branch around the loads would make the compiler lose count of them at the join and wait for all of them --
 // i.e. for the whole prefetch -- at the next vector-memory dependency, long before the walk.
-template <int KCH>
-__device__ __forceinline__ void tile_issue_loads(const TileInfo& t, uint32_t lane, u32x4 (&pre)[KCH], const uint8_t* __restrict__ dummy) {
+// WIDE: a staged chunk is the low bytes of 16 code units = 32 bytes of the buffer; the lane loads both halves (two instructions
+// whose lanes sit 32 bytes apart: together they sweep the span once).
+template <int KCH, bool WIDE>
+__device__ __forceinline__ void tile_issue_loads(const TileInfo& t, uint32_t lane, u32x4 (&pre)[WIDE ? 2 * KCH : KCH], const uint8_t* __restrict__ dummy) {
     // wave-uniform: scalar base + 32-bit lane offset (readfirstlane keeps the selects on the scalar unit; folded into
     // the per-lane offsets they cost two vector instructions per load)
     const uint64_t src_u = reinterpret_cast<uint64_t>(t.mode == 0 ? t.g_al : dummy);
     const uint32_t src_lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(src_u));  // (the builtin returns int: no sign extension)
     const uint32_t src_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(src_u >> 32));
     const uint64_t src = (static_cast<uint64_t>(src_hi) << 32) | src_lo;
-    const uint32_t last16 = __builtin_amdgcn_readfirstlane(t.mode == 0 ? (t.nch - 1u) << 4 : 0u);
-    const uint32_t lane16 = lane << 4;
+    const uint32_t last16 = __builtin_amdgcn_readfirstlane(t.mode == 0 ? (t.nch - 1u) << (WIDE ? 5 : 4) : 0u);
+    const uint32_t lane16 = lane << (WIDE ? 5 : 4);
 #pragma unroll
     for (int k = 0; k < KCH; ++k) {
-        const uint32_t o = min(lane16 + 1024u * k, last16);
-        pre[k] = __builtin_nontemporal_load((__attribute__((address_space(1))) const u32x4*)(src + o));  // a global_load, not a flat one
+        const uint32_t o = min(lane16 + (WIDE ? 2048u : 1024u) * k, last16);
+        if (WIDE) {
+            pre[2 * k] = __builtin_nontemporal_load((__attribute__((address_space(1))) const u32x4*)(src + o));
+            // (the dummy chunk of a round that is not prefetched is 16 bytes of the table image: its second half is the same again)
+            pre[2 * k + 1] = __builtin_nontemporal_load((__attribute__((address_space(1))) const u32x4*)(src + o + (t.mode == 0 ? 16u : 0u)));
+        } else pre[k] = __builtin_nontemporal_load((__attribute__((address_space(1))) const u32x4*)(src + o));  // a global_load, not a flat one
     }
+}
+// the low bytes of 16 code units
+__device__ __forceinline__ u32x4 narrow16(const u32x4& a, const u32x4& b) {
+    return u32x4{__builtin_amdgcn_perm(a.y, a.x, 0x06040200u), __builtin_amdgcn_perm(a.w, a.z, 0x06040200u),
+                 __builtin_amdgcn_perm(b.y, b.x, 0x06040200u), __builtin_amdgcn_perm(b.w, b.z, 0x06040200u)};
 }
 // Registers -> staging area, and the hot-interval bit of every chunk -> the wave's bitmap (bit 64 k + lane of the
 // map belongs to the chunk lane `lane` holds in pre[k]; a clamped lane describes a chunk beyond the span, which no
 // line of the round reaches).
-template <int KCH, int MAP>  // MAP 0: no bitmap; 1: general hot interval; 2: hot interval ends at 0x7F; 3: no bitmap (TIER_HOP)
-__device__ __forceinline__ void commit_chunks(const TileInfo& t, uint32_t lane, const u32x4 (&pre)[KCH], uint32_t stage, uint32_t bitmap,
+// WIDE: returns true for a lane whose line holds a code unit above 0xFF (its staged low bytes are not the line).
+template <int KCH, int MAP, bool WIDE>  // MAP 0: no bitmap; 1: general hot interval; 2: hot interval ends at 0x7F; 3: no bitmap (TIER_HOP)
+__device__ __forceinline__ bool commit_chunks(const TileInfo& t, uint32_t lane, const u32x4 (&pre)[WIDE ? 2 * KCH : KCH], uint32_t stage, uint32_t bitmap,
                                               uint32_t hot_lo4, uint32_t hot_k4) {
     const uint32_t last = stage + ((t.nch - 1u) << 4), mine = stage + (lane << 4);
+    bool wide_line = false;
 #pragma unroll
     for (int k = 0; k < KCH; ++k) {
-        lds_st<u32x4>(min(mine + 1024u * k, last), pre[k]);
+        const u32x4 v = WIDE ? narrow16(pre[2 * k], pre[2 * k + 1]) : pre[k];
+        lds_st<u32x4>(min(mine + 1024u * k, last), v);
         if (MAP == 1 || MAP == 2) {
-            const unsigned long long m = __ballot(chunk_inside<MAP == 2>(pre[k], hot_lo4, hot_k4));
+            const unsigned long long m = __ballot(chunk_inside<MAP == 2>(v, hot_lo4, hot_k4));
             if (lane == 0) lds_st<u32x2>(bitmap + 8u * k, u32x2{static_cast<uint32_t>(m), static_cast<uint32_t>(m >> 32)});
         }
+        if (WIDE) {
+            const u32x4 &a = pre[2 * k], &b = pre[2 * k + 1];
+            const uint32_t high = (or3(a.x, a.y, a.z) | or3(a.w, b.x, b.y) | b.z | b.w) & 0xFF00FF00u;
+            unsigned long long wm = __builtin_amdgcn_ballot_w64(high != 0u);
+            while (wm != 0ull) {   // (rare: log text is Latin-1) the lines that reach into a chunk with such a unit
+                const uint32_t src = static_cast<uint32_t>(__builtin_ctzll(wm));
+                wm &= wm - 1ull;
+                const uint32_t c16 = min((src << 4) + 1024u * k, (t.nch - 1u) << 4);   // the chunk's first staged byte (a clamped lane's: the last chunk again)
+                if (t.active && t.start < c16 + 16u && t.end > c16) wide_line = true;
+            }
+        }
     }
+    return wide_line;
 }
-template <int KCH, bool CLASSES>
-__device__ __forceinline__ void tile_commit(const TileInfo& t, uint32_t lane, const u32x4 (&pre)[KCH], uint32_t stage, uint32_t bitmap,
+template <int KCH, bool HOP, bool WIDE>
+__device__ __forceinline__ bool tile_commit(const TileInfo& t, uint32_t lane, const u32x4 (&pre)[WIDE ? 2 * KCH : KCH], uint32_t stage, uint32_t bitmap,
                                             bool use_map, uint32_t hot_lo4, uint32_t hot_k4, const uint8_t* data, const uint8_t* data_end) {
+    bool wide_line = false;
     if (t.mode == 0) {
-        if (CLASSES) commit_chunks<KCH, 3>(t, lane, pre, stage, bitmap, hot_lo4, hot_k4);
-        else if (!use_map) commit_chunks<KCH, 0>(t, lane, pre, stage, bitmap, hot_lo4, hot_k4);
-        else if (hot_k4 == 0u) commit_chunks<KCH, 2>(t, lane, pre, stage, bitmap, hot_lo4, hot_k4);
-        else commit_chunks<KCH, 1>(t, lane, pre, stage, bitmap, hot_lo4, hot_k4);
+        if (HOP) wide_line = commit_chunks<KCH, 3, WIDE>(t, lane, pre, stage, bitmap, hot_lo4, hot_k4);
+        else if (!use_map) wide_line = commit_chunks<KCH, 0, WIDE>(t, lane, pre, stage, bitmap, hot_lo4, hot_k4);
+        else if (hot_k4 == 0u) wide_line = commit_chunks<KCH, 2, WIDE>(t, lane, pre, stage, bitmap, hot_lo4, hot_k4);
+        else wide_line = commit_chunks<KCH, 1, WIDE>(t, lane, pre, stage, bitmap, hot_lo4, hot_k4);
     } else if (t.mode == 1) {
-        stage_span_guarded<CLASSES>(t.g_al, t.nch, stage, lane, data, data_end);
+        stage_span_guarded<WIDE>(t.g_al, t.nch, stage, lane, data, data_end);
         if (use_map && lane < 2u * KCH) lds_st<uint32_t>(bitmap + 4u * lane, 0u);  // no chunk of a guarded round is skipped
+        if (WIDE && t.active) {   // (the first and the last round of a buffer: every lane looks at its own line's units)
+            const uint16_t* u = reinterpret_cast<const uint16_t*>(data) + t.o0;
+            for (uint64_t q = 0; q < t.o1 - t.o0; ++q) wide_line = wide_line || u[q] > 0xFFu;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return wide_line;
 }
 
 #ifdef GX_DEV
@@ -223,8 +259,10 @@ __device__ __forceinline__ void tile_commit(const TileInfo& t, uint32_t lane, co
 // and land while the wave computes out of LDS, so HBM latency is hidden without a second LDS buffer.
 // PACKED: 1 = results leave as compact u16 rows, 2 = as u8 rows (gx_batch_opts.compact_results) -- kernels of their own, so that profiles tell
 // the two result formats apart.
-template <typename OFF, int KCH, int TIER, int MODE, int PACKED>
-__global__ void __launch_bounds__(KCH > 13 ? 512 : 768) __attribute__((amdgpu_waves_per_eu(1, KCH > 13 ? 2 : 3)))
+// WIDE: `data` holds UTF-16 code units (gx_batch_opts.utf16), offsets count units; the units' low bytes are staged (26 prefetch
+// registers per 13 staged chunks: two waves per SIMD) and the lines that hold a unit above 0xFF are flagged for the per-line walk.
+template <typename OFF, int KCH, int TIER, int MODE, int PACKED, bool WIDE = false>
+__global__ void __launch_bounds__((KCH > 13 || WIDE) ? 512 : 768) __attribute__((amdgpu_waves_per_eu(1, (KCH > 13 || WIDE) ? 2 : 3)))
 k_extract_tile(GxLds L, TileIO io) {
     // ---- prologue: table image -> LDS (the only access through the __shared__ symbol; its address is 0) ----
     {
@@ -276,7 +314,7 @@ k_extract_tile(GxLds L, TileIO io) {
     const int G = io.max_groups;
     const uint32_t slots = 2u * static_cast<uint32_t>(G);
     const uint64_t tiles = (n + 63) >> 6;
-    const uint8_t* data_end = data + static_cast<uint64_t>(off[n]);
+    const uint8_t* data_end = data + (static_cast<uint64_t>(off[n]) << (WIDE ? 1 : 0));
 
     auto load_offsets = [&](uint64_t tile, uint64_t& o0, uint64_t& o1) {
         const uint64_t i = (tile << 6) + lane;
@@ -300,9 +338,10 @@ k_extract_tile(GxLds L, TileIO io) {
         t.o0 = o0; t.o1 = o1;
         t.a = a;
         const uint64_t lo = lane_value(o0, a);  // lane a holds a valid line
-        const uint8_t* g_lo = data + lo;
-        const uint32_t skew = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(g_lo) & 15u);
-        t.g_al = g_lo - skew;  // 16-byte aligned; still a global-address-space pointer for the compiler
+        const uint8_t* g_lo = data + (lo << (WIDE ? 1 : 0));
+        const uint32_t skew_b = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(g_lo) & (WIDE ? 31u : 15u));   // (WIDE: a staged chunk is 32 bytes of the buffer)
+        const uint32_t skew = skew_b >> (WIDE ? 1 : 0);   // ... in staged bytes
+        t.g_al = g_lo - skew_b;  // 16-byte aligned; still a global-address-space pointer for the compiler
         // offsets ascend, so the lines that fit are a run of lanes starting at a (+48: the walk looks ahead of the line)
         const bool fits = lane >= a && valid && (o1 - lo) + skew + 48u <= L.stage_bytes;
         const uint32_t cnt = static_cast<uint32_t>(__popcll(__ballot(fits)));
@@ -315,7 +354,7 @@ k_extract_tile(GxLds L, TileIO io) {
             const uint64_t hi = lane_value(o1, t.b - 1u);
             const uint64_t span = (hi - lo) + skew;
             t.nch = max(static_cast<uint32_t>((span + 15) >> 4), 1u);
-            t.mode = (t.g_al >= data && t.g_al + (static_cast<uint64_t>(t.nch) << 4) <= data_end) ? 0u : 1u;
+            t.mode = (t.g_al >= data && t.g_al + (static_cast<uint64_t>(t.nch) << (WIDE ? 5 : 4)) <= data_end) ? 0u : 1u;
         }
         t.active = (lane >= a && lane < t.b) ? 1u : 0u;
         t.start = t.active ? skew + static_cast<uint32_t>(o0 - lo) : 0u;
@@ -419,7 +458,7 @@ k_extract_tile(GxLds L, TileIO io) {
     const unsigned long long dev_begin = __builtin_amdgcn_s_memrealtime();   // (100 MHz, one clock for the whole chip)
     unsigned long long dev_tiles = 0;
 #endif
-    u32x4 pre[KCH];  // the next round's bytes, in flight or landed
+    u32x4 pre[WIDE ? 2 * KCH : KCH];  // the next round's bytes, in flight or landed
     uint64_t no0 = 0, no1 = 0;
     TileInfo cur;
     {
@@ -428,10 +467,10 @@ k_extract_tile(GxLds L, TileIO io) {
         cur = make_round(tile, 0, o0, o1);
     }
     load_offsets(min(t1, tiles - 1), no0, no1);
-    tile_issue_loads<KCH>(cur, lane, pre, io.image);
+    tile_issue_loads<KCH, WIDE>(cur, lane, pre, io.image);
 
     for (;;) {
-        tile_commit<KCH, HOP>(cur, lane, pre, stage, bitmap, use_map, L.hot_lo4, L.hot_k4, data, data_end);
+        const bool wide_line = tile_commit<KCH, HOP, WIDE>(cur, lane, pre, stage, bitmap, use_map, L.hot_lo4, L.hot_k4, data, data_end);
         GX_STAMP(0);
         // ---- software pipeline: start fetching the next round (and the offsets of the group after it) ----
         const uint32_t group_lines = static_cast<uint32_t>(min(static_cast<uint64_t>(64), n - (tile << 6)));
@@ -462,7 +501,7 @@ k_extract_tile(GxLds L, TileIO io) {
         TileInfo nxt = make_round(has_next ? ntile : tile, has_next ? (same_group ? cur.b : 0u) : cur.a,
                                   has_next && !same_group ? no0 : cur.o0, has_next && !same_group ? no1 : cur.o1);
         if (!has_next) nxt.mode = 3;  // nothing to fetch: the loop ends after this round
-        tile_issue_loads<KCH>(nxt, lane, pre, io.image);
+        tile_issue_loads<KCH, WIDE>(nxt, lane, pre, io.image);
         jn = draw_own(drew ? 1u : 0u, gn, shn);
         drew_before = drew;
         GX_STAMP(1);
@@ -615,6 +654,13 @@ k_extract_tile(GxLds L, TileIO io) {
                 }
             }
         }
+        if (WIDE) {
+            // the per-line walk on the code units takes the flagged lines again (gx_kernels.hip: k_extract_flagged); a line left to
+            // the follow-up launch (mode 2) is walked on its units there anyway
+            if (valid || (cur.mode == 2 && lane == cur.a)) io.wide_flags[i] = (wide_line && cur.mode != 2) ? 1 : 0;
+            if (__builtin_amdgcn_ballot_w64(wide_line && valid && cur.mode != 2) != 0ull && lane == 0)
+                __hip_atomic_store(io.wide_any, io.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         // the staging area is reused by the next tile: all lanes must be done reading it
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -646,18 +692,27 @@ k_extract_tile(GxLds L, TileIO io) {
 #endif
 }
 
-template <typename OFF, int KCH, int TIER, int MODE, int PACKED>
+template <typename OFF, int KCH, int TIER, int MODE, int PACKED, bool WIDE = false>
 hipError_t launch_tile_p(const GxLds& lds, const TileIO& io, dim3 grid, dim3 block, hipStream_t stream) {
-    hipError_t e = allow_full_lds(&k_extract_tile<OFF, KCH, TIER, MODE, PACKED>);
+    hipError_t e = allow_full_lds(&k_extract_tile<OFF, KCH, TIER, MODE, PACKED, WIDE>);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_extract_tile<OFF, KCH, TIER, MODE, PACKED>), grid, block, lds.total_bytes, stream, lds, io);
+    hipLaunchKernelGGL((k_extract_tile<OFF, KCH, TIER, MODE, PACKED, WIDE>), grid, block, lds.total_bytes, stream, lds, io);
     return hipGetLastError();
 }
-template <typename OFF, int KCH, int TIER, int MODE>
+template <typename OFF, int KCH, int TIER, int MODE, bool WIDE = false>
 hipError_t launch_tile_t(const GxLds& lds, const TileIO& io, dim3 grid, dim3 block, hipStream_t stream) {
-    if (MODE != 0 && io.packed && io.narrow) return launch_tile_p<OFF, KCH, TIER, MODE, MODE != 0 ? 2 : 0>(lds, io, grid, block, stream);
-    if (MODE != 0 && io.packed) return launch_tile_p<OFF, KCH, TIER, MODE, MODE != 0 ? 1 : 0>(lds, io, grid, block, stream);
-    return launch_tile_p<OFF, KCH, TIER, MODE, 0>(lds, io, grid, block, stream);
+    if (MODE != 0 && io.packed && io.narrow) return launch_tile_p<OFF, KCH, TIER, MODE, MODE != 0 ? 2 : 0, WIDE>(lds, io, grid, block, stream);
+    if (MODE != 0 && io.packed) return launch_tile_p<OFF, KCH, TIER, MODE, MODE != 0 ? 1 : 0, WIDE>(lds, io, grid, block, stream);
+    return launch_tile_p<OFF, KCH, TIER, MODE, 0, WIDE>(lds, io, grid, block, stream);
+}
+// UTF-16 batches: the one variant with 13 staged chunks per lane (lds.stage_bytes <= 13 KB, at most 8 waves: plan_tile_layout)
+template <typename OFF, int TIER>
+hipError_t launch_tile_wide(int mode, const GxLds& lds, const TileIO& io, dim3 grid, dim3 block, hipStream_t stream) {
+    if (lds.stage_bytes > 13u * 1024u || lds.nwaves > 8u) return hipErrorInvalidValue;
+    if (mode == 0) return launch_tile_t<OFF, 13, TIER, 0, true>(lds, io, grid, block, stream);
+    if (mode == 1) return launch_tile_t<OFF, 13, TIER, 1, true>(lds, io, grid, block, stream);
+    if (TIER == TIER_HOP) return hipErrorInvalidValue;
+    return launch_tile_t<OFF, 13, TIER, TIER == TIER_HOP ? 1 : 2, true>(lds, io, grid, block, stream);
 }
 template <typename OFF, int TIER, int MODE>
 hipError_t launch_tile_k(const GxLds& lds, const TileIO& io, dim3 grid, dim3 block, hipStream_t stream) {

@@ -653,6 +653,25 @@ def unpack_rows(rows):
     return mid, caps
 
 
+def extract_batch_multi_device(shards, match_only=False, strip_eol=False, compact=False, line_bytes_hint=0, max_line_bytes=0, no_sync=False,
+                               offsets64=False):
+    """gx_extract_batch_multi_device: device-resident CSR batches, one per Gorp object (= per device), in one call.
+    shards: list of (gorp, data_ptr, offsets_ptr, n, match_id_ptr, caps_ptr, overflow_ptr or None, stream or None)."""
+    arr = (N.gx_device_shard * len(shards))()
+    for a, (g, d, o_, n, m, c, ov, st) in zip(arr, shards):
+        a.handle, a.bytes, a.offsets, a.n, a.match_id, a.caps, a.overflow, a.stream = g._h.ptr, d, o_, n, m, c, ov, st
+    o = N.gx_batch_opts()
+    o.struct_size = C.sizeof(N.gx_batch_opts)
+    o.match_only = 1 if match_only else 0
+    o.strip_eol = 1 if strip_eol else 0
+    o.compact_results = int(compact)
+    o.line_bytes_hint = int(line_bytes_hint)
+    o.max_line_bytes = int(max_line_bytes)
+    o.no_sync = 1 if no_sync else 0
+    o.offsets64 = 1 if offsets64 else 0
+    _check(N.lib().gx_extract_batch_multi_device(arr, len(shards), C.byref(o)))
+
+
 def split_lines(data, cap_lines=None, offsets_dtype=np.uint32, want_flags=False):
     """gx_split_lines on a host buffer: raw bytes -> (offsets[n+1], flags[n] or None) with readLine() line
     boundaries; every line keeps its terminator (pass strip_eol=True to extract_batch)."""

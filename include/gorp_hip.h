@@ -102,7 +102,10 @@ int32_t gx_max_groups(const gx_handle* h);
  * these tables / of the hop slice kernel, 20 = branching states whose dense row is in LDS too, 22 / 23 = states / states with
  * their records in LDS of the second hop image, built from the match automaton alone for match-only batches;
  * 24 = batches so far that broke their gx_batch_opts.max_line_bytes promise; 25 = the kernel the most recent batch ran on
- * (a GX_KERNEL_* value; 0: none yet) */
+ * (a GX_KERNEL_* value; 0: none yet); 26 = why capture batches have no hop tables (0: they have; 1: no fused automaton or no
+ * capture regexps; 2: a step with capture programs other than one "register := position" -- groups that may match the empty string
+ * write two registers in one step; 3: beyond a limit of the tier; 4: not built -- the dense rows fit LDS, or the caller named another
+ * tier; 5: the tables leave no room for a wave) */
 int64_t gx_stat(const gx_handle* h, int32_t which);
 
 typedef struct gx_batch_opts {
@@ -317,6 +320,25 @@ int gx_handle_device(const gx_handle* h);   /* -1 for a host-only handle */
  * handles must come from the same definition.  opts as for gx_extract_batch (host pointers only; stream is ignored). */
 int gx_extract_batch_multi(gx_handle* const* handles, int32_t n_handles, const uint8_t* bytes, const void* offsets, uint64_t n,
                            int32_t* match_id, int32_t* caps, const gx_batch_opts* opts);
+
+/* The same for batches that are RESIDENT on the devices (the one-process-many-GPUs layout without the bus in the way): shard k is a
+ * CSR batch in the memory of shards[k].handle's device -- bytes / offsets / n / match_id / caps as for gx_extract_batch with
+ * device_pointers, `overflow` a device uint64_t on that device (or NULL), `stream` a hipStream_t of that device (NULL: a stream the
+ * handle keeps for this purpose).  One call enqueues every shard on its device from the calling thread, then -- unless
+ * opts->no_sync -- waits for all of them; the shards run concurrently.  No exchange between the shards: lines are independent.
+ * opts as for gx_extract_batch (device_pointers is implied; stream and overflow are per shard, those of opts are ignored).  A shard
+ * that fails does not stop the others; the first failure is returned. */
+typedef struct gx_device_shard {
+    gx_handle* handle;
+    const uint8_t* bytes;
+    const void* offsets;
+    uint64_t n;
+    int32_t* match_id;
+    int32_t* caps;
+    void* overflow;
+    void* stream;
+} gx_device_shard;
+int gx_extract_batch_multi_device(const gx_device_shard* shards, int32_t n_shards, const gx_batch_opts* opts);
 
 /* Host buffers that are handed to gx_extract_batch again and again (a JNI caller's direct ByteBuffers) can be pinned
  * once: copies from and to pinned memory run at the bus' rate without a staging copy by the CPU (hipHostRegister /

@@ -1378,3 +1378,60 @@ def test_launches_of_many_streams_share_a_handle():
     for d, o, mid, caps, data, offsets in outs:
         omid, ocaps = orc.extract_batch(data, offsets, nthreads=4)
         assert np.array_equal(mid.cpu().numpy(), omid) and np.array_equal(caps.cpu().numpy(), ocaps)
+
+
+def test_device_resident_shards_in_one_call():
+    """gx_extract_batch_multi_device: three handles (one GPU here: three handles on the one device -- DESIGN section 7), each with its
+    own device-resident shard, enqueued by one call on the handles' own streams and on the caller's; dense, u16 and u8 rows; an empty
+    shard; no_sync with the caller's streams."""
+    import torch
+    definition = W.readme3_definition()
+    gorps = [Gorp.construct(definition) for _ in range(3)]
+    orc = oracle_for(definition)
+    parts = []
+    for k, n in enumerate((30000, 0, 12345)):
+        data, offsets, cat = W.readme3_lines(max(n, 1), seed=40 + k, device="cuda")
+        parts.append((data, offsets, n))
+    for compact, dtype, width in ((0, torch.int32, 8), (1, torch.int16, 9), (2, torch.uint8, 9)):
+        for own_streams in (False, True):
+            streams = [torch.cuda.Stream() for _ in gorps]
+            outs, shards = [], []
+            for g, (data, offsets, n), st in zip(gorps, parts, streams):
+                mid = torch.full((max(n, 1),), -7, dtype=torch.int32, device="cuda")
+                rows = torch.full((max(n, 1), width), 7, dtype=dtype, device="cuda")
+                over = torch.zeros(1, dtype=torch.int64, device="cuda")
+                outs.append((mid, rows, over))
+                shards.append((g, data.data_ptr(), offsets.data_ptr(), n, None if compact else mid.data_ptr(), rows.data_ptr(), over.data_ptr(),
+                               st.cuda_stream if own_streams else None))
+            torch.cuda.synchronize()
+            G.extract_batch_multi_device(shards, compact=compact, line_bytes_hint=200, max_line_bytes=200, no_sync=own_streams)
+            if own_streams:
+                for st in streams:
+                    st.synchronize()
+            for (data, offsets, n), (mid, rows, over) in zip(parts, outs):
+                if n == 0:
+                    continue
+                omid, ocaps = orc.extract_batch(data.cpu().numpy(), offsets.cpu().numpy()[:n + 1], nthreads=4)
+                if compact:
+                    m, c = G.unpack_rows(rows.cpu().numpy().view(np.uint16 if compact == 1 else np.uint8))
+                else:
+                    m, c = mid.cpu().numpy(), rows.cpu().numpy()
+                assert np.array_equal(m, omid) and np.array_equal(c, ocaps) and int(over.item()) == 0
+
+
+def test_hop_tier_refusals_are_reported():
+    """A definition whose capture programs are not all "register := position" (groups that may be empty write two registers in one
+    step) gets no hop tables even when asked: gx_stat(h, 26) says why, and the other tables answer -- bit-exact."""
+    csv = [FlattenedExtraction("csv", [["extractor", "a", [["pattern", "[^,]*"]]], ["text", ","], ["extractor", "b", [["pattern", "[^,]*"]]],
+                                       ["text", ","], ["extractor", "c", [["pattern", "[^,]*"]]]])]
+    gorp, orc = Gorp.construct(csv, flags=N.GX_CREATE_TIER_HOP), oracle_for(csv)
+    rng = random.Random(8)
+    lines = [",".join("".join(rng.choice("abc1 ") for _ in range(rng.randrange(0, 6))) for _ in range(rng.choice([2, 3, 3, 3, 4]))) for _ in range(4000)]
+    check_batch(gorp, orc, lines)
+    assert (gorp.stat(14) > 0) == (gorp.stat(26) == 0)
+    if gorp.stat(14) == 0:
+        assert gorp.stat(26) == 2          # general capture programs
+    readme = Gorp.construct(W.readme3_definition(), flags=N.GX_CREATE_TIER_HOP)
+    assert readme.stat(14) > 0 and readme.stat(26) == 0
+    plain = Gorp.construct(W.readme3_definition())
+    assert plain.stat(14) == 0 and plain.stat(26) == 4   # not built: the dense rows fit LDS
