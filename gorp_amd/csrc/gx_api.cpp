@@ -140,6 +140,7 @@ struct gx_handle {
     uint32_t steal_parity[N_SLOTS] = {};  // the row the slot's next tile-kernel launch draws from
     uint32_t promise_seq[N_SLOTS] = {};   // the sequence number of the slot's last launch under a promise (0: none)
     std::atomic<uint64_t> promises_broken{0};
+    int32_t* d_pike_scratch = nullptr;    // thread lists of the lanes that run an extraction's program as it is (GxDev::pike_scratch)
     int hop_reason = 4;                   // why capture batches have no hop tables (gx_stat(h, 26); 0: they have)
     hipStream_t multi_stream = nullptr;   // gx_extract_batch_multi_device: the stream of shards that bring none
     std::atomic<int> last_kernel{0};      // GX_KERNEL_* of the most recent batch launch (gx_stat(h, 25))
@@ -789,7 +790,8 @@ bool plan_hop_slice_launch(const gx_handle* h, GxLds* out, bool match_only = fal
 // memory (L2), else the per-line kernel alone.  Host work only (also done for host-only handles, where it is a check
 // of the builders and feeds gx_stat).
 void choose_tile_image(gx_handle* h) {
-    const bool no_tiles = (h->create_flags & GX_CREATE_NO_TILES) != 0, force_l2 = (h->create_flags & GX_CREATE_TIER_L2) != 0;
+    // (a definition with an extraction that has no capture automaton: the per-line kernel alone -- it is the one that runs programs)
+    const bool no_tiles = (h->create_flags & GX_CREATE_NO_TILES) != 0 || h->T.has_pike(), force_l2 = (h->create_flags & GX_CREATE_TIER_L2) != 0;
     const bool force_rec = (h->create_flags & GX_CREATE_TIER_RECORDS) != 0;
     auto records = [&](int tier) {
         if (build_tile_image(h, tier)) return true;
@@ -919,6 +921,21 @@ void upload(gx_handle* h) {
     std::vector<uint16_t> fin_tags = T.fin_tags;
     if (fin_tags.empty()) fin_tags.push_back(0);
     const size_t o_fintags = img.put(fin_tags);
+    // extractions without a capture automaton: their programs (gx_compile.hpp: Tables::pike_*)
+    size_t o_pike_off = 0, o_pike_code = 0, o_pike_sets = 0;
+    uint32_t pike_lane_ints = 0;
+    if (T.has_pike()) {
+        o_pike_off = img.put(T.pike_off);
+        o_pike_code = img.put(T.pike_code);
+        o_pike_sets = img.put(T.pike_sets);
+        for (size_t k = 0; k < T.rules.size(); ++k) {
+            const uint32_t ni = T.pike_off[k + 1] - T.pike_off[k], W = 1u + 2u * static_cast<uint32_t>(T.rules[k].n_groups);
+            if (ni) pike_lane_ints = std::max(pike_lane_ints, 2u * ni * W + 3u * (2u * ni + 2u) + ni + 2u * static_cast<uint32_t>(T.rules[k].n_groups));
+        }
+        pike_lane_ints += 2u * static_cast<uint32_t>(T.max_groups) + 2u;
+        if (static_cast<uint64_t>(pike_lane_ints) * 4u * (GX_PIKE_LANES + 1u) > (2ull << 30))
+            throw GxError(GX_E_LIMIT, "capture program too large to run as it is (thread lists beyond 2 GiB)");
+    }
 
     GX_HIP(hipMalloc(&h->dimage, img.bytes.size()));
     h->image_bytes = img.bytes.size();
@@ -947,6 +964,14 @@ void upload(gx_handle* h) {
     d.max_groups = T.max_groups;
     d.max_regs = max_regs;
     d.has_capture = T.has_capture ? 1 : 0;
+    if (T.has_pike()) {
+        d.pike_off = reinterpret_cast<const uint32_t*>(base + o_pike_off);
+        d.pike_code = reinterpret_cast<const uint32_t*>(base + o_pike_code);
+        d.pike_sets = reinterpret_cast<const uint32_t*>(base + o_pike_sets);
+        d.pike_lane_ints = pike_lane_ints;
+        GX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_pike_scratch), static_cast<size_t>(pike_lane_ints) * 4u * (GX_PIKE_LANES + 1u)));
+        d.pike_scratch = h->d_pike_scratch;
+    }
 
     choose_tile_image(h);
     if (h->tile_ok) {
@@ -1372,6 +1397,7 @@ void gx_destroy(gx_handle* h) {
     for (void* q : h->scratch) if (q) (void)hipFree(q);
     if (h->pool) (void)hipMemPoolDestroy(h->pool);
     if (h->multi_stream) (void)hipStreamDestroy(h->multi_stream);
+    if (h->d_pike_scratch) (void)hipFree(h->d_pike_scratch);
     if (h->one_dev) (void)hipFree(h->one_dev);
     if (h->one_host) (void)hipHostFree(h->one_host);
     delete h;
@@ -1411,6 +1437,7 @@ int64_t gx_stat(const gx_handle* h, int32_t which) {
     case 24: return static_cast<int64_t>(h->promises_broken.load());
     case 25: return h->last_kernel.load();
     case 26: return h->hop_reason;
+    case 27: { int64_t c = 0; for (auto& r : h->T.rules) c += r.pike ? 1 : 0; return c; }
     case 23: return h->hop_mo_ok ? static_cast<int64_t>(h->hop_mo.full.n_hot) : 0; // ... whose records are in LDS
     case 19: { GxLds L; return plan_hop_slice_launch(h, &L) ? static_cast<int64_t>(L.nwaves) : 0; }  // ... of the hop slice kernel
     case 9: return !h->tile_ok ? 0 : !h->has_mo ? gx_stat(h, 7) : h->lds_mo.tier == 3 ? 4 : h->lds_mo.tier == 2 ? 3 : h->lds_mo.tier == 1 ? 2 : 1;

@@ -417,6 +417,10 @@ Dfa product(const std::vector<Dfa>& parts, int ncls, std::vector<std::vector<int
 // its captures in a single pass.
 const int MAX_TAGS = 64;
 const int TDFA_STATE_LIMIT = 60000;
+// One extraction whose capture automaton passes this many states is ambiguous in many independent places (n fields that may be empty
+// between blanks: 2^n register patterns -- 12 such fields are 4 097 states and 22 s of building, 14 fields 16 385 states and minutes):
+// it keeps its program and is run as one (RuleTables::pike).  Extractions of real definitions have tens to hundreds of states.
+const int PROGRAM_INSTEAD_STATES = 4096;
 const int16_t R_NIL = -1, R_NEW = -2;   // (while a step is built: R_NEW - k = "the current position", k = the tag's run, see tag_run_)
 
 struct Thread {
@@ -493,8 +497,10 @@ public:
     // with_rule_id: final-tag records start with the extraction index (union automaton)
     // fused != nullptr: run in product with the match automaton of *fused (see Tables::uni);
     // final-tag records then start with the extraction index.
-    TdfaBuilder(const MultiProg& p, const Classes& C, OpListPool& ops, std::vector<uint16_t>& fin_tags, const Tables* fused)
-        : p_(p), C_(C), ops_(ops), fin_tags_(fin_tags), with_rule_id_(fused != nullptr), fused_(fused) {
+    // state_limit: what the caller is ready to build ahead of time (one extraction alone: PROGRAM_INSTEAD_STATES -- beyond it the
+    // extraction is run as a program; the fused automaton: TDFA_STATE_LIMIT -- beyond it the kernels take two passes)
+    TdfaBuilder(const MultiProg& p, const Classes& C, OpListPool& ops, std::vector<uint16_t>& fin_tags, const Tables* fused, int state_limit = TDFA_STATE_LIMIT)
+        : p_(p), C_(C), ops_(ops), fin_tags_(fin_tags), with_rule_id_(fused != nullptr), fused_(fused), state_limit_(state_limit) {
         for (int t : p.ntags) if (t > MAX_TAGS) throw GxError(GX_E_LIMIT, "more than 32 capture groups in one extraction");
         // Tags that are set in one step all receive the current position.  Which of them SHARE the register that receives it is a
         // matter of the automaton's shape only, and it is decided by the program, not by the line: tags whose TAG instructions
@@ -558,6 +564,7 @@ private:
     std::vector<uint16_t>& fin_tags_;
     bool with_rule_id_;
     const Tables* fused_;
+    int state_limit_;
     int nregs_ = 0;
     int scratch_ = -1;
     std::vector<TState> states_;
@@ -617,7 +624,7 @@ private:
     }
 
     int add_state(const TState& s) {
-        if (static_cast<int>(states_.size()) >= TDFA_STATE_LIMIT) throw GxError(GX_E_LIMIT, "capture automaton too large");
+        if (static_cast<int>(states_.size()) >= state_limit_) throw GxError(GX_E_LIMIT, "capture automaton too large");
         int id = static_cast<int>(states_.size());
         states_.push_back(s);
         exact_.emplace(s, id);
@@ -858,17 +865,66 @@ Tables compile_tables(const std::vector<ustr>& automaton_rx, const std::vector<u
     T.union_ok = false;
     if (jdk_rx) {
         OpListPool ops;
+        std::vector<char> is_pike(n, 0);
+        bool any_pike = false;
         for (size_t k = 0; k < n; ++k) {
             MultiProg mp = join_programs({&jprog[k]});
-            TdfaBuilder b(mp, C, ops, T.fin_tags, nullptr);
-            T.rules.push_back(b.build());
+            const OpListPool ops_before = ops;
+            const std::vector<uint16_t> fin_before = T.fin_tags;
+            try {
+                TdfaBuilder b(mp, C, ops, T.fin_tags, nullptr, PROGRAM_INSTEAD_STATES);
+                T.rules.push_back(b.build());
+            } catch (GxError& e) {
+                if (e.code != GX_E_LIMIT || C.ncls > 256 || 2 * jprog[k].ngroups > MAX_TAGS) throw;
+                // Too large ahead of time.  java.util.regex backtracks at run time and never builds anything: the extraction keeps its
+                // program and the kernels run it as it is (gx_kernels.hip: pike_capture).
+                ops = ops_before;
+                T.fin_tags = fin_before;
+                RuleTables R;
+                R.n_groups = jprog[k].ngroups;
+                R.n_states = 1;
+                R.dead = 0;
+                R.trans.assign(static_cast<size_t>(C.ncls), 0u);
+                R.fin.assign(1, -1);
+                R.pike = true;
+                T.rules.push_back(R);
+                is_pike[k] = 1;
+                any_pike = true;
+            }
             T.max_groups = std::max(T.max_groups, T.rules.back().n_groups);
+        }
+        if (any_pike) {
+            std::map<int, uint32_t> set_index;
+            T.pike_off.push_back(0);
+            for (size_t k = 0; k < n; ++k) {
+                if (is_pike[k]) {
+                    for (const Inst& in : jprog[k].code) {
+                        uint32_t x = static_cast<uint32_t>(in.x);
+                        if (in.op == Inst::CHAR) {
+                            auto it = set_index.find(in.x);
+                            if (it == set_index.end()) {
+                                it = set_index.emplace(in.x, static_cast<uint32_t>(T.pike_sets.size() / 8)).first;
+                                for (int w = 0; w < 4; ++w) {
+                                    const uint64_t m = w < C.words ? C.set_mask[static_cast<size_t>(in.x)][static_cast<size_t>(w)] : 0ull;
+                                    T.pike_sets.push_back(static_cast<uint32_t>(m));
+                                    T.pike_sets.push_back(static_cast<uint32_t>(m >> 32));
+                                }
+                            }
+                            x = it->second;
+                        }
+                        if (x >= (1u << 24)) throw GxError(GX_E_LIMIT, "capture program too large");
+                        T.pike_code.push_back(static_cast<uint32_t>(in.op) | x << 8);
+                        T.pike_code.push_back(static_cast<uint32_t>(in.y));
+                    }
+                }
+                T.pike_off.push_back(static_cast<uint32_t>(T.pike_code.size() / 2));
+            }
         }
         // Fused automaton (single pass): every extraction's capture automaton, joined in priority order,
         // run in product with the match automaton.  The match component decides WHICH extraction wins
         // (automaton dialect, exactly as PolyMatcher does), the tagged component supplies that
         // extraction's captures (JDK dialect) or proves that its regex rejects the line.
-        if (n <= 4096) {
+        if (n <= 4096 && !any_pike) {
             try {
                 std::vector<const Prog*> ps;
                 for (auto& p : jprog) ps.push_back(&p);
@@ -900,7 +956,7 @@ Tables compile_tables(const std::vector<ustr>& automaton_rx, const std::vector<u
 // ===========================================================================
 namespace {
 const uint32_t BLOB_MAGIC = 0x31425847u;  // "GXB1"
-const uint32_t BLOB_VERSION = 2;
+const uint32_t BLOB_VERSION = 3;   // 3: + the programs of extractions without an automaton (version 2 blobs are still read)
 
 struct Writer {
     std::vector<uint8_t> buf;
@@ -952,13 +1008,15 @@ std::vector<uint8_t> pack_blob(const Tables& t) {
         w.pod<int32_t>(t.uni.n_groups); w.pod<int32_t>(t.uni.n_states); w.pod<int32_t>(t.uni.n_regs); w.pod<int32_t>(t.uni.dead);
         w.vec(t.uni.trans); w.vec(t.uni.fin);
     }
+    w.vec(t.pike_off); w.vec(t.pike_code); w.vec(t.pike_sets);
     return w.buf;
 }
 
 Tables unpack_blob(const void* data, size_t size) {
     Reader r{static_cast<const uint8_t*>(data), size};
     if (r.pod<uint32_t>() != BLOB_MAGIC) throw GxError(GX_E_ARG, "not a gorp_amd table blob");
-    if (r.pod<uint32_t>() != BLOB_VERSION) throw GxError(GX_E_ARG, "table blob version mismatch");
+    const uint32_t version = r.pod<uint32_t>();
+    if (version != BLOB_VERSION && version != 2u) throw GxError(GX_E_ARG, "table blob version mismatch");
     Tables t;
     t.n_rules = r.pod<int32_t>(); t.ncls = r.pod<int32_t>(); t.max_groups = r.pod<int32_t>(); t.has_capture = r.pod<int32_t>() != 0;
     t.m_states = r.pod<int32_t>(); t.m_dead = r.pod<int32_t>();
@@ -986,6 +1044,7 @@ Tables unpack_blob(const void* data, size_t size) {
         if (t.uni.trans.size() != static_cast<size_t>(t.uni.n_states) * t.ncls || t.uni.fin.size() != static_cast<size_t>(t.uni.n_states))
             throw GxError(GX_E_ARG, "corrupt table blob");
     }
+    if (version >= 3u) { t.pike_off = r.vec<uint32_t>(); t.pike_code = r.vec<uint32_t>(); t.pike_sets = r.vec<uint32_t>(); }
     if (t.m_next.size() != static_cast<size_t>(t.m_states) * t.ncls || t.hi_lo.size() != t.hi_cls.size() || t.hi_lo.empty())
         throw GxError(GX_E_ARG, "corrupt table blob");
     // Everything the host walkers (gx_state_accepts, gx_match_one_utf16) and the kernels index with values read from
@@ -1037,6 +1096,30 @@ Tables unpack_blob(const void* data, size_t size) {
         if (t.ops[i + 1] != GX_SRC_POS && t.ops[i + 1] >= max_regs) throw bad("capture program source");
     }
     for (uint16_t v : t.fin_tags) if (v != GX_SRC_POS && v != GX_SRC_NIL && v >= std::max(max_regs, t.n_rules)) throw bad("final tag");
+    // the programs of the extractions without an automaton: every target inside the extraction's own program, every set and tag in range
+    if (!t.pike_code.empty() || !t.pike_off.empty() || !t.pike_sets.empty()) {
+        if (!t.has_capture || t.union_ok || t.ncls > 256 || t.pike_off.size() != static_cast<size_t>(t.n_rules) + 1 || t.pike_code.size() % 2 || t.pike_sets.size() % 8 ||
+            t.pike_off[0] != 0 || t.pike_off.back() != t.pike_code.size() / 2)
+            throw bad("capture programs of extractions without an automaton");
+        for (size_t k = 0; k < static_cast<size_t>(t.n_rules); ++k) {
+            if (t.pike_off[k] > t.pike_off[k + 1]) throw bad("capture program offsets of extractions without an automaton");
+            const uint32_t len = t.pike_off[k + 1] - t.pike_off[k];
+            t.rules[k].pike = len != 0;
+            if (len > 65535u) throw bad("capture program length");
+            for (uint32_t q = 0; q < len; ++q) {
+                const uint32_t w0 = t.pike_code[2 * (t.pike_off[k] + q)], y = t.pike_code[2 * (t.pike_off[k] + q) + 1];
+                const uint32_t op = w0 & 0xFFu, x = w0 >> 8;
+                switch (op) {
+                case 0: if (x >= t.pike_sets.size() / 8 || q + 1 >= len) throw bad("capture program: set"); break;
+                case 1: if (x >= len || y >= len) throw bad("capture program: split"); break;
+                case 2: if (x >= len) throw bad("capture program: jump"); break;
+                case 3: if (x >= 2u * static_cast<uint32_t>(t.rules[k].n_groups) || q + 1 >= len) throw bad("capture program: tag"); break;
+                case 4: case 5: break;
+                default: throw bad("capture program: instruction");
+                }
+            }
+        }
+    }
     return t;
 }
 

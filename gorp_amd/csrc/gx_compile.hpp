@@ -18,6 +18,10 @@ struct RuleTables {
     int dead = 0;
     std::vector<uint32_t> trans;  // [n_states * ncls]: next state | (op-list id << 16)
     std::vector<int32_t> fin;     // [n_states]: offset into Tables::fin_tags of 2*n_groups entries, or -1
+    // The automaton would be too large ahead of time (many independent ambiguities: 2^n register patterns where java.util.regex
+    // backtracks at run time): the extraction keeps its PROGRAM instead (Tables::pike_*) and the kernels run that -- a Pike VM,
+    // thread lists in priority order, linear in line x program.  trans / fin are then a one-state placeholder.
+    bool pike = false;
 };
 
 struct Tables {
@@ -54,6 +58,14 @@ struct Tables {
     std::vector<uint32_t> ops_off;   // [n_oplists + 1]; list 0 is empty
     std::vector<uint16_t> ops;       // (dst, src) pairs, executed in order
     std::vector<uint16_t> fin_tags;  // register id | GX_SRC_POS (= line length) | GX_SRC_NIL
+
+    // Programs of the extractions whose capture automaton is not built ahead of time (RuleTables::pike).  Empty when there is none.
+    // An instruction is two words: op | x << 8, y (op: 0 CHAR x = set, 1 SPLIT x preferred over y, 2 JMP x, 3 TAG x, 4 MATCH, 5 FAIL;
+    // targets are relative to the extraction's first instruction); a set is eight words, one bit per character class.
+    std::vector<uint32_t> pike_off;    // [n_rules + 1], in instructions; equal neighbours: the extraction has its automaton
+    std::vector<uint32_t> pike_code;
+    std::vector<uint32_t> pike_sets;
+    bool has_pike() const { return !pike_code.empty(); }
 
     int class_of(int c) const {
         if (c < 256) return cls256[c];

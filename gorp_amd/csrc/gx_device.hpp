@@ -32,7 +32,15 @@ struct GxDev {
     int32_t max_groups;
     int32_t max_regs;
     int32_t has_capture;
+    // extractions without a capture automaton (gx_compile.hpp: Tables::pike_*): their programs, run as they are.  pike_off null: none.
+    const uint32_t* pike_off;    // [n_rules + 1]
+    const uint32_t* pike_code;   // two words per instruction
+    const uint32_t* pike_sets;   // eight words per set
+    int32_t* pike_scratch;       // [GX_PIKE_LANES + 1][pike_lane_ints]: the thread lists of the lanes that run one (the last: the one-line calls)
+    uint32_t pike_lane_ints;
 };
+constexpr uint32_t GX_PIKE_BLOCKS = 64;                     // the per-line kernels of a handle that has such extractions: 64 x 256 lanes
+constexpr uint32_t GX_PIKE_LANES = GX_PIKE_BLOCKS * 256u;
 
 // Layout of the LDS-resident table image used by the tile kernel: byte offsets
 // from the start of dynamic LDS.  The image [0, table_bytes) is built on the

@@ -64,11 +64,90 @@ struct LineOut {
 };
 
 // ---------------------------------------------------------------------------
+// An extraction whose capture automaton is not built ahead of time (2^n register patterns: gx_compile.hpp, RuleTables::pike):
+// its prioritised Thompson program run as it is -- a Pike VM.  Thread lists in priority order, a thread = (pc, its group
+// boundaries); a step moves every thread whose CHAR takes the code unit's class and closes over SPLIT (preferred branch first) /
+// JMP / TAG (:= position), first arrival at a pc wins.  Matcher.matches() (core/jdkre/JDKRegexpCookedExtraction.java:36-39) is
+// the first thread, in that order, that stands on MATCH when the line is over: the path backtracking would have found first.
+// Linear in line x program, exact, slow: the fallback that lets gx_create_* accept what Pattern.compile accepts.
+// scratch: this lane's ints (GxDev::pike_lane_ints): clist | nlist [n_inst][1 + 2 G] each, stack [3][2 n_inst + 2], mark [n_inst], caps [2 G].
+// ---------------------------------------------------------------------------
+template <typename CH>
+__device__ bool pike_capture(const GxDev& T, int k, const CH* __restrict__ s, int64_t len, int32_t* __restrict__ scratch, int32_t* __restrict__ caps_out) {
+    const uint32_t base = T.pike_off[k], n_inst = T.pike_off[k + 1] - base;
+    const uint32_t* code = T.pike_code + 2ull * base;
+    const int ng = T.c_ngroups[k];
+    const uint32_t W = 1u + 2u * static_cast<uint32_t>(ng);
+    int32_t* clist = scratch;
+    int32_t* nlist = clist + static_cast<size_t>(n_inst) * W;
+    int32_t* stack = nlist + static_cast<size_t>(n_inst) * W;   // entries of three ints: pc (or -1: restore), slot, value
+    int32_t* mark = stack + 3u * (2u * n_inst + 2u);
+    int32_t* caps = mark + n_inst;
+    for (uint32_t q = 0; q < n_inst; ++q) mark[q] = 0;
+    for (uint32_t t = 0; t < 2u * static_cast<uint32_t>(ng); ++t) caps[t] = -1;
+    int32_t gen = 1;
+    uint32_t ccount = 0, ncount = 0;
+    // the closure of pc0 with the boundaries in `caps`, appended to list[0 .. count) in priority order
+    auto add_thread = [&](int32_t* list, uint32_t& count, uint32_t pc0, int32_t pos) {
+        uint32_t sp = 0;
+        stack[0] = static_cast<int32_t>(pc0); stack[1] = 0; stack[2] = 0; sp = 1;
+        while (sp) {
+            --sp;
+            const int32_t pc = stack[3 * sp];
+            if (pc < 0) { caps[stack[3 * sp + 1]] = stack[3 * sp + 2]; continue; }   // (a TAG's branch is done: its boundary as it was)
+            if (mark[pc] == gen) continue;
+            mark[pc] = gen;
+            const uint32_t w0 = code[2 * pc], op = w0 & 0xFFu, x = w0 >> 8, y = code[2 * pc + 1];
+            if (op == 1u) {           // SPLIT: x first
+                stack[3 * sp] = static_cast<int32_t>(y); ++sp;
+                stack[3 * sp] = static_cast<int32_t>(x); ++sp;
+            } else if (op == 2u) {    // JMP
+                stack[3 * sp] = static_cast<int32_t>(x); ++sp;
+            } else if (op == 3u) {    // TAG
+                stack[3 * sp] = -1; stack[3 * sp + 1] = static_cast<int32_t>(x); stack[3 * sp + 2] = caps[x]; ++sp;
+                caps[x] = pos;
+                stack[3 * sp] = pc + 1; ++sp;
+            } else if (op == 0u || op == 4u) {   // CHAR / MATCH: a thread
+                int32_t* t = list + static_cast<size_t>(count) * W;
+                t[0] = pc;
+                for (uint32_t q = 1; q < W; ++q) t[q] = caps[q - 1];
+                ++count;
+            }
+        }
+    };
+    add_thread(clist, ccount, 0u, 0);
+    for (int64_t p = 0; p < len && ccount; ++p) {
+        const uint32_t c = static_cast<uint32_t>(class_of(T, s[p]));
+        ++gen;
+        ncount = 0;
+        for (uint32_t i = 0; i < ccount; ++i) {
+            const int32_t* t = clist + static_cast<size_t>(i) * W;
+            const uint32_t w0 = code[2 * t[0]];
+            if ((w0 & 0xFFu) != 0u) continue;   // (a thread on MATCH with input left: over)
+            if (!((T.pike_sets[8u * (w0 >> 8) + (c >> 5)] >> (c & 31u)) & 1u)) continue;
+            for (uint32_t q = 1; q < W; ++q) caps[q - 1] = t[q];
+            add_thread(nlist, ncount, static_cast<uint32_t>(t[0]) + 1u, static_cast<int32_t>(p + 1));
+        }
+        int32_t* sw = clist; clist = nlist; nlist = sw;
+        ccount = ncount;
+    }
+    for (uint32_t i = 0; i < ccount; ++i) {
+        const int32_t* t = clist + static_cast<size_t>(i) * W;
+        if ((code[2 * t[0]] & 0xFFu) != 4u) continue;
+        for (uint32_t q = 1; q < W; ++q) caps_out[q - 1] = t[q];
+        return true;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------
 // One line, tables read through L1/L2 (any table size, any line length).
 // ---------------------------------------------------------------------------
+// pike_slot: the lane's area in GxDev::pike_scratch (0xFFFFFFFF: its index in the grid -- the launchers keep the grids of a handle
+// that has such extractions within GX_PIKE_LANES)
 template <typename CH, typename MS>
 __device__ void extract_line_global(const GxDev& T, const MS* __restrict__ m_next, const CH* __restrict__ s, int64_t len,
-                                    uint64_t i, const LineOut& out, int32_t* __restrict__ state_out, int match_only) {
+                                    uint64_t i, const LineOut& out, int32_t* __restrict__ state_out, int match_only, uint32_t pike_slot = 0xFFFFFFFFu) {
     const int ncls = T.ncls;
     const int slots = out.slots;
     // match_only < 0: CookedExtraction.match(String) alone (core/jdkre/JDKRegexpCookedExtraction.java:36-39) for
@@ -91,6 +170,27 @@ __device__ void extract_line_global(const GxDev& T, const MS* __restrict__ m_nex
     if (k < 0) {
         out.id(i, -1);
         for (int t = 0; t < slots; ++t) out.cap(i, t, -1);
+        return;
+    }
+    if (T.pike_off && T.pike_off[k + 1] != T.pike_off[k]) {
+        // ---- hot loop #2 for an extraction without a capture automaton: its program, run as it is ----
+        const uint32_t lane_slot = pike_slot == 0xFFFFFFFFu ? blockIdx.x * blockDim.x + threadIdx.x : pike_slot;
+        int32_t* scratch = T.pike_scratch + static_cast<size_t>(lane_slot) * T.pike_lane_ints;
+        int32_t* got = scratch + T.pike_lane_ints - 2u * static_cast<uint32_t>(T.max_groups) - 2u;   // (the area's last ints)
+        if (!pike_capture<CH>(T, k, s, len, scratch, got)) {
+            out.id(i, capture_only ? -1 : -2 - k);
+            for (int t = 0; t < slots; ++t) out.cap(i, t, -1);
+            return;
+        }
+        const int ng = T.c_ngroups[k];
+        for (int g = 0; g < ng; ++g) {
+            int32_t pb = got[2 * g], pe = got[2 * g + 1];
+            if (pb < 0 || pe < 0) { pb = -1; pe = -1; }
+            out.cap(i, 2 * g, pb);
+            out.cap(i, 2 * g + 1, pe);
+        }
+        for (int t = 2 * ng; t < slots; ++t) out.cap(i, t, -1);
+        out.id(i, k);
         return;
     }
     // ---- hot loop #2: walk extraction k's tagged automaton ----
@@ -255,6 +355,7 @@ hipError_t launch_generic_t(const GxDev& dev, const GxBatch& b, hipStream_t stre
     const int block = 256;
     uint64_t blocks = (b.n + block - 1) / block;
     if (blocks > 256u * 8u) blocks = 256u * 8u;
+    if (dev.pike_off && blocks > GX_PIKE_BLOCKS) blocks = GX_PIKE_BLOCKS;   // (every lane that may run a program has its own thread lists)
     dim3 grid(static_cast<unsigned>(blocks));
     if (dev.m_next16)
         hipLaunchKernelGGL((k_extract_generic<CH, OFF, uint16_t>), grid, dim3(block), 0, stream, dev,
@@ -280,7 +381,7 @@ k_extract_one(GxDev T, const uint16_t* __restrict__ units, uint32_t len, LineOut
     const uint32_t pairs = (len + 1u) >> 1;   // (the buffer is padded to a multiple of 8 bytes)
     for (uint32_t q = threadIdx.x; q < pairs; q += 64u) reinterpret_cast<uint32_t*>(line)[q] = reinterpret_cast<const uint32_t*>(units)[q];
     __syncthreads();
-    if (threadIdx.x == 0) extract_line_global<uint16_t, MS>(T, m_next, line, static_cast<int64_t>(len), 0, out, state_out, match_only);
+    if (threadIdx.x == 0) extract_line_global<uint16_t, MS>(T, m_next, line, static_cast<int64_t>(len), 0, out, state_out, match_only, GX_PIKE_LANES);
 }
 // ---------------------------------------------------------------------------
 // Slice kernel: lines staged 64 bytes at a time, lanes refilled as their lines end
@@ -647,7 +748,7 @@ hipError_t launch_narrow_units(const GxBatch& b, uint8_t* bytes_at_first_unit, u
 }
 hipError_t launch_extract_flagged(const GxDev& dev, const GxBatch& b, const uint8_t* flags, hipStream_t stream, const uint32_t* any_word) {
     if (b.n == 0) return hipSuccess;
-    const dim3 grid(256u * 4u), block(256);
+    const dim3 grid(dev.pike_off ? GX_PIKE_BLOCKS : 256u * 4u), block(256);
     const uint16_t* units = static_cast<const uint16_t*>(b.data);
 #define GX_FLAGGED(OFF, MS, NEXT) hipLaunchKernelGGL((k_extract_flagged<OFF, MS>), grid, block, 0, stream, dev, units, static_cast<const OFF*>(b.offsets), b.n, flags, line_out(dev, b), b.match_only, NEXT, b.strip_eol, any_word, b.seq)
     if (b.offsets64) { if (dev.m_next16) GX_FLAGGED(uint64_t, uint16_t, dev.m_next16); else GX_FLAGGED(uint64_t, uint32_t, dev.m_next32); }
@@ -675,7 +776,7 @@ hipError_t launch_extract_generic(const GxDev& dev, const GxBatch& b, hipStream_
 hipError_t launch_extract_oversize(const GxDev& dev, const GxBatch& b, uint32_t limit, int by_length, hipStream_t stream) {
     if (b.n == 0) return hipSuccess;
     // a small grid: without the flag every wave leaves at once; with it, the lines in question are few and long
-    const dim3 grid(256), block(256);
+    const dim3 grid(dev.pike_off ? GX_PIKE_BLOCKS : 256u), block(256);
 #define GX_OVERSIZE(OFF, CH) hipLaunchKernelGGL((k_extract_oversize<OFF, CH>), grid, block, 0, stream, dev, static_cast<const CH*>(b.data), \
                            static_cast<const OFF*>(b.offsets), b.n, line_out(dev, b), b.match_only, b.strip_eol, b.oversize_flag, b.seq, limit, by_length)
     if (b.wide) { if (b.offsets64) GX_OVERSIZE(uint64_t, uint16_t); else GX_OVERSIZE(uint32_t, uint16_t); }

@@ -105,7 +105,9 @@ int32_t gx_max_groups(const gx_handle* h);
  * (a GX_KERNEL_* value; 0: none yet); 26 = why capture batches have no hop tables (0: they have; 1: no fused automaton or no
  * capture regexps; 2: a step with capture programs other than one "register := position" -- groups that may match the empty string
  * write two registers in one step; 3: beyond a limit of the tier; 4: not built -- the dense rows fit LDS, or the caller named another
- * tier; 5: the tables leave no room for a wave) */
+ * tier; 5: the tables leave no room for a wave); 27 = extractions whose capture automaton would be too large ahead of time and
+ * whose regexp is therefore RUN as a program, thread lists in priority order (exact, linear in line x program; such a definition's
+ * batches go through the per-line kernel) */
 int64_t gx_stat(const gx_handle* h, int32_t which);
 
 typedef struct gx_batch_opts {

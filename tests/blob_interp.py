@@ -36,7 +36,8 @@ class Blob:
     def __init__(self, buf):
         r = _Reader(buf)
         assert r.pod("I") == 0x31425847, "bad magic"
-        assert r.pod("I") == 2, "bad version"
+        version = r.pod("I")
+        assert version in (2, 3), "bad version"
         self.n_rules = r.pod("i")
         self.ncls = r.pod("i")
         self.max_groups = r.pod("i")
@@ -67,6 +68,60 @@ class Blob:
             u["trans"] = r.vec(np.uint32).reshape(u["n_states"], self.ncls)
             u["fin"] = r.vec(np.int32)
             self.uni = u
+        # version 3: programs of the extractions whose capture automaton is not built ahead of time
+        self.pike_off = self.pike_code = self.pike_sets = None
+        if version >= 3:
+            self.pike_off, self.pike_code, self.pike_sets = r.vec(np.uint32), r.vec(np.uint32), r.vec(np.uint32)
+            if len(self.pike_code) == 0:
+                self.pike_off = None
+
+    def is_pike(self, k):
+        return self.pike_off is not None and int(self.pike_off[k + 1]) != int(self.pike_off[k])
+
+    def pike_capture(self, k, cls):
+        """gx_kernels.hip: pike_capture -- extraction k's program run as it is: thread lists in priority order."""
+        base, n_inst = int(self.pike_off[k]), int(self.pike_off[k + 1]) - int(self.pike_off[k])
+        code = [(int(self.pike_code[2 * (base + q)]) & 0xFF, int(self.pike_code[2 * (base + q)]) >> 8, int(self.pike_code[2 * (base + q) + 1])) for q in range(n_inst)]
+        ng = self.rules[k]["n_groups"]
+
+        def add_thread(lst, seen, pc0, caps, pos):
+            stack = [(pc0, None, None)]
+            while stack:
+                pc, slot, val = stack.pop()
+                if pc < 0:
+                    caps[slot] = val
+                    continue
+                if pc in seen:
+                    continue
+                seen.add(pc)
+                op, x, y = code[pc]
+                if op == 1:
+                    stack.append((y, None, None)); stack.append((x, None, None))
+                elif op == 2:
+                    stack.append((x, None, None))
+                elif op == 3:
+                    stack.append((-1, x, caps[x]))
+                    caps[x] = pos
+                    stack.append((pc + 1, None, None))
+                elif op in (0, 4):
+                    lst.append((pc, list(caps)))
+
+        clist = []
+        add_thread(clist, set(), 0, [-1] * (2 * ng), 0)
+        for p, c in enumerate(cls):
+            nlist, seen = [], set()
+            for pc, caps in clist:
+                op, x, _ = code[pc]
+                if op != 0 or not (int(self.pike_sets[8 * x + (c >> 5)]) >> (c & 31)) & 1:
+                    continue
+                add_thread(nlist, seen, pc + 1, list(caps), p + 1)
+            clist = nlist
+            if not clist:
+                break
+        for pc, caps in clist:
+            if code[pc][0] == 4:
+                return caps
+        return None
 
     # -- kernel contract ---------------------------------------------------
     def class_of(self, c):
@@ -102,6 +157,11 @@ class Blob:
         if k < 0:
             return -1, []
         rt = self.rules[k]
+        if self.is_pike(k):
+            got = self.pike_capture(k, cls)
+            if got is None:
+                return -2 - k, []
+            return k, [None if got[2 * g] < 0 or got[2 * g + 1] < 0 else (got[2 * g], got[2 * g + 1]) for g in range(rt["n_groups"])]
         regs = {}
         ts = 0
         for p, c in enumerate(cls):

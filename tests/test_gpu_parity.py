@@ -1435,3 +1435,42 @@ def test_hop_tier_refusals_are_reported():
     assert readme.stat(14) > 0 and readme.stat(26) == 0
     plain = Gorp.construct(W.readme3_definition())
     assert plain.stat(14) == 0 and plain.stat(26) == 4   # not built: the dense rows fit LDS
+
+
+def test_extractions_run_as_programs_on_the_device():
+    """gx_stat(h, 27): an extraction whose capture automaton would be too large ahead of time is run as a program (Pike VM, the
+    per-line kernel) -- fourteen and twenty blank-separated fields that may be empty, refused until round 4 -- through batches
+    (host and device pointers, every result format), the one-String calls and CookedExtraction.match; bit-exact against the
+    backtracking oracle."""
+    rng = random.Random(20)
+    for n_fields in (14, 20):
+        pieces = []
+        for k in range(n_fields):
+            pieces.append(["extractor", "f%d" % k, [["pattern", "\\S*"]]])
+            if k + 1 < n_fields:
+                pieces.append(["text", " "])
+        definition = [FlattenedExtraction("other", [["text", "#"], ["extractor", "rest", [["pattern", ".*"]]]]), FlattenedExtraction("fields", pieces)]
+        gorp, orc = Gorp.construct(definition), oracle_for(definition)
+        assert gorp.stat(27) == 1 and gorp.stat(7) == 0
+        lines = []
+        for _ in range(3000):
+            fields = ["".join(rng.choice("ab1") for _ in range(rng.choice([0, 1, 2, 4]))) for _ in range(n_fields)]
+            line = " ".join(fields)
+            if rng.random() < 0.3:
+                line = line.replace(" ", rng.choice(["  ", " \t", "   "]), rng.randrange(1, 4))
+            if rng.random() < 0.1:
+                line = "#" + line
+            if rng.random() < 0.1:
+                line = " ".join(fields[: n_fields // 2])
+            lines.append(line)
+        mid, caps = check_batch(gorp, orc, lines)
+        assert (mid == 1).sum() > 1500 and (mid == 0).sum() > 100
+        for ln in lines[:40]:
+            r = gorp.extract(ln)
+            want = orc.extract(ln)
+            assert (r is None) == (want[0] < 0)
+            if r is not None and want[0] == 1:
+                assert [r.asMap()["f%d" % k] for k in range(n_fields)] == [ln[b:e] for b, e in want[1]]
+        # CookedExtraction.match: the capture regexp alone
+        cooked = gorp.getExtractions()[1]
+        assert cooked.match(lines[0]) is not None or orc.extract(lines[0])[0] != 1
