@@ -24,6 +24,7 @@ GX_CREATE_NO_FUSED = 8
 GX_CREATE_TIER_RECORDS = 16
 GX_CREATE_TIER_RECORDS_GLOBAL = 32
 GX_CREATE_TIER_HOP = 64
+GX_CREATE_RESIDENT_ONE = 128
 GX_KERNEL_AUTO, GX_KERNEL_TILES, GX_KERNEL_SLICES, GX_KERNEL_PER_LINE, GX_KERNEL_LANES, GX_KERNEL_HOPS, GX_KERNEL_HOP_SLICES = 0, 1, 2, 3, 4, 5, 6
 
 # every symbol include/gorp_hip.h declares

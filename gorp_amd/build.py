@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgorp_hip.so")
 LIB_DEV = os.path.join(HERE, "libgorp_hip_dev.so")
 SOURCES = ["gx_tile_lds.hip", "gx_tile_l2.hip", "gx_tile_rec.hip", "gx_tile_recg.hip", "gx_tile_lds_w.hip", "gx_tile_hop.hip", "gx_tile_hop_w.hip", "gx_hop.cpp", "gx_kernels.hip", "gx_lanes.hip", "gx_jsonl.hip", "gx_api.cpp",
-           "gx_compile.cpp", "gx_dsl.cpp", "gx_json.cpp", "gx_regex.cpp", "gx_host.cpp", "gx_tile.hip", "gx_ingest.hip"]   # (the long ones first)
+           "gx_compile.cpp", "gx_dsl.cpp", "gx_json.cpp", "gx_regex.cpp", "gx_host.cpp", "gx_tile.hip", "gx_ingest.hip", "gx_service.hip"]   # (the long ones first)
 HEADERS = ["gx_common.hpp", "gx_compile.hpp", "gx_device.hpp", "gx_dsl.hpp", "gx_walk.hpp", "gx_tile_body.hpp", "gx_hop.hpp", "gx_hop_dev.hpp",
            os.path.join("..", "..", "include", "gorp_hip.h")]
 

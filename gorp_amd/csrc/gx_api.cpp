@@ -140,6 +140,18 @@ struct gx_handle {
     uint32_t steal_parity[N_SLOTS] = {};  // the row the slot's next tile-kernel launch draws from
     uint32_t promise_seq[N_SLOTS] = {};   // the sequence number of the slot's last launch under a promise (0: none)
     std::atomic<uint64_t> promises_broken{0};
+    // the resident one-line service (gx_service.hip; GX_CREATE_RESIDENT_ONE)
+    struct Service {
+        bool enabled = false;
+        int mode = 0;
+        GxLds L{};
+        hipStream_t stream = nullptr;
+        uint32_t* host = nullptr;      // pinned block: mailbox [17 x 16 dwords] | answer [2 + 2 G dwords, padded] | state
+        uint32_t* dev = nullptr;       // the device's address of the same block
+        uint32_t seq = 0;
+        bool started = false;
+        uint64_t launches = 0;
+    } svc;
     int32_t* d_pike_scratch = nullptr;    // thread lists of the lanes that run an extraction's program as it is (GxDev::pike_scratch)
     int hop_reason = 4;                   // why capture batches have no hop tables (gx_stat(h, 26); 0: they have)
     hipStream_t multi_stream = nullptr;   // gx_extract_batch_multi_device: the stream of shards that bring none
@@ -1012,6 +1024,29 @@ void upload(gx_handle* h) {
         GX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_broken), h->h_broken, 0));
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->num_cus = cus;
+        // the resident one-line service: dense rows in LDS, and either no captures or the fused automaton with simple programs
+        if ((h->create_flags & GX_CREATE_RESIDENT_ONE) && h->tile_ok && !h->tile_global && h->lds.tier == 0 && h->T.max_groups <= 32 &&
+            (!h->T.has_capture || (h->lds.u_start != 0xFFFFFFFFu && h->lds.simple_ops))) {
+            gx_handle::Service& sv = h->svc;
+            sv.mode = h->T.has_capture ? 1 : 0;
+            GxLds L = h->lds;
+            L.nwaves = 1;
+            L.stage_bytes = ((GX_SERVICE_MAX_BYTES + 8u + 64u + 15u) & ~15u) + 272u;   // (+ the answer's words: gx_service.hip)
+            L.regs = L.table_bytes;
+            L.bitmap = L.regs + L.regs_wave_bytes;
+            L.counter = L.bitmap + GX_BITMAP_WAVE_BYTES;
+            L.stage = (L.counter + 16u + 15u) & ~15u;
+            L.total_bytes = L.stage + L.stage_bytes;
+            if (L.total_bytes <= LDS_BYTES) {
+                sv.L = L;
+                const size_t dwords = 17 * 16 + 80 + 16;
+                GX_HIP(hipHostMalloc(reinterpret_cast<void**>(&sv.host), dwords * 4, hipHostMallocMapped));
+                memset(sv.host, 0, dwords * 4);
+                GX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&sv.dev), sv.host, 0));
+                GX_HIP(hipStreamCreateWithFlags(&sv.stream, hipStreamNonBlocking));
+                sv.enabled = true;
+            }
+        }
     }
     h->on_device = true;
 }
@@ -1396,6 +1431,14 @@ void gx_destroy(gx_handle* h) {
     for (auto& e : h->jsonl) if (e.second.d) (void)hipFree(e.second.d);
     for (void* q : h->scratch) if (q) (void)hipFree(q);
     if (h->pool) (void)hipMemPoolDestroy(h->pool);
+    if (h->svc.enabled) {
+        if (h->svc.started) {   // tell the wave to leave, wait for it
+            __atomic_store_n(&h->svc.host[1], (h->svc.host[1] & 0xFFFFu) | 0x10000u, __ATOMIC_RELEASE);
+            (void)hipStreamSynchronize(h->svc.stream);
+        }
+        if (h->svc.stream) (void)hipStreamDestroy(h->svc.stream);
+        if (h->svc.host) (void)hipHostFree(h->svc.host);
+    }
     if (h->multi_stream) (void)hipStreamDestroy(h->multi_stream);
     if (h->d_pike_scratch) (void)hipFree(h->d_pike_scratch);
     if (h->one_dev) (void)hipFree(h->one_dev);
@@ -1437,6 +1480,7 @@ int64_t gx_stat(const gx_handle* h, int32_t which) {
     case 24: return static_cast<int64_t>(h->promises_broken.load());
     case 25: return h->last_kernel.load();
     case 26: return h->hop_reason;
+    case 28: return static_cast<int64_t>(h->svc.enabled ? h->svc.launches : -1);
     case 27: { int64_t c = 0; for (auto& r : h->T.rules) c += r.pike ? 1 : 0; return c; }
     case 23: return h->hop_mo_ok ? static_cast<int64_t>(h->hop_mo.full.n_hot) : 0; // ... whose records are in LDS
     case 19: { GxLds L; return plan_hop_slice_launch(h, &L) ? static_cast<int64_t>(L.nwaves) : 0; }  // ... of the hop slice kernel
@@ -2195,6 +2239,50 @@ static int one_line(gx_handle* h, const uint16_t* s, int32_t len, int32_t* match
         if (len) memcpy(hb + 8, s, static_cast<size_t>(len) * 2);
         bool latin1 = mode == 0 && len > 0 && len <= 4096 && h->tile_ok;
         for (int32_t q = 0; latin1 && q < len; ++q) latin1 = s[q] <= 0xFFu;
+        if (latin1 && h->svc.enabled && static_cast<uint32_t>(len) <= GX_SERVICE_MAX_BYTES) {
+            // the resident wave (gx_service.hip): the line into the mailbox -- every cache line's text before its tag, the first cache
+            // line, whose tag is what the wave polls, last -- and a spin on the answer's sequence number
+            gx_handle::Service& sv = h->svc;
+            uint32_t* mb = sv.host;
+            int32_t* ans = reinterpret_cast<int32_t*>(sv.host + 17 * 16);
+            uint32_t* state = sv.host + 17 * 16 + 80;
+            const uint32_t seq = ++sv.seq ? sv.seq : ++sv.seq;   // (never 0... the wave compares for inequality only, but keep it tidy)
+            const uint32_t ulen = static_cast<uint32_t>(len);
+            for (uint32_t cl = 1; 56u + 60u * (cl - 1u) < ulen; ++cl) {
+                uint8_t* dst = reinterpret_cast<uint8_t*>(mb + 16u * cl) + 4;
+                const uint32_t from = 56u + 60u * (cl - 1u), cnt = std::min(60u, ulen - from);
+                for (uint32_t q = 0; q < cnt; ++q) dst[q] = static_cast<uint8_t>(s[from + q]);
+                __atomic_store_n(mb + 16u * cl, seq, __ATOMIC_RELEASE);
+            }
+            {
+                uint8_t* dst = reinterpret_cast<uint8_t*>(mb) + 8;
+                for (uint32_t q = 0; q < std::min(56u, ulen); ++q) dst[q] = static_cast<uint8_t>(s[q]);
+                mb[1] = ulen;   // (flags 0)
+                __atomic_store_n(mb, seq, __ATOMIC_RELEASE);
+            }
+            auto start_wave = [&]() {
+                __atomic_store_n(state, 1u, __ATOMIC_RELEASE);
+                // the wave starts with the PREVIOUS sequence number as the last one it has seen: the request that is waiting is new to it
+                GX_HIP(launch_one_service(sv.mode, sv.L, static_cast<const uint8_t*>(h->d_lds_image), sv.dev, reinterpret_cast<int32_t*>(sv.dev + 17 * 16),
+                                          sv.dev + 17 * 16 + 80, seq - 1u, h->T.max_groups, 30000ull, 2000000ull, sv.stream));
+                sv.started = true;
+                ++sv.launches;
+            };
+            if (!sv.started) start_wave();
+            const uint32_t* ans_seq = reinterpret_cast<const uint32_t*>(ans) + 1 + 2 * h->T.max_groups;
+            uint64_t spins = 0;
+            while (__atomic_load_n(ans_seq, __ATOMIC_ACQUIRE) != seq) {
+                if ((++spins & 63u) == 0 && __atomic_load_n(state, __ATOMIC_ACQUIRE) == 2u && hipStreamQuery(sv.stream) == hipSuccess) {
+                    // the wave has left (idle, or its time was up) -- without this request's answer: a fresh one
+                    if (__atomic_load_n(ans_seq, __ATOMIC_ACQUIRE) == seq) break;
+                    start_wave();
+                }
+                if (spins > (1ull << 34)) throw GxError(GX_E_DEVICE, "the resident one-line service does not answer");
+            }
+            if (match_id) *match_id = ans[0];
+            if (caps) for (size_t t = 0; t < slots; ++t) caps[t] = h->T.has_capture ? ans[1 + t] : -1;
+            return GX_OK;
+        }
         if (latin1) {
             // Gorp.extract(String) on a Latin-1 line -- nearly every call: the line's BYTES go through the batch kernels as a batch of
             // one (tables in LDS, the line staged there too: a step costs an LDS round trip, not two trips to L2 as in the per-line

@@ -195,6 +195,13 @@ hipError_t launch_extract_slices(const GxDev& dev, const GxLds& lds, const uint8
 hipError_t launch_extract_hop_slices(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
                                      const GxBatch& b, hipStream_t stream);
 
+// The resident one-line service (gx_service.hip): one wave, the dense-rows image in LDS, requests through `mailbox` and answers
+// through `answer` (both pinned host memory, device addresses), `state` (pinned): 1 resident, 2 gone.  mode 0: match automaton
+// alone, 1: fused automaton with "register := position" programs.
+hipError_t launch_one_service(int mode, const GxLds& lds, const uint8_t* lds_image, const uint32_t* mailbox, int32_t* answer, uint32_t* state,
+                              uint32_t last_seq, int max_groups, unsigned long long idle_ticks, unsigned long long life_ticks, hipStream_t stream);
+constexpr uint32_t GX_SERVICE_MAX_BYTES = 56u + 16u * 60u;   // the longest line a request holds (1 016 bytes)
+
 // Line ingestion (gx_ingest.hip): raw bytes -> CSR offsets of readLine()-style lines, terminators included.
 // `workspace` holds split_workspace_bytes(size) bytes; *d_n_lines receives the device address of the line count.
 size_t split_workspace_bytes(uint64_t size);

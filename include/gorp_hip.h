@@ -63,6 +63,15 @@ enum {
                                       global memory as the backstop) even when the dense rows fit LDS; the default for capture
                                       batches when they do not */
 
+#define GX_CREATE_RESIDENT_ONE 128u /* gx_extract_one_utf16 without a kernel launch per call: while such calls keep coming the handle keeps
+                                      one wave resident on the device (tables in LDS) that takes the line out of pinned host memory and
+                                      puts the answer back -- a few stores and a spin on the host's side, about 5 us instead of 22.  The wave
+                                      leaves by itself when no call has come for 0.3 ms (the next call starts it again, at the price of
+                                      a launch) and after 20 ms in any case, so a device-wide synchronisation elsewhere in the process
+                                      waits milliseconds at most.  For definitions whose dense rows fit LDS and Latin-1 lines of up to
+                                      1 016 characters; every other call takes the usual path.  Off by default: it holds LDS and a
+                                      wave slot of one CU while it is resident. */
+
 /* Replaces Gorp.construct's per-extraction back half (core/Gorp.java:58-92):
  * PolyMatcher.create(automatonInputs) (core/autom/PolyMatcher.java:64-84 ->
  * Automata.construct, core/autom/Automata.java:57-124) and
@@ -107,7 +116,8 @@ int32_t gx_max_groups(const gx_handle* h);
  * write two registers in one step; 3: beyond a limit of the tier; 4: not built -- the dense rows fit LDS, or the caller named another
  * tier; 5: the tables leave no room for a wave); 27 = extractions whose capture automaton would be too large ahead of time and
  * whose regexp is therefore RUN as a program, thread lists in priority order (exact, linear in line x program; such a definition's
- * batches go through the per-line kernel) */
+ * batches go through the per-line kernel); 28 = times the resident one-line wave was started (GX_CREATE_RESIDENT_ONE; -1: the
+ * handle has none) */
 int64_t gx_stat(const gx_handle* h, int32_t which);
 
 typedef struct gx_batch_opts {

@@ -1474,3 +1474,35 @@ def test_extractions_run_as_programs_on_the_device():
         # CookedExtraction.match: the capture regexp alone
         cooked = gorp.getExtractions()[1]
         assert cooked.match(lines[0]) is not None or orc.extract(lines[0])[0] != 1
+
+
+def test_resident_one_line_service():
+    """GX_CREATE_RESIDENT_ONE: Gorp.extract(String) answered by a wave that stays resident while the calls keep coming (gx_service.hip)
+    -- the same results as the launch-per-call path and the oracle: short lines, lines over several mailbox cache lines, lines too
+    long for the mailbox and lines with a code unit above 0xFF (both take the usual path), null and ExtractionException outcomes;
+    the wave leaves when idle and comes back (gx_stat(h, 28) counts its starts)."""
+    import time
+    definition = W.readme3_definition()
+    plain, resident, orc = Gorp.construct(definition), Gorp.construct(definition, flags=N.GX_CREATE_RESIDENT_ONE), oracle_for(definition)
+    assert plain.stat(28) == -1 and resident.stat(28) == 0
+    rng = random.Random(31)
+    lines = ["[123456789]: %s %dms /%s" % (rng.choice(["GET", "PUT", "HEAD", "XX"]), rng.randrange(10000), "p" * rng.choice([1, 20, 30, 31, 32, 33, 90, 91, 92, 150, 400, 900, 990]))
+             for _ in range(400)]
+    lines += ["", "[", "[1]: GET 5ms /x", "[1]: GET 5ms /" + "y" * 2000, "[1]: PUT 5ms /\u4e2d\u6587", "nope " * 30, "[1]: GET 5ms /" + "z" * (1016 - 14), "[1]: GET 5ms /" + "z" * (1017 - 14)]
+    for ln in lines:
+        a, b = plain.extract(ln), resident.extract(ln)
+        want = orc.extract(ln)
+        assert (a is None) == (b is None) == (want[0] < 0), ln[:40]
+        if a is not None:
+            assert a.getId() == b.getId() and a.asMap() == b.asMap(), ln[:40]
+    starts = resident.stat(28)
+    assert starts >= 1
+    time.sleep(0.05)                       # idle: the wave leaves by itself ...
+    r = resident.extract(lines[0])         # ... and the next call starts a fresh one
+    assert r is not None and resident.stat(28) > starts
+    # a definition with an ExtractionException outcome and one without capture regexps
+    g2 = Gorp.construct([FlattenedExtraction("r", [["text", "a"], ["extractor", "x", [["pattern", ".*"]]], ["text", "b"]])], flags=N.GX_CREATE_RESIDENT_ONE)
+    assert g2.extract("a--b").asMap() == {"x": "--"} and g2.extract("zzz") is None and g2.extractSafe("a\rb") is None
+    with pytest.raises(ExtractionException):
+        g2.extract("a\rb")
+    del resident, g2                       # gx_destroy tells the wave to leave and waits for it

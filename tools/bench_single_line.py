@@ -1,25 +1,29 @@
 #!/usr/bin/env python3
-"""Developer tool: latency of the one-line drop-in call (gx_extract_one_utf16 through ctypes)."""
+"""Developer tool: latency of the one-line drop-in call (gx_extract_one_utf16 through ctypes): a launch per call (the default) and the
+resident wave of GX_CREATE_RESIDENT_ONE (gx_service.hip), lines of 41 and 193 characters."""
 import os, sys, time, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gorp_amd import workloads as W, _native as N
 from gorp_amd.gorp import Gorp
-g = Gorp.construct(W.readme3_definition())
-line = "[123456789]: GET 12ms /index.html?x=1&y=2"
-u = np.frombuffer(line.encode("utf-16-le"), np.uint16)
-mid = C.c_int32(0)
-caps = np.zeros(2 * g.max_groups, np.int32)
 L = N.lib()
-for _ in range(50):
-    L.gx_extract_one_utf16(g._h.ptr, u.ctypes.data, len(u), C.byref(mid), caps.ctypes.data)
-t0 = time.perf_counter()
-reps = 2000
-for _ in range(reps):
-    L.gx_extract_one_utf16(g._h.ptr, u.ctypes.data, len(u), C.byref(mid), caps.ctypes.data)
-dt = (time.perf_counter() - t0) / reps
-print("gx_extract_one_utf16: %.1f us per call (match_id %d)" % (dt * 1e6, mid.value))
-t0 = time.perf_counter()
-for _ in range(500):
-    r = g.extract(line)
-print("Gorp.extract (Python mirror): %.1f us per call -> %s" % ((time.perf_counter() - t0) / 500 * 1e6, r.asMap()))
+for name, flags in (("a launch per call", 0), ("resident wave (GX_CREATE_RESIDENT_ONE)", N.GX_CREATE_RESIDENT_ONE)):
+    g = Gorp.construct(W.readme3_definition(), flags=flags)
+    for line in ("[123456789]: GET 12ms /index.html?x=1&y=2", "[123456789]: GET 12ms /" + "a" * 170):
+        u = np.frombuffer(line.encode("utf-16-le"), np.uint16)
+        mid = C.c_int32(0)
+        caps = np.zeros(2 * g.max_groups, np.int32)
+        for _ in range(50):
+            L.gx_extract_one_utf16(g._h.ptr, u.ctypes.data, len(u), C.byref(mid), caps.ctypes.data)
+        reps = 5000
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            L.gx_extract_one_utf16(g._h.ptr, u.ctypes.data, len(u), C.byref(mid), caps.ctypes.data)
+        dt = (time.perf_counter() - t0) / reps
+        print("%-42s %3d characters: %5.1f us per call (match_id %d, caps %s; the wave was started %d times)" %
+              (name, len(line), dt * 1e6, mid.value, caps.tolist(), g.stat(28)))
+    t0 = time.perf_counter()
+    for _ in range(500):
+        r = g.extract("[123456789]: GET 12ms /index.html?x=1&y=2")
+    print("%-42s Gorp.extract (Python mirror): %.1f us per call -> %s" % (name, (time.perf_counter() - t0) / 500 * 1e6, r.asMap()))
+    del g
