@@ -1717,13 +1717,17 @@ int gx_text_to_jsonl(gx_handle* h, const uint8_t* text, uint64_t size, const cha
         uint64_t cap = size / 64 + 4096;
         void* d_off2 = handle_scratch(h, 3, (cap + 1) * 4);
         uint64_t* d_n = nullptr;
-        GX_HIP(launch_split_lines(src, size, d_off2, 0, cap, nullptr, ws_split, &d_n, stream));
-        uint64_t n = 0;
-        GX_HIP(hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, stream));
+        uint64_t* d_max = nullptr;
+        GX_HIP(launch_split_lines(src, size, d_off2, 0, cap, nullptr, ws_split, &d_n, stream, &d_max));
+        uint64_t n_and_max[2] = {0, 0};   // (the line count and the longest line are neighbours in the workspace)
+        GX_HIP(hipMemcpyAsync(n_and_max, d_n, 16, hipMemcpyDeviceToHost, stream));
         GX_HIP(hipStreamSynchronize(stream));
+        const uint64_t n = n_and_max[0];
+        uint64_t longest = n_and_max[1];
         if (n > cap) {
             d_off2 = handle_scratch(h, 3, (n + 1) * 4);
             GX_HIP(launch_split_lines(src, size, d_off2, 0, n, nullptr, ws_split, &d_n, stream));
+            longest = 0;   // (measured over the first `cap` lines only: no promise)
         }
         // 2. the path
         void* d_mid = handle_scratch(h, 4, n * 4 + 16);
@@ -1733,6 +1737,7 @@ int gx_text_to_jsonl(gx_handle* h, const uint8_t* text, uint64_t size, const cha
         b.caps = h->T.has_capture ? static_cast<int32_t*>(d_caps) : nullptr;
         b.match_only = h->T.has_capture ? 0 : 1;
         b.strip_eol = 1;
+        b.max_line_bytes = static_cast<uint32_t>(std::min<uint64_t>(longest, 0xFFFFFFFFull));   // (what the split pass saw: no follow-up launch)
         const uint32_t mean_in = n ? static_cast<uint32_t>(std::min<uint64_t>((size + n - 1) / n, 1u << 20)) : 1u;
         launch_batch(h, b, mean_in, GX_KERNEL_AUTO, stream);
         if (!h->T.has_capture && n && slots) GX_HIP(hipMemsetAsync(d_caps, 0xFF, n * slots * 4, stream));
