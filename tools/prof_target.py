@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool: a few launches of the batch kernel on config 2 for rocprofv3 counter runs.
-Usage: prof_target.py [lines] [dense|compact|match_only] [rules (0 = README definition)]
+Usage: prof_target.py [lines] [dense|compact|narrow|match_only] [rules (0 = README definition)]
 Environment: GX_BENCH_KERNEL (gx_batch_opts.kernel), GX_BENCH_FLAGS (GX_CREATE_*), as tools/bench_config3.py."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,11 +33,13 @@ caps = torch.empty((n, 2 * G), dtype=torch.int32, device="cuda")
 rows = torch.empty((n, 1 + 2 * G), dtype=torch.int16, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
-    if fmt == "compact":
-        g.extract_batch_device(data.data_ptr(), off.data_ptr(), n, None, rows.data_ptr(), stream=st, no_sync=True, line_bytes_hint=200, compact=True, kernel=kernel)
+    if fmt in ("compact", "narrow"):
+        g.extract_batch_device(data.data_ptr(), off.data_ptr(), n, None, rows.data_ptr(), stream=st, no_sync=True, line_bytes_hint=200, compact=True if fmt == "compact" else 2,
+                               kernel=kernel, max_line_bytes=200)
     else:
         g.extract_batch_device(data.data_ptr(), off.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=st, no_sync=True, line_bytes_hint=200,
-                               match_only=fmt == "match_only", kernel=kernel)
+                               match_only=fmt == "match_only", kernel=kernel, max_line_bytes=200)
 torch.cuda.synchronize()
 if cat is not None:
-    assert torch.equal(rows[:, 0].to(torch.int32) if fmt == "compact" else mid, cat.to(torch.int32))
+    got = rows[:, 0].to(torch.int32) if fmt == "compact" else rows.view(-1).view(torch.int8)[: n * (1 + 2 * G)].view(n, 1 + 2 * G)[:, 0].to(torch.int32) if fmt == "narrow" else mid
+    assert torch.equal(got, cat.to(torch.int32))

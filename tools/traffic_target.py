@@ -20,12 +20,12 @@ st = torch.cuda.current_stream().cuda_stream
 torch.cuda.synchronize()
 for _ in range(3):
     if fmt == "narrow":
-        g.extract_batch_device(data.data_ptr(), off.data_ptr(), n, None, rows8.data_ptr(), stream=st, no_sync=True, line_bytes_hint=200, compact=2)
+        g.extract_batch_device(data.data_ptr(), off.data_ptr(), n, None, rows8.data_ptr(), stream=st, no_sync=True, line_bytes_hint=200, compact=2, max_line_bytes=200)
     elif fmt == "compact":
-        g.extract_batch_device(data.data_ptr(), off.data_ptr(), n, None, rows.data_ptr(), stream=st, no_sync=True, line_bytes_hint=200, compact=True)
+        g.extract_batch_device(data.data_ptr(), off.data_ptr(), n, None, rows.data_ptr(), stream=st, no_sync=True, line_bytes_hint=200, compact=True, max_line_bytes=200)
     else:
         g.extract_batch_device(data.data_ptr(), off.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), match_only=fmt == "match_only", stream=st,
-                               no_sync=True, line_bytes_hint=200)
+                               no_sync=True, line_bytes_hint=200, max_line_bytes=200)
 torch.cuda.synchronize()
 # calibration: a copy kernel that reads and writes exactly data.numel() bytes, 16 B per lane
 src = data.view(torch.int32).view(-1, 4)
