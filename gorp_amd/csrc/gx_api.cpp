@@ -935,7 +935,7 @@ void upload(gx_handle* h) {
     const size_t o_fintags = img.put(fin_tags);
     // extractions without a capture automaton: their programs (gx_compile.hpp: Tables::pike_*)
     size_t o_pike_off = 0, o_pike_code = 0, o_pike_sets = 0;
-    uint32_t pike_lane_ints = 0;
+    uint32_t pike_lane_ints = 0, pike_blocks = 0;
     if (T.has_pike()) {
         o_pike_off = img.put(T.pike_off);
         o_pike_code = img.put(T.pike_code);
@@ -945,8 +945,11 @@ void upload(gx_handle* h) {
             if (ni) pike_lane_ints = std::max(pike_lane_ints, 2u * ni * W + 3u * (2u * ni + 2u) + ni + 2u * static_cast<uint32_t>(T.rules[k].n_groups));
         }
         pike_lane_ints += 2u * static_cast<uint32_t>(T.max_groups) + 2u;
-        if (static_cast<uint64_t>(pike_lane_ints) * 4u * (GX_PIKE_LANES + 1u) > (2ull << 30))
-            throw GxError(GX_E_LIMIT, "capture program too large to run as it is (thread lists beyond 2 GiB)");
+        // as many workgroups of 256 lanes as the scratch budget holds thread lists for (64 at most, one at least)
+        pike_blocks = static_cast<uint32_t>(std::min<uint64_t>(GX_PIKE_BLOCKS, GX_PIKE_SCRATCH_BYTES / (static_cast<uint64_t>(pike_lane_ints) * 4u * 256u)));
+        if (pike_blocks == 0) pike_blocks = 1;
+        if (static_cast<uint64_t>(pike_lane_ints) * 4u * (256u * pike_blocks + 1u) > (1ull << 30))
+            throw GxError(GX_E_LIMIT, "capture program too large to run as it is (the thread lists of one workgroup beyond 1 GiB)");
     }
 
     GX_HIP(hipMalloc(&h->dimage, img.bytes.size()));
@@ -981,7 +984,8 @@ void upload(gx_handle* h) {
         d.pike_code = reinterpret_cast<const uint32_t*>(base + o_pike_code);
         d.pike_sets = reinterpret_cast<const uint32_t*>(base + o_pike_sets);
         d.pike_lane_ints = pike_lane_ints;
-        GX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_pike_scratch), static_cast<size_t>(pike_lane_ints) * 4u * (GX_PIKE_LANES + 1u)));
+        d.pike_blocks = pike_blocks;
+        GX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_pike_scratch), static_cast<size_t>(pike_lane_ints) * 4u * (256u * pike_blocks + 1u)));
         d.pike_scratch = h->d_pike_scratch;
     }
 
@@ -1090,8 +1094,7 @@ SlotUse take_slot(gx_handle* h, GxBatch& b, hipStream_t stream) {
     if (!h->d_steal[slot]) {   // (the slot's first launch: 768 KB, zeroed once -- every launch leaves the next one's row zeroed)
         const size_t bytes = 2 * static_cast<size_t>(GX_STEAL_MAX) * GX_STEAL_STRIDE * sizeof(uint32_t);
         GX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_steal[slot]), bytes));
-        GX_HIP(hipMemset(h->d_steal[slot], 0, bytes));   // (the null stream's memset: done before any later launch begins? not with non-blocking streams: wait for it)
-        GX_HIP(hipDeviceSynchronize());
+        GX_HIP(hipMemsetAsync(h->d_steal[slot], 0, bytes, stream));   // (on the launch's own stream: in order before its kernel; the shared slot's later users wait for its event)
     }
     b.steal = h->d_steal[slot];
     b.steal_parity = h->steal_parity[slot];

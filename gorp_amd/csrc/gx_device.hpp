@@ -36,11 +36,12 @@ struct GxDev {
     const uint32_t* pike_off;    // [n_rules + 1]
     const uint32_t* pike_code;   // two words per instruction
     const uint32_t* pike_sets;   // eight words per set
-    int32_t* pike_scratch;       // [GX_PIKE_LANES + 1][pike_lane_ints]: the thread lists of the lanes that run one (the last: the one-line calls)
+    int32_t* pike_scratch;       // [256 pike_blocks + 1][pike_lane_ints]: the thread lists of the lanes that run one (the last: the one-line calls)
     uint32_t pike_lane_ints;
+    uint32_t pike_blocks;        // the per-line kernels of a handle that has such extractions run this many workgroups of 256 lanes at most
 };
-constexpr uint32_t GX_PIKE_BLOCKS = 64;                     // the per-line kernels of a handle that has such extractions: 64 x 256 lanes
-constexpr uint32_t GX_PIKE_LANES = GX_PIKE_BLOCKS * 256u;
+constexpr uint32_t GX_PIKE_BLOCKS = 64;                     // ... 64 when the thread lists of 16 K lanes stay within GX_PIKE_SCRATCH_BYTES, else fewer
+constexpr uint64_t GX_PIKE_SCRATCH_BYTES = 256ull << 20;
 
 // Layout of the LDS-resident table image used by the tile kernel: byte offsets
 // from the start of dynamic LDS.  The image [0, table_bytes) is built on the

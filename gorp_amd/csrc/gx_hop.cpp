@@ -151,7 +151,9 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
     }
 
     // chains
-    struct Chain { int klen = 0; uint8_t lo[HOP_CHAIN], span[HOP_CHAIN]; uint32_t target = 0, col[2] = {0, 0}, off[2] = {0, 0}; };
+    // (at most ONE element of a chain is a proper interval -- the "tail": typically the first byte of the next field; the others are
+    // single bytes, which the walk compares four at a time with v_msad_u8)
+    struct Chain { int klen = 0, tail = -1; uint8_t lo[HOP_CHAIN], span[HOP_CHAIN]; uint32_t target = 0, col[2] = {0, 0}, off[2] = {0, 0}; };
     std::vector<Chain> chain(S);
     for (size_t s = 0; s < S; ++s) {
         if (s == dead) continue;
@@ -164,6 +166,8 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
             if (k > 0 && run_weight[cur] > 4) break;
             const Exit& x = exit_of[cur];
             if (!x.any || x.r.hi < x.r.lo) break;
+            const bool ranged = x.r.hi > x.r.lo || x.r.lo == 0;   // (a literal NUL cannot be told from "no byte here": it goes as an interval)
+            if (ranged && ch.tail >= 0) break;
             const uint32_t col = x.entry >> 16;
             if (col) {
                 if (nops == 2) break;
@@ -171,6 +175,7 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
                 ch.off[nops] = k;
                 ++nops;
             }
+            if (ranged) ch.tail = static_cast<int>(k);
             ch.lo[k] = static_cast<uint8_t>(x.r.lo);
             ch.span[k] = static_cast<uint8_t>(x.r.hi - x.r.lo);
             ch.klen = static_cast<int>(k) + 1;
@@ -245,17 +250,19 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
         const Chain& ch = chain[s];
         uint32_t run_lo = 0, run_k = 0x80;  // none: every byte fails the test
         if (run[s].hi >= run[s].lo && s != dead) { run_lo = static_cast<uint32_t>(run[s].lo); run_k = 0x7Fu - static_cast<uint32_t>(run[s].hi); ++out.n_runs; }
-        r[0] = run_lo | run_k << 8 | static_cast<uint32_t>(ch.klen) << 16 | ch.off[0] << 20 | ch.off[1] << 23;
-        r[1] = (ch.klen ? perm[ch.target] : 0u) | ch.col[0] << 16 | ch.col[1] << 24;   // (no chain: the field is the LDS row's address / 4, below)
-        uint8_t el[HOP_CHAIN], ns[HOP_CHAIN];
-        for (uint32_t k = 0; k < HOP_CHAIN; ++k) {
-            if (static_cast<int>(k) < ch.klen) { el[k] = static_cast<uint8_t>(0x80u - ch.lo[k]); ns[k] = static_cast<uint8_t>(0x7Fu - ch.span[k]); }
-            else { el[k] = 0x80; ns[k] = 0; }             // any byte below 0x80
-        }
-        if (ch.klen == 0) ns[0] = 0x80;                   // no chain: element 0 never matches
+        // w0: run_lo | run_k << 8 | klen << 16 | (spare) ; w1: target | off1 << 16 | off2 << 24 ; w2: column1 * 128 | column2 * 128 << 16 ;
+        // w3: tail position (a v_perm selector: 0 .. 7) | tail_lo << 8 | tail_span << 16 ; w4, w5: the chain's single bytes, 0 = no byte to compare
+        // (fields sit where SDWA operands can take them: gx_hop_dev.hpp)
+        r[0] = run_lo | run_k << 8 | static_cast<uint32_t>(ch.klen) << 16;
+        r[1] = (ch.klen ? perm[ch.target] : 0u) | ch.off[0] << 16 | ch.off[1] << 24;   // (no chain: the field is the LDS row's address / 4, below)
+        r[2] = (ch.col[0] << 7) | (ch.col[1] << 7) << 16;
+        uint8_t lits[HOP_CHAIN];
+        for (uint32_t k = 0; k < HOP_CHAIN; ++k) lits[k] = (static_cast<int>(k) < ch.klen && static_cast<int>(k) != ch.tail) ? ch.lo[k] : 0;
+        if (ch.tail >= 0) r[3] = static_cast<uint32_t>(ch.tail) | static_cast<uint32_t>(ch.lo[ch.tail]) << 8 | static_cast<uint32_t>(ch.span[ch.tail]) << 16;
+        else r[3] = 0u | 0u << 8 | 0xFFu << 16;           // no tail: byte 0, any value
+        if (ch.klen == 0) r[3] = 0u | 2u << 8 | 0u << 16, lits[0] = 0x01;   // no chain: never matches (byte 0 would have to be 1 and 2 at once); an exact step follows
         else ++out.n_chains;
-        memcpy(&r[2], el, 8);
-        memcpy(&r[4], ns, 8);
+        memcpy(&r[4], lits, 8);
     }
 
     // self-check against the dense rows: every byte of a run loops with no program; every byte sequence a chain accepts
@@ -266,14 +273,21 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
         if (run_k != 0x80u)
             for (uint32_t bt = run_lo; bt <= 0x7Fu - run_k; ++bt)
                 if (rows[s * cols + T.cls256[bt]] != static_cast<uint32_t>(s)) throw GxError(GX_E_ARG, "internal: hop tier run does not match the dense rows");
-        const uint32_t klen = (r[0] >> 16) & 0xFu;
-        const uint8_t* el = reinterpret_cast<const uint8_t*>(&r[2]);
-        const uint8_t* ns = reinterpret_cast<const uint8_t*>(&r[4]);
+        const uint32_t klen = (r[0] >> 16) & 0xFFu;
+        const uint8_t* lits = reinterpret_cast<const uint8_t*>(&r[4]);
+        const uint32_t tail_pos = r[3] & 0xFFu, tail_lo = (r[3] >> 8) & 0xFFu, tail_span = (r[3] >> 16) & 0xFFu;
         uint32_t cur = static_cast<uint32_t>(s), nops = 0;
-        const uint32_t want_col[2] = {(r[1] >> 16) & 0xFFu, r[1] >> 24}, want_off[2] = {(r[0] >> 20) & 7u, (r[0] >> 23) & 7u};
+        const uint32_t want_col[2] = {(r[2] & 0xFFFFu) >> 7, (r[2] >> 16) >> 7}, want_off[2] = {(r[1] >> 16) & 0xFFu, r[1] >> 24};
+        if (klen > HOP_CHAIN || tail_pos >= HOP_CHAIN) throw GxError(GX_E_ARG, "internal: hop tier chain length");
         for (uint32_t k = 0; k < klen; ++k) {
-            const uint32_t lo = 0x80u - el[k], hi = lo + (0x7Fu - ns[k]);
+            // what the walk accepts at position k: the single byte, or -- at the tail position -- the interval (with a single byte too: both)
+            uint32_t lo = lits[k], hi = lits[k];
+            if (lits[k] == 0) {
+                if (k != tail_pos) throw GxError(GX_E_ARG, "internal: hop tier chain element without a test");
+                lo = tail_lo; hi = tail_lo + tail_span;
+            } else if (k == tail_pos && (lits[k] < tail_lo || lits[k] > tail_lo + tail_span)) lo = 1, hi = 0;   // (accepts nothing: fine)
             if (hi > 0x7Fu) throw GxError(GX_E_ARG, "internal: hop tier chain element out of range");
+            if (hi < lo) continue;
             const uint32_t e0 = rows[cur * cols + T.cls256[lo]];
             for (uint32_t bt = lo; bt <= hi; ++bt) if (rows[cur * cols + T.cls256[bt]] != e0) throw GxError(GX_E_ARG, "internal: hop tier chain element is not one group");
             if (e0 >> 16) {
@@ -282,6 +296,7 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
             }
             cur = e0 & 0xFFFFu;
         }
+        if (klen && tail_pos >= klen && !(tail_lo == 0 && tail_span == 0xFFu)) throw GxError(GX_E_ARG, "internal: hop tier chain tail beyond the chain");
         if (klen && (cur != (r[1] & 0xFFFFu) || (nops < 2 && want_col[nops] != 0))) throw GxError(GX_E_ARG, "internal: hop tier chain target");
     }
 

@@ -10,7 +10,8 @@
 // line at its own position:
 //   1. the state's hop record (24 bytes; LDS for the hot states, global memory / L2 for the others);
 //   2. 16 bytes at the lane's position; one SWAR interval test finds how many of them the state's RUN covers;
-//   3. 8 bytes behind the run; one SWAR test against the chain's 8 (lo, span) elements.  Match: the lane is at the
+//   3. 8 bytes behind the run against the chain: its single bytes with two v_msad_u8 (a reference byte of 0 is not compared), its one
+//      interval element -- the "tail", typically the first byte of the next field -- picked with v_perm.  Match: the lane is at the
 //      chain's target, klen bytes further, and the chain's (at most two) capture programs are written;
 //   4. no match: ONE exact step through the state's dense row (global memory / L2; the byte's class id from the map at LDS
 //      address 0) -- a wave-uniform branch that the waves of a well-formed log take for the branching nodes of the literal
@@ -50,6 +51,24 @@ __device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) {
 __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
     uint32_t r;
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    return r;
+}
+// The record's fields sit on byte and word boundaries so that an SDWA operand takes them as they are: a + byte / word N of w
+#define GX_SDWA_ADD(NAME, SEL)                                                                                                   \
+    __device__ __forceinline__ uint32_t NAME(uint32_t a, uint32_t w) {                                                           \
+        uint32_t r;                                                                                                              \
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL : "=v"(r) : "v"(a), "v"(w)); \
+        return r;                                                                                                                \
+    }
+GX_SDWA_ADD(add_byte2, "BYTE_2")
+GX_SDWA_ADD(add_byte3, "BYTE_3")
+GX_SDWA_ADD(add_word0, "WORD_0")
+GX_SDWA_ADD(add_word1, "WORD_1")
+#undef GX_SDWA_ADD
+// byte 0 of a, minus byte 1 of w
+__device__ __forceinline__ uint32_t sub_b0_b1(uint32_t a, uint32_t w) {
+    uint32_t r;
+    asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1" : "=v"(r) : "v"(a), "v"(w));
     return r;
 }
 
@@ -128,30 +147,32 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
         const u32x2 r01 = lds_pair4(a2);
         const uint32_t r2 = lds_ld<uint32_t>(a2 + 8u);
         const uint32_t v0 = __builtin_amdgcn_alignbyte(r01.y, r01.x, sh2), v1 = __builtin_amdgcn_alignbyte(r2, r01.y, sh2);
-        // per byte: a = v + (0x80 - lo) has bit 7 set iff v >= lo; t = (a & 0x7F) + (0x7F - span) has bit 7 set iff v - lo > span
-        const uint32_t ca0 = v0 + h1.x, ca1 = v1 + h1.y;
-        const uint32_t ct0 = (ca0 & LOW7) + h2.x, ct1 = (ca1 & LOW7) + h2.y;
-        // (a byte with its top bit set fails its element -- and may spoil the sums of the bytes above it, which no longer matters)
-        const uint32_t ok8 = bfi(ct0 | v0, 0u, ca0) & bfi(ct1 | v1, 0u, ca1) & HI_BITS;  // byte j: elements j and j + 4 both hold
-        const uint64_t m_chain = m_step & __builtin_amdgcn_ballot_w64(ok8 == HI_BITS) & __builtin_amdgcn_ballot_w64(q + ((h0.x >> 16) & 0xFu) <= e_chain);
+        // the single bytes: sum of |v - literal| over the reference bytes that are not 0; the tail: byte `pos` of the eight in [lo, lo + span]
+        // (record: h0.x run_lo | run_k << 8 | klen << 16; h0.y target | off1 << 16 | off2 << 24; h1.x column1 * 128 | column2 * 128 << 16;
+        //  h1.y tail pos | lo << 8 | span << 16; h2 the single bytes)
+        const uint32_t sad = __builtin_amdgcn_msad_u8(v1, h2.y, __builtin_amdgcn_msad_u8(v0, h2.x, 0u));
+        const uint32_t tail = sub_b0_b1(__builtin_amdgcn_perm(v1, v0, h1.y), h1.y);   // (the selector's other bytes pick what nobody reads)
+        const uint32_t qk = add_byte2(q, h0.x);   // where the chain ends
+        const bool chain_ok = sad == 0u && tail <= ((h1.y >> 16) & 0xFFu) && qk <= e_chain;
+        const uint64_t m_chain = m_step & __builtin_amdgcn_ballot_w64(chain_ok);
         const bool stepping = n < 16u && q < e && p < limit;  // (the same compares, per lane: their masks ARE the select conditions)
-        const bool chained = stepping && ok8 == HI_BITS && q + ((h0.x >> 16) & 0xFu) <= e_chain;
+        const bool chained = stepping && chain_ok;
         // a lane that does not take its chain reads its record as "no bytes, same state, no programs"
-        const uint32_t c0 = chained ? h0.x : 0u, c1 = chained ? h0.y : s;
+        const uint32_t cols = chained ? h1.x : 0u;
         // ---- capture programs of the chain: register column := position (column 0 is the write-only dummy) ----
         const uint32_t rel = q - p0;  // (the position in the line)
         if (CAPTURE) {
-            lds_st<uint16_t>(dummy_col + (((c1 >> 16) & 0xFFu) << 7), static_cast<uint16_t>(rel + ((c0 >> 20) & 7u)));
-            lds_st<uint16_t>(dummy_col + ((c1 >> 24) << 7), static_cast<uint16_t>(rel + ((c0 >> 23) & 7u)));
+            lds_st<uint16_t>(add_word0(dummy_col, cols), static_cast<uint16_t>(add_byte2(rel, h0.y)));
+            lds_st<uint16_t>(add_word1(dummy_col, cols), static_cast<uint16_t>(add_byte3(rel, h0.y)));
         }
-        p = p < limit ? q + ((c0 >> 16) & 0xFu) : p;
-        s = c1 & 0xFFFFu;
+        p = p < limit ? (chained ? qk : q) : p;
+        s = chained ? (h0.y & 0xFFFFu) : s;
         // ---- 4. one exact step where the chain does not apply ----
         const uint64_t m_exact = m_step & ~m_chain;
         if (m_exact != 0ull) {
             if (stepping && !chained) {
                 // a state without a chain keeps the LDS address / 4 of its dense row's copy in the target field (0: none)
-                exact_step(((h0.x >> 16) & 0xFu) == 0u ? (h0.y & 0xFFFFu) << 2 : 0u, v0 & 0xFFu, q);
+                exact_step(((h0.x >> 16) & 0xFFu) == 0u ? (h0.y & 0xFFFFu) << 2 : 0u, v0 & 0xFFu, q);
                 if (ALL_HOT)
                     while (s > last_hot && p < limit) exact_step(0u, lds_ld<uint8_t>(p), p);   // (off the expected path: rare, and short)
             }

@@ -144,7 +144,7 @@ __device__ bool pike_capture(const GxDev& T, int k, const CH* __restrict__ s, in
 // One line, tables read through L1/L2 (any table size, any line length).
 // ---------------------------------------------------------------------------
 // pike_slot: the lane's area in GxDev::pike_scratch (0xFFFFFFFF: its index in the grid -- the launchers keep the grids of a handle
-// that has such extractions within GX_PIKE_LANES)
+// that has such extractions within GxDev::pike_blocks workgroups)
 template <typename CH, typename MS>
 __device__ void extract_line_global(const GxDev& T, const MS* __restrict__ m_next, const CH* __restrict__ s, int64_t len,
                                     uint64_t i, const LineOut& out, int32_t* __restrict__ state_out, int match_only, uint32_t pike_slot = 0xFFFFFFFFu) {
@@ -355,7 +355,7 @@ hipError_t launch_generic_t(const GxDev& dev, const GxBatch& b, hipStream_t stre
     const int block = 256;
     uint64_t blocks = (b.n + block - 1) / block;
     if (blocks > 256u * 8u) blocks = 256u * 8u;
-    if (dev.pike_off && blocks > GX_PIKE_BLOCKS) blocks = GX_PIKE_BLOCKS;   // (every lane that may run a program has its own thread lists)
+    if (dev.pike_off && blocks > dev.pike_blocks) blocks = dev.pike_blocks;   // (every lane that may run a program has its own thread lists)
     dim3 grid(static_cast<unsigned>(blocks));
     if (dev.m_next16)
         hipLaunchKernelGGL((k_extract_generic<CH, OFF, uint16_t>), grid, dim3(block), 0, stream, dev,
@@ -381,7 +381,7 @@ k_extract_one(GxDev T, const uint16_t* __restrict__ units, uint32_t len, LineOut
     const uint32_t pairs = (len + 1u) >> 1;   // (the buffer is padded to a multiple of 8 bytes)
     for (uint32_t q = threadIdx.x; q < pairs; q += 64u) reinterpret_cast<uint32_t*>(line)[q] = reinterpret_cast<const uint32_t*>(units)[q];
     __syncthreads();
-    if (threadIdx.x == 0) extract_line_global<uint16_t, MS>(T, m_next, line, static_cast<int64_t>(len), 0, out, state_out, match_only, GX_PIKE_LANES);
+    if (threadIdx.x == 0) extract_line_global<uint16_t, MS>(T, m_next, line, static_cast<int64_t>(len), 0, out, state_out, match_only, 256u * T.pike_blocks);
 }
 // ---------------------------------------------------------------------------
 // Slice kernel: lines staged 64 bytes at a time, lanes refilled as their lines end
@@ -748,7 +748,7 @@ hipError_t launch_narrow_units(const GxBatch& b, uint8_t* bytes_at_first_unit, u
 }
 hipError_t launch_extract_flagged(const GxDev& dev, const GxBatch& b, const uint8_t* flags, hipStream_t stream, const uint32_t* any_word) {
     if (b.n == 0) return hipSuccess;
-    const dim3 grid(dev.pike_off ? GX_PIKE_BLOCKS : 256u * 4u), block(256);
+    const dim3 grid(dev.pike_off ? dev.pike_blocks : 256u * 4u), block(256);
     const uint16_t* units = static_cast<const uint16_t*>(b.data);
 #define GX_FLAGGED(OFF, MS, NEXT) hipLaunchKernelGGL((k_extract_flagged<OFF, MS>), grid, block, 0, stream, dev, units, static_cast<const OFF*>(b.offsets), b.n, flags, line_out(dev, b), b.match_only, NEXT, b.strip_eol, any_word, b.seq)
     if (b.offsets64) { if (dev.m_next16) GX_FLAGGED(uint64_t, uint16_t, dev.m_next16); else GX_FLAGGED(uint64_t, uint32_t, dev.m_next32); }
@@ -776,7 +776,7 @@ hipError_t launch_extract_generic(const GxDev& dev, const GxBatch& b, hipStream_
 hipError_t launch_extract_oversize(const GxDev& dev, const GxBatch& b, uint32_t limit, int by_length, hipStream_t stream) {
     if (b.n == 0) return hipSuccess;
     // a small grid: without the flag every wave leaves at once; with it, the lines in question are few and long
-    const dim3 grid(dev.pike_off ? GX_PIKE_BLOCKS : 256u), block(256);
+    const dim3 grid(dev.pike_off ? dev.pike_blocks : 256u), block(256);
 #define GX_OVERSIZE(OFF, CH) hipLaunchKernelGGL((k_extract_oversize<OFF, CH>), grid, block, 0, stream, dev, static_cast<const CH*>(b.data), \
                            static_cast<const OFF*>(b.offsets), b.n, line_out(dev, b), b.match_only, b.strip_eol, b.oversize_flag, b.seq, limit, by_length)
     if (b.wide) { if (b.offsets64) GX_OVERSIZE(uint64_t, uint16_t); else GX_OVERSIZE(uint32_t, uint16_t); }

@@ -58,21 +58,22 @@ Outcome hop_outcome(const Tables& T, const HopImage& H, const std::vector<uint8_
         ++*iterations;
         uint32_t r[6];
         memcpy(r, hops + static_cast<size_t>(s) * HOP_REC_BYTES, HOP_REC_BYTES);
-        const uint32_t run_lo = r[0] & 0xFFu, run_k = (r[0] >> 8) & 0xFFu, klen = (r[0] >> 16) & 0xFu;
+        const uint32_t run_lo = r[0] & 0xFFu, run_k = (r[0] >> 8) & 0xFFu, klen = (r[0] >> 16) & 0xFFu;
         size_t n = 0;
         while (n < 16 && p + n < e && run_k != 0x80u && cls[p + n] < 0x80u && cls[p + n] >= run_lo && cls[p + n] <= 0x7Fu - run_k) ++n;
         const size_t q = p + n;
         if (n == 16 || q >= e) { p = q; continue; }
-        const uint8_t* el = reinterpret_cast<const uint8_t*>(&r[2]);
-        const uint8_t* ns = reinterpret_cast<const uint8_t*>(&r[4]);
+        // (w1: target | off1 << 16 | off2 << 24; w2: column1 * 128 | column2 * 128 << 16; w3: tail pos | lo << 8 | span << 16; w4, w5: single bytes)
+        const uint8_t* lits = reinterpret_cast<const uint8_t*>(&r[4]);
         bool ok = q + klen <= e;
-        for (int j = 0; j < 8 && ok; ++j) {
-            const uint32_t a = cls[q + j] + el[j], t = (a & 0x7Fu) + ns[j];
-            ok = cls[q + j] < 0x80u && (a & 0x80u) && !(t & 0x80u);
+        for (int j = 0; j < 8 && ok; ++j) ok = lits[j] == 0 || cls[q + j] == lits[j];
+        {
+            const uint32_t tb = cls[q + (r[3] & 0xFFu)], lo = (r[3] >> 8) & 0xFFu, span = (r[3] >> 16) & 0xFFu;
+            ok = ok && tb >= lo && tb - lo <= span;
         }
         if (ok) {
-            col[(r[1] >> 16) & 0xFFu] = static_cast<int>(q + ((r[0] >> 20) & 7u));
-            col[r[1] >> 24] = static_cast<int>(q + ((r[0] >> 23) & 7u));
+            col[(r[2] & 0xFFFFu) >> 7] = static_cast<int>(q + ((r[1] >> 16) & 0xFFu));
+            col[(r[2] >> 16) >> 7] = static_cast<int>(q + (r[1] >> 24));
             p = q + klen;
             s = r[1] & 0xFFFFu;
         } else {

@@ -48,18 +48,18 @@ int main(int argc, char** argv) {
                 ++iters;
                 uint32_t r[6];
                 memcpy(r, hops + static_cast<size_t>(s) * HOP_REC_BYTES, HOP_REC_BYTES);
-                const uint32_t run_lo = r[0] & 0xFFu, run_k = (r[0] >> 8) & 0xFFu, klen = (r[0] >> 16) & 0xFu;
+                const uint32_t run_lo = r[0] & 0xFFu, run_k = (r[0] >> 8) & 0xFFu, klen = (r[0] >> 16) & 0xFFu;
                 size_t n = 0;
                 while (n < 16 && p + n < e && run_k != 0x80u && b[p + n] < 0x80u && b[p + n] >= run_lo && b[p + n] <= 0x7Fu - run_k) ++n;
                 run_bytes += n;
                 const size_t q = p + n;
                 if (n == 16 || q >= e) { p = q; ++run_full; continue; }
-                const uint8_t* el = reinterpret_cast<const uint8_t*>(&r[2]);
-                const uint8_t* ns = reinterpret_cast<const uint8_t*>(&r[4]);
+                const uint8_t* lits = reinterpret_cast<const uint8_t*>(&r[4]);
                 bool ok = q + klen <= e;
-                for (int j = 0; j < 8 && ok; ++j) {
-                    const uint32_t a = b[q + j] + el[j], t = (a & 0x7Fu) + ns[j];
-                    ok = b[q + j] < 0x80u && (a & 0x80u) && !(t & 0x80u);
+                for (int j = 0; j < 8 && ok; ++j) ok = lits[j] == 0 || b[q + j] == lits[j];
+                {
+                    const uint32_t tb = b[q + (r[3] & 0xFFu)], lo = (r[3] >> 8) & 0xFFu, span = (r[3] >> 16) & 0xFFu;
+                    ok = ok && tb >= lo && tb - lo <= span;
                 }
                 if (ok) { p = q + klen; s = r[1] & 0xFFFFu; ++chains; chain_bytes += klen; }
                 else {
