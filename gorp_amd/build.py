@@ -41,16 +41,23 @@ def needs_build(lib=LIB):
     return False
 
 
-def build(force=False, verbose=False, dev=False):
+def build(force=False, verbose=False, dev=False, variant=None):
+    """variant: (name, [defines]) -- an experiment's build of the product library as libgorp_hip_<name>.so (tools/ab_bench.py compares
+    such builds on one device)."""
     lib = LIB_DEV if dev else LIB
+    if variant:
+        lib = os.path.join(HERE, "libgorp_hip_%s.so" % variant[0])
     if not force and not needs_build(lib):
         return lib
     common = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-result"]
     if dev:
         common.append("-DGX_DEV")
+        common += os.environ.get("GX_BUILD_DEFINES", "").split()   # (experiments of the developer build: e.g. -DGX_HOP_SLICE_BYTES=256)
+    if variant:
+        common += list(variant[1])
     jobs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, ("dev_" if dev else "") + os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(CSRC, ("dev_" if dev else "") + (variant[0] + "_" if variant else "") + os.path.splitext(src)[0] + ".o")
         cmd = [_hipcc()] + common + ["-c", os.path.join(CSRC, src), "-o", obj]
         if src == "gx_api.cpp":
             cmd[1:1] = ["-x", "hip"]
@@ -84,3 +91,6 @@ if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     if "--dev" in sys.argv:
         print(build(force="--force" in sys.argv, verbose=True, dev=True))
+    if "--variant" in sys.argv:   # --variant NAME -DX -DY=1 ...
+        at = sys.argv.index("--variant")
+        print(build(force=True, verbose=False, variant=(sys.argv[at + 1], [a for a in sys.argv[at + 2:] if a.startswith("-D")])))

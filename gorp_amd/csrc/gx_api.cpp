@@ -784,7 +784,7 @@ bool plan_slice_launch(const gx_handle* h, GxLds* out, bool match_only = false) 
 bool plan_hop_slice_launch(const gx_handle* h, GxLds* out, bool match_only = false) {
     if (!(match_only ? h->hop_mo_ok : h->hop_ok)) return false;
     GxLds L = match_only ? h->lds_hop_mo_small : h->lds_hop_small;
-    L.stage_bytes = 64u * (GX_HOP_SLICE_BYTES + 16u) + 16u;  // (+ 16: a window read at a row's last bytes runs a few bytes past it)
+    L.stage_bytes = 64u * (GX_HOP_SLICE_BYTES + 16u) + 48u;  // (+ 48: a window read at a row's last bytes runs a few bytes past it)
     const uint32_t per_wave = L.stage_bytes + L.regs_wave_bytes;
     if (L.table_bytes + 4u * per_wave > LDS_BYTES) return false;
     uint32_t nw = (LDS_BYTES - L.table_bytes) / per_wave;

@@ -127,7 +127,12 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
         // ---- 2. the run: how many of the next 16 class ids lie in [run_lo, run_hi] ----
         const uint32_t a1 = p & ~3u, sh1 = p & 3u;
         const u32x2 d01 = lds_pair4(a1), d23 = lds_pair4(a1 + 8u);
+#ifdef GX_HOP_ONE_WINDOW
+        const u32x2 d45 = lds_pair4(a1 + 16u), d67 = lds_pair4(a1 + 24u);
+        const uint32_t d4 = d45.x;
+#else
         const uint32_t d4 = lds_ld<uint32_t>(a1 + 16u);
+#endif
         const uint32_t x0 = __builtin_amdgcn_alignbyte(d01.y, d01.x, sh1), x1 = __builtin_amdgcn_alignbyte(d23.x, d01.y, sh1);
         const uint32_t x2 = __builtin_amdgcn_alignbyte(d23.y, d23.x, sh1), x3 = __builtin_amdgcn_alignbyte(d4, d23.y, sh1);
         const uint32_t lo4 = splat_byte0(h0.x), k4 = splat_byte1(h0.x);
@@ -140,13 +145,26 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
         const uint32_t q = p + n;
         // (a lane steps when its run ended inside the window and inside the staged bytes; a lane past its limit does not)
         const uint64_t m_step = __builtin_amdgcn_ballot_w64(n < 16u) & __builtin_amdgcn_ballot_w64(q < e) & unfinished;
-        // ---- 3. the chain: the 8 class ids at q against 8 (lo, span) elements ----
-        // (a second, dependent LDS read: picking the bytes out of a 24-byte first window with selects was measured -- 1.106
-        // against 1.084 ms on config 3, one device -- the walk is bound by issue slots, not by this round trip)
+        // ---- 3. the chain: the 8 bytes at q ----
+#ifdef GX_HOP_ONE_WINDOW
+        // out of the window that is already here (8 dwords were read at a1: bytes p .. p + 28 at least), picked with selects: no second,
+        // dependent LDS round trip.  t = byte offset of q from a1 (0 .. 18), j = its dword.  (An experiment: python -m gorp_amd.build
+        // --variant onewin -DGX_HOP_ONE_WINDOW, tools/ab_bench.py.  Measured twice, in round 3 and again in round 4 on the byte-space
+        // tables: 7 % SLOWER on config 3 -- 0.968 against 0.903 ms, dense results, one device -- and 2.5 % on config 5: the 19 more
+        // vector instructions cost more than the round trip they save.  Both pipes, vector and LDS, are near their share.)
+        const uint32_t t = sh1 + n, j = t >> 2, sh2 = t & 3u;
+        const bool b0 = (j & 1u) != 0u, b1 = (j & 2u) != 0u, b2 = (j & 4u) != 0u;
+        const uint32_t A0 = b0 ? d01.y : d01.x, A1 = b0 ? d23.x : d01.y, A2 = b0 ? d23.y : d23.x, A3 = b0 ? d45.x : d23.y, A4 = b0 ? d45.y : d45.x;
+        const uint32_t B0 = b1 ? A2 : A0, B1 = b1 ? A3 : A1, B2 = b1 ? A4 : A2;
+        const uint32_t X0 = b2 ? d45.x : B0, X1 = b2 ? d45.y : B1, X2 = b2 ? d67.x : B2;   // (j = 4: b0 = b1 = 0)
+        const uint32_t v0 = __builtin_amdgcn_alignbyte(X1, X0, sh2), v1 = __builtin_amdgcn_alignbyte(X2, X1, sh2);
+#else
+        // (a second, dependent LDS read: see above for what picking the bytes out of the first window costs instead)
         const uint32_t a2 = q & ~3u, sh2 = q & 3u;
         const u32x2 r01 = lds_pair4(a2);
         const uint32_t r2 = lds_ld<uint32_t>(a2 + 8u);
         const uint32_t v0 = __builtin_amdgcn_alignbyte(r01.y, r01.x, sh2), v1 = __builtin_amdgcn_alignbyte(r2, r01.y, sh2);
+#endif
         // the single bytes: sum of |v - literal| over the reference bytes that are not 0; the tail: byte `pos` of the eight in [lo, lo + span]
         // (record: h0.x run_lo | run_k << 8 | klen << 16; h0.y target | off1 << 16 | off2 << 24; h1.x column1 * 128 | column2 * 128 << 16;
         //  h1.y tail pos | lo << 8 | span << 16; h2 the single bytes)
