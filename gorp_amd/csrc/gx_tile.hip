@@ -45,7 +45,10 @@ hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t
     io.steal_parity = b.steal_parity & 1u;
     io.wide_flags = b.wide_flags;
     io.wide_any = b.wide_any;
-    io.share64 = 8;   // an eighth: the XCDs of a chip differ by up to a tenth in what they finish (dense results; 3 % with u8 rows)
+#ifndef GX_SHARE64
+#define GX_SHARE64 8   // an eighth: the XCDs of a chip differ by up to a tenth in what they finish (dense results; 3 % with u8 rows)
+#endif
+    io.share64 = GX_SHARE64;
     io.max_groups = dev.max_groups;
     io.strip_eol = b.strip_eol;
 #ifdef GX_DEV

@@ -391,17 +391,22 @@ k_extract_tile(GxLds L, TileIO io) {
     };
     uint32_t local_own;
     const uint32_t shared_own = shared_of(blockIdx.x, local_own);
-    // The next draw of this workgroup (inc 0: none wanted -- the LDS instruction is issued all the same): lane 0's `j` is the
-    // LDS ticket; a ticket beyond the local part is followed by a draw of the global counter, lane 0's `g`.
-    auto draw_own = [&](uint32_t inc, uint32_t& g, bool& from_shared) -> uint32_t {
+    // The next draw of this workgroup, in two steps: the LDS ticket (inc 0: none wanted -- the instruction is issued all the same;
+    // lane 0's value counts) at the top of a round, and -- behind the round's prefetch, when the ticket has long answered -- for a
+    // ticket beyond the local part a draw of the global counter, lane 0's `g`.  (Both in one place behind the prefetch: the wave
+    // waited out an LDS round trip per tile there, 1 % of the kernel on boxes whose XCDs are even.)
+    auto draw_ticket = [&](uint32_t inc) -> uint32_t {
         uint32_t j = 0;
         if (lane == 0) j = __hip_atomic_fetch_add((GX_LDS uint32_t*)(uintptr_t)L.counter, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        from_shared = inc != 0u && __builtin_amdgcn_readfirstlane(j) >= local_own;
+        return j;
+    };
+    auto draw_shared = [&](uint32_t j, uint32_t inc, uint32_t& g) -> bool {
+        const bool from_shared = inc != 0u && __builtin_amdgcn_readfirstlane(j) >= local_own;
         g = 0;
         if (from_shared) {   // (wave-uniform; the last `share` of the launch only)
             if (lane == 0) g = __hip_atomic_fetch_add(ctr + blockIdx.x * GX_STEAL_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        return j;
+        return from_shared;
     };
     // a tile from another workgroup's shared part, or `tiles` when nobody has one left (wave-uniform; waits for its loads)
     uint32_t steal_salt = (blockIdx.x * L.nwaves + wave) * 2654435761u;
@@ -449,7 +454,8 @@ k_extract_tile(GxLds L, TileIO io) {
     uint64_t t2 = tiles;                        // and the one after that: from the draw (j3, g3), once that has answered (need_t2)
     uint32_t g3 = 0, jn = 0u, gn = 0u;
     bool sh3 = false, shn = false;
-    uint32_t j3 = draw_own(1u, g3, sh3);
+    uint32_t j3 = draw_ticket(1u);
+    sh3 = draw_shared(j3, 1u, g3);
     bool need_t2 = true, stealing = false, drew_before = false;   // (wave-uniform)
     if (tile >= tiles) return;
 #ifdef GX_DEV
@@ -489,8 +495,9 @@ k_extract_tile(GxLds L, TileIO io) {
             }
             if (stealing) t2 = steal();
         }
-        const bool drew = need_t2 && !stealing;     // ... and the next one goes out behind the prefetch, below
+        const bool drew = need_t2 && !stealing;     // ... and the next one: its ticket now, its global draw (if any) behind the prefetch, below
         need_t2 = false;
+        jn = draw_ticket(drew ? 1u : 0u);
         const uint64_t after = same_group ? t1 : t2;  // the group after `ntile`
         // Offsets of the group after the next one first, then the prefetch, and nothing in between that depends on
         // vector memory: both are unconditional (index clamped -- the same values again while the group is
@@ -502,7 +509,7 @@ k_extract_tile(GxLds L, TileIO io) {
                                   has_next && !same_group ? no0 : cur.o0, has_next && !same_group ? no1 : cur.o1);
         if (!has_next) nxt.mode = 3;  // nothing to fetch: the loop ends after this round
         tile_issue_loads<KCH, WIDE>(nxt, lane, pre, io.image);
-        jn = draw_own(drew ? 1u : 0u, gn, shn);
+        shn = draw_shared(jn, drew ? 1u : 0u, gn);
         drew_before = drew;
         GX_STAMP(1);
 
