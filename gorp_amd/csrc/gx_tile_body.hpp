@@ -380,10 +380,23 @@ k_extract_tile(GxLds L, TileIO io) {
     const uint32_t j_base = 2u * L.nwaves;   // (the first two tiles of every wave are fixed: draw j is the workgroup's tile j_base + j)
     uint32_t* const ctr = io.steal + io.steal_parity * (GX_STEAL_MAX * GX_STEAL_STRIDE);
     const uint32_t tiles32 = static_cast<uint32_t>(tiles);   // (n < 2^32 lines: at most 2^26 tiles)
-    auto tile_at = [&](uint32_t wg, uint32_t k) -> uint64_t { return min(static_cast<uint64_t>(wg) + static_cast<uint64_t>(k) * grid, tiles); };
+#ifndef GX_TILE_CHUNK
+#define GX_TILE_CHUNK 1u   // consecutive tiles a workgroup takes before the next workgroup's begin (1: tiles b, b + grid, ...)
+#endif
+    constexpr uint32_t CH = GX_TILE_CHUNK;
+    // workgroup wg's k-th tile: chunks of CH consecutive tiles, dealt round robin
+    auto own_of = [&](uint32_t v) -> uint32_t {
+        if (CH == 1u) return v < tiles32 ? (tiles32 - v + grid - 1u) / grid : 0u;   // tiles v, v + grid, ...
+        const uint32_t round = grid * CH, full = tiles32 / round, rem = tiles32 % round;
+        return full * CH + (rem > v * CH ? min(rem - v * CH, CH) : 0u);
+    };
+    auto tile_at = [&](uint32_t wg, uint32_t k) -> uint64_t {
+        if (CH == 1u) return min(static_cast<uint64_t>(wg) + static_cast<uint64_t>(k) * grid, tiles);
+        return min((static_cast<uint64_t>(k / CH) * grid + wg) * CH + k % CH, tiles);
+    };
     // workgroup v's draws: `local` from its LDS counter, then `shared` from its global one
     auto shared_of = [&](uint32_t v, uint32_t& local) -> uint32_t {
-        const uint32_t own = v < tiles32 ? (tiles32 - v + grid - 1u) / grid : 0u;   // tiles v, v + grid, ...
+        const uint32_t own = own_of(v);
         const uint32_t avail = own > j_base ? own - j_base : 0u;
         const uint32_t shared = (avail * io.share64 + 63u) >> 6;
         local = avail - shared;
