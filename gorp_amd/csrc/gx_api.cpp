@@ -1216,7 +1216,10 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
         GX_HIP(e);
         return;
     }
-    const bool batchable = !b.wide && !b.state_out && b.match_only >= 0 && kernel != GX_KERNEL_PER_LINE;
+    // (gx_match_batch wants the product-DFA state a line ends in: the tile kernel on dense rows -- a row is a state -- gives it for
+    // match-only batches; every other kernel and table keeps only the first accepting extraction)
+    const bool want_states = b.state_out != nullptr;
+    const bool batchable = !b.wide && (!want_states || b.match_only == 1) && b.match_only >= 0 && kernel != GX_KERNEL_PER_LINE;
     // Which kernel (gx_batch_opts.kernel 0), by the tables and the mean line length.  Measured, one device (ms; captures /
     // match only):
     //   README definition (dense rows in LDS), 2 M lines of 50-2000 bytes: tiles 0.39, slices 0.73, lanes on sorted tiles 0.75;
@@ -1238,7 +1241,7 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
     // hop tier: capture batches of definitions whose dense rows do not fit LDS, lines of ordinary length and evenness (the
     // tile kernel wants a tile's lines to be neighbours in memory and about as long as each other)
     // ... and for long or uneven lines the hop slice kernel: a piece of every lane's own line at a time, lanes refilled
-    const bool have_hop = mo ? h->hop_mo_ok : h->hop_ok;
+    const bool have_hop = (mo ? h->hop_mo_ok : h->hop_ok) && !want_states;
     const uint8_t* hop_image = static_cast<const uint8_t*>(mo ? h->d_lds_image_hop_mo : h->d_lds_image_hop);
     const uint8_t* hop_image_small = static_cast<const uint8_t*>(mo ? h->d_lds_image_hop_mo_small : h->d_lds_image_hop_small);
     const uint8_t* hop_global = static_cast<const uint8_t*>(mo ? h->d_hop_mo_global : h->d_hop_global);
@@ -1272,14 +1275,14 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
         done_slot(h, u, stream);
         return;
     }
-    const bool slices = kernel == GX_KERNEL_SLICES || (kernel == GX_KERNEL_AUTO && very_long);
+    const bool slices = (kernel == GX_KERNEL_SLICES || (kernel == GX_KERNEL_AUTO && very_long)) && !want_states;
     if (batchable && slices && plan_slice_launch(h, &L, mo)) {
         h->last_kernel = GX_KERNEL_SLICES;
         GX_HIP(launch_extract_slices(h->dev, L, image, at_global, h->num_cus, b, stream));
         return;
     }
     // records in LDS: the lane kernel (every lane keeps its own line in registers, 16 waves share the tables)
-    const bool lanes = kernel == GX_KERNEL_LANES || (kernel == GX_KERNEL_AUTO && (image_tier == 2 || (image_tier != 0 && long_lines)));
+    const bool lanes = (kernel == GX_KERNEL_LANES || (kernel == GX_KERNEL_AUTO && (image_tier == 2 || (image_tier != 0 && long_lines)))) && !want_states;
     // (long lines: tiles of lines of similar length, see gx_lanes.hip; where LDS has no room for that, the slice kernel)
     bool lanes_ok = batchable && lanes && plan_lanes_launch(h, &L, mo, b.packed != nullptr, sorted, b.n);
     if (lanes_ok && kernel == GX_KERNEL_AUTO && long_lines && L.sort_chunk == 0) {
@@ -1313,7 +1316,7 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
         done_slot(h, u, stream);
         return;
     }
-    if (batchable && plan_tile_launch(h, line_bytes_hint, &L, mo)) {
+    if (batchable && (!want_states || image_tier <= 1u) && plan_tile_launch(h, line_bytes_hint, &L, mo)) {
         // a slot for the "lines I could not stage" word of this launch, free again once its follow-up kernel has run
         // (submission of tile launches is serialised per handle; the launches themselves are asynchronous)
         std::lock_guard<std::mutex> lock(h->slot_mu);

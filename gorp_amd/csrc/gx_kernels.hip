@@ -317,7 +317,7 @@ k_extract_flagged(GxDev T, const uint16_t* __restrict__ units, const OFF* __rest
 template <typename OFF, typename CH>
 __global__ void __launch_bounds__(256)
 k_extract_oversize(GxDev T, const CH* __restrict__ data, const OFF* __restrict__ off, uint64_t n, LineOut out, int match_only,
-                   int strip_eol, const uint32_t* __restrict__ flag, uint32_t seq, uint32_t limit, int by_length) {
+                   int strip_eol, const uint32_t* __restrict__ flag, uint32_t seq, uint32_t limit, int by_length, int32_t* __restrict__ state_out) {
     if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) return;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -333,8 +333,8 @@ k_extract_oversize(GxDev T, const CH* __restrict__ data, const OFF* __restrict__
             if (strip_eol) len = trim_eol(data + b, len);
             if (len <= static_cast<int64_t>(limit)) continue;
         }
-        if (T.m_next16) extract_line_global<CH, uint16_t>(T, T.m_next16, data + b, len, i, out, nullptr, match_only);
-        else extract_line_global<CH, uint32_t>(T, T.m_next32, data + b, len, i, out, nullptr, match_only);
+        if (T.m_next16) extract_line_global<CH, uint16_t>(T, T.m_next16, data + b, len, i, out, state_out, match_only);
+        else extract_line_global<CH, uint32_t>(T, T.m_next32, data + b, len, i, out, state_out, match_only);
     }
 }
 
@@ -778,7 +778,7 @@ hipError_t launch_extract_oversize(const GxDev& dev, const GxBatch& b, uint32_t 
     // a small grid: without the flag every wave leaves at once; with it, the lines in question are few and long
     const dim3 grid(dev.pike_off ? dev.pike_blocks : 256u), block(256);
 #define GX_OVERSIZE(OFF, CH) hipLaunchKernelGGL((k_extract_oversize<OFF, CH>), grid, block, 0, stream, dev, static_cast<const CH*>(b.data), \
-                           static_cast<const OFF*>(b.offsets), b.n, line_out(dev, b), b.match_only, b.strip_eol, b.oversize_flag, b.seq, limit, by_length)
+                           static_cast<const OFF*>(b.offsets), b.n, line_out(dev, b), b.match_only, b.strip_eol, b.oversize_flag, b.seq, limit, by_length, b.state_out)
     if (b.wide) { if (b.offsets64) GX_OVERSIZE(uint64_t, uint16_t); else GX_OVERSIZE(uint32_t, uint16_t); }
     else { if (b.offsets64) GX_OVERSIZE(uint64_t, uint8_t); else GX_OVERSIZE(uint32_t, uint8_t); }
 #undef GX_OVERSIZE

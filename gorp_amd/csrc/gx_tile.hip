@@ -43,6 +43,8 @@ hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t
     io.seq = b.seq;
     io.steal = b.steal;
     io.steal_parity = b.steal_parity & 1u;
+    io.state_out = b.state_out;
+    if (b.state_out && (b.match_only == 0 || lds.tier > 1u || b.wide)) return hipErrorInvalidValue;   // (states: match-only batches on dense rows)
     io.wide_flags = b.wide_flags;
     io.wide_any = b.wide_any;
 #ifndef GX_SHARE64

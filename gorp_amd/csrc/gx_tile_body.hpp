@@ -52,6 +52,7 @@ struct TileIO {
     uint32_t share64;            // 64ths of a workgroup's tiles that are handed out through its global counter (other workgroups may take them)
     uint8_t* wide_flags;         // WIDE (UTF-16 code units in `data`): [n], 1 for a line that holds a unit above 0xFF -- the per-line walk takes it again
     uint32_t* wide_any;          // ... and the launch's sequence number here when there is any such line
+    int32_t* state_out;          // MODE 0 on dense rows (gx_match_batch): [n], the product-DFA state a line ends in (-1: the dead state)
 #ifdef GX_DEV
     unsigned long long* stamps;  // developer build: [8] per wave -- per-phase cycle totals [0..3], begin / end on the chip's 100 MHz clock, tiles, XCC id
     uint32_t dev_flags;          // developer build: experiments (bit 1: nontemporal result stores;
@@ -550,6 +551,8 @@ k_extract_tile(GxLds L, TileIO io) {
             // ---- hot loop #1 alone: PolyMatcher.match ----
             const uint32_t mrow = walk<TIER, false, false>(Wm, stage, bitmap, use_map, L.m_start, start, end, true, L.m_dead, regs);
             if (valid) io.match_id[i] = state_info<TIER>(Wm, mrow);
+            if ((TIER == TIER_LDS || TIER == TIER_L2) && io.state_out && valid)   // (a row IS a state of the match automaton: gx_state_accepts reads the rest)
+                io.state_out[i] = mrow == L.m_dead ? -1 : static_cast<int32_t>(TIER == TIER_LDS ? (mrow - L.m_start) / L.row_bytes : mrow - L.m_start);
             GX_STAMP(2);
         } else {
             int32_t info;  // of the state the line's walk ended in: -1 null, -2-k ExtractionException, else its final record

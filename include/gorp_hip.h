@@ -262,7 +262,8 @@ int gx_extract_one_utf16(gx_handle* h, const uint16_t* s, int32_t len, int32_t* 
  * state, the reference's early return, core/autom/PolyMatcher.java:128-130); gx_state_accepts(h, state, ...) is
  * Automata.accept(state) (core/autom/Automata.java:137-139): all extraction indexes accepting there, ascending
  * (returns the count, <= cap written; 0 for -1).  first_match[i] = their first element or -1, as with
- * gx_extract_batch + match_only.  Runs on the per-line kernel (the batch kernels keep only the first match). */
+ * gx_extract_batch + match_only.  Runs on the tile kernel where the automaton's dense rows are the tables (in LDS, or in global
+ * memory: a row is a state), else on the per-line kernel (the record and hop tables keep only the first match). */
 int gx_match_batch(gx_handle* h, const uint8_t* bytes, const void* offsets, uint64_t n, int32_t* first_match,
                    int32_t* states, const gx_batch_opts* opts);
 int gx_state_accepts(const gx_handle* h, int32_t state, int32_t* indexes, int32_t cap);

@@ -1506,3 +1506,33 @@ def test_resident_one_line_service():
     with pytest.raises(ExtractionException):
         g2.extract("a\rb")
     del resident, g2                       # gx_destroy tells the wave to leave and waits for it
+
+
+@pytest.mark.parametrize("flags", [0, N.GX_CREATE_TIER_L2, N.GX_CREATE_TIER_RECORDS, N.GX_CREATE_NO_TILES])
+def test_match_batch_states_from_the_tile_kernel(flags):
+    """gx_match_batch at scale: where the automaton's dense rows are the tables (LDS or global memory) the tile kernel returns the
+    product-DFA state a line ends in -- a row is a state -- and gx_state_accepts reads Automata.accept(state) off it; the record tier
+    and the per-line kernel give the same answer (gx_stat(h, 25) says which kernel ran).  40 k lines of the README definition and of a
+    16-extraction one, damaged and over-long lines among them, against the oracle's PolyMatcher.match."""
+    for definition, lines in ((W.readme3_definition(), None), (W.syslog_definition(16, seed=3)[0], W.syslog_definition(16, seed=3)[1])):
+        gorp = Gorp.construct(definition, flags=flags)
+        built = [e.build() for e in definition]
+        orc = O.OracleGorp([b[0] for b in built])
+        if lines is None:
+            data, offsets, _ = W.readme3_lines(40000, seed=77)
+            data, offsets = data.numpy().copy(), offsets.numpy()
+        else:
+            data, offsets, _ = W.syslog_lines(lines, 40000, seed=78, corrupt_frac=0.1)
+        raw = [bytes(data[int(offsets[i]):int(offsets[i + 1])]) for i in range(len(offsets) - 1)]
+        raw[5] = raw[5] + b"x" * 30000          # a line no wave can stage: the follow-up launch answers, with its state
+        raw[6] = b""
+        data, offsets = lines_to_csr(raw)
+        got = gorp.getMatcher().match_batch(data, offsets)
+        ran = gorp.stat(25)
+        # (gx_stat(h, 9): the tables of match-only batches -- 1 dense rows in LDS, 2 dense rows in global memory, 3 / 4 range records)
+        assert ran == (N.GX_KERNEL_TILES if gorp.stat(9) in (1, 2) else N.GX_KERNEL_PER_LINE), (flags, ran, gorp.stat(9))
+        sample = list(range(0, len(raw), 37)) + [5, 6]
+        for i in sample:
+            assert got[i] == orc.match(raw[i].decode("latin-1")), (flags, i, raw[i][:60])
+        first, _ = gorp.extract_batch(data, offsets, match_only=True)
+        assert [g[0] if g else -1 for g in got] == first.tolist()
