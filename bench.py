@@ -174,6 +174,8 @@ def main():
     ap.add_argument("--lines", type=int, default=0, help="lines per GPU (0: the config's size)")
     ap.add_argument("--results", default="auto", choices=["auto", "narrow", "compact", "dense"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spin-up-ms", type=float, default=150.0,
+                    help="untimed steps for this long before the W warm-up steps of a timed region: the device at its steady clocks (0: none)")
     ap.add_argument("--no-gather", action="store_true")
     args = ap.parse_args()
 
@@ -255,12 +257,21 @@ def main():
             gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=stream, no_sync=True,
                                       line_bytes_hint=hint, max_line_bytes=max_line)
 
-    def timed(fmt, steps, warmup, per_step=False):
+    def timed(fmt, steps, warmup, per_step=False, spin_ms=0.0):
         """K steps bracketed by barrier + synchronize, max over ranks, and the launches' average duration from two events on the
         launch stream, one before the first step and one behind the last (per_step: an event behind every step instead -- the
         spread of the steps, at the price of a marker between the kernels; never used for the headline).
-        fmt: a result format of this workload's step(), or any callable that launches one step."""
+        fmt: a result format of this workload's step(), or any callable that launches one step.
+        spin_ms: untimed steps for that long BEFORE the W warm-up steps -- the device's power management needs ~25 ms of
+        unbroken load to reach its steady clocks (profiles/r04_clock_ramp.txt: 0.54 -> 0.36 -> 0.334 ms per launch over the first
+        30 ms from idle, and 0.39 ms for ever when every 7 ms of work is followed by 50 ms of idling); W = 5 steps of 0.35 ms are
+        not that.  The throughput of a job that keeps the device busy is the steady one; the from-idle figure is reported beside it."""
         one = fmt if callable(fmt) else (lambda: step(fmt))
+        t_spin = time.perf_counter() + spin_ms * 1e-3
+        while time.perf_counter() < t_spin:
+            for _ in range(16):
+                one()
+            torch.cuda.current_stream().synchronize()
         for _ in range(warmup):
             one()
         torch.cuda.synchronize()
@@ -289,9 +300,12 @@ def main():
         return float(t.item()), [ev[0].elapsed_time(ev[1]) / steps] * steps
 
     runs = {}
+    torch.cuda.synchronize()
+    time.sleep(0.25)                                                         # (an idle device, as a first batch finds it)
+    from_idle = timed(headline, args.steps, args.warmup)                     # the same W + K steps from idle: reported beside, never `value`
     for fmt in [f for f in formats if f != headline]:
-        runs[fmt] = timed(fmt, args.steps, args.warmup)                      # the other result formats, same step count, reported beside
-    elapsed, kernel_ms = runs[headline] = timed(headline, args.steps, args.warmup)   # THE timed region
+        runs[fmt] = timed(fmt, args.steps, args.warmup, spin_ms=args.spin_up_ms)     # the other result formats, same step count, reported beside
+    elapsed, kernel_ms = runs[headline] = timed(headline, args.steps, args.warmup, spin_ms=args.spin_up_ms)   # THE timed region
     _, step_ms = timed(headline, args.steps, 1, per_step=True)                       # (afterwards: the spread of single steps)
 
     # ---- correctness of what was timed: the generator knows every (uncorrupted) line's answer ----
@@ -356,7 +370,7 @@ def main():
         step4 = lambda: gorp4.extract_batch_device(data4.data_ptr(), offsets4.data_ptr(), n4, None, rows4.data_ptr(), stream=stream, no_sync=True,
                                                    line_bytes_hint=hint4, compact=2 if narrow4 else True, overflow_ptr=over4.data_ptr(),
                                                    max_line_bytes=max4)
-        elapsed4, kernel4_ms = timed(step4, args.steps, args.warmup)
+        elapsed4, kernel4_ms = timed(step4, args.steps, args.warmup, spin_ms=args.spin_up_ms)
         got4 = (rows4[:, 0].view(torch.int8) if narrow4 else rows4[:, 0]).to(torch.int32)
         ok4 = (bool(torch.equal(got4, want4)) if known4 is None else bool(torch.equal(got4[known4], want4[known4]))) and int(over4.item()) == 0
         ok4t = torch.tensor([1 if ok4 else 0], device=dev)
@@ -442,6 +456,10 @@ def main():
                        "parallelism": "lines sharded by rank (dp%d), no collective in a step" % world},
             "gb_per_s_scanned": total_bytes * world * steps / elapsed / 1e9,
             "kernel_ms": {"avg": k_avg, "clock": "two events on the launch stream around the %d timed steps" % steps,
+                          "spin_up_ms": args.spin_up_ms,   # untimed steps before the W warm-up steps: the device at its steady clocks (see timed())
+                          "from_idle": {"avg": sum(from_idle[1]) / len(from_idle[1]), "ms_per_step": from_idle[0] * 1e3 / steps,
+                                        "lines_per_s": n * world * steps / from_idle[0],
+                                        "protocol": "0.25 s of idling, then the same W + K steps without the spin-up"},
                           "single_steps_after": {"min": k_sorted[0], "median": k_sorted[len(k_sorted) // 2], "max": k_sorted[-1],
                                                  "clock": "an event behind every step, a second run of %d steps" % steps}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -47,8 +47,13 @@ hipError_t launch_extract_tile(const GxDev& dev, const GxLds& lds, const uint8_t
     if (b.state_out && (b.match_only == 0 || lds.tier > 1u || b.wide)) return hipErrorInvalidValue;   // (states: match-only batches on dense rows)
     io.wide_flags = b.wide_flags;
     io.wide_any = b.wide_any;
+    // How much of a workgroup's tiles other workgroups may take (64ths; gx_tile_body.hpp).  With DENSE results the XCDs of a chip finish
+    // an equal share up to a tenth apart (the odd ones later, on half of the boxes of the pool): an eighth evens that out -- 43 -> 6 us
+    // between the median and the last wave -- at the price of 1 % (a returning global atomic per tile and wave in that eighth).  With
+    // compact or u8 rows, or no captures at all, they are 0-3 % apart: sharing then costs what it gives or more (same-box comparisons:
+    // profiles/r04_ab_tile.txt), so those launches share nothing.
 #ifndef GX_SHARE64
-#define GX_SHARE64 8   // an eighth: the XCDs of a chip differ by up to a tenth in what they finish (dense results; 3 % with u8 rows)
+#define GX_SHARE64 ((b.packed || b.match_only != 0) ? 0u : 8u)
 #endif
     io.share64 = GX_SHARE64;
     io.max_groups = dev.max_groups;

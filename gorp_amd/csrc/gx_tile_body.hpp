@@ -415,7 +415,7 @@ k_extract_tile(GxLds L, TileIO io) {
         return j;
     };
     auto draw_shared = [&](uint32_t j, uint32_t inc, uint32_t& g) -> bool {
-        const bool from_shared = inc != 0u && __builtin_amdgcn_readfirstlane(j) >= local_own;
+        const bool from_shared = inc != 0u && io.share64 != 0u && __builtin_amdgcn_readfirstlane(j) >= local_own;
         g = 0;
         if (from_shared) {   // (wave-uniform; the last `share` of the launch only)
             if (lane == 0) g = __hip_atomic_fetch_add(ctr + blockIdx.x * GX_STEAL_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -425,6 +425,7 @@ k_extract_tile(GxLds L, TileIO io) {
     // a tile from another workgroup's shared part, or `tiles` when nobody has one left (wave-uniform; waits for its loads)
     uint32_t steal_salt = (blockIdx.x * L.nwaves + wave) * 2654435761u;
     auto steal = [&]() -> uint64_t {
+        if (io.share64 == 0u) return tiles;   // (a launch that shares nothing: gx_tile.hip)
         for (;;) {
             // workgroups with shared draws left, and how many there are
             uint32_t cands = 0;
