@@ -844,6 +844,10 @@ void choose_tile_image(gx_handle* h) {
 #ifdef GX_DEV
     if (getenv("GX_DEV_HOT_BUDGET")) hot_budget = static_cast<uint32_t>(atoi(getenv("GX_DEV_HOT_BUDGET")));
 #endif
+    uint32_t small_budget = 12u * 1024u;   // the hop slice kernel's share of LDS for hot records
+#ifdef GX_DEV
+    if (getenv("GX_DEV_SMALL_BUDGET")) small_budget = static_cast<uint32_t>(atoi(getenv("GX_DEV_SMALL_BUDGET")));
+#endif
     // layouts of one hop image: the tile kernel's (full) and the hop slice kernel's (small: fewer hot records, more waves)
     auto layouts = [&](const HopImage& I, GxLds* full, GxLds* small) {
         GxLds L{};
@@ -873,7 +877,7 @@ void choose_tile_image(gx_handle* h) {
     };
     h->hop_reason = 4;   // not built: the dense rows fit LDS (or the caller named another tier)
     if (!no_tiles && want_hop && h->T.has_capture && !(h->create_flags & GX_CREATE_NO_FUSED)) {
-        if (build_hop_image(h->T, false, hot_budget, 12u * 1024u, h->hop)) {
+        if (build_hop_image(h->T, false, hot_budget, small_budget, h->hop)) {
             layouts(h->hop, &h->lds_hop, &h->lds_hop_small);
             GxLds P;
             h->hop_ok = plan_tile_layout(h->lds_hop, 200, &P);
@@ -882,7 +886,7 @@ void choose_tile_image(gx_handle* h) {
     } else if (want_hop && !no_tiles) h->hop_reason = 1;
     // ... and of the match automaton alone, for match-only batches (PolyMatcher.match over a batch)
     h->hop_mo_ok = false;
-    if (!no_tiles && want_hop && build_hop_image(h->T, true, hot_budget, 12u * 1024u, h->hop_mo)) {
+    if (!no_tiles && want_hop && build_hop_image(h->T, true, hot_budget, small_budget, h->hop_mo)) {
         layouts(h->hop_mo, &h->lds_hop_mo, &h->lds_hop_mo_small);
         GxLds P;
         h->hop_mo_ok = plan_tile_layout(h->lds_hop_mo, 200, &P);
@@ -1252,7 +1256,11 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
         const bool followup = plan_followup(h, b, u, 65535u, launched);
         if (launched) { launched->limit = 65535u; launched->by_length = 1; }
         h->last_kernel = GX_KERNEL_HOP_SLICES;
-        GX_HIP(launch_extract_hop_slices(h->dev, L, hop_image_small, hop_global, h->num_cus, b, stream));
+        unsigned long long* stamps = nullptr;
+#ifdef GX_DEV
+        stamps = h->dev_stamps;
+#endif
+        GX_HIP(launch_extract_hop_slices(h->dev, L, hop_image_small, hop_global, h->num_cus, b, stream, stamps));
         if (followup) GX_HIP(launch_extract_oversize(h->dev, b, 65535u, 1, stream));   // (lines beyond the 16-bit positions, if the kernel met any)
         done_slot(h, u, stream);
         return;

@@ -194,7 +194,7 @@ hipError_t launch_extract_slices(const GxDev& dev, const GxLds& lds, const uint8
 #define GX_HOP_SLICE_BYTES 128u   // (a power of two times 16, at most 1024: one piece is loaded by 64 / (bytes / 16) ... lanes per line)
 #endif
 hipError_t launch_extract_hop_slices(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
-                                     const GxBatch& b, hipStream_t stream);
+                                     const GxBatch& b, hipStream_t stream, unsigned long long* stamps = nullptr);
 
 // The resident one-line service (gx_service.hip): one wave, the dense-rows image in LDS, requests through `mailbox` and answers
 // through `answer` (both pinned host memory, device addresses), `state` (pinned): 1 resident, 2 gone.  mode 0: match automaton

@@ -97,7 +97,7 @@ __device__ __forceinline__ uint32_t run_flags(uint32_t x, uint32_t lo4, uint32_t
 // CAPTURE false: the match automaton's tables (no programs anywhere): the register writes are left out.
 template <bool ALL_HOT, bool CAPTURE>
 __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, uint32_t e, uint32_t limit, uint32_t e_chain, uint32_t p0,
-                                                  uint32_t s, uint32_t dead, uint32_t regs) {
+                                                  uint32_t s, uint32_t dead, uint32_t regs, uint32_t leave_at = 0u) {
     const uint32_t dummy_col = regs - 128u;
     const uint32_t last_hot = H.n_hot - 1u;
     // one exact step of this lane from state s on the byte `bt` at LDS address q: the dense row (lrow: its copy in LDS, 0: none)
@@ -112,17 +112,28 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
     };
     if (ALL_HOT && __builtin_amdgcn_ballot_w64(s > last_hot) != 0ull)   // (the slice kernel: a lane may come back off the path)
         while (s > last_hot && p < limit) exact_step(0u, lds_ld<uint8_t>(p), p);
+    // (a record that came out of global memory stays with its lane while the lane stays in that state: a value of several windows
+    // is as many iterations in one state -- configs[4]: 34 of a line's 43 iterations sit in states whose records are not in LDS, 8 of
+    // them enter one: tools/hop_stats.py)
+    uint32_t kept = 0xFFFFFFFFu;
+    u32x2 k0 = {0u, 0u}, k1 = {0u, 0u}, k2 = {0u, 0u};
     for (;;) {
+        // (leave_at: the hop slice kernel leaves a round's walk when no more than that many lanes still have bytes -- the others have
+        // used up their pieces, and a lane in a long value does so in a third of the iterations a lane in literals needs)
         const uint64_t unfinished = __builtin_amdgcn_ballot_w64(p < limit);
-        if (unfinished == 0ull) break;
+        if (static_cast<uint32_t>(__builtin_popcountll(unfinished)) <= leave_at) break;
         // ---- 1. the state's record ----
         const uint32_t la = __umul24(min(s, last_hot), HOP_REC_B) + HOP_LDS_AT;  // (a lane that is done may sit in any state)
         u32x2 h0 = lds_ld<u32x2>(la), h1 = lds_ld<u32x2>(la + 8u), h2 = lds_ld<u32x2>(la + 16u);
         if (!ALL_HOT && (__builtin_amdgcn_ballot_w64(s > last_hot) & unfinished) != 0ull) {
-            if (s > last_hot && p < limit) {
-                const u32x2* g = reinterpret_cast<const u32x2*>(H.hops + static_cast<uint64_t>(s) * HOP_REC_B);
-                h0 = g[0]; h1 = g[1]; h2 = g[2];
+            if ((__builtin_amdgcn_ballot_w64(s > last_hot && s != kept) & unfinished) != 0ull) {
+                if (s > last_hot && s != kept && p < limit) {
+                    const u32x2* g = reinterpret_cast<const u32x2*>(H.hops + static_cast<uint64_t>(s) * HOP_REC_B);
+                    k0 = g[0]; k1 = g[1]; k2 = g[2];
+                    kept = s;
+                }
             }
+            if (s > last_hot && s == kept) { h0 = k0; h1 = k1; h2 = k2; }
         }
         // ---- 2. the run: how many of the next 16 class ids lie in [run_lo, run_hi] ----
         const uint32_t a1 = p & ~3u, sh1 = p & 3u;

@@ -1190,18 +1190,33 @@ hipError_t launch_unpack_results(const uint16_t* packed, uint64_t n, int slots, 
 // counts[0] = lines with match_id >= 0, counts[1] = lines with match_id <= -2 (capture regexp rejected the line)
 namespace {
 __global__ void __launch_bounds__(256) k_count_outcomes(const int32_t* __restrict__ match_id, uint64_t n, unsigned long long* __restrict__ counts) {
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    // (one pair of atomics per workgroup: atomics on one cache line take their turns at 11 ns apiece -- one pair per WAVE of 2 048
+    // workgroups made this kernel 108 us for 10 M lines, the read of 40 MB a tenth of that)
+    __shared__ uint32_t sums[2][4];
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x * 4u;
     uint32_t matched = 0, rejected = 0;
-    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int32_t k = match_id[i];
-        matched += k >= 0 ? 1u : 0u;
-        rejected += k <= -2 ? 1u : 0u;
+    for (uint64_t i = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 4u; i < n; i += stride) {
+        int32_t k[4] = {-1, -1, -1, -1};
+        if (i + 4 <= n && (reinterpret_cast<uintptr_t>(match_id) & 15u) == 0u) {
+            const int4 v = *reinterpret_cast<const int4*>(match_id + i);
+            k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+        } else {
+            for (int q = 0; q < 4; ++q) if (i + q < n) k[q] = match_id[i + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            matched += k[q] >= 0 ? 1u : 0u;
+            rejected += k[q] <= -2 ? 1u : 0u;
+        }
     }
     matched = wave_sum(matched);
     rejected = wave_sum(rejected);
-    if ((threadIdx.x & 63u) == 0) {
-        if (matched) atomicAdd(counts, static_cast<unsigned long long>(matched));
-        if (rejected) atomicAdd(counts + 1, static_cast<unsigned long long>(rejected));
+    if ((threadIdx.x & 63u) == 0) { sums[0][threadIdx.x >> 6] = matched; sums[1][threadIdx.x >> 6] = rejected; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t m = sums[0][0] + sums[0][1] + sums[0][2] + sums[0][3], r = sums[1][0] + sums[1][1] + sums[1][2] + sums[1][3];
+        if (m) atomicAdd(counts, static_cast<unsigned long long>(m));
+        if (r) atomicAdd(counts + 1, static_cast<unsigned long long>(r));
     }
 }
 }  // namespace
@@ -1209,7 +1224,7 @@ __global__ void __launch_bounds__(256) k_count_outcomes(const int32_t* __restric
 hipError_t launch_count_outcomes(const int32_t* match_id, uint64_t n, unsigned long long* d_counts, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(d_counts, 0, 16, stream);
     if (e != hipSuccess || n == 0) return e;
-    uint64_t blocks = std::min<uint64_t>((n + 255) / 256, 256u * 8u);
+    uint64_t blocks = std::min<uint64_t>((n + 1023) / 1024, 256u * 2u);
     hipLaunchKernelGGL(k_count_outcomes, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, match_id, n, d_counts);
     return hipGetLastError();
 }

@@ -63,6 +63,107 @@ struct LineOut {
     }
 };
 
+// A line's whole result row from its lane in as few stores as the format allows (the slice kernels: a lane holds a line of its
+// own, its row goes where no neighbour's does -- 1 + 2 G scattered stores of two bytes each were a sixth of the hop slice kernel on
+// BASELINE configs[4]).  Four groups at a time, as the final records hold their tags: dense results leave as two 16-byte stores,
+// u16 rows as one (the row's first halfword is the id, so a word is one group's end and the next group's begin: `carry`), u8 rows
+// as one of 8 bytes; global memory takes them at any alignment.  Returns nothing: the id is the row's (or match_id's) to keep.
+struct __attribute__((packed)) UnalignedU32x4 { u32x4 v; };
+struct __attribute__((packed)) UnalignedU32x2 { u32x2 v; };
+struct __attribute__((packed)) UnalignedU32 { uint32_t v; };
+struct __attribute__((packed)) UnalignedU16 { uint16_t v; };
+
+template <int TIER>
+__device__ __forceinline__ void write_row(const LineOut& out, uint64_t i, int32_t info, uint32_t fin_lds, const uint8_t* fin_g, uint32_t regs,
+                                          uint32_t len, int G) {
+    const uint32_t rec = info >= 0 ? static_cast<uint32_t>(info) : 0u;
+    const uint32_t dummy_col = regs - 128u;
+    const uint32_t id_at = rec + 16u * static_cast<uint32_t>((G + 3) >> 2);
+    const bool FIN_GLOBAL = TIER == TIER_L2 || TIER == TIER_RECG || (TIER == TIER_HOP && fin_g != nullptr);
+    uint32_t idw;
+    if (FIN_GLOBAL) idw = *reinterpret_cast<const uint16_t*>(fin_g + id_at);
+    else idw = lds_ld<uint16_t>(fin_lds + id_at);
+    const int32_t mid = info >= 0 ? static_cast<int32_t>(static_cast<int16_t>(idw)) : info;
+    const uint32_t unit = out.packed ? (out.narrow ? 1u : 2u) : 4u;
+    uint8_t* row = out.packed ? reinterpret_cast<uint8_t*>(out.packed) + i * static_cast<uint64_t>(1 + out.slots) * unit
+                              : reinterpret_cast<uint8_t*>(out.caps + i * static_cast<uint64_t>(out.slots));
+    if (!out.packed) out.match_id[i] = mid;
+    uint32_t carry = static_cast<uint32_t>(mid) & (out.narrow ? 0xFFu : 0xFFFFu);
+    uint32_t clipped = 0u;
+    for (int g0 = 0; g0 < G; g0 += 4) {
+        u32x4 t;
+        if (FIN_GLOBAL) t = *reinterpret_cast<const u32x4*>(fin_g + rec + 4u * g0);
+        else t = lds_ld<u32x4>(fin_lds + rec + 4u * g0);
+        const uint32_t tw[4] = {t.x, t.y, t.z, t.w};
+        uint32_t vb[4], ve[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            vb[q] = lds_ld<uint16_t>(dummy_col + (tw[q] & 0xFF80u));
+            ve[q] = lds_ld<uint16_t>(dummy_col + ((tw[q] >> 16) & 0xFF80u));
+        }
+        int32_t pb[4], pe[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t tb = tw[q] & 0xFFFFu, te = tw[q] >> 16;
+            pb[q] = tb == 1u ? static_cast<int32_t>(len) : static_cast<int32_t>(vb[q]);
+            pe[q] = te == 1u ? static_cast<int32_t>(len) : static_cast<int32_t>(ve[q]);
+            if (tb == 0u || te == 0u || info < 0) { pb[q] = -1; pe[q] = -1; }
+        }
+        const int cnt = G - g0 < 4 ? G - g0 : 4;
+        if (!out.packed) {
+            uint8_t* dst = row + 8u * g0;
+            if (cnt == 4) {
+                reinterpret_cast<UnalignedU32x4*>(dst)->v = u32x4{static_cast<uint32_t>(pb[0]), static_cast<uint32_t>(pe[0]), static_cast<uint32_t>(pb[1]), static_cast<uint32_t>(pe[1])};
+                reinterpret_cast<UnalignedU32x4*>(dst + 16)->v = u32x4{static_cast<uint32_t>(pb[2]), static_cast<uint32_t>(pe[2]), static_cast<uint32_t>(pb[3]), static_cast<uint32_t>(pe[3])};
+            } else {
+                for (int q = 0; q < cnt; ++q) reinterpret_cast<UnalignedU32x2*>(dst + 8 * q)->v = u32x2{static_cast<uint32_t>(pb[q]), static_cast<uint32_t>(pe[q])};
+            }
+        } else if (!out.narrow) {
+            uint32_t hb[4], he[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                clipped += (pb[q] > 65534 ? 1u : 0u) + (pe[q] > 65534 ? 1u : 0u);
+                hb[q] = pb[q] < 0 ? 0xFFFFu : static_cast<uint32_t>(min(pb[q], 65534));
+                he[q] = pe[q] < 0 ? 0xFFFFu : static_cast<uint32_t>(min(pe[q], 65534));
+            }
+            uint8_t* dst = row + 4u * g0;   // (the halfword before group g0's begin: the id, or the end of the group before)
+            if (cnt == 4) {
+                reinterpret_cast<UnalignedU32x4*>(dst)->v = u32x4{carry | hb[0] << 16, he[0] | hb[1] << 16, he[1] | hb[2] << 16, he[2] | hb[3] << 16};
+                carry = he[3];
+            } else {
+                for (int q = 0; q < cnt; ++q) {
+                    reinterpret_cast<UnalignedU32*>(dst + 4 * q)->v = carry | hb[q] << 16;
+                    carry = he[q];
+                }
+            }
+        } else {
+            uint32_t hb[4], he[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                clipped += (pb[q] > 254 ? 1u : 0u) + (pe[q] > 254 ? 1u : 0u);
+                hb[q] = pb[q] < 0 ? 0xFFu : static_cast<uint32_t>(min(pb[q], 254));
+                he[q] = pe[q] < 0 ? 0xFFu : static_cast<uint32_t>(min(pe[q], 254));
+            }
+            uint8_t* dst = row + 2u * g0;
+            if (cnt == 4) {
+                reinterpret_cast<UnalignedU32x2*>(dst)->v = u32x2{carry | hb[0] << 8 | he[0] << 16 | hb[1] << 24, he[1] | hb[2] << 8 | he[2] << 16 | hb[3] << 24};
+                carry = he[3];
+            } else {
+                for (int q = 0; q < cnt; ++q) {
+                    reinterpret_cast<UnalignedU16*>(dst + 2 * q)->v = static_cast<uint16_t>(carry | hb[q] << 8);
+                    carry = he[q];
+                }
+            }
+        }
+    }
+    if (out.packed) {
+        // the row's last unit; slots beyond the definition's groups do not exist (slots == 2 * max_groups == 2 G)
+        if (out.narrow) row[2 * G] = static_cast<uint8_t>(carry);
+        else reinterpret_cast<UnalignedU16*>(row + 4 * G)->v = static_cast<uint16_t>(carry);
+        if (clipped && out.overflow) atomicAdd(out.overflow, static_cast<unsigned long long>(clipped));
+    }
+}
+
 // ---------------------------------------------------------------------------
 // An extraction whose capture automaton is not built ahead of time (2^n register patterns: gx_compile.hpp, RuleTables::pike):
 // its prioritised Thompson program run as it is -- a Pike VM.  Thread lists in priority order, a thread = (pc, its group
@@ -452,10 +553,7 @@ k_extract_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const 
         if (done) {
             const int32_t info = state_info<TIER>(W, row);
             if (!want_caps) out.id(i, info);
-            else out.id(i, line_result<TIER>(info, L.fin_tags, fin_g, regs, len, T.max_groups, [&](int g, int32_t pb, int32_t pe) {
-                out.cap(i, 2 * g, pb);
-                out.cap(i, 2 * g + 1, pe);
-            }));
+            else write_row<TIER>(out, i, info, L.fin_tags, fin_g, regs, len, T.max_groups);
             has_line = false;
         }
         // ---- free lanes take the next lines of the range, in lane order ----
@@ -577,13 +675,19 @@ hipError_t launch_slices_t(const GxDev& dev, const GxLds& lds, const uint8_t* ld
 // and comes back for the next piece 24 bytes before the end of what is staged (a whole window and a whole chain are
 // always there); a lane whose line has ended writes its result and takes the wave's next line.  A line's padding, fields
 // and literals cost iterations, not bytes, so lanes of a wave stay roughly level however long their lines are.
+#ifndef GX_HOP_LEAVE
+#define GX_HOP_LEAVE 24u   // (64: a round's walk goes on until every lane has used up its piece)
+#endif
+#ifndef GX_HOP_SERVICE
+#define GX_HOP_SERVICE 24u  // finished lanes write their results and take new lines once that many lanes have nothing to walk
+#endif
 constexpr uint32_t HOP_SLICE = GX_HOP_SLICE_BYTES, HOP_SLICE_ROW = GX_HOP_SLICE_BYTES + 16u, HOP_SLICE_KEEP = 24;
 
 template <typename OFF>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4)))
 k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const uint8_t* __restrict__ at_global,
                      const uint8_t* __restrict__ data, const OFF* __restrict__ off, uint64_t n, LineOut out, int match_only, int strip_eol,
-                     uint32_t* __restrict__ oversize_flag, uint32_t seq) {
+                     uint32_t* __restrict__ oversize_flag, uint32_t seq, unsigned long long* __restrict__ stamps) {
     {
         extern __shared__ __attribute__((aligned(16))) uint8_t gx_smem[];
         const uint4* src = reinterpret_cast<const uint4*>(lds_image);
@@ -591,6 +695,14 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
         for (uint32_t c = threadIdx.x; c < L.table_bytes / 16; c += blockDim.x) dst[c] = src[c];
     }
     __syncthreads();
+#ifdef GX_DEV
+    // developer build: cycles per phase summed per wave (tools/hop_slice_phases.py): 0 results + handing out lines, 1 loads issued,
+    // 2 waiting for them + LDS stores, 3 walk, 4 rounds
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
+#define HS_STAMP(slot) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[slot] += now_ - ph_t; ph_t = now_; } while (0)
+#else
+#define HS_STAMP(slot) do { } while (0)
+#endif
     HopTab H;
     H.rows = at_global;
     H.hops = at_global + L.c_base;
@@ -623,18 +735,16 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
         // ---- finished lanes write their results once a quarter of the wave is idle (k_extract_slices says why) ----
         const bool finished = has_line && (pos >= len || row == dead_row);
         const uint32_t idle = static_cast<uint32_t>(__popcll(__ballot(finished || !has_line)));
-        const bool service = idle >= 16u || !__any(has_line && !finished);
+        const bool service = idle >= GX_HOP_SERVICE || !__any(has_line && !finished);
         if (service && finished) {
             const int32_t hot_info = static_cast<int16_t>(lds_ld<uint16_t>(L.acc_tab + 2u * min(row, H.n_hot - 1u)));
             int32_t info = hot_info >= 0 && !match_only ? hot_info * 16 : hot_info;
             if (row >= H.n_hot) info = *reinterpret_cast<const int32_t*>(H.rows + (static_cast<uint64_t>(row) * H.row_bytes + H.info_off));
             if (match_only) out.id(i, info);
-            else out.id(i, line_result<TIER_HOP>(info, fin_lds, fin_g, regs, len, T.max_groups, [&](int g, int32_t pb, int32_t pe) {
-                out.cap(i, 2 * g, pb);
-                out.cap(i, 2 * g + 1, pe);
-            }));
+            else write_row<TIER_HOP>(out, i, info, fin_lds, fin_g, regs, len, T.max_groups);
             has_line = false;
         }
+        HS_STAMP(5);
         // ---- free lanes take the next lines of the range, in lane order ----
         const uint64_t free_mask = __ballot(!has_line);
         if (service && free_mask && next < range_hi) {
@@ -662,11 +772,13 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
             if (next >= range_hi) break;
             continue;  // (only lines for the follow-up launch were handed out: hand out more)
         }
+        HS_STAMP(0);
         // ---- stage the next piece of every lane's line, from the lane's own position: lane l fetches 16 bytes (l & 7) of the
         // line of lane (l >> 3) + 8 r, as class ids ----
         const bool walking = has_line && pos < len && row != dead_row;
         // (HOP_SLICE / 16 lanes per line: 8 for 128 bytes)
         constexpr uint32_t LPL = HOP_SLICE / 16u, LINES_PER_LOAD = 64u / LPL;
+        u32x4 pv[LPL];
 #pragma unroll
         for (uint32_t r = 0; r < LPL; ++r) {
             const int q = static_cast<int>(lane / LPL + LINES_PER_LOAD * r);
@@ -685,11 +797,16 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
                     v = u32x4{w[0], w[1], w[2], w[3]};
                 }
             }
-            lds_st<u32x4>(slice + static_cast<uint32_t>(q) * HOP_SLICE_ROW + (lane % LPL) * 16u, v);
+            pv[r] = v;
         }
+        HS_STAMP(1);
+#pragma unroll
+        for (uint32_t r = 0; r < LPL; ++r)
+            lds_st<u32x4>(slice + (lane / LPL + LINES_PER_LOAD * r) * HOP_SLICE_ROW + (lane % LPL) * 16u, pv[r]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        HS_STAMP(2);
         // ---- walk the piece ----
         {
             const uint32_t left = walking ? len - pos : 0u;          // bytes of the line from pos on
@@ -699,23 +816,40 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
             uint32_t p = my;
             const uint32_t e_chain = whole ? e : 0xFFFFFFF0u;
             const bool all_hot = L.rec_indexed >= L.sort_chunk;
-            if (match_only) row = all_hot ? walk_hop_span<true, false>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs)
-                                          : walk_hop_span<false, false>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs);
-            else row = all_hot ? walk_hop_span<true, true>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs)
-                               : walk_hop_span<false, true>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs);
+            // the round ends when GX_HOP_LEAVE of the lanes that went into it have used up their pieces (or their lines).  BASELINE
+            // configs[4], 2 M lines, ms per launch (captures / match only), one device: 64 (the last lane) 0.955 / 0.712, 48 0.914 / 0.666,
+            // 32 0.892 / 0.660, 16 0.907 / 0.670; then with 32: results and new lines at 8 idle lanes 0.954, 16 0.877, 24 0.853, 32 0.854;
+            // 24 and 24: 0.849 / 0.627 (tools/hop_stats.py replays the rounds: 58 % of the lanes have something to walk in an iteration
+            // of a round that waits for its last lane, 85 % with 24)
+            const uint32_t went_in = static_cast<uint32_t>(__popcll(__ballot(p < limit)));
+            const uint32_t leave_at = went_in > GX_HOP_LEAVE ? went_in - GX_HOP_LEAVE : 0u;
+            if (match_only) row = all_hot ? walk_hop_span<true, false>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at)
+                                          : walk_hop_span<false, false>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at);
+            else row = all_hot ? walk_hop_span<true, true>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at)
+                               : walk_hop_span<false, true>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at);
             pos += p - my;
         }
         // the slice buffer is rewritten by the next iteration
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        HS_STAMP(3);
+#ifdef GX_DEV
+        ++ph[4];
+#endif
     }
+#ifdef GX_DEV
+    if (stamps && lane == 0) {
+        unsigned long long* st = stamps + 8ull * (static_cast<uint64_t>(blockIdx.x) * L.nwaves + wave);
+        for (int q = 0; q < 6; ++q) st[q] = ph[q];
+    }
+#endif
 }
 
 }  // namespace
 
 // lds: a layout from plan_hop_slice_launch (gx_api.cpp): the hop tier's tables, per wave a register block and a [64][144]-byte piece buffer
 hipError_t launch_extract_hop_slices(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
-                                     const GxBatch& b, hipStream_t stream) {
+                                     const GxBatch& b, hipStream_t stream, unsigned long long* stamps) {
     if (b.n == 0) return hipSuccess;
     uint64_t blocks = static_cast<uint64_t>(num_cus);
     const uint64_t need = (b.n + 256ull * lds.nwaves - 1) / (256ull * lds.nwaves);
@@ -725,12 +859,12 @@ hipError_t launch_extract_hop_slices(const GxDev& dev, const GxLds& lds, const u
         hipError_t e = allow_full_lds(&k_extract_hop_slices<uint64_t>);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_extract_hop_slices<uint64_t>), grid, block, lds.total_bytes, stream, dev, lds, lds_image, at_global,
-                           static_cast<const uint8_t*>(b.data), static_cast<const uint64_t*>(b.offsets), b.n, line_out(dev, b), (b.match_only != 0 || !dev.has_capture) ? 1 : 0, b.strip_eol, b.oversize_flag, b.seq);
+                           static_cast<const uint8_t*>(b.data), static_cast<const uint64_t*>(b.offsets), b.n, line_out(dev, b), (b.match_only != 0 || !dev.has_capture) ? 1 : 0, b.strip_eol, b.oversize_flag, b.seq, stamps);
     } else {
         hipError_t e = allow_full_lds(&k_extract_hop_slices<uint32_t>);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_extract_hop_slices<uint32_t>), grid, block, lds.total_bytes, stream, dev, lds, lds_image, at_global,
-                           static_cast<const uint8_t*>(b.data), static_cast<const uint32_t*>(b.offsets), b.n, line_out(dev, b), (b.match_only != 0 || !dev.has_capture) ? 1 : 0, b.strip_eol, b.oversize_flag, b.seq);
+                           static_cast<const uint8_t*>(b.data), static_cast<const uint32_t*>(b.offsets), b.n, line_out(dev, b), (b.match_only != 0 || !dev.has_capture) ? 1 : 0, b.strip_eol, b.oversize_flag, b.seq, stamps);
     }
     return hipGetLastError();
 }

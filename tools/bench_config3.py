@@ -9,6 +9,8 @@ import numpy as np, torch
 from gorp_amd import _native as N
 if os.environ.get("GX_BENCH_DEV_LIB"):   # the developer build (libgorp_hip_dev.so: GX_DEV_* experiment hooks)
     N.LIB_PATH = os.path.join(os.path.dirname(N.LIB_PATH), "libgorp_hip_dev.so")
+if os.environ.get("GX_BENCH_LIB"):       # a variant build (python -m gorp_amd.build --variant NAME -D...)
+    N.LIB_PATH = os.path.abspath(os.environ["GX_BENCH_LIB"])
 from gorp_amd import workloads as W
 from gorp_amd.gorp import Gorp
 

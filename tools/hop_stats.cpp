@@ -37,15 +37,22 @@ int main(int argc, char** argv) {
         std::ifstream f(argv[2]);
         std::string ln;
         size_t by_byte[256] = {0}, failed_chain = 0, no_chain = 0;
+        size_t cold_small = 0, cold_full = 0, cold_switch = 0, next_is_plus1 = 0, cold_moves = 0, in_block4 = 0; uint32_t block = 0xFFFFFFFFu;
         size_t lines = 0, bytes = 0, iters = 0, chains = 0, exacts = 0, exact_cold = 0, run_full = 0, run_bytes = 0, chain_bytes = 0;
+        std::vector<std::vector<uint16_t>> traces;
         while (std::getline(f, ln)) {
+            traces.emplace_back();
             std::vector<uint8_t> b(ln.begin(), ln.end());
             b.resize(b.size() + 32, 0);
             const size_t e = ln.size();
             uint32_t s = H.start;
             size_t p = 0;
             while (p < e) {
+                struct Rec { std::vector<uint16_t>& t; size_t& p; size_t p0; ~Rec() { t.push_back(static_cast<uint16_t>(p - p0)); } } rec{traces.back(), p, p};
                 ++iters;
+                if (s >= H.small.n_hot) { ++cold_small; if ((s >> 2) != block) { ++cold_switch; block = s >> 2; } }
+                if (s >= H.full.n_hot) ++cold_full;
+                const uint32_t s_before = s;
                 uint32_t r[6];
                 memcpy(r, hops + static_cast<size_t>(s) * HOP_REC_BYTES, HOP_REC_BYTES);
                 const uint32_t run_lo = r[0] & 0xFFu, run_k = (r[0] >> 8) & 0xFFu, klen = (r[0] >> 16) & 0xFFu;
@@ -54,6 +61,7 @@ int main(int argc, char** argv) {
                 run_bytes += n;
                 const size_t q = p + n;
                 if (n == 16 || q >= e) { p = q; ++run_full; continue; }
+                struct Moved { uint32_t from; uint32_t* to; size_t *moves, *plus1, *b4; uint32_t nh; ~Moved() { if (from >= nh && *to != from) { ++*moves; if (*to == from + 1) ++*plus1; if (*to > from && *to < from + 4) ++*b4; } } } moved{s_before, &s, &cold_moves, &next_is_plus1, &in_block4, H.small.n_hot};
                 const uint8_t* lits = reinterpret_cast<const uint8_t*>(&r[4]);
                 bool ok = q + klen <= e;
                 for (int j = 0; j < 8 && ok; ++j) ok = lits[j] == 0 || b[q + j] == lits[j];
@@ -77,6 +85,50 @@ int main(int argc, char** argv) {
         printf("  %zu lines, %.1f bytes/line; per line: %.1f iterations (%.1f chains of %.1f bytes, %.1f exact steps of which %.1f through a global row, %.1f whole-window runs), %.1f bytes in runs\n",
                lines, double(bytes) / lines, double(iters) / lines, double(chains) / lines, chains ? double(chain_bytes) / chains : 0.0, double(exacts) / lines,
                double(exact_cold) / lines, double(run_full) / lines, double(run_bytes) / lines);
+        printf("  iterations at states whose record is not in LDS: %.1f per line with %u hot records, %.1f with %u; block-of-4 switches %.1f per line; moves out of such a state %.1f per line, %.1f to state + 1, %.1f to state + 1..3\n",
+               double(cold_small) / lines, H.small.n_hot, double(cold_full) / lines, H.full.n_hot, double(cold_switch) / lines, double(cold_moves) / lines, double(next_is_plus1) / lines, double(in_block4) / lines);
+        if (pass == 0) {
+            // ---- the hop slice kernel's rounds, replayed: 64 lanes, pieces of 128 bytes from a lane's own position, a lane comes back 24 bytes
+            // before the end of its piece; service (results + new lines) when 16 lanes are idle.  leave_at: the walk of a round ends
+            // when that many lanes have nothing to walk (64: when all have: the kernel as it is). ----
+            for (int leave_at : {64, 48, 32, 24, 16, 8, 4, 1}) {
+                const size_t L = traces.size();
+                size_t next = 0, rounds = 0, walk_iters = 0, lane_iters = 0, services = 0, staged_bytes = 0;
+                struct Lane { bool has = false; size_t line = 0, it = 0, pos = 0, len = 0; } lanes[64];
+                auto line_len = [&](size_t i) { size_t t = 0; for (auto v : traces[i]) t += v; return t; };
+                for (;;) {
+                    int idle = 0; bool any_walking = false;
+                    for (auto& l : lanes) { const bool fin = l.has && l.it >= traces[l.line].size(); if (fin || !l.has) ++idle; else any_walking = true; }
+                    const bool service = idle >= (leave_at < 16 ? leave_at : 16) || !any_walking;
+                    if (service) {
+                        ++services;
+                        for (auto& l : lanes) if (l.has && l.it >= traces[l.line].size()) l.has = false;
+                        for (auto& l : lanes) if (!l.has && next < L * 8) { l.has = true; l.line = next % L; l.it = 0; l.pos = 0; l.len = line_len(l.line); ++next; }
+                    }
+                    bool any = false; for (auto& l : lanes) any = any || l.has;
+                    if (!any) break;
+                    ++rounds;
+                    size_t lim[64];
+                    for (int q = 0; q < 64; ++q) { auto& l = lanes[q]; const size_t left = l.has ? l.len - l.pos : 0; lim[q] = left <= 128 ? l.pos + left : l.pos + 128 - 24; if (l.has) staged_bytes += left < 128 ? left : 128; }
+                    for (;;) {
+                        int starving = 0, walking = 0;   // starving: lanes that a new round would give something to walk
+                        for (int q = 0; q < 64; ++q) {
+                            auto& l = lanes[q];
+                            const bool unfinished = l.has && l.it < traces[l.line].size();
+                            if (unfinished && l.pos < lim[q]) ++walking;
+                            else if (unfinished || next < L * 8) ++starving;
+                        }
+                        if (walking == 0 || starving >= leave_at) break;
+                        ++walk_iters;
+                        for (int q = 0; q < 64; ++q) { auto& l = lanes[q]; if (l.has && l.it < traces[l.line].size() && l.pos < lim[q]) { l.pos += traces[l.line][l.it++]; ++lane_iters; } }
+                    }
+                }
+                const double lines_done = double(next);
+                printf("  leave the walk when %2d lanes have nothing to walk: %.2f rounds and %.1f wave iterations per 64 lines-worth (lane utilisation %.0f %%), %.2f services; staged %.0f bytes per line; cost at 12 K + 1.15 K per iteration: %.0f K cycles per 64 lines, at 7 K: %.0f K\n",
+                       leave_at, rounds / (lines_done / 64), walk_iters / (lines_done / 64), 100.0 * lane_iters / (64.0 * walk_iters), services / (lines_done / 64), staged_bytes / lines_done,
+                       (rounds * 12.0 + walk_iters * 1.15) / (lines_done / 64), (rounds * 7.0 + walk_iters * 1.15) / (lines_done / 64));
+            }
+        }
         printf("  exact steps: %.1f per line in states with a chain that did not apply, %.1f in states without one; by byte:", double(failed_chain) / lines, double(no_chain) / lines);
         for (int bt = 0; bt < 256; ++bt) if (by_byte[bt] * 20 > lines) printf(" %c:%.1f", bt >= 0x20 && bt < 0x7F ? bt : '.', double(by_byte[bt]) / lines);
         printf("\n");
