@@ -112,9 +112,12 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
     };
     if (ALL_HOT && __builtin_amdgcn_ballot_w64(s > last_hot) != 0ull)   // (the slice kernel: a lane may come back off the path)
         while (s > last_hot && p < limit) exact_step(0u, lds_ld<uint8_t>(p), p);
-    // (a record that came out of global memory stays with its lane while the lane stays in that state: a value of several windows
-    // is as many iterations in one state -- configs[4]: 34 of a line's 43 iterations sit in states whose records are not in LDS, 8 of
-    // them enter one: tools/hop_stats.py)
+    // Where not every reachable state's record is in LDS (the hop slice kernel on definitions of hundreds of extractions), a record
+    // stays with its lane while the lane stays in its state: a value of several windows is as many iterations in one state
+    // (configs[4]: 34 of a line's 43 iterations sit in states whose records are not in LDS, 8 of them enter one -- tools/hop_stats.py;
+    // re-reading them came out of L1, keeping them was worth nothing by itself, keeping the hot ones' LDS reads down as well 4 %:
+    // 0.856 -> 0.825 ms per 2 M lines).  With every record in LDS (config 3) the plain read per iteration is faster (0.895 against
+    // 0.939 ms per 10 M lines): ALL_HOT keeps nothing.
     uint32_t kept = 0xFFFFFFFFu;
     u32x2 k0 = {0u, 0u}, k1 = {0u, 0u}, k2 = {0u, 0u};
     for (;;) {
@@ -123,17 +126,24 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
         const uint64_t unfinished = __builtin_amdgcn_ballot_w64(p < limit);
         if (static_cast<uint32_t>(__builtin_popcountll(unfinished)) <= leave_at) break;
         // ---- 1. the state's record ----
-        const uint32_t la = __umul24(min(s, last_hot), HOP_REC_B) + HOP_LDS_AT;  // (a lane that is done may sit in any state)
-        u32x2 h0 = lds_ld<u32x2>(la), h1 = lds_ld<u32x2>(la + 8u), h2 = lds_ld<u32x2>(la + 16u);
-        if (!ALL_HOT && (__builtin_amdgcn_ballot_w64(s > last_hot) & unfinished) != 0ull) {
-            if ((__builtin_amdgcn_ballot_w64(s > last_hot && s != kept) & unfinished) != 0ull) {
-                if (s > last_hot && s != kept && p < limit) {
-                    const u32x2* g = reinterpret_cast<const u32x2*>(H.hops + static_cast<uint64_t>(s) * HOP_REC_B);
-                    k0 = g[0]; k1 = g[1]; k2 = g[2];
+        u32x2 h0, h1, h2;
+        if (ALL_HOT) {
+            const uint32_t la = __umul24(min(s, last_hot), HOP_REC_B) + HOP_LDS_AT;  // (a lane that is done may sit in any state)
+            h0 = lds_ld<u32x2>(la); h1 = lds_ld<u32x2>(la + 8u); h2 = lds_ld<u32x2>(la + 16u);
+        } else {
+            if ((__builtin_amdgcn_ballot_w64(s != kept) & unfinished) != 0ull) {
+                if (s != kept && p < limit) {
+                    if (s <= last_hot) {
+                        const uint32_t la = __umul24(s, HOP_REC_B) + HOP_LDS_AT;
+                        k0 = lds_ld<u32x2>(la); k1 = lds_ld<u32x2>(la + 8u); k2 = lds_ld<u32x2>(la + 16u);
+                    } else {
+                        const u32x2* g = reinterpret_cast<const u32x2*>(H.hops + static_cast<uint64_t>(s) * HOP_REC_B);
+                        k0 = g[0]; k1 = g[1]; k2 = g[2];
+                    }
                     kept = s;
                 }
             }
-            if (s > last_hot && s == kept) { h0 = k0; h1 = k1; h2 = k2; }
+            h0 = k0; h1 = k1; h2 = k2;   // (a lane that is done may hold any record: nothing of it is used)
         }
         // ---- 2. the run: how many of the next 16 class ids lie in [run_lo, run_hi] ----
         const uint32_t a1 = p & ~3u, sh1 = p & 3u;

@@ -778,17 +778,29 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
         const bool walking = has_line && pos < len && row != dead_row;
         // (HOP_SLICE / 16 lanes per line: 8 for 128 bytes)
         constexpr uint32_t LPL = HOP_SLICE / 16u, LINES_PER_LOAD = 64u / LPL;
+        // (what a loading lane has to know of the line it loads for -- where its piece begins and how many bytes are left of it -- goes
+        // through the piece buffer itself, which holds nothing at this point: one 16-byte store per lane and one broadcast read per
+        // load, instead of four shuffles per load)
+        {
+            const uint8_t* mine = data + o0 + pos;
+            const uint64_t mv = reinterpret_cast<uint64_t>(mine);
+            lds_st<u32x4>(slice + lane * 16u, u32x4{static_cast<uint32_t>(mv), static_cast<uint32_t>(mv >> 32), walking ? len - pos : 0u, 0u});
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        u32x4 who[LPL];
+#pragma unroll
+        for (uint32_t r = 0; r < LPL; ++r) who[r] = lds_ld<u32x4>(slice + (lane / LPL + LINES_PER_LOAD * r) * 16u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // (every lane has read before the first piece is stored)
         u32x4 pv[LPL];
 #pragma unroll
         for (uint32_t r = 0; r < LPL; ++r) {
-            const int q = static_cast<int>(lane / LPL + LINES_PER_LOAD * r);
-            const uint64_t oq = __shfl(static_cast<unsigned long long>(o0), q);
-            const uint32_t pq = static_cast<uint32_t>(__shfl(static_cast<int>(pos), q));
-            const uint32_t lq = static_cast<uint32_t>(__shfl(static_cast<int>(walking ? len : 0u), q));
-            const uint32_t at_byte = pq + (lane % LPL) * 16u;
+            const uint32_t at_byte = (lane % LPL) * 16u;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (at_byte < lq) {
-                const uint8_t* src = data + oq + at_byte;
+            if (at_byte < who[r].z) {
+                const uint8_t* src = reinterpret_cast<const uint8_t*>(static_cast<uint64_t>(who[r].y) << 32 | who[r].x) + at_byte;
                 if (src + 16 <= data_end) v = reinterpret_cast<const UnalignedWindow*>(src)->v;
                 else {
                     uint32_t w[4] = {0, 0, 0, 0};
