@@ -1260,7 +1260,11 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
 #ifdef GX_DEV
         stamps = h->dev_stamps;
 #endif
+        // (the pool of chunks the launch's waves share at its end: the slot's chunk counter, as the lane kernel's sorted tiles)
+        b.chunk_ctr = h->d_slots + gx_handle::N_SLOTS + u.slot;
+        b.chunk_base = h->chunk_tickets[u.slot];
         GX_HIP(launch_extract_hop_slices(h->dev, L, hop_image_small, hop_global, h->num_cus, b, stream, stamps));
+        h->chunk_tickets[u.slot] += hop_slices_tickets(b.n, L.nwaves, h->num_cus);
         if (followup) GX_HIP(launch_extract_oversize(h->dev, b, 65535u, 1, stream));   // (lines beyond the 16-bit positions, if the kernel met any)
         done_slot(h, u, stream);
         return;

@@ -195,6 +195,8 @@ hipError_t launch_extract_slices(const GxDev& dev, const GxLds& lds, const uint8
 #endif
 hipError_t launch_extract_hop_slices(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
                                      const GxBatch& b, hipStream_t stream, unsigned long long* stamps = nullptr);
+// (with b.chunk_ctr set the launch draws hop_slices_tickets(...) tickets from it: the pool of chunks its waves share)
+uint32_t hop_slices_tickets(uint64_t n, uint32_t nwaves, int num_cus);
 
 // The resident one-line service (gx_service.hip): one wave, the dense-rows image in LDS, requests through `mailbox` and answers
 // through `answer` (both pinned host memory, device addresses), `state` (pinned): 1 resident, 2 gone.  mode 0: match automaton

@@ -681,13 +681,15 @@ hipError_t launch_slices_t(const GxDev& dev, const GxLds& lds, const uint8_t* ld
 #ifndef GX_HOP_SERVICE
 #define GX_HOP_SERVICE 24u  // finished lanes write their results and take new lines once that many lanes have nothing to walk
 #endif
+constexpr uint64_t HOP_POOL_CHUNK = 64;   // lines per draw from the pool (the last quarter of a batch's lines)
 constexpr uint32_t HOP_SLICE = GX_HOP_SLICE_BYTES, HOP_SLICE_ROW = GX_HOP_SLICE_BYTES + 16u, HOP_SLICE_KEEP = 24;
 
 template <typename OFF>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4)))
 k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const uint8_t* __restrict__ at_global,
                      const uint8_t* __restrict__ data, const OFF* __restrict__ off, uint64_t n, LineOut out, int match_only, int strip_eol,
-                     uint32_t* __restrict__ oversize_flag, uint32_t seq, unsigned long long* __restrict__ stamps) {
+                     uint32_t* __restrict__ oversize_flag, uint32_t seq, unsigned long long* __restrict__ stamps,
+                     uint32_t* __restrict__ pool_ctr, uint32_t pool_base, uint64_t n_static) {
     {
         extern __shared__ __attribute__((aligned(16))) uint8_t gx_smem[];
         const uint4* src = reinterpret_cast<const uint4*>(lds_image);
@@ -699,6 +701,7 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
     // developer build: cycles per phase summed per wave (tools/hop_slice_phases.py): 0 results + handing out lines, 1 loads issued,
     // 2 waiting for them + LDS stores, 3 walk, 4 rounds
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long hs_begin = __builtin_amdgcn_s_memrealtime();
 #define HS_STAMP(slot) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[slot] += now_ - ph_t; ph_t = now_; } while (0)
 #else
 #define HS_STAMP(slot) do { } while (0)
@@ -720,11 +723,19 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
     const uint8_t* fin_g = L.at != 0u ? nullptr : at_global + L.fin_tags;
     const uint32_t fin_lds = L.at;
 
+    // A wave's own range of lines (of the first n_static), then chunks of HOP_POOL_CHUNK lines out of the rest, drawn from a counter
+    // in global memory: lines of 50-2000 bytes make equal shares of LINES unequal shares of bytes -- the last wave of BASELINE
+    // configs[4] ended 8.5 % behind the median one (1 413 against 1 302 us; tools/hop_slice_phases.py).  The counter is never reset:
+    // chunk = ticket - pool_base, and every wave draws until its ticket is past the last chunk -- once: the host knows what the counter
+    // reads when the launch is over (hop_slices_tickets).
     const uint64_t nwaves = static_cast<uint64_t>(gridDim.x) * L.nwaves;
-    const uint64_t per_wave = (n + nwaves - 1) / nwaves;
+    const uint64_t per_wave = (n_static + nwaves - 1) / nwaves;
     const uint64_t wid = static_cast<uint64_t>(blockIdx.x) * L.nwaves + wave;
-    const uint64_t range_lo = min(n, wid * per_wave), range_hi = min(n, range_lo + per_wave);
+    const uint64_t range_lo = min(n_static, wid * per_wave);
+    uint64_t range_hi = min(n_static, range_lo + per_wave);
     uint64_t next = range_lo;   // first line of the range not yet handed to a lane (wave-uniform)
+    const uint64_t pool_chunks = (n - n_static + HOP_POOL_CHUNK - 1) / HOP_POOL_CHUNK;
+    bool pool_done = pool_ctr == nullptr;
 
     bool has_line = false;
     uint64_t i = 0, o0 = 0;
@@ -745,6 +756,16 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
             has_line = false;
         }
         HS_STAMP(5);
+        // ---- the range is used up: the next chunk of the pool ----
+        if (service && next >= range_hi && !pool_done) {
+            uint32_t t = 0u;
+            if (lane == 0u) t = __hip_atomic_fetch_add(pool_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - pool_base;
+            t = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(t)));
+            if (t < pool_chunks) {
+                next = n_static + static_cast<uint64_t>(t) * HOP_POOL_CHUNK;
+                range_hi = min(n, next + HOP_POOL_CHUNK);
+            } else pool_done = true;
+        }
         // ---- free lanes take the next lines of the range, in lane order ----
         const uint64_t free_mask = __ballot(!has_line);
         if (service && free_mask && next < range_hi) {
@@ -769,8 +790,8 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
             next = min(range_hi, next + static_cast<uint64_t>(__popcll(free_mask)));
         }
         if (!__any(has_line)) {
-            if (next >= range_hi) break;
-            continue;  // (only lines for the follow-up launch were handed out: hand out more)
+            if (next >= range_hi && pool_done) break;
+            continue;  // (only lines for the follow-up launch were handed out, or the range is used up: hand out more / draw a chunk)
         }
         HS_STAMP(0);
         // ---- stage the next piece of every lane's line, from the lane's own position: lane l fetches 16 bytes (l & 7) of the
@@ -853,6 +874,8 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
     if (stamps && lane == 0) {
         unsigned long long* st = stamps + 8ull * (static_cast<uint64_t>(blockIdx.x) * L.nwaves + wave);
         for (int q = 0; q < 6; ++q) st[q] = ph[q];
+        st[6] = hs_begin;
+        st[7] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
 }
@@ -860,23 +883,40 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
 }  // namespace
 
 // lds: a layout from plan_hop_slice_launch (gx_api.cpp): the hop tier's tables, per wave a register block and a [64][144]-byte piece buffer
+namespace {
+uint64_t hop_slices_blocks(uint64_t n, uint32_t nwaves, int num_cus) {
+    uint64_t blocks = static_cast<uint64_t>(num_cus);
+    const uint64_t need = (n + 256ull * nwaves - 1) / (256ull * nwaves);
+    return blocks > need ? need : blocks;
+}
+uint64_t hop_slices_static(uint64_t n) { return n - (n / 4) / HOP_POOL_CHUNK * HOP_POOL_CHUNK; }   // the lines outside the pool
+}  // namespace
+
+// what a launch with b.chunk_ctr set adds to that counter: a draw per chunk of the pool and the one draw past it of every wave
+uint32_t hop_slices_tickets(uint64_t n, uint32_t nwaves, int num_cus) {
+    if (n == 0) return 0u;
+    const uint64_t chunks = (n - hop_slices_static(n) + HOP_POOL_CHUNK - 1) / HOP_POOL_CHUNK;
+    return static_cast<uint32_t>(chunks + hop_slices_blocks(n, nwaves, num_cus) * nwaves);
+}
+
 hipError_t launch_extract_hop_slices(const GxDev& dev, const GxLds& lds, const uint8_t* lds_image, const uint8_t* at_global, int num_cus,
                                      const GxBatch& b, hipStream_t stream, unsigned long long* stamps) {
     if (b.n == 0) return hipSuccess;
-    uint64_t blocks = static_cast<uint64_t>(num_cus);
-    const uint64_t need = (b.n + 256ull * lds.nwaves - 1) / (256ull * lds.nwaves);
-    if (blocks > need) blocks = need;
+    const uint64_t blocks = hop_slices_blocks(b.n, lds.nwaves, num_cus);
+    const uint64_t n_static = b.chunk_ctr ? hop_slices_static(b.n) : b.n;
     const dim3 grid(static_cast<unsigned>(blocks)), block(lds.nwaves * 64);
     if (b.offsets64) {
         hipError_t e = allow_full_lds(&k_extract_hop_slices<uint64_t>);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_extract_hop_slices<uint64_t>), grid, block, lds.total_bytes, stream, dev, lds, lds_image, at_global,
-                           static_cast<const uint8_t*>(b.data), static_cast<const uint64_t*>(b.offsets), b.n, line_out(dev, b), (b.match_only != 0 || !dev.has_capture) ? 1 : 0, b.strip_eol, b.oversize_flag, b.seq, stamps);
+                           static_cast<const uint8_t*>(b.data), static_cast<const uint64_t*>(b.offsets), b.n, line_out(dev, b), (b.match_only != 0 || !dev.has_capture) ? 1 : 0, b.strip_eol, b.oversize_flag, b.seq, stamps,
+                           b.chunk_ctr, b.chunk_base, n_static);
     } else {
         hipError_t e = allow_full_lds(&k_extract_hop_slices<uint32_t>);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_extract_hop_slices<uint32_t>), grid, block, lds.total_bytes, stream, dev, lds, lds_image, at_global,
-                           static_cast<const uint8_t*>(b.data), static_cast<const uint32_t*>(b.offsets), b.n, line_out(dev, b), (b.match_only != 0 || !dev.has_capture) ? 1 : 0, b.strip_eol, b.oversize_flag, b.seq, stamps);
+                           static_cast<const uint8_t*>(b.data), static_cast<const uint32_t*>(b.offsets), b.n, line_out(dev, b), (b.match_only != 0 || !dev.has_capture) ? 1 : 0, b.strip_eol, b.oversize_flag, b.seq, stamps,
+                           b.chunk_ctr, b.chunk_base, n_static);
     }
     return hipGetLastError();
 }

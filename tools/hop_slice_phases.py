@@ -38,5 +38,8 @@ for mo in (False, True):
     s = stamps.view(-1, 8).cpu().numpy()
     s = s[s[:, 4] > 0]
     rounds = s[:, 4].sum()
+    t0 = s[:, 6].min()
+    ends = np.sort((s[:, 7] - t0) / 100.0)   # us (100 MHz)
+    print("   waves end (us after the first began): min %.0f  p10 %.0f  median %.0f  p90 %.0f  max %.0f" % (ends[0], ends[len(ends) // 10], ends[len(ends) // 2], ends[len(ends) * 9 // 10], ends[-1]))
     print("match_only=%s: %.3f ms (with stamps), kernel %d, %d waves, %.0f rounds per wave; cycles per round and wave: results %.0f, handing out lines %.0f, loads issued %.0f, wait + LDS stores %.0f, walk %.0f"
           % (mo, e0.elapsed_time(e1), g.stat(25), len(s), rounds / len(s), s[:, 5].sum() / rounds, s[:, 0].sum() / rounds, s[:, 1].sum() / rounds, s[:, 2].sum() / rounds, s[:, 3].sum() / rounds))
