@@ -1736,12 +1736,16 @@ int gx_text_to_jsonl(gx_handle* h, const uint8_t* text, uint64_t size, const cha
         void* d_off2 = handle_scratch(h, 3, (cap + 1) * 4);
         uint64_t* d_n = nullptr;
         uint64_t* d_max = nullptr;
-        GX_HIP(launch_split_lines(src, size, d_off2, 0, cap, nullptr, ws_split, &d_n, stream, &d_max));
-        uint64_t n_and_max[2] = {0, 0};   // (the line count and the longest line are neighbours in the workspace)
-        GX_HIP(hipMemcpyAsync(n_and_max, d_n, 16, hipMemcpyDeviceToHost, stream));
+        // (the split pass also leaves a bit per byte that takes one more byte inside a JSON string, and says whether some byte takes five
+        // more -- a control character --: without one, the sizes pass below does not read the text again)
+        uint16_t* esc_bits = static_cast<uint16_t*>(handle_scratch(h, 7, ((size + 15) / 16) * 2 + 64));
+        GX_HIP(launch_split_lines(src, size, d_off2, 0, cap, nullptr, ws_split, &d_n, stream, &d_max, esc_bits, o.utf8_passthrough ? 1 : 0));
+        uint64_t n_and_max[3] = {0, 0, 0};   // (the line count, the longest line and the control-character word are neighbours in the workspace)
+        GX_HIP(hipMemcpyAsync(n_and_max, d_n, 24, hipMemcpyDeviceToHost, stream));
         GX_HIP(hipStreamSynchronize(stream));
         const uint64_t n = n_and_max[0];
         uint64_t longest = n_and_max[1];
+        const bool sizes_from_bits = n_and_max[2] == 0;
         if (n > cap) {
             d_off2 = handle_scratch(h, 3, (n + 1) * 4);
             GX_HIP(launch_split_lines(src, size, d_off2, 0, n, nullptr, ws_split, &d_n, stream));
@@ -1765,7 +1769,8 @@ int gx_text_to_jsonl(gx_handle* h, const uint8_t* text, uint64_t size, const cha
         // 3. the text
         void* ws_json = handle_scratch(h, 0, jsonl_workspace_bytes(n));
         uint64_t* loff = static_cast<uint64_t*>(handle_scratch(h, 1, (n + 1) * 8));
-        GX_HIP(launch_jsonl_sizes(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, mean_in, loff, ws_json, stream));
+        GX_HIP(launch_jsonl_sizes(tm, b, static_cast<int>(slots), o.utf8_passthrough ? 1 : 0, mean_in, loff, ws_json, stream,
+                                  sizes_from_bits ? reinterpret_cast<const uint32_t*>(esc_bits) : nullptr));
         uint64_t total = 0;
         unsigned long long counts[2] = {0, 0};
         GX_HIP(hipMemcpyAsync(&total, loff + n, 8, hipMemcpyDeviceToHost, stream));

@@ -209,8 +209,11 @@ constexpr uint32_t GX_SERVICE_MAX_BYTES = 56u + 16u * 60u;   // the longest line
 // `workspace` holds split_workspace_bytes(size) bytes; *d_n_lines receives the device address of the line count.
 size_t split_workspace_bytes(uint64_t size);
 // d_max_line (optional): *d_max_line receives the device address of the longest line's length, terminator included.
+// esc_bits (optional, 32-bit offsets): (size + 15) / 16 u16, a bit per byte of the text that takes ONE more byte inside a JSON string, and
+// the word behind the longest line (d_max_line[1]) != 0 when some byte takes five more (a control character): launch_jsonl_sizes.
 hipError_t launch_split_lines(const uint8_t* data, uint64_t size, void* offsets, int offsets64, uint64_t cap_lines, uint8_t* flags,
-                              void* workspace, uint64_t** d_n_lines, hipStream_t stream, uint64_t** d_max_line = nullptr);
+                              void* workspace, uint64_t** d_n_lines, hipStream_t stream, uint64_t** d_max_line = nullptr,
+                              uint16_t* esc_bits = nullptr, int passthrough = 0);
 
 
 // Result materialisation (gx_jsonl.hip): per-extraction JSON templates on the device.  A template is a list of
@@ -228,8 +231,9 @@ size_t jsonl_workspace_bytes(uint64_t n);
 // one line out of / into pinned host memory (gx_kernels.hip: k_extract_one); hipErrorInvalidValue for a line of more than 16 384 code units
 hipError_t launch_extract_one(const GxDev& dev, const uint16_t* units, uint32_t len, const GxBatch& b, hipStream_t stream);
 // mean_in / mean_out: mean bytes per line of input and of output text; they size the LDS staging of the tile kernels
+// esc_bits (optional): launch_split_lines' bits of this batch's text, when its hard word is 0: the sizes come from the bits, not the text
 hipError_t launch_jsonl_sizes(const GxJsonl& tm, const GxBatch& b, int slots, int passthrough, uint32_t mean_in, uint64_t* line_out_off,
-                              void* workspace, hipStream_t stream);
+                              void* workspace, hipStream_t stream, const uint32_t* esc_bits = nullptr);
 hipError_t launch_count_outcomes(const int32_t* match_id, uint64_t n, unsigned long long* d_counts, hipStream_t stream);
 hipError_t launch_pack_results(const int32_t* match_id, const int32_t* caps, uint64_t n, int slots, uint16_t* packed,
                                unsigned long long* d_overflow, hipStream_t stream);

@@ -45,12 +45,15 @@ __device__ __forceinline__ uint32_t pack_hi_bits(uint32_t a, uint32_t b, uint32_
 struct Chunk {
     uint32_t ends;    // bit j: byte j ends a line
     uint32_t high;    // bit j: byte j >= 0x80
+    uint32_t esc;     // ESC: bit j: byte j takes one more byte inside a JSON string ('"', '\\', tab; a byte >= 0x80 unless it passes as it is)
+    uint32_t hard;    // ESC: some byte is a control character other than tab, LF and CR (six bytes in JSON: the sizes pass reads the text then)
 };
 
 // Classify the 16 bytes at `pos` (pos is a multiple of 16; bytes at and beyond `size` do not exist).
 // next_byte = the byte at pos + 16 (or 0 when there is none): decides whether a '\r' in the last slot stands alone.
-__device__ __forceinline__ Chunk classify(const uint8_t* __restrict__ data, uint64_t pos, uint64_t size) {
-    Chunk c{0, 0};
+template <bool ESC = false>
+__device__ __forceinline__ Chunk classify(const uint8_t* __restrict__ data, uint64_t pos, uint64_t size, bool passthrough = false) {
+    Chunk c{0, 0, 0, 0};
     if (pos >= size) return c;
     uint32_t w[4];
     uint32_t next_byte = 0;
@@ -62,16 +65,39 @@ __device__ __forceinline__ Chunk classify(const uint8_t* __restrict__ data, uint
         w[0] = w[1] = w[2] = w[3] = 0;
         for (uint64_t q = pos; q < size; ++q) w[(q - pos) >> 2] |= static_cast<uint32_t>(data[q]) << (((q - pos) & 3) * 8);
     }
-    const uint32_t lf = pack_hi_bits(zero_bytes(w[0] ^ 0x0A0A0A0Au), zero_bytes(w[1] ^ 0x0A0A0A0Au), zero_bytes(w[2] ^ 0x0A0A0A0Au),
-                                     zero_bytes(w[3] ^ 0x0A0A0A0Au));
-    const uint32_t cr = pack_hi_bits(zero_bytes(w[0] ^ 0x0D0D0D0Du), zero_bytes(w[1] ^ 0x0D0D0D0Du), zero_bytes(w[2] ^ 0x0D0D0D0Du),
-                                     zero_bytes(w[3] ^ 0x0D0D0D0Du));
     uint32_t valid = 0xFFFFu;
     if (pos + 16 > size) valid = (1u << (size - pos)) - 1u;  // the zero padding above is neither LF nor CR
+    uint32_t lf, cr;
+    if (ESC) {
+        // one sweep over the four words for everything (on the low seven bits of every byte, where v + 0x7F.. sets bit 7 exactly when
+        // v != 0 and nothing carries); the >= 0x80 mask is not made here (the JSON Lines pipeline asks for no line flags)
+        uint32_t e[4], zl[4], zc[4], hard = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t v = w[q], v7 = v & 0x7F7F7F7Fu;
+            const uint32_t nq = (v7 ^ 0x22222222u) + 0x7F7F7F7Fu, nb = (v7 ^ 0x5C5C5C5Cu) + 0x7F7F7F7Fu, nt = (v7 ^ 0x09090909u) + 0x7F7F7F7Fu;
+            const uint32_t nl = (v7 ^ 0x0A0A0A0Au) + 0x7F7F7F7Fu, nr = (v7 ^ 0x0D0D0D0Du) + 0x7F7F7F7Fu;
+            zl[q] = ~(nl | v);                                               // bit 7 of a byte: LF
+            zc[q] = ~(nr | v);                                               // ... CR
+            e[q] = (~(nq & nb & nt) & ~v) | (passthrough ? 0u : v);          // ... quote, backslash or tab -- or >= 0x80
+            // ... below 0x20 and not tab, LF or CR (LF and CR end lines wherever they stand: never inside a line's text)
+            hard |= ~((v7 + 0x60606060u) | v) & nt & nl & nr;
+        }
+        lf = pack_hi_bits(zl[0], zl[1], zl[2], zl[3]);
+        cr = pack_hi_bits(zc[0], zc[1], zc[2], zc[3]);
+        c.esc = pack_hi_bits(e[0], e[1], e[2], e[3]) & valid;
+        // (the zero padding behind the text's last byte reads as control characters: only whole chunks are asked)
+        c.hard = pos + 16 <= size ? (hard & 0x80808080u) : 0u;
+        if (pos + 16 > size)
+            for (uint64_t q = pos; q < size; ++q) { const uint32_t bt = data[q]; if (bt < 0x20u && bt != 0x09u && bt != 0x0Au && bt != 0x0Du) c.hard = 1u; }
+    } else {
+        lf = pack_hi_bits(zero_bytes(w[0] ^ 0x0A0A0A0Au), zero_bytes(w[1] ^ 0x0A0A0A0Au), zero_bytes(w[2] ^ 0x0A0A0A0Au), zero_bytes(w[3] ^ 0x0A0A0A0Au));
+        cr = pack_hi_bits(zero_bytes(w[0] ^ 0x0D0D0D0Du), zero_bytes(w[1] ^ 0x0D0D0D0Du), zero_bytes(w[2] ^ 0x0D0D0D0Du), zero_bytes(w[3] ^ 0x0D0D0D0Du));
+        c.high = pack_hi_bits(w[0], w[1], w[2], w[3]) & valid;
+    }
     // a CR ends a line unless the next byte is LF
     const uint32_t lf_after = (lf >> 1) | (next_byte == 0x0Au ? 0x8000u : 0u);
     c.ends = (lf | (cr & ~lf_after)) & valid;
-    c.high = pack_hi_bits(w[0], w[1], w[2], w[3]) & valid;
     return c;
 }
 
@@ -148,9 +174,12 @@ __global__ void __launch_bounds__(1024) k_split_scan(const uint32_t* __restrict_
 }
 
 // pass 3: offsets[1 + rank(p)] = p + 1 for every line end p; flags[line] = 1 for lines with a byte >= 0x80
-template <typename OFF>
+// ESC: also esc_bits[chunk] (a bit per byte of the text: Chunk::esc) and *hard_any != 0 when the text holds a control character that
+// JSON writes as six bytes -- what the JSON Lines sizes pass needs to know of the text (gx_jsonl.hip: k_jsonl_sizes_bits)
+template <typename OFF, bool ESC>
 __global__ void __launch_bounds__(SPLIT_THREADS) k_split_write(const uint8_t* __restrict__ data, uint64_t size, const uint64_t* __restrict__ prefix,
-                                                               OFF* __restrict__ offsets, uint64_t cap_lines, uint8_t* __restrict__ flags) {
+                                                               OFF* __restrict__ offsets, uint64_t cap_lines, uint8_t* __restrict__ flags,
+                                                               uint16_t* __restrict__ esc_bits, uint64_t* __restrict__ hard_any, int passthrough) {
     constexpr int WAVES = SPLIT_THREADS / 64;
     __shared__ uint32_t wsum[SPLIT_ITERS][WAVES];
     const uint64_t base = static_cast<uint64_t>(blockIdx.x) * SPLIT_BLOCK_BYTES;
@@ -160,8 +189,18 @@ __global__ void __launch_bounds__(SPLIT_THREADS) k_split_write(const uint8_t* __
     // all of a thread's chunks first (sixteen loads in flight, as in the counting pass), their masks kept in registers; the waves leave
     // their sums per iteration in LDS, and after one barrier every thread knows the rank of each of its chunks
     Chunk c[SPLIT_ITERS];
+    uint32_t hard = 0;
 #pragma unroll
-    for (int it = 0; it < SPLIT_ITERS; ++it) c[it] = classify(data, base + (static_cast<uint64_t>(it) * SPLIT_THREADS + threadIdx.x) * 16, size);
+    for (int it = 0; it < SPLIT_ITERS; ++it) {
+        const uint64_t pos = base + (static_cast<uint64_t>(it) * SPLIT_THREADS + threadIdx.x) * 16;
+        c[it] = classify<ESC>(data, pos, size, passthrough != 0);
+        if (ESC) {
+            if (pos < size) esc_bits[pos >> 4] = static_cast<uint16_t>(c[it].esc);
+            hard |= c[it].hard;
+            c[it].esc = 0u; c[it].hard = 0u;   // (nothing below reads them: not kept)
+        }
+    }
+    if (ESC && hard) *hard_any = 1;   // (plain stores of the same value: no atomic)
     uint32_t before[SPLIT_ITERS];   // line ends in the wave's chunks of the iteration before this thread's
 #pragma unroll
     for (int it = 0; it < SPLIT_ITERS; ++it) {
@@ -248,17 +287,18 @@ __global__ void __launch_bounds__(256) k_split_max(const OFF* __restrict__ offse
 
 size_t split_workspace_bytes(uint64_t size) {
     const uint64_t nblocks = (size + SPLIT_BLOCK_BYTES - 1) / SPLIT_BLOCK_BYTES;
-    return static_cast<size_t>((nblocks + 1) * 4 + (nblocks + 2) * 8 + 64);
+    return static_cast<size_t>((nblocks + 1) * 4 + (nblocks + 3) * 8 + 64);
 }
 
-// workspace: [total_ends u64][n_lines u64][max_line u64][prefix u64 * nblocks][counts u32 * nblocks]
+// workspace: [total_ends u64][n_lines u64][max_line u64][hard_any u64][prefix u64 * nblocks][counts u32 * nblocks]
 hipError_t launch_split_lines(const uint8_t* data, uint64_t size, void* offsets, int offsets64, uint64_t cap_lines, uint8_t* flags,
-                              void* workspace, uint64_t** d_n_lines, hipStream_t stream, uint64_t** d_max_line) {
+                              void* workspace, uint64_t** d_n_lines, hipStream_t stream, uint64_t** d_max_line, uint16_t* esc_bits, int passthrough) {
     const uint64_t nblocks = (size + SPLIT_BLOCK_BYTES - 1) / SPLIT_BLOCK_BYTES;
     uint64_t* total_ends = static_cast<uint64_t*>(workspace);
     uint64_t* n_lines = total_ends + 1;
     uint64_t* max_line = total_ends + 2;
-    uint64_t* prefix = total_ends + 3;
+    uint64_t* hard_any = total_ends + 3;
+    uint64_t* prefix = total_ends + 4;
     uint32_t* counts = reinterpret_cast<uint32_t*>(prefix + nblocks + 1);
     *d_n_lines = n_lines;
     if (d_max_line) *d_max_line = max_line;
@@ -267,22 +307,32 @@ hipError_t launch_split_lines(const uint8_t* data, uint64_t size, void* offsets,
         e = hipMemsetAsync(flags, 0, cap_lines, stream);
         if (e != hipSuccess) return e;
     }
+    if (esc_bits) {
+        e = hipMemsetAsync(hard_any, 0, 8, stream);
+        if (e != hipSuccess) return e;
+    }
     if (nblocks == 0) {
-        e = hipMemsetAsync(workspace, 0, 24, stream);  // no ends, no lines
+        e = hipMemsetAsync(workspace, 0, 32, stream);  // no ends, no lines
         if (e != hipSuccess) return e;
         return hipMemsetAsync(offsets, 0, offsets64 ? 8 : 4, stream);
     }
     if (nblocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_split_count, dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, counts);
     hipLaunchKernelGGL(k_split_scan, dim3(1), dim3(1024), 0, stream, counts, prefix, nblocks, total_ends);
-    if (offsets64) {
-        hipLaunchKernelGGL(k_split_write<uint64_t>, dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, prefix,
-                           static_cast<uint64_t*>(offsets), cap_lines, flags);
+    if (esc_bits && (offsets64 || flags)) return hipErrorInvalidValue;   // (the escape bits come with 32-bit offsets and without line flags)
+    if (esc_bits) {
+        hipLaunchKernelGGL((k_split_write<uint32_t, true>), dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, prefix,
+                           static_cast<uint32_t*>(offsets), cap_lines, flags, esc_bits, hard_any, passthrough);
+        hipLaunchKernelGGL(k_split_finish<uint32_t>, dim3(1), dim3(1), 0, stream, data, size, total_ends, static_cast<uint32_t*>(offsets), cap_lines,
+                           n_lines);
+    } else if (offsets64) {
+        hipLaunchKernelGGL((k_split_write<uint64_t, false>), dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, prefix,
+                           static_cast<uint64_t*>(offsets), cap_lines, flags, nullptr, nullptr, 0);
         hipLaunchKernelGGL(k_split_finish<uint64_t>, dim3(1), dim3(1), 0, stream, data, size, total_ends, static_cast<uint64_t*>(offsets), cap_lines,
                            n_lines);
     } else {
-        hipLaunchKernelGGL(k_split_write<uint32_t>, dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, prefix,
-                           static_cast<uint32_t*>(offsets), cap_lines, flags);
+        hipLaunchKernelGGL((k_split_write<uint32_t, false>), dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, prefix,
+                           static_cast<uint32_t*>(offsets), cap_lines, flags, nullptr, nullptr, 0);
         hipLaunchKernelGGL(k_split_finish<uint32_t>, dim3(1), dim3(1), 0, stream, data, size, total_ends, static_cast<uint32_t*>(offsets), cap_lines,
                            n_lines);
     }

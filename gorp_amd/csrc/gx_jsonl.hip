@@ -1025,6 +1025,77 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
 #endif
 }
 
+// ---- the sizes pass without the text (gx_text_to_jsonl): the split pass left a bit per byte of the text that takes one more byte
+// inside a JSON string (gx_ingest.hip: Chunk::esc), and the text holds no byte that takes five more -- a capture's escaped length is
+// its length plus the bits of its range.  One lane per line, no staging: a line's offsets, its capture row and the few words of bits
+// its captures cover come through the caches (neighbouring lanes, neighbouring lines).  What it leaves is what k_jsonl_tile<.., false,
+// ..> leaves, value for value: sizes[i], split[i] / split_at[i] (where the write pass's two waves divide the line's text, chosen by
+// the same rule) and tile_flags[tile] (1: nothing in the tile's captures takes an escape). ----
+template <typename OFF>
+__global__ void __launch_bounds__(256) k_jsonl_sizes_bits(JsonlTemplates tm, const OFF* __restrict__ off, uint64_t n, const int32_t* __restrict__ match_id,
+                                                         const int32_t* __restrict__ caps, int slots, const uint32_t* __restrict__ bits,
+                                                         uint32_t* __restrict__ sizes, uint32_t* __restrict__ split, uint32_t* __restrict__ split_at,
+                                                         uint32_t* __restrict__ tile_flags) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t tiles = (n + 63) >> 6;
+    const uint64_t wstride = static_cast<uint64_t>(gridDim.x) * (blockDim.x >> 6);
+    // the bits of the text's bytes [x, y)
+    auto count = [&](uint64_t x, uint64_t y) -> uint32_t {
+        if (x >= y) return 0u;
+        const uint64_t wa = x >> 5, wb = (y - 1) >> 5;
+        const uint32_t first = 0xFFFFFFFFu << (x & 31u), last = 0xFFFFFFFFu >> (31u - static_cast<uint32_t>((y - 1) & 31u));
+        if (wa == wb) return __popc(bits[wa] & first & last);
+        uint32_t c = __popc(bits[wa] & first) + __popc(bits[wb] & last);
+        for (uint64_t w = wa + 1; w < wb; ++w) c += __popc(bits[w]);
+        return c;
+    };
+    for (uint64_t tile = static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < tiles; tile += wstride) {
+        const uint64_t i = (tile << 6) + lane;
+        bool dirty = false;
+        if (i < n) {
+            const int32_t k = match_id[i];
+            uint32_t total = 0u;
+            if (k >= 0) {
+                const uint64_t o0 = off[i], o1 = off[i + 1];
+                const int32_t* cp = caps + i * static_cast<uint64_t>(slots);
+                const uint32_t s0 = tm.seg_off[k], s1 = tm.seg_off[k + 1], fixed_k = tm.fixed_len[k];
+                const uint32_t half = ((fixed_k + static_cast<uint32_t>(o1 - o0)) * SPLIT_AT_256) >> 8;
+                const bool splittable = s1 - s0 < 0xFFFFu;
+                uint32_t sp_m = s1, sp_q = 0u, cum = 0u, lit_cum = 0u, before = 0u;
+                total = fixed_k;
+                for (uint32_t s = s0; s < s1; ++s) {
+                    const uint32_t ll = tm.lit_len[s];
+                    const int32_t g = tm.group[s];
+                    int32_t cb = -1, ce = -1;
+                    if (g >= 0) { cb = cp[2 * g]; ce = cp[2 * g + 1]; }
+                    lit_cum += ll;
+                    const bool text = g >= 0 && cb >= 0;
+                    const uint32_t len = text ? static_cast<uint32_t>(ce - cb) : 0u;
+                    const uint32_t e = ll + (g < 0 ? 0u : (text ? len + 2u : 4u));
+                    if (splittable && sp_m == s1 && cum + e > half) {
+                        sp_m = s;
+                        const uint32_t at = cum + ll + 1u;
+                        sp_q = (text && half > at) ? ((half - at) & ~15u) : 0u;
+                        if (sp_q > (len & ~15u)) sp_q = len & ~15u;
+                    }
+                    cum += e;
+                    if (g < 0) { if (s == sp_m) before = lit_cum + (total - fixed_k); continue; }
+                    if (cb < 0) { total += 4u; if (s == sp_m) before = lit_cum + (total - fixed_k); continue; }
+                    const uint64_t x = o0 + static_cast<uint32_t>(cb);
+                    if (s == sp_m) before = lit_cum + (total - fixed_k) + 1u + sp_q + count(x, x + sp_q);
+                    total += 2u + len + count(x, x + len);
+                }
+                split[i] = sp_m < s1 ? before : total;
+                split_at[i] = sp_m < s1 ? ((sp_m - s0) << 16 | (sp_q >> 4)) : 0xFFFF0000u;
+                dirty = total != cum;
+            }
+            sizes[i] = total;
+        }
+        const bool any_dirty = __ballot(dirty) != 0ull;
+        if (lane == 0u) tile_flags[tile] = any_dirty ? 0u : 1u;
+    }
+}
+
 // ---- exclusive scan u32[n] -> u64[n + 1] (out[n] = total): block sums, one-workgroup scan, block scans ----
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;
@@ -1291,7 +1362,7 @@ hipError_t launch_jsonl_tile(const JsonlTemplates& t, const JsonlTileCfg& cfg, c
 // Pass 1 + scan: line_out_off[0..n] (device, u64) receives the output offset of every line's text and, in
 // [n], the total size.  workspace: jsonl_workspace_bytes(n).
 hipError_t launch_jsonl_sizes(const GxJsonl& tm, const GxBatch& b, int slots, int passthrough, uint32_t mean_in, uint64_t* line_out_off,
-                              void* workspace, hipStream_t stream) {
+                              void* workspace, hipStream_t stream, const uint32_t* esc_bits) {
     if (b.n == 0) return hipMemsetAsync(line_out_off, 0, 8, stream);
     const uint64_t nblocks = (b.n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     uint32_t* sizes = static_cast<uint32_t*>(workspace);
@@ -1302,7 +1373,15 @@ hipError_t launch_jsonl_sizes(const GxJsonl& tm, const GxBatch& b, int slots, in
     JsonlTemplates t{tm.seg_off, tm.lit_off, tm.lit_len, tm.group, tm.fixed_len, tm.lits};
     JsonlTileCfg cfg;
     if (!plan_jsonl_tile(tm, slots, mean_in, 0, &cfg)) return hipErrorInvalidValue;
-    {
+    if (esc_bits && !b.offsets64) {
+        // (the text's escape bits are there and say that no byte takes more than one: no look at the text)
+        const uint64_t tiles = (b.n + 63) >> 6;
+        const uint64_t blocks = std::min<uint64_t>((tiles + 3) / 4, 256u * 16u);
+        hipLaunchKernelGGL(k_jsonl_sizes_bits<uint32_t>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, t, static_cast<const uint32_t*>(b.offsets), b.n,
+                           b.match_id, b.caps, slots, esc_bits, sizes, split, split_at, tile_flags);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    } else {
         const uint32_t lds = cfg.stage0 + cfg.waves * (cfg.in_bytes + cfg.out_bytes + cfg.caps_bytes);
         const uint64_t tiles = (b.n + 63) >> 6;
         uint64_t blocks = std::min<uint64_t>((tiles + cfg.waves - 1) / cfg.waves, 256u * 4u);

@@ -280,3 +280,63 @@ def test_many_capture_groups(n_groups):
     for t in text.decode("utf-8").split("\n")[:50]:
         if t:
             assert len(json.loads(t)) == n_groups + 1
+
+
+def _text_to_jsonl_vs_oracle(gorp, orc, lines, rng, id_as=None, utf8_passthrough=False):
+    raw = b"".join(ln + rng.choice([b"\n", b"\r\n", b"\r"]) for ln in lines)
+    text, n_lines, n_matched, n_exc = gorp.text_to_jsonl(raw, id_as=id_as, utf8_passthrough=utf8_passthrough)
+    _, want_lines, _ = O.read_lines(raw)
+    assert n_lines == len(want_lines)
+    omid, ocaps = orc.extract_batch(*lines_to_csr(want_lines), nthreads=4)
+    xs = gorp.getExtractions()
+    want, _ = O.results_to_jsonl(want_lines, omid, ocaps, [x.getName() for x in xs], [x._extractorNames for x in xs],
+                                 [x.getExtra() for x in xs], id_as=id_as, utf8_passthrough=utf8_passthrough)
+    assert text == want, (text[:200], want[:200])
+    assert n_matched == int((omid >= 0).sum()) and n_exc == int((omid <= -2).sum())
+
+
+def test_text_to_jsonl_sizes_from_the_split_pass_bits():
+    """gx_text_to_jsonl's sizes come from the split pass's escape bits (k_jsonl_sizes_bits: no second look at the text) unless the
+    text holds a control character that JSON writes as six bytes; both ways the text is the oracle's, byte for byte: quotes,
+    backslashes and tabs at every alignment of a capture, bytes >= 0x80 with and without utf8_passthrough, nested extractors (their
+    bytes are counted twice), null groups, lines that match nothing, and the control characters that send the batch back to the
+    sizes pass that reads the text."""
+    from test_gpu_parity import oracle_for
+    definition = [
+        FlattenedExtraction("kv", [["extractor", "key", [["pattern", "[a-z]+"]]], ["text", "="],
+                                   ["extractor", "outer", [["text", "<"], ["extractor", "inner", [["pattern", "[^>]*"]]], ["text", ">"]]],
+                                   ["pattern", "( (x))?"], ["extractor", "rest", [["pattern", ".*"]]]]),
+        FlattenedExtraction("msg", [["text", "msg "], ["extractor", "body", [["pattern", ".+"]]]]),
+    ]
+    gorp, orc = Gorp.construct(definition), oracle_for(definition)
+    rng = random.Random(77)
+    special = ['"', "\\", "\t", "\x80", "\xe9", "\xff", "a", "b", " ", "~", "\x7f"]
+
+    def noise(n, alphabet):
+        return "".join(rng.choice(alphabet) for _ in range(n))
+
+    def make_lines(alphabet, count):
+        out = []
+        for _ in range(count):
+            r = rng.random()
+            if r < 0.45:
+                out.append("%s=<%s>%s%s" % (noise(rng.randint(1, 9), "abcxyz"), noise(rng.randint(0, 90), [c for c in alphabet if c != ">"]),
+                                            rng.choice(["", " x"]), noise(rng.randint(0, 60), alphabet)))
+            elif r < 0.85:
+                out.append("msg " + noise(rng.randint(1, 300), alphabet))
+            else:
+                out.append(noise(rng.randint(0, 40), alphabet))
+        return [ln.encode("latin-1") for ln in out]
+
+    for pt in (False, True):
+        _text_to_jsonl_vs_oracle(gorp, orc, make_lines(special, 6000), rng, id_as="rule", utf8_passthrough=pt)
+    # one control character somewhere in 6000 lines, and many of them: the sizes pass reads the text
+    for extra in (["\x0b"], ["\x01", "\x08", "\x0c", "\x1f"] * 3):
+        lines = make_lines(special, 6000)
+        if len(extra) == 1:
+            lines[4321] = b"msg a\x0bb"
+        else:
+            lines += make_lines(special + extra, 3000)
+        _text_to_jsonl_vs_oracle(gorp, orc, lines, rng, id_as=None, utf8_passthrough=False)
+    # nothing to escape at all (every tile's flag says so: the write pass copies the captures as they are)
+    _text_to_jsonl_vs_oracle(gorp, orc, make_lines(list("abcdefgh 0123456789-_/"), 5000), rng)

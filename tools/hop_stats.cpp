@@ -87,6 +87,17 @@ int main(int argc, char** argv) {
                double(exact_cold) / lines, double(run_full) / lines, double(run_bytes) / lines);
         printf("  iterations at states whose record is not in LDS: %.1f per line with %u hot records, %.1f with %u; block-of-4 switches %.1f per line; moves out of such a state %.1f per line, %.1f to state + 1, %.1f to state + 1..3\n",
                double(cold_small) / lines, H.small.n_hot, double(cold_full) / lines, H.full.n_hot, double(cold_switch) / lines, double(cold_moves) / lines, double(next_is_plus1) / lines, double(in_block4) / lines);
+        {
+            // the tile kernel: a wave walks 64 consecutive lines until the last of them is through
+            size_t tiles = 0, sum_max = 0, sum_all = 0;
+            for (size_t t0 = 0; t0 + 64 <= traces.size(); t0 += 64) {
+                size_t mx = 0;
+                for (size_t q = 0; q < 64; ++q) { mx = std::max(mx, traces[t0 + q].size()); sum_all += traces[t0 + q].size(); }
+                sum_max += mx; ++tiles;
+            }
+            if (tiles) printf("  tiles of 64 consecutive lines: %.1f iterations until the last lane is through, %.1f per lane on average (lanes busy %.0f %%)\n",
+                              double(sum_max) / tiles, double(sum_all) / (64.0 * tiles), 100.0 * sum_all / (64.0 * sum_max));
+        }
         if (pass == 0) {
             // ---- the hop slice kernel's rounds, replayed: 64 lanes, pieces of 128 bytes from a lane's own position, a lane comes back 24 bytes
             // before the end of its piece; service (results + new lines) when 16 lanes are idle.  leave_at: the walk of a round ends
