@@ -269,7 +269,7 @@ def main():
         one = fmt if callable(fmt) else (lambda: step(fmt))
         t_spin = time.perf_counter() + spin_ms * 1e-3
         while time.perf_counter() < t_spin:
-            for _ in range(16):
+            for _ in range(4):   # (short groups: ranks leave the spin-up within a group's time of each other, and wait that long at the barrier)
                 one()
             torch.cuda.current_stream().synchronize()
         for _ in range(warmup):
