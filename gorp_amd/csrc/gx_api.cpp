@@ -1178,6 +1178,52 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
             return;
         }
     }
+    if (b.wide && !b.state_out && b.match_only >= 0 && b.n > 0 && (line_bytes_hint > 255u || uneven || kernel == GX_KERNEL_HOP_SLICES) &&
+        (kernel == GX_KERNEL_AUTO || kernel == GX_KERNEL_HOP_SLICES)) {
+        // UTF-16 code units, long or uneven lines, hop tables: the hop slice kernel reads the units itself (a loading lane fetches 16
+        // units and stages their low bytes) and flags the lines that hold a unit above 0xFF, as the tile kernel above.
+        const bool mo = b.match_only != 0 || !h->T.has_capture;
+        if ((mo ? h->hop_mo_ok : h->hop_ok) && plan_hop_slice_launch(h, &L, mo)) {
+            {
+              std::lock_guard<std::mutex> pool_lock(h->slot_mu);
+              if (!h->pool) {
+                hipMemPoolProps props{};
+                props.allocType = hipMemAllocationTypePinned;
+                props.handleTypes = hipMemHandleTypeNone;
+                props.location.type = hipMemLocationTypeDevice;
+                props.location.id = h->device;
+                GX_HIP(hipMemPoolCreate(&h->pool, &props));
+                uint64_t keep = ~0ull;
+                GX_HIP(hipMemPoolSetAttribute(h->pool, hipMemPoolAttrReleaseThreshold, &keep));
+              }
+            }
+            void* flags = nullptr;
+            GX_HIP(hipMallocFromPoolAsync(&flags, b.n + 64, h->pool, stream));
+            hipError_t e = hipSuccess;
+            {
+                std::lock_guard<std::mutex> lock(h->slot_mu);
+                const SlotUse u = take_slot(h, b, stream);
+                const bool followup = plan_followup(h, b, u, 65535u, launched);
+                if (launched) { launched->limit = 65535u; launched->by_length = 1; }
+                b.wide_flags = static_cast<uint8_t*>(flags);
+                b.wide_any = h->d_slots + 2 * gx_handle::N_SLOTS + u.slot;
+                b.chunk_ctr = h->d_slots + gx_handle::N_SLOTS + u.slot;
+                b.chunk_base = h->chunk_tickets[u.slot];
+                h->last_kernel = GX_KERNEL_HOP_SLICES;
+                e = launch_extract_hop_slices(h->dev, L, static_cast<const uint8_t*>(mo ? h->d_lds_image_hop_mo_small : h->d_lds_image_hop_small),
+                                              static_cast<const uint8_t*>(mo ? h->d_hop_mo_global : h->d_hop_global), h->num_cus, b, stream);
+                if (e == hipSuccess) {
+                    h->chunk_tickets[u.slot] += hop_slices_tickets(b.n, L.nwaves, h->num_cus);
+                    e = launch_extract_flagged(h->dev, b, static_cast<const uint8_t*>(flags), stream, b.wide_any);
+                }
+                if (e == hipSuccess && followup) e = launch_extract_oversize(h->dev, b, 65535u, 1, stream);
+                if (e == hipSuccess) done_slot(h, u, stream);
+            }
+            (void)hipFreeAsync(flags, stream);
+            GX_HIP(e);
+            return;
+        }
+    }
     if (b.wide && !b.state_out && b.match_only >= 0 && kernel != GX_KERNEL_PER_LINE && b.n > 0) {
         // UTF-16 code units: their low bytes through the byte kernels, then the lines that hold a unit above 0xFF again through
         // the per-line walk (gx_kernels.hip: k_narrow_units).  The copy is n units long -- the one thing this path has to

@@ -684,12 +684,15 @@ hipError_t launch_slices_t(const GxDev& dev, const GxLds& lds, const uint8_t* ld
 constexpr uint64_t HOP_POOL_CHUNK = 64;   // lines per draw from the pool (the last quarter of a batch's lines)
 constexpr uint32_t HOP_SLICE = GX_HOP_SLICE_BYTES, HOP_SLICE_ROW = GX_HOP_SLICE_BYTES + 16u, HOP_SLICE_KEEP = 24;
 
-template <typename OFF>
+// WIDE: `data` holds UTF-16 code units (offsets in units): a loading lane fetches 16 units = 32 bytes and stages their low bytes; a line
+// with a unit above 0xFF is flagged (wide_flags[i], *wide_any) for the per-line walk on the units (k_extract_flagged), as the tile kernel's.
+template <typename OFF, bool WIDE>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4)))
 k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const uint8_t* __restrict__ at_global,
                      const uint8_t* __restrict__ data, const OFF* __restrict__ off, uint64_t n, LineOut out, int match_only, int strip_eol,
                      uint32_t* __restrict__ oversize_flag, uint32_t seq, unsigned long long* __restrict__ stamps,
-                     uint32_t* __restrict__ pool_ctr, uint32_t pool_base, uint64_t n_static) {
+                     uint32_t* __restrict__ pool_ctr, uint32_t pool_base, uint64_t n_static,
+                     uint8_t* __restrict__ wide_flags, uint32_t* __restrict__ wide_any) {
     {
         extern __shared__ __attribute__((aligned(16))) uint8_t gx_smem[];
         const uint4* src = reinterpret_cast<const uint4*>(lds_image);
@@ -717,7 +720,7 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t slice = L.stage + wave * L.stage_bytes;
     const uint32_t regs = L.regs + wave * L.regs_wave_bytes + 128u + lane * 2u;
-    const uint8_t* data_end = data + static_cast<uint64_t>(off[n]);
+    const uint8_t* data_end = data + (static_cast<uint64_t>(off[n]) << (WIDE ? 1 : 0));
     // (match only: the tables are the match automaton's, a state's info word is its first accepting extraction)
     const uint32_t row0 = match_only ? L.m_start : L.u_start, dead_row = match_only ? L.m_dead : L.u_dead;
     const uint8_t* fin_g = L.at != 0u ? nullptr : at_global + L.fin_tags;
@@ -741,6 +744,7 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
     uint64_t i = 0, o0 = 0;
     uint32_t len = 0, pos = 0, row = row0;
     const uint32_t my = slice + lane * HOP_SLICE_ROW;
+    bool line_wide = false;   // WIDE: the line holds a unit above 0xFF
 
     for (;;) {
         // ---- finished lanes write their results once a quarter of the wave is idle (k_extract_slices says why) ----
@@ -753,6 +757,10 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
             if (row >= H.n_hot) info = *reinterpret_cast<const int32_t*>(H.rows + (static_cast<uint64_t>(row) * H.row_bytes + H.info_off));
             if (match_only) out.id(i, info);
             else write_row<TIER_HOP>(out, i, info, fin_lds, fin_g, regs, len, T.max_groups);
+            if (WIDE) {   // (a flagged line's result is the per-line walk's to write again)
+                wide_flags[i] = line_wide ? 1 : 0;
+                if (line_wide) __hip_atomic_store(wide_any, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             has_line = false;
         }
         HS_STAMP(5);
@@ -775,7 +783,9 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
                 i = cand;
                 o0 = off[i];
                 int64_t len64 = static_cast<int64_t>(static_cast<uint64_t>(off[i + 1]) - o0);
-                if (strip_eol) len64 = trim_eol(data + o0, len64);
+                if (strip_eol) len64 = WIDE ? trim_eol(reinterpret_cast<const uint16_t*>(data) + o0, len64) : trim_eol(data + o0, len64);
+                line_wide = false;
+                if (WIDE && len64 > 65535) wide_flags[i] = 0;   // (the follow-up launch walks its units)
                 if (len64 > 65535) {
                     // positions are 16-bit in the register block: such a line is left to the follow-up launch of the per-line
                     // kernel (not walked here: its 96 capture registers would give every lane of this kernel a scratch frame)
@@ -803,7 +813,7 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
         // through the piece buffer itself, which holds nothing at this point: one 16-byte store per lane and one broadcast read per
         // load, instead of four shuffles per load)
         {
-            const uint8_t* mine = data + o0 + pos;
+            const uint8_t* mine = data + ((o0 + pos) << (WIDE ? 1 : 0));
             const uint64_t mv = reinterpret_cast<uint64_t>(mine);
             lds_st<u32x4>(slice + lane * 16u, u32x4{static_cast<uint32_t>(mv), static_cast<uint32_t>(mv >> 32), walking ? len - pos : 0u, 0u});
         }
@@ -816,21 +826,63 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();   // (every lane has read before the first piece is stored)
         u32x4 pv[LPL];
+        uint32_t high_or[LPL];   // WIDE: the high bytes of the units a lane loaded, ORed
 #pragma unroll
         for (uint32_t r = 0; r < LPL; ++r) {
-            const uint32_t at_byte = (lane % LPL) * 16u;
+            const uint32_t at_byte = (lane % LPL) * 16u;   // (in staged bytes = code units)
             u32x4 v = {0u, 0u, 0u, 0u};
+            high_or[r] = 0u;
             if (at_byte < who[r].z) {
-                const uint8_t* src = reinterpret_cast<const uint8_t*>(static_cast<uint64_t>(who[r].y) << 32 | who[r].x) + at_byte;
-                if (src + 16 <= data_end) v = reinterpret_cast<const UnalignedWindow*>(src)->v;
-                else {
-                    uint32_t w[4] = {0, 0, 0, 0};
-                    for (int b = 0; b < 16; ++b)
-                        if (src + b < data_end) w[b >> 2] |= static_cast<uint32_t>(src[b]) << ((b & 3) * 8);
-                    v = u32x4{w[0], w[1], w[2], w[3]};
+                const uint8_t* src = reinterpret_cast<const uint8_t*>(static_cast<uint64_t>(who[r].y) << 32 | who[r].x) + (at_byte << (WIDE ? 1 : 0));
+                if (!WIDE) {
+                    if (src + 16 <= data_end) v = reinterpret_cast<const UnalignedWindow*>(src)->v;
+                    else {
+                        uint32_t w[4] = {0, 0, 0, 0};
+                        for (int b = 0; b < 16; ++b)
+                            if (src + b < data_end) w[b >> 2] |= static_cast<uint32_t>(src[b]) << ((b & 3) * 8);
+                        v = u32x4{w[0], w[1], w[2], w[3]};
+                    }
+                } else {
+                    u32x4 a = {0u, 0u, 0u, 0u}, b2 = {0u, 0u, 0u, 0u};   // units 0-7, 8-15
+                    if (src + 32 <= data_end) { a = reinterpret_cast<const UnalignedWindow*>(src)->v; b2 = reinterpret_cast<const UnalignedWindow*>(src + 16)->v; }
+                    else {
+                        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                        for (int q = 0; q < 32; ++q)
+                            if (src + q < data_end) w[q >> 2] |= static_cast<uint32_t>(src[q]) << ((q & 3) * 8);
+                        a = u32x4{w[0], w[1], w[2], w[3]}; b2 = u32x4{w[4], w[5], w[6], w[7]};
+                    }
+                    // the low bytes of two units per dword -> four staged bytes per pair of dwords (v_perm_b32: bytes 0, 2 of each)
+                    v = u32x4{__builtin_amdgcn_perm(a.y, a.x, 0x06040200u), __builtin_amdgcn_perm(a.w, a.z, 0x06040200u),
+                              __builtin_amdgcn_perm(b2.y, b2.x, 0x06040200u), __builtin_amdgcn_perm(b2.w, b2.z, 0x06040200u)};
+                    // (only the units of the line count: the units behind its end are another line's)
+                    const uint32_t units_left = who[r].z - at_byte;   // >= 1
+                    uint32_t hi[8] = {a.x, a.y, a.z, a.w, b2.x, b2.y, b2.z, b2.w};
+                    uint32_t acc = 0u;
+#pragma unroll
+                    for (uint32_t q = 0; q < 8u; ++q) {
+                        uint32_t m = 0xFF00FF00u;
+                        if (2u * q + 1u >= units_left) m = 2u * q >= units_left ? 0u : 0x0000FF00u;
+                        acc |= hi[q] & m;
+                    }
+                    high_or[r] = acc;
                 }
             }
             pv[r] = v;
+        }
+        if (WIDE) {
+            // which lines hold a unit above 0xFF: eight loaders per line and instruction -> one byte of the instruction's ballot per line;
+            // the ballots go through the piece buffer's first 64 bytes (read again below, before the pieces are stored)
+#pragma unroll
+            for (uint32_t r = 0; r < LPL; ++r) {
+                const uint64_t bal = __builtin_amdgcn_ballot_w64(high_or[r] != 0u);
+                if (lane == 0u) lds_st<u32x2>(slice + 8u * r, u32x2{static_cast<uint32_t>(bal), static_cast<uint32_t>(bal >> 32)});
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lds_ld<uint8_t>(slice + lane) != 0u && walking) line_wide = true;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         HS_STAMP(1);
 #pragma unroll
@@ -905,20 +957,21 @@ hipError_t launch_extract_hop_slices(const GxDev& dev, const GxLds& lds, const u
     const uint64_t blocks = hop_slices_blocks(b.n, lds.nwaves, num_cus);
     const uint64_t n_static = b.chunk_ctr ? hop_slices_static(b.n) : b.n;
     const dim3 grid(static_cast<unsigned>(blocks)), block(lds.nwaves * 64);
-    if (b.offsets64) {
-        hipError_t e = allow_full_lds(&k_extract_hop_slices<uint64_t>);
+    auto go = [&](auto kernel, auto offsets) -> hipError_t {
+        hipError_t e = allow_full_lds(kernel);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_extract_hop_slices<uint64_t>), grid, block, lds.total_bytes, stream, dev, lds, lds_image, at_global,
-                           static_cast<const uint8_t*>(b.data), static_cast<const uint64_t*>(b.offsets), b.n, line_out(dev, b), (b.match_only != 0 || !dev.has_capture) ? 1 : 0, b.strip_eol, b.oversize_flag, b.seq, stamps,
-                           b.chunk_ctr, b.chunk_base, n_static);
-    } else {
-        hipError_t e = allow_full_lds(&k_extract_hop_slices<uint32_t>);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_extract_hop_slices<uint32_t>), grid, block, lds.total_bytes, stream, dev, lds, lds_image, at_global,
-                           static_cast<const uint8_t*>(b.data), static_cast<const uint32_t*>(b.offsets), b.n, line_out(dev, b), (b.match_only != 0 || !dev.has_capture) ? 1 : 0, b.strip_eol, b.oversize_flag, b.seq, stamps,
-                           b.chunk_ctr, b.chunk_base, n_static);
+        hipLaunchKernelGGL(kernel, grid, block, lds.total_bytes, stream, dev, lds, lds_image, at_global, static_cast<const uint8_t*>(b.data), offsets, b.n, line_out(dev, b),
+                           (b.match_only != 0 || !dev.has_capture) ? 1 : 0, b.strip_eol, b.oversize_flag, b.seq, stamps, b.chunk_ctr, b.chunk_base, n_static,
+                           b.wide_flags, b.wide_any);
+        return hipGetLastError();
+    };
+    if (b.wide) {   // UTF-16 code units (b.wide_flags / b.wide_any set by the caller: gx_api.cpp)
+        if (!b.wide_flags || !b.wide_any) return hipErrorInvalidValue;
+        if (b.offsets64) return go(&k_extract_hop_slices<uint64_t, true>, static_cast<const uint64_t*>(b.offsets));
+        return go(&k_extract_hop_slices<uint32_t, true>, static_cast<const uint32_t*>(b.offsets));
     }
-    return hipGetLastError();
+    if (b.offsets64) return go(&k_extract_hop_slices<uint64_t, false>, static_cast<const uint64_t*>(b.offsets));
+    return go(&k_extract_hop_slices<uint32_t, false>, static_cast<const uint32_t*>(b.offsets));
 }
 
 // b: the UTF-16 batch (data = code units, offsets in units).  bytes: room for the batch's units as bytes, addressed like the

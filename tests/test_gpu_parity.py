@@ -1536,3 +1536,54 @@ def test_match_batch_states_from_the_tile_kernel(flags):
             assert got[i] == orc.match(raw[i].decode("latin-1")), (flags, i, raw[i][:60])
         first, _ = gorp.extract_batch(data, offsets, match_only=True)
         assert [g[0] if g else -1 for g in got] == first.tolist()
+
+
+def test_utf16_long_lines_on_the_hop_slice_kernel():
+    """gx_batch_opts.utf16 with long or uneven lines on a definition that has hop tables: the hop slice kernel reads the code units
+    itself (no narrowed copy), flags the lines that hold a unit above 0xFF -- at the start, in the middle and at the very end of a
+    line, in a piece boundary's overlap -- for the per-line walk, and leaves lines of more than 65 535 units to the follow-up launch;
+    dense / u16 rows, match only, terminators, 64-bit offsets, all against the oracle on the Strings."""
+    rng = random.Random(53)
+    rules, meta = W.syslog_definition(200, seed=9)
+    gorp, orc = Gorp.construct(rules), oracle_for(rules)
+    assert gorp.stat(14) > 0                                 # hop tables
+    data8, off8, _ = W.syslog_lines(meta, 1500, seed=4, min_len=50, max_len=2000, corrupt_frac=0.1)
+    lines = [bytes(data8[off8[i]:off8[i + 1]]).decode("latin-1") for i in range(1500)]
+    for i in range(0, 1500, 5):                              # units above 0xFF here and there (a matched line then only if a value takes them)
+        s = lines[i]
+        at = rng.choice([0, len(s) // 2, max(0, len(s) - 1), min(len(s), 104), min(len(s), 127), min(len(s), 128)])
+        lines[i] = s[:at] + rng.choice(["中", "Ā", "\U0001F600", "￿"]) + s[at:]
+    for i in range(3, 1500, 17):
+        lines[i] = lines[i].replace("a", "é")          # Latin-1 above 0x7F: still a byte
+    lines += ["", "中", lines[1] + " " + "x" * 70000, "中" + lines[2] + "y" * 66000]
+    units = [np.frombuffer(s.encode("utf-16-le", "surrogatepass"), dtype=np.uint16) for s in lines]
+    data = np.concatenate([u for u in units if len(u)])
+    offsets = np.zeros(len(lines) + 1, np.uint32)
+    offsets[1:] = np.cumsum([len(u) for u in units])
+    want = [orc.extract(s) for s in lines]
+    G_ = gorp.max_groups
+    omid = np.array([w[0] for w in want], np.int32)
+    ocaps = np.full((len(lines), 2 * G_), -1, np.int32)
+    for i, w in enumerate(want):
+        for g, span in enumerate(w[1]):
+            if span is not None:
+                ocaps[i, 2 * g], ocaps[i, 2 * g + 1] = span
+    assert (omid >= 0).sum() > 800
+    for kernel in (N.GX_KERNEL_AUTO, N.GX_KERNEL_HOP_SLICES):
+        mid, caps = gorp.extract_batch(data, offsets, kernel=kernel, uneven=2)
+        assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps), kernel
+        assert gorp.stat(25) == 6                            # the hop slice kernel, on the units
+    m64, c64 = gorp.extract_batch(data, offsets.astype(np.uint64), uneven=2)
+    assert np.array_equal(m64, omid) and np.array_equal(c64, ocaps)
+    rows, over = gorp.extract_batch(data, offsets, compact=True, uneven=2)
+    cm, cc = G.unpack_rows(rows)
+    big = ocaps > 65534
+    assert over == int(big.sum()) and np.array_equal(cm, omid) and np.array_equal(cc, np.where(big, 65534, ocaps))
+    mo, _ = gorp.extract_batch(data, offsets, match_only=True, uneven=2)
+    assert np.array_equal(mo, np.where(omid <= -2, -2 - omid, omid))
+    term = [s + rng.choice(["\n", "\r\n", "\r"]) for s in lines[:500]]
+    tu = [np.frombuffer(s.encode("utf-16-le", "surrogatepass"), dtype=np.uint16) for s in term]
+    to = np.zeros(len(term) + 1, np.uint32)
+    to[1:] = np.cumsum([len(u) for u in tu])
+    m3, c3 = gorp.extract_batch(np.concatenate(tu), to, strip_eol=True, uneven=2)
+    assert np.array_equal(m3, omid[:500]) and np.array_equal(c3, ocaps[:500])

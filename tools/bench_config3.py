@@ -44,17 +44,20 @@ o = o.to(torch.uint32)
 n = base_n * reps
 mean_len = total / base_n
 print("lines", n, "mean length %.1f B" % mean_len, "total %.2f GB" % (total * reps / 1e9))
+utf16 = bool(int(os.environ.get("GX_BENCH_UTF16", "0")))   # the same lines as UTF-16 code units (what a JVM holds)
+if utf16:
+    d = d.to(torch.int16)
 mid = torch.empty(n, dtype=torch.int32, device="cuda")
 caps = torch.empty((n, 2 * g.max_groups), dtype=torch.int32, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 for mo in (False, True):
     for _ in range(2):
-        g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), match_only=mo, stream=st, no_sync=True, line_bytes_hint=int(mean_len + 0.999), kernel=kernel, uneven=uneven)
+        g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), match_only=mo, stream=st, no_sync=True, line_bytes_hint=int(mean_len + 0.999), kernel=kernel, uneven=uneven, utf16=utf16)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5):
-        g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), match_only=mo, stream=st, no_sync=True, line_bytes_hint=int(mean_len + 0.999), kernel=kernel, uneven=uneven)
+        g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), match_only=mo, stream=st, no_sync=True, line_bytes_hint=int(mean_len + 0.999), kernel=kernel, uneven=uneven, utf16=utf16)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
     print("match_only=%s: %.3f ms for %d lines -> %.2f G lines/s, %.0f GB/s" % (mo, ms, n, n / ms / 1e6, total * reps / ms / 1e6))
