@@ -34,7 +34,9 @@ variants = [(0, 0, False), (N.GX_CREATE_TIER_L2, 0, False), (0, N.GX_KERNEL_SLIC
             # round 4: the same lines as UTF-16 code units (a fourth entry: the tile kernel reads the units itself on the dense-rows-in-LDS
             # and hop tiers; a few units above 0xFF are mixed in below, whose lines the per-line walk takes again)
             (0, 0, False, True), (0, 0, True, True), (0, 0, 2, True), (N.GX_CREATE_TIER_HOP, N.GX_KERNEL_HOPS, False, True), (N.GX_CREATE_TIER_HOP, N.GX_KERNEL_HOPS, 2, True),
-            (N.GX_CREATE_TIER_L2, 0, True, True)]
+            (N.GX_CREATE_TIER_L2, 0, True, True),
+            # ... and by the hop slice kernel
+            (N.GX_CREATE_TIER_HOP, N.GX_KERNEL_HOP_SLICES, False, True), (N.GX_CREATE_TIER_HOP, N.GX_KERNEL_HOP_SLICES, True, True), (N.GX_CREATE_TIER_HOP, N.GX_KERNEL_HOP_SLICES, 2, True)]
 done = bad = 0
 while done < n_defs:
     exts = [FlattenedExtraction("e%d" % i, TC.gen_pieces(rng)) for i in range(rng.randint(1, 5))]
