@@ -1587,3 +1587,22 @@ def test_utf16_long_lines_on_the_hop_slice_kernel():
     to[1:] = np.cumsum([len(u) for u in tu])
     m3, c3 = gorp.extract_batch(np.concatenate(tu), to, strip_eol=True, uneven=2)
     assert np.array_equal(m3, omid[:500]) and np.array_equal(c3, ocaps[:500])
+
+
+def test_hop_slice_kernel_pool_of_chunks_at_every_size():
+    """The hop slice kernel hands the last quarter of a batch's lines out in chunks of 64 from a counter (equal shares of lines are
+    unequal shares of bytes): batches of every size around the chunk and grid boundaries -- no pool at all, one chunk, a last chunk
+    that is not full, more chunks than waves -- and many launches on one stream (the counter is never reset: chunk = ticket - base),
+    against the oracle."""
+    rules, meta = W.syslog_definition(64, seed=3)
+    gorp, orc = Gorp.construct(rules, flags=N.GX_CREATE_TIER_HOP), oracle_for(rules)
+    data, offsets, _ = W.syslog_lines(meta, 70000, seed=8, min_len=30, max_len=600)
+    omid, ocaps = orc.extract_batch(data, offsets, nthreads=8)
+    for n in (1, 2, 63, 64, 65, 255, 256, 257, 319, 320, 321, 511, 512, 513, 4095, 4097, 33333, 70000):
+        d, o = data[:int(offsets[n])], offsets[:n + 1]
+        mid, caps = gorp.extract_batch(d, o, kernel=N.GX_KERNEL_HOP_SLICES)
+        assert gorp.stat(25) == 6
+        assert np.array_equal(mid, omid[:n]) and np.array_equal(caps, ocaps[:n]), n
+        rows, over = gorp.extract_batch(d, o, kernel=N.GX_KERNEL_HOP_SLICES, compact=True)
+        cm, cc = G.unpack_rows(rows)
+        assert over == 0 and np.array_equal(cm, omid[:n]) and np.array_equal(cc, ocaps[:n]), n
