@@ -74,6 +74,23 @@ while done < n_defs:
             for t in text.decode("utf-8").split("\n")[:20]:
                 if t:
                     json.loads(t)
+    # the whole pipeline on the same lines as one text (gx_text_to_jsonl: the sizes from the split pass's escape bits, or -- a control
+    # character in the text -- from the text): line feeds and carriage returns inside a line would be line ends there
+    tl = [ln.replace("\n", "\t").replace("\r", "\t").encode("latin-1") for ln in lines]
+    if done % 3 == 0:
+        tl = [ln.replace(b"\x00", b"a").replace(b"\x07", b"b").replace(b"\x1f", b"c") for ln in tl]   # (no six-byte escapes: the bits path)
+    rawtext = b"\n".join(tl) + b"\n"
+    orc = O.OracleGorp([q[0] for q in built], [q[1] for q in built])
+    _, wl, _ = O.read_lines(rawtext)
+    omid, ocaps = orc.extract_batch(*lines_to_csr(wl), nthreads=4)
+    for id_as, pt in ((None, False), ("_k", True)):
+        text2, nl, nm, nx = gorp.text_to_jsonl(rawtext, id_as=id_as, utf8_passthrough=pt)
+        want2, _ = O.results_to_jsonl(wl, omid, ocaps, [x.getName() for x in xs], [x._extractorNames for x in xs], [x.getExtra() for x in xs],
+                                      id_as=id_as, utf8_passthrough=pt)
+        if text2 != want2 or nl != len(wl) or nm != int((omid >= 0).sum()):
+            bad += 1
+            print("TEXT MISMATCH definition", done, "id_as", id_as, "passthrough", pt, len(text2), len(want2))
+            print("  definition:", [(e.name, e.pieces) for e in exts])
     done += 1
     if done % 50 == 0:
         print("jsonl fuzz: %d definitions so far, %d mismatches" % (done, bad), flush=True)
