@@ -15,6 +15,11 @@
 // relaxed atomics, wave-wide look-back) took 1.30 ms with 32 KiB blocks and 3.7 ms with 128 KiB blocks -- the polling
 // of the predecessors' words goes to the memory side of the XCDs' L2s and competes with the text stream; and pass 1
 // spilling its 16-bit chunk masks for pass 3 (text read once, 2-byte stores) took 1.02 ms.  Neither was kept.
+// A third one in round 4: one workgroup of 1 024 threads per CU, a MiB per step, the line-end masks of its 64 chunks per thread kept in 32
+// registers, ONE barrier of the grid per step (eight for 2 GB), offsets written out of the masks -- the text read once, no look-back:
+// 0.84 ms against 0.79 for the two sweeps: while a step's offsets are written (1 024 LDS-ranked chunks per thread-row) and the grid
+// waits at its barrier nothing is loaded, and the masks leave no registers to load the next step's text under them (with the escape
+// bits the kernel spilled: 7.5 ms for the pipeline).  Not kept.
 // Round 3 (per kernel before: count 328 us = 6.1 TB/s, scan 95 us, write 546 us): the scan takes 4096 counts per step and one barrier
 // (52 us); the write pass classifies a thread's eight chunks first -- sixteen loads in flight, as in the counting pass -- and needs
 // one barrier per block instead of sixteen; the wave scans run on DPP, not through LDS (491 us).  Measured and not kept: the byte
