@@ -1411,6 +1411,26 @@ struct DevBuf {
     void alloc(size_t bytes) { GX_HIP(hipMalloc(&p, bytes ? bytes : 16)); }
 };
 
+// gx_split_lines has no handle to keep its workspace on (an eighth of the text since the text-read-once split: a hipMalloc + hipFree
+// of 250 MB per call were 0.1 ms of a 0.7 ms call): one workspace per device, kept between calls, grown as needed; a call holds the
+// lock while it runs (calls on one device take turns: they would on the device anyway).
+struct SplitScratch {
+    std::mutex mu;
+    void* p[64] = {};
+    size_t cap[64] = {};
+    void* get(int dev, size_t bytes) {   // (the caller holds mu)
+        if (dev < 0 || dev >= 64) throw GxError(GX_E_DEVICE, "gx_split_lines: device ordinal beyond 63");
+        if (cap[dev] < bytes) {
+            if (p[dev]) { (void)hipFree(p[dev]); p[dev] = nullptr; cap[dev] = 0; }
+            const size_t want = bytes + bytes / 8 + 256;
+            GX_HIP(hipMalloc(&p[dev], want));
+            cap[dev] = want;
+        }
+        return p[dev];
+    }
+};
+SplitScratch g_split_scratch;
+
 // the handle's scratch buffer `which`, at least `bytes` long (the caller holds h->mu)
 void* handle_scratch(gx_handle* h, int which, size_t bytes) {
     if (h->scratch_cap[which] < bytes) {
@@ -1580,8 +1600,11 @@ int gx_split_lines_max(const uint8_t* bytes, uint64_t size, void* offsets, uint6
             throw GxError(GX_E_DEVICE, "no HIP device available (libgorp_hip needs a gfx950 GPU; there is no CPU fallback)");
         hipStream_t stream = static_cast<hipStream_t>(o.stream);
         const size_t off_w = o.offsets64 ? 8 : 4;
-        DevBuf ws, d_bytes, d_off, d_flags;
-        ws.alloc(split_workspace_bytes(size));
+        DevBuf d_bytes, d_off, d_flags;
+        int dev = 0;
+        GX_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> ws_lock(g_split_scratch.mu);
+        struct { void* p; } ws{g_split_scratch.get(dev, split_workspace_bytes(size))};
         const uint8_t* src = bytes;
         void* dst_off = offsets;
         uint8_t* dst_flags = line_flags;
@@ -1784,7 +1807,7 @@ int gx_text_to_jsonl(gx_handle* h, const uint8_t* text, uint64_t size, const cha
         uint64_t* d_max = nullptr;
         // (the split pass also leaves a bit per byte that takes one more byte inside a JSON string, and says whether some byte takes five
         // more -- a control character --: without one, the sizes pass below does not read the text again)
-        uint16_t* esc_bits = static_cast<uint16_t*>(handle_scratch(h, 7, ((size + 15) / 16) * 2 + 64));
+        uint16_t* esc_bits = static_cast<uint16_t*>(handle_scratch(h, 7, ((size + 32767) / 32768) * 4096 + 64));   // (written in whole blocks of 32 KiB of text)
         GX_HIP(launch_split_lines(src, size, d_off2, 0, cap, nullptr, ws_split, &d_n, stream, &d_max, esc_bits, o.utf8_passthrough ? 1 : 0));
         uint64_t n_and_max[3] = {0, 0, 0};   // (the line count, the longest line and the control-character word are neighbours in the workspace)
         GX_HIP(hipMemcpyAsync(n_and_max, d_n, 24, hipMemcpyDeviceToHost, stream));

@@ -209,7 +209,7 @@ constexpr uint32_t GX_SERVICE_MAX_BYTES = 56u + 16u * 60u;   // the longest line
 // `workspace` holds split_workspace_bytes(size) bytes; *d_n_lines receives the device address of the line count.
 size_t split_workspace_bytes(uint64_t size);
 // d_max_line (optional): *d_max_line receives the device address of the longest line's length, terminator included.
-// esc_bits (optional, 32-bit offsets): (size + 15) / 16 u16, a bit per byte of the text that takes ONE more byte inside a JSON string, and
+// esc_bits (optional, 32-bit offsets, no line flags): 2 048 u16 per 32 KiB of text (whole blocks: ((size + 32767) / 32768) * 4096 bytes), a bit per byte of the text that takes ONE more byte inside a JSON string, and
 // the word behind the longest line (d_max_line[1]) != 0 when some byte takes five more (a control character): launch_jsonl_sizes.
 hipError_t launch_split_lines(const uint8_t* data, uint64_t size, void* offsets, int offsets64, uint64_t cap_lines, uint8_t* flags,
                               void* workspace, uint64_t** d_n_lines, hipStream_t stream, uint64_t** d_max_line = nullptr,

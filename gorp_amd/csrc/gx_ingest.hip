@@ -7,14 +7,18 @@
 // extract kernels strip the terminator when gx_batch_opts.strip_eol is set (gx_kernels.hip: trim_eol), so
 // match offsets stay relative to the start of the line exactly as for a Java String.
 //
-// Three bandwidth-bound passes (the buffer is read twice): count line ends per block -> exclusive scan of the
-// block counts -> write offsets (and, optionally, a per-line flag "contains a byte >= 0x80": such a line is
-// only Latin-1 if the file is; UTF-8 input needs the UTF-16 route).
+// Three bandwidth-bound passes: count line ends per block -> exclusive scan of the block counts -> write offsets.  Since the end
+// of round 4 the text is read ONCE when no line flags are asked for: the counting pass leaves its masks of line ends (16 bits per
+// 16-byte chunk: an eighth of a byte per byte of text, stored 16 bytes per thread through LDS) and the writing pass reads those --
+// 0.57 ms of kernels per 2 GB against 0.78 (count 0.44 instead of 0.32, write 0.08 instead of 0.41; gx_split_lines 0.55 against 0.79 ms, its workspace kept between calls).
+// With line flags (a per-line "contains a byte >= 0x80": such a line is only Latin-1 if the file is; UTF-8 input needs the UTF-16
+// route) the writing pass still sweeps the text (k_split_write).
 // Two single-sweep variants were built and measured in round 2 (10 M x 201-byte lines; this version: 0.96 ms):
 // one pass with decoupled look-back between workgroups (tickets, one 64-bit [tag | count] word per block, agent-scope
 // relaxed atomics, wave-wide look-back) took 1.30 ms with 32 KiB blocks and 3.7 ms with 128 KiB blocks -- the polling
 // of the predecessors' words goes to the memory side of the XCDs' L2s and competes with the text stream; and pass 1
-// spilling its 16-bit chunk masks for pass 3 (text read once, 2-byte stores) took 1.02 ms.  Neither was kept.
+// spilling its 16-bit chunk masks for pass 3 (text read once, 2-byte stores) took 1.02 ms.  Neither was kept (the second came back in
+// round 4 with 16-byte stores: above).
 // A third one in round 4: one workgroup of 1 024 threads per CU, a MiB per step, the line-end masks of its 64 chunks per thread kept in 32
 // registers, ONE barrier of the grid per step (eight for 2 GB), offsets written out of the masks -- the text read once, no look-back:
 // 0.84 ms against 0.79 for the two sweeps: while a step's offsets are written (1 024 LDS-ranked chunks per thread-row) and the grid
@@ -140,6 +144,75 @@ __global__ void __launch_bounds__(SPLIT_THREADS) k_split_count(const uint8_t* __
         uint32_t t = 0;
         for (int w = 0; w < SPLIT_THREADS / 64; ++w) t += wsum[w];
         block_counts[blockIdx.x] = t;
+    }
+}
+
+// pass 1 of the text-read-once split (no line flags): line ends per block AND the blocks' masks of line ends, 16 bits per 16-byte chunk
+// in chunk order (end_masks[pos / 16]), so that pass 3 reads an eighth of a byte per byte of text instead of the text.  The masks go
+// through LDS and leave as 16-byte stores (a thread's eight masks sit 512 bytes apart; two-byte stores were what made this layout
+// lose in round 2: 1.02 against 0.96 ms).  ESC: the escape bits of the text the same way (Chunk::esc: gx_jsonl.hip's sizes pass).
+template <bool ESC>
+__global__ void __launch_bounds__(SPLIT_THREADS) k_split_count_masks(const uint8_t* __restrict__ data, uint64_t size, uint32_t* __restrict__ block_counts,
+                                                                      uint16_t* __restrict__ end_masks, uint16_t* __restrict__ esc_bits,
+                                                                      uint64_t* __restrict__ hard_any, int passthrough) {
+    constexpr int CHUNKS = SPLIT_THREADS * SPLIT_ITERS;   // 2 048 per block
+    __shared__ uint32_t wsum[SPLIT_THREADS / 64];
+    __shared__ __attribute__((aligned(16))) uint16_t tr[(ESC ? 2 : 1) * CHUNKS];
+    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * SPLIT_BLOCK_BYTES;
+    uint32_t cnt = 0, hard = 0;
+#pragma unroll
+    for (int it = 0; it < SPLIT_ITERS; ++it) {
+        const uint64_t pos = base + (static_cast<uint64_t>(it) * SPLIT_THREADS + threadIdx.x) * 16;
+        const Chunk c = classify<ESC>(data, pos, size, passthrough != 0);
+        cnt += __popc(c.ends);
+        tr[it * SPLIT_THREADS + threadIdx.x] = static_cast<uint16_t>(c.ends);
+        if (ESC) { tr[CHUNKS + it * SPLIT_THREADS + threadIdx.x] = static_cast<uint16_t>(c.esc); hard |= c.hard; }
+    }
+    if (ESC && hard) *hard_any = 1;   // (plain stores of the same value: no atomic)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t inc = wave_inclusive_sum(cnt, lane);
+    if (lane == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < SPLIT_THREADS / 64; ++w) t += wsum[w];
+        block_counts[blockIdx.x] = t;
+    }
+    // eight masks = 16 bytes per thread, in chunk order (the arrays are 16-byte aligned and padded to whole blocks)
+    const uint64_t first = static_cast<uint64_t>(blockIdx.x) * CHUNKS + 8u * threadIdx.x;
+    *reinterpret_cast<uint4*>(end_masks + first) = *reinterpret_cast<const uint4*>(tr + 8u * threadIdx.x);
+    if (ESC) *reinterpret_cast<uint4*>(esc_bits + first) = *reinterpret_cast<const uint4*>(tr + CHUNKS + 8u * threadIdx.x);
+}
+
+// pass 3 of the same: offsets[1 + rank(p)] = p + 1 for every line end p, out of the masks: a thread takes eight chunks in a row
+template <typename OFF>
+__global__ void __launch_bounds__(SPLIT_THREADS) k_split_write_masks(const uint16_t* __restrict__ end_masks, const uint64_t* __restrict__ prefix,
+                                                                     OFF* __restrict__ offsets, uint64_t cap_lines) {
+    constexpr int CHUNKS = SPLIT_THREADS * SPLIT_ITERS;
+    __shared__ uint32_t wsum[SPLIT_THREADS / 64];
+    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * SPLIT_BLOCK_BYTES;
+    if (blockIdx.x == 0 && threadIdx.x == 0) offsets[0] = 0;
+    const uint4 v = *reinterpret_cast<const uint4*>(end_masks + static_cast<uint64_t>(blockIdx.x) * CHUNKS + 8u * threadIdx.x);
+    const uint32_t mw[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t cnt = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_inclusive_sum(cnt, lane);
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < SPLIT_THREADS / 64; ++q) if (q < wave) wbase += wsum[q];
+    uint64_t k = prefix[blockIdx.x] + wbase + inc - cnt;   // line ends before this thread's first chunk
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        uint32_t e = (q & 1) ? (mw[q >> 1] >> 16) : (mw[q >> 1] & 0xFFFFu);
+        const uint64_t pos = base + (8ull * threadIdx.x + q) * 16;
+        while (e) {
+            const uint32_t j = __ffs(e) - 1u;
+            e &= e - 1u;
+            ++k;  // the line that starts after this end
+            if (k <= cap_lines) offsets[k] = static_cast<OFF>(pos + j + 1);
+        }
     }
 }
 
@@ -296,7 +369,8 @@ __global__ void __launch_bounds__(256) k_split_max(const OFF* __restrict__ offse
 
 size_t split_workspace_bytes(uint64_t size) {
     const uint64_t nblocks = (size + SPLIT_BLOCK_BYTES - 1) / SPLIT_BLOCK_BYTES;
-    return static_cast<size_t>((nblocks + 1) * 4 + (nblocks + 3) * 8 + 64);
+    // (+ the masks of line ends of the text-read-once split: 4 KiB per block = an eighth of the text, 16-byte aligned)
+    return static_cast<size_t>((nblocks + 1) * 4 + (nblocks + 3) * 8 + 64 + nblocks * 4096 + 32);
 }
 
 // workspace: [total_ends u64][n_lines u64][max_line u64][hard_any u64][prefix u64 * nblocks][counts u32 * nblocks]
@@ -326,9 +400,28 @@ hipError_t launch_split_lines(const uint8_t* data, uint64_t size, void* offsets,
         return hipMemsetAsync(offsets, 0, offsets64 ? 8 : 4, stream);
     }
     if (nblocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (esc_bits && (offsets64 || flags)) return hipErrorInvalidValue;   // (the escape bits come with 32-bit offsets and without line flags)
+    if (!flags) {
+        // the text is read once: pass 1 leaves the masks of line ends (and the escape bits), pass 3 reads those
+        uint16_t* end_masks = reinterpret_cast<uint16_t*>((reinterpret_cast<uintptr_t>(counts + nblocks + 1) + 15u) & ~static_cast<uintptr_t>(15u));
+        if (esc_bits) hipLaunchKernelGGL(k_split_count_masks<true>, dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, counts, end_masks,
+                                         esc_bits, hard_any, passthrough);
+        else hipLaunchKernelGGL(k_split_count_masks<false>, dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, counts, end_masks,
+                                nullptr, nullptr, 0);
+        hipLaunchKernelGGL(k_split_scan, dim3(1), dim3(1024), 0, stream, counts, prefix, nblocks, total_ends);
+        if (offsets64) {
+            hipLaunchKernelGGL(k_split_write_masks<uint64_t>, dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, end_masks, prefix,
+                               static_cast<uint64_t*>(offsets), cap_lines);
+            hipLaunchKernelGGL(k_split_finish<uint64_t>, dim3(1), dim3(1), 0, stream, data, size, total_ends, static_cast<uint64_t*>(offsets), cap_lines, n_lines);
+        } else {
+            hipLaunchKernelGGL(k_split_write_masks<uint32_t>, dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, end_masks, prefix,
+                               static_cast<uint32_t*>(offsets), cap_lines);
+            hipLaunchKernelGGL(k_split_finish<uint32_t>, dim3(1), dim3(1), 0, stream, data, size, total_ends, static_cast<uint32_t*>(offsets), cap_lines, n_lines);
+        }
+        goto longest;
+    }
     hipLaunchKernelGGL(k_split_count, dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, counts);
     hipLaunchKernelGGL(k_split_scan, dim3(1), dim3(1024), 0, stream, counts, prefix, nblocks, total_ends);
-    if (esc_bits && (offsets64 || flags)) return hipErrorInvalidValue;   // (the escape bits come with 32-bit offsets and without line flags)
     if (esc_bits) {
         hipLaunchKernelGGL((k_split_write<uint32_t, true>), dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, prefix,
                            static_cast<uint32_t*>(offsets), cap_lines, flags, esc_bits, hard_any, passthrough);
@@ -345,6 +438,7 @@ hipError_t launch_split_lines(const uint8_t* data, uint64_t size, void* offsets,
         hipLaunchKernelGGL(k_split_finish<uint32_t>, dim3(1), dim3(1), 0, stream, data, size, total_ends, static_cast<uint32_t*>(offsets), cap_lines,
                            n_lines);
     }
+longest:
     if (d_max_line) {
         e = hipMemsetAsync(max_line, 0, 8, stream);
         if (e != hipSuccess) return e;
