@@ -1604,7 +1604,7 @@ int gx_split_lines_max(const uint8_t* bytes, uint64_t size, void* offsets, uint6
         int dev = 0;
         GX_HIP(hipGetDevice(&dev));
         std::lock_guard<std::mutex> ws_lock(g_split_scratch.mu);
-        struct { void* p; } ws{g_split_scratch.get(dev, split_workspace_bytes(size))};
+        struct { void* p; } ws{g_split_scratch.get(dev, split_workspace_bytes(size, line_flags != nullptr))};
         const uint8_t* src = bytes;
         void* dst_off = offsets;
         uint8_t* dst_flags = line_flags;

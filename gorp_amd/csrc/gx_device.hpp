@@ -207,7 +207,7 @@ constexpr uint32_t GX_SERVICE_MAX_BYTES = 56u + 16u * 60u;   // the longest line
 
 // Line ingestion (gx_ingest.hip): raw bytes -> CSR offsets of readLine()-style lines, terminators included.
 // `workspace` holds split_workspace_bytes(size) bytes; *d_n_lines receives the device address of the line count.
-size_t split_workspace_bytes(uint64_t size);
+size_t split_workspace_bytes(uint64_t size, bool with_flags = false);
 // d_max_line (optional): *d_max_line receives the device address of the longest line's length, terminator included.
 // esc_bits (optional, 32-bit offsets, no line flags): 2 048 u16 per 32 KiB of text (whole blocks: ((size + 32767) / 32768) * 4096 bytes), a bit per byte of the text that takes ONE more byte inside a JSON string, and
 // the word behind the longest line (d_max_line[1]) != 0 when some byte takes five more (a control character): launch_jsonl_sizes.

@@ -7,12 +7,12 @@
 // extract kernels strip the terminator when gx_batch_opts.strip_eol is set (gx_kernels.hip: trim_eol), so
 // match offsets stay relative to the start of the line exactly as for a Java String.
 //
-// Three bandwidth-bound passes: count line ends per block -> exclusive scan of the block counts -> write offsets.  Since the end
-// of round 4 the text is read ONCE when no line flags are asked for: the counting pass leaves its masks of line ends (16 bits per
-// 16-byte chunk: an eighth of a byte per byte of text, stored 16 bytes per thread through LDS) and the writing pass reads those --
-// 0.57 ms of kernels per 2 GB against 0.78 (count 0.44 instead of 0.32, write 0.08 instead of 0.41; gx_split_lines 0.55 against 0.79 ms, its workspace kept between calls).
-// With line flags (a per-line "contains a byte >= 0x80": such a line is only Latin-1 if the file is; UTF-8 input needs the UTF-16
-// route) the writing pass still sweeps the text (k_split_write).
+// Three bandwidth-bound passes: count line ends per block -> exclusive scan of the block counts -> write offsets (and, optionally,
+// a per-line flag "contains a byte >= 0x80": such a line is only Latin-1 if the file is; UTF-8 input needs the UTF-16 route).  Since
+// the end of round 4 the text is read ONCE: the counting pass leaves its masks of line ends (16 bits per 16-byte chunk: an eighth of
+// a byte per byte of text, stored 16 bytes per thread through LDS; with line flags the masks of the bytes >= 0x80 as well) and the
+// writing pass reads those -- 0.57 ms of kernels per 2 GB against 0.78 when pass 3 swept the text again (count 0.44 instead of 0.32,
+// write 0.08 instead of 0.41; gx_split_lines 0.55 against 0.79 ms, its workspace kept between calls).
 // Two single-sweep variants were built and measured in round 2 (10 M x 201-byte lines; this version: 0.96 ms):
 // one pass with decoupled look-back between workgroups (tickets, one 64-bit [tag | count] word per block, agent-scope
 // relaxed atomics, wave-wide look-back) took 1.30 ms with 32 KiB blocks and 3.7 ms with 128 KiB blocks -- the polling
@@ -126,38 +126,18 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t) {
     return v;
 }
 
-// pass 1: line ends per block
-__global__ void __launch_bounds__(SPLIT_THREADS) k_split_count(const uint8_t* __restrict__ data, uint64_t size, uint32_t* __restrict__ block_counts) {
-    __shared__ uint32_t wsum[SPLIT_THREADS / 64];
-    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * SPLIT_BLOCK_BYTES;
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int it = 0; it < SPLIT_ITERS; ++it) {
-        const uint64_t pos = base + (static_cast<uint64_t>(it) * SPLIT_THREADS + threadIdx.x) * 16;
-        cnt += __popc(classify(data, pos, size).ends);
-    }
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t inc = wave_inclusive_sum(cnt, lane);
-    if (lane == 63) wsum[threadIdx.x >> 6] = inc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
-        for (int w = 0; w < SPLIT_THREADS / 64; ++w) t += wsum[w];
-        block_counts[blockIdx.x] = t;
-    }
-}
-
-// pass 1 of the text-read-once split (no line flags): line ends per block AND the blocks' masks of line ends, 16 bits per 16-byte chunk
+// pass 1: line ends per block AND the blocks' masks of line ends, 16 bits per 16-byte chunk
 // in chunk order (end_masks[pos / 16]), so that pass 3 reads an eighth of a byte per byte of text instead of the text.  The masks go
 // through LDS and leave as 16-byte stores (a thread's eight masks sit 512 bytes apart; two-byte stores were what made this layout
 // lose in round 2: 1.02 against 0.96 ms).  ESC: the escape bits of the text the same way (Chunk::esc: gx_jsonl.hip's sizes pass).
-template <bool ESC>
+// HIGH (not with ESC): the masks of the bytes >= 0x80 as well (high_masks: the line flags of pass 3).
+template <bool ESC, bool HIGH>
 __global__ void __launch_bounds__(SPLIT_THREADS) k_split_count_masks(const uint8_t* __restrict__ data, uint64_t size, uint32_t* __restrict__ block_counts,
                                                                       uint16_t* __restrict__ end_masks, uint16_t* __restrict__ esc_bits,
-                                                                      uint64_t* __restrict__ hard_any, int passthrough) {
+                                                                      uint64_t* __restrict__ hard_any, int passthrough, uint16_t* __restrict__ high_masks) {
     constexpr int CHUNKS = SPLIT_THREADS * SPLIT_ITERS;   // 2 048 per block
     __shared__ uint32_t wsum[SPLIT_THREADS / 64];
-    __shared__ __attribute__((aligned(16))) uint16_t tr[(ESC ? 2 : 1) * CHUNKS];
+    __shared__ __attribute__((aligned(16))) uint16_t tr[((ESC || HIGH) ? 2 : 1) * CHUNKS];
     const uint64_t base = static_cast<uint64_t>(blockIdx.x) * SPLIT_BLOCK_BYTES;
     uint32_t cnt = 0, hard = 0;
 #pragma unroll
@@ -167,6 +147,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) k_split_count_masks(const uint8
         cnt += __popc(c.ends);
         tr[it * SPLIT_THREADS + threadIdx.x] = static_cast<uint16_t>(c.ends);
         if (ESC) { tr[CHUNKS + it * SPLIT_THREADS + threadIdx.x] = static_cast<uint16_t>(c.esc); hard |= c.hard; }
+        if (HIGH) tr[CHUNKS + it * SPLIT_THREADS + threadIdx.x] = static_cast<uint16_t>(c.high);
     }
     if (ESC && hard) *hard_any = 1;   // (plain stores of the same value: no atomic)
     const uint32_t lane = threadIdx.x & 63u;
@@ -182,12 +163,15 @@ __global__ void __launch_bounds__(SPLIT_THREADS) k_split_count_masks(const uint8
     const uint64_t first = static_cast<uint64_t>(blockIdx.x) * CHUNKS + 8u * threadIdx.x;
     *reinterpret_cast<uint4*>(end_masks + first) = *reinterpret_cast<const uint4*>(tr + 8u * threadIdx.x);
     if (ESC) *reinterpret_cast<uint4*>(esc_bits + first) = *reinterpret_cast<const uint4*>(tr + CHUNKS + 8u * threadIdx.x);
+    if (HIGH) *reinterpret_cast<uint4*>(high_masks + first) = *reinterpret_cast<const uint4*>(tr + CHUNKS + 8u * threadIdx.x);
 }
 
-// pass 3 of the same: offsets[1 + rank(p)] = p + 1 for every line end p, out of the masks: a thread takes eight chunks in a row
+// pass 3: offsets[1 + rank(p)] = p + 1 for every line end p, out of the masks: a thread takes eight chunks in a row
+// flags (optional, with high_masks): flags[line] = 1 for lines with a byte >= 0x80
 template <typename OFF>
 __global__ void __launch_bounds__(SPLIT_THREADS) k_split_write_masks(const uint16_t* __restrict__ end_masks, const uint64_t* __restrict__ prefix,
-                                                                     OFF* __restrict__ offsets, uint64_t cap_lines) {
+                                                                     OFF* __restrict__ offsets, uint64_t cap_lines, const uint16_t* __restrict__ high_masks,
+                                                                     uint8_t* __restrict__ flags) {
     constexpr int CHUNKS = SPLIT_THREADS * SPLIT_ITERS;
     __shared__ uint32_t wsum[SPLIT_THREADS / 64];
     const uint64_t base = static_cast<uint64_t>(blockIdx.x) * SPLIT_BLOCK_BYTES;
@@ -203,10 +187,20 @@ __global__ void __launch_bounds__(SPLIT_THREADS) k_split_write_masks(const uint1
 #pragma unroll
     for (uint32_t q = 0; q < SPLIT_THREADS / 64; ++q) if (q < wave) wbase += wsum[q];
     uint64_t k = prefix[blockIdx.x] + wbase + inc - cnt;   // line ends before this thread's first chunk
+    uint4 hv = make_uint4(0u, 0u, 0u, 0u);
+    if (flags) hv = *reinterpret_cast<const uint4*>(high_masks + static_cast<uint64_t>(blockIdx.x) * CHUNKS + 8u * threadIdx.x);
+    const uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w};
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         uint32_t e = (q & 1) ? (mw[q >> 1] >> 16) : (mw[q >> 1] & 0xFFFFu);
         const uint64_t pos = base + (8ull * threadIdx.x + q) * 16;
+        uint32_t hb = (q & 1) ? (hw[q >> 1] >> 16) : (hw[q >> 1] & 0xFFFFu);
+        while (hb) {   // (k: the line this chunk's first byte belongs to)
+            const uint32_t j = __ffs(hb) - 1u;
+            hb &= hb - 1u;
+            const uint64_t line = k + __popc(e & ((1u << j) - 1u));
+            if (line < cap_lines) flags[line] = 1;
+        }
         while (e) {
             const uint32_t j = __ffs(e) - 1u;
             e &= e - 1u;
@@ -255,77 +249,6 @@ __global__ void __launch_bounds__(1024) k_split_scan(const uint32_t* __restrict_
     if (threadIdx.x == 0) *total_ends = carry;
 }
 
-// pass 3: offsets[1 + rank(p)] = p + 1 for every line end p; flags[line] = 1 for lines with a byte >= 0x80
-// ESC: also esc_bits[chunk] (a bit per byte of the text: Chunk::esc) and *hard_any != 0 when the text holds a control character that
-// JSON writes as six bytes -- what the JSON Lines sizes pass needs to know of the text (gx_jsonl.hip: k_jsonl_sizes_bits)
-template <typename OFF, bool ESC>
-__global__ void __launch_bounds__(SPLIT_THREADS) k_split_write(const uint8_t* __restrict__ data, uint64_t size, const uint64_t* __restrict__ prefix,
-                                                               OFF* __restrict__ offsets, uint64_t cap_lines, uint8_t* __restrict__ flags,
-                                                               uint16_t* __restrict__ esc_bits, uint64_t* __restrict__ hard_any, int passthrough) {
-    constexpr int WAVES = SPLIT_THREADS / 64;
-    __shared__ uint32_t wsum[SPLIT_ITERS][WAVES];
-    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * SPLIT_BLOCK_BYTES;
-    const uint64_t block_rank = prefix[blockIdx.x];
-    if (blockIdx.x == 0 && threadIdx.x == 0) offsets[0] = 0;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    // all of a thread's chunks first (sixteen loads in flight, as in the counting pass), their masks kept in registers; the waves leave
-    // their sums per iteration in LDS, and after one barrier every thread knows the rank of each of its chunks
-    Chunk c[SPLIT_ITERS];
-    uint32_t hard = 0;
-#pragma unroll
-    for (int it = 0; it < SPLIT_ITERS; ++it) {
-        const uint64_t pos = base + (static_cast<uint64_t>(it) * SPLIT_THREADS + threadIdx.x) * 16;
-        c[it] = classify<ESC>(data, pos, size, passthrough != 0);
-        if (ESC) {
-            if (pos < size) esc_bits[pos >> 4] = static_cast<uint16_t>(c[it].esc);
-            hard |= c[it].hard;
-            c[it].esc = 0u; c[it].hard = 0u;   // (nothing below reads them: not kept)
-        }
-    }
-    if (ESC && hard) *hard_any = 1;   // (plain stores of the same value: no atomic)
-    uint32_t before[SPLIT_ITERS];   // line ends in the wave's chunks of the iteration before this thread's
-#pragma unroll
-    for (int it = 0; it < SPLIT_ITERS; ++it) {
-        const uint32_t cnt = __popc(c[it].ends);
-        const uint32_t inc = wave_inclusive_sum(cnt, lane);
-        if (lane == 63) wsum[it][wave] = inc;
-        before[it] = inc - cnt;
-    }
-    __syncthreads();
-    uint32_t running = 0;   // line ends of the block before the iteration
-#pragma unroll
-    for (int it = 0; it < SPLIT_ITERS; ++it) {
-        uint32_t wbase = 0, total = 0;
-#pragma unroll
-        for (int q = 0; q < WAVES; ++q) {
-            const uint32_t t = wsum[it][q];
-            if (static_cast<uint32_t>(q) < wave) wbase += t;
-            total += t;
-        }
-        const uint64_t pos = base + (static_cast<uint64_t>(it) * SPLIT_THREADS + threadIdx.x) * 16;
-        // number of line ends before this thread's first byte = index of the line that byte belongs to
-        const uint64_t rank = block_rank + running + wbase + before[it];
-        uint32_t e = c[it].ends;
-        uint64_t k = rank;
-        while (e) {
-            const uint32_t j = __ffs(e) - 1u;
-            e &= e - 1u;
-            ++k;  // the line that starts after this end
-            if (k <= cap_lines) offsets[k] = static_cast<OFF>(pos + j + 1);
-        }
-        if (flags) {
-            uint32_t hb = c[it].high;
-            while (hb) {
-                const uint32_t j = __ffs(hb) - 1u;
-                hb &= hb - 1u;
-                const uint64_t line = rank + __popc(c[it].ends & ((1u << j) - 1u));
-                if (line < cap_lines) flags[line] = 1;
-            }
-        }
-        running += total;
-    }
-}
-
 // the last line has no terminator: close it with offsets[n] = size
 template <typename OFF>
 __global__ void k_split_finish(const uint8_t* __restrict__ data, uint64_t size, const uint64_t* __restrict__ total_ends, OFF* __restrict__ offsets,
@@ -367,10 +290,10 @@ __global__ void __launch_bounds__(256) k_split_max(const OFF* __restrict__ offse
 
 }  // namespace
 
-size_t split_workspace_bytes(uint64_t size) {
+size_t split_workspace_bytes(uint64_t size, bool with_flags) {
     const uint64_t nblocks = (size + SPLIT_BLOCK_BYTES - 1) / SPLIT_BLOCK_BYTES;
     // (+ the masks of line ends of the text-read-once split: 4 KiB per block = an eighth of the text, 16-byte aligned)
-    return static_cast<size_t>((nblocks + 1) * 4 + (nblocks + 3) * 8 + 64 + nblocks * 4096 + 32);
+    return static_cast<size_t>((nblocks + 1) * 4 + (nblocks + 3) * 8 + 64 + (with_flags ? 2 : 1) * nblocks * 4096 + 32);
 }
 
 // workspace: [total_ends u64][n_lines u64][max_line u64][hard_any u64][prefix u64 * nblocks][counts u32 * nblocks]
@@ -401,44 +324,27 @@ hipError_t launch_split_lines(const uint8_t* data, uint64_t size, void* offsets,
     }
     if (nblocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     if (esc_bits && (offsets64 || flags)) return hipErrorInvalidValue;   // (the escape bits come with 32-bit offsets and without line flags)
-    if (!flags) {
-        // the text is read once: pass 1 leaves the masks of line ends (and the escape bits), pass 3 reads those
+    {
+        // the text is read once: pass 1 leaves the masks of line ends (and the escape bits, or the masks of the bytes >= 0x80), pass 3 reads those
         uint16_t* end_masks = reinterpret_cast<uint16_t*>((reinterpret_cast<uintptr_t>(counts + nblocks + 1) + 15u) & ~static_cast<uintptr_t>(15u));
-        if (esc_bits) hipLaunchKernelGGL(k_split_count_masks<true>, dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, counts, end_masks,
-                                         esc_bits, hard_any, passthrough);
-        else hipLaunchKernelGGL(k_split_count_masks<false>, dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, counts, end_masks,
-                                nullptr, nullptr, 0);
+        uint16_t* high_masks = flags ? end_masks + nblocks * 2048 : nullptr;
+        if (esc_bits) hipLaunchKernelGGL((k_split_count_masks<true, false>), dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, counts, end_masks,
+                                         esc_bits, hard_any, passthrough, nullptr);
+        else if (flags) hipLaunchKernelGGL((k_split_count_masks<false, true>), dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, counts, end_masks,
+                                           nullptr, nullptr, 0, high_masks);
+        else hipLaunchKernelGGL((k_split_count_masks<false, false>), dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, counts, end_masks,
+                                nullptr, nullptr, 0, nullptr);
         hipLaunchKernelGGL(k_split_scan, dim3(1), dim3(1024), 0, stream, counts, prefix, nblocks, total_ends);
         if (offsets64) {
             hipLaunchKernelGGL(k_split_write_masks<uint64_t>, dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, end_masks, prefix,
-                               static_cast<uint64_t*>(offsets), cap_lines);
+                               static_cast<uint64_t*>(offsets), cap_lines, high_masks, flags);
             hipLaunchKernelGGL(k_split_finish<uint64_t>, dim3(1), dim3(1), 0, stream, data, size, total_ends, static_cast<uint64_t*>(offsets), cap_lines, n_lines);
         } else {
             hipLaunchKernelGGL(k_split_write_masks<uint32_t>, dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, end_masks, prefix,
-                               static_cast<uint32_t*>(offsets), cap_lines);
+                               static_cast<uint32_t*>(offsets), cap_lines, high_masks, flags);
             hipLaunchKernelGGL(k_split_finish<uint32_t>, dim3(1), dim3(1), 0, stream, data, size, total_ends, static_cast<uint32_t*>(offsets), cap_lines, n_lines);
         }
-        goto longest;
     }
-    hipLaunchKernelGGL(k_split_count, dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, counts);
-    hipLaunchKernelGGL(k_split_scan, dim3(1), dim3(1024), 0, stream, counts, prefix, nblocks, total_ends);
-    if (esc_bits) {
-        hipLaunchKernelGGL((k_split_write<uint32_t, true>), dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, prefix,
-                           static_cast<uint32_t*>(offsets), cap_lines, flags, esc_bits, hard_any, passthrough);
-        hipLaunchKernelGGL(k_split_finish<uint32_t>, dim3(1), dim3(1), 0, stream, data, size, total_ends, static_cast<uint32_t*>(offsets), cap_lines,
-                           n_lines);
-    } else if (offsets64) {
-        hipLaunchKernelGGL((k_split_write<uint64_t, false>), dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, prefix,
-                           static_cast<uint64_t*>(offsets), cap_lines, flags, nullptr, nullptr, 0);
-        hipLaunchKernelGGL(k_split_finish<uint64_t>, dim3(1), dim3(1), 0, stream, data, size, total_ends, static_cast<uint64_t*>(offsets), cap_lines,
-                           n_lines);
-    } else {
-        hipLaunchKernelGGL((k_split_write<uint32_t, false>), dim3(static_cast<unsigned>(nblocks)), dim3(SPLIT_THREADS), 0, stream, data, size, prefix,
-                           static_cast<uint32_t*>(offsets), cap_lines, flags, nullptr, nullptr, 0);
-        hipLaunchKernelGGL(k_split_finish<uint32_t>, dim3(1), dim3(1), 0, stream, data, size, total_ends, static_cast<uint32_t*>(offsets), cap_lines,
-                           n_lines);
-    }
-longest:
     if (d_max_line) {
         e = hipMemsetAsync(max_line, 0, 8, stream);
         if (e != hipSuccess) return e;

@@ -29,7 +29,7 @@ for with_flags in (False, True):
     ms = e0.elapsed_time(e1) / 5
     assert got == n
     print("split_lines flags=%s: %.3f ms for %d B -> %.2f TB/s of text (%s)" % (with_flags, ms, text.numel(), text.numel() / ms / 1e9,
-          "the text is read twice: the line flags come from the second sweep" if with_flags else "the text is read once: the second pass reads the first one's masks of line ends"))
+          "the text is read once: the second pass reads the first one's masks of line ends" + (" and of the bytes >= 0x80" if with_flags else "")))
 assert torch.equal(offs.view(torch.int32).to(torch.int64), torch.arange(n + 1, device="cuda") * (W.LINE_BYTES + 1))
 mid = torch.empty(n, dtype=torch.int32, device="cuda")
 caps = torch.empty((n, 8), dtype=torch.int32, device="cuda")
