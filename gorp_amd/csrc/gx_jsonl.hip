@@ -1031,41 +1031,77 @@ __global__ void __launch_bounds__(WRITE ? 128 : 768) k_jsonl_tile(JsonlTemplates
 // its captures cover come through the caches (neighbouring lanes, neighbouring lines).  What it leaves is what k_jsonl_tile<.., false,
 // ..> leaves, value for value: sizes[i], split[i] / split_at[i] (where the write pass's two waves divide the line's text, chosen by
 // the same rule) and tile_flags[tile] (1: nothing in the tile's captures takes an escape). ----
+// Everything a lane looks up sits in LDS: the template arrays (when they fit), per wave the tile's capture rows and the bit words of
+// its span of the text, all fetched coalesced -- a segment is three lookups, each behind the one before (its record, its capture's
+// offsets, the bits of that range): out of global memory that was three trips to L1 / L2 per segment and lane.
+constexpr uint32_t SB_BIT_WORDS = 1024;   // per wave: 32 KiB of text per 64 lines; a tile beyond that reads its bits from global memory
 template <typename OFF>
 __global__ void __launch_bounds__(256) k_jsonl_sizes_bits(JsonlTemplates tm, const OFF* __restrict__ off, uint64_t n, const int32_t* __restrict__ match_id,
                                                          const int32_t* __restrict__ caps, int slots, const uint32_t* __restrict__ bits,
                                                          uint32_t* __restrict__ sizes, uint32_t* __restrict__ split, uint32_t* __restrict__ split_at,
-                                                         uint32_t* __restrict__ tile_flags) {
-    const uint32_t lane = threadIdx.x & 63u;
+                                                         uint32_t* __restrict__ tile_flags, uint32_t n_rules, uint32_t n_segs, uint32_t tm_lds, uint32_t caps_lds) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t sb_smem[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* l_seg_off = reinterpret_cast<uint32_t*>(sb_smem);
+    uint32_t* l_fixed = l_seg_off + (n_rules + 1u);
+    uint32_t* l_seg = l_fixed + n_rules;            // {lit_len, group} per segment
+    if (tm_lds) {
+        for (uint32_t q = threadIdx.x; q <= n_rules; q += blockDim.x) l_seg_off[q] = tm.seg_off[q];
+        for (uint32_t q = threadIdx.x; q < n_rules; q += blockDim.x) l_fixed[q] = tm.fixed_len[q];
+        for (uint32_t q = threadIdx.x; q < n_segs; q += blockDim.x) { l_seg[2u * q] = tm.lit_len[q]; l_seg[2u * q + 1u] = static_cast<uint32_t>(tm.group[q]); }
+    }
+    __syncthreads();
+    uint32_t* l_bits = reinterpret_cast<uint32_t*>(sb_smem + tm_lds) + wave * SB_BIT_WORDS;
+    int32_t* l_caps = reinterpret_cast<int32_t*>(sb_smem + tm_lds + 4u * SB_BIT_WORDS * 4u) + wave * 64u * static_cast<uint32_t>(slots);
     const uint64_t tiles = (n + 63) >> 6;
     const uint64_t wstride = static_cast<uint64_t>(gridDim.x) * (blockDim.x >> 6);
-    // the bits of the text's bytes [x, y)
-    auto count = [&](uint64_t x, uint64_t y) -> uint32_t {
-        if (x >= y) return 0u;
-        const uint64_t wa = x >> 5, wb = (y - 1) >> 5;
-        const uint32_t first = 0xFFFFFFFFu << (x & 31u), last = 0xFFFFFFFFu >> (31u - static_cast<uint32_t>((y - 1) & 31u));
-        if (wa == wb) return __popc(bits[wa] & first & last);
-        uint32_t c = __popc(bits[wa] & first) + __popc(bits[wb] & last);
-        for (uint64_t w = wa + 1; w < wb; ++w) c += __popc(bits[w]);
-        return c;
-    };
-    for (uint64_t tile = static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < tiles; tile += wstride) {
+    for (uint64_t tile = static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + wave; tile < tiles; tile += wstride) {
         const uint64_t i = (tile << 6) + lane;
+        const uint32_t lines = static_cast<uint32_t>(min(static_cast<uint64_t>(64), n - (tile << 6)));
         bool dirty = false;
+        int32_t k = -1;
+        uint64_t o0 = 0, o1 = 0;
+        if (i < n) { k = match_id[i]; o0 = off[i]; o1 = off[i + 1]; }
+        // the tile's span of the text and its bit words
+        const uint64_t lo = uni(static_cast<uint64_t>(__shfl(static_cast<unsigned long long>(o0), 0)));
+        const uint64_t hi = uni(static_cast<uint64_t>(__shfl(static_cast<unsigned long long>(o1), static_cast<int>(lines - 1u))));
+        const uint64_t w0 = lo >> 5;
+        const uint64_t nw = hi > lo ? ((hi + 31) >> 5) - w0 : 0;
+        const bool bits_lds = nw <= SB_BIT_WORDS;   // uniform
+        if (bits_lds) for (uint32_t q = lane; q < static_cast<uint32_t>(nw); q += 64u) l_bits[q] = bits[w0 + q];
+        if (caps_lds) {
+            const uint64_t row0 = (tile << 6) * static_cast<uint64_t>(slots);
+            const uint32_t words = lines * static_cast<uint32_t>(slots);
+            for (uint32_t q = lane; q < words; q += 64u) l_caps[q] = caps[row0 + q];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        auto word = [&](uint32_t w) -> uint32_t { return bits_lds ? l_bits[w] : bits[w0 + w]; };   // (word w of the tile's span)
+        // the bits of the text's bytes [x, y), positions relative to the span's first word (32-bit arithmetic: a line is < 4 GiB from it)
+        auto count = [&](uint32_t x, uint32_t y) -> uint32_t {
+            if (x >= y) return 0u;
+            const uint32_t wa = x >> 5, wb = (y - 1u) >> 5;
+            const uint32_t first = 0xFFFFFFFFu << (x & 31u), last = 0xFFFFFFFFu >> (31u - ((y - 1u) & 31u));
+            if (wa == wb) return __popc(word(wa) & first & last);
+            uint32_t c = __popc(word(wa) & first) + __popc(word(wb) & last);
+            for (uint32_t w = wa + 1u; w < wb; ++w) c += __popc(word(w));
+            return c;
+        };
+        const uint32_t line_rel = static_cast<uint32_t>(o0 - (w0 << 5));   // this lane's line, in bytes from the span's first word
         if (i < n) {
-            const int32_t k = match_id[i];
             uint32_t total = 0u;
             if (k >= 0) {
-                const uint64_t o0 = off[i], o1 = off[i + 1];
-                const int32_t* cp = caps + i * static_cast<uint64_t>(slots);
-                const uint32_t s0 = tm.seg_off[k], s1 = tm.seg_off[k + 1], fixed_k = tm.fixed_len[k];
+                const int32_t* cp = caps_lds ? l_caps + lane * static_cast<uint32_t>(slots) : caps + i * static_cast<uint64_t>(slots);
+                const uint32_t s0 = tm_lds ? l_seg_off[k] : tm.seg_off[k], s1 = tm_lds ? l_seg_off[k + 1] : tm.seg_off[k + 1];
+                const uint32_t fixed_k = tm_lds ? l_fixed[k] : tm.fixed_len[k];
                 const uint32_t half = ((fixed_k + static_cast<uint32_t>(o1 - o0)) * SPLIT_AT_256) >> 8;
                 const bool splittable = s1 - s0 < 0xFFFFu;
                 uint32_t sp_m = s1, sp_q = 0u, cum = 0u, lit_cum = 0u, before = 0u;
                 total = fixed_k;
                 for (uint32_t s = s0; s < s1; ++s) {
-                    const uint32_t ll = tm.lit_len[s];
-                    const int32_t g = tm.group[s];
+                    const uint32_t ll = tm_lds ? l_seg[2u * s] : tm.lit_len[s];
+                    const int32_t g = tm_lds ? static_cast<int32_t>(l_seg[2u * s + 1u]) : tm.group[s];
                     int32_t cb = -1, ce = -1;
                     if (g >= 0) { cb = cp[2 * g]; ce = cp[2 * g + 1]; }
                     lit_cum += ll;
@@ -1081,7 +1117,7 @@ __global__ void __launch_bounds__(256) k_jsonl_sizes_bits(JsonlTemplates tm, con
                     cum += e;
                     if (g < 0) { if (s == sp_m) before = lit_cum + (total - fixed_k); continue; }
                     if (cb < 0) { total += 4u; if (s == sp_m) before = lit_cum + (total - fixed_k); continue; }
-                    const uint64_t x = o0 + static_cast<uint32_t>(cb);
+                    const uint32_t x = line_rel + static_cast<uint32_t>(cb);
                     if (s == sp_m) before = lit_cum + (total - fixed_k) + 1u + sp_q + count(x, x + sp_q);
                     total += 2u + len + count(x, x + len);
                 }
@@ -1093,6 +1129,9 @@ __global__ void __launch_bounds__(256) k_jsonl_sizes_bits(JsonlTemplates tm, con
         }
         const bool any_dirty = __ballot(dirty) != 0ull;
         if (lane == 0u) tile_flags[tile] = any_dirty ? 0u : 1u;
+        // (the wave's LDS is rewritten by its next tile)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1377,8 +1416,15 @@ hipError_t launch_jsonl_sizes(const GxJsonl& tm, const GxBatch& b, int slots, in
         // (the text's escape bits are there and say that no byte takes more than one: no look at the text)
         const uint64_t tiles = (b.n + 63) >> 6;
         const uint64_t blocks = std::min<uint64_t>((tiles + 3) / 4, 256u * 16u);
-        hipLaunchKernelGGL(k_jsonl_sizes_bits<uint32_t>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, t, static_cast<const uint32_t*>(b.offsets), b.n,
-                           b.match_id, b.caps, slots, esc_bits, sizes, split, split_at, tile_flags);
+        // LDS: the template arrays when they are small, per wave 4 KiB of bit words and, when they fit beside all that, the tile's capture rows
+        const uint32_t n_rules = static_cast<uint32_t>(tm.n_rules), n_segs = static_cast<uint32_t>(tm.n_segs);
+        uint32_t tm_lds = ((2u * n_rules + 1u + 2u * n_segs) * 4u + 15u) & ~15u;
+        if (tm_lds > 24576u) tm_lds = 0u;
+        const uint32_t bits_bytes = 4u * SB_BIT_WORDS * 4u, caps_bytes = 4u * 64u * static_cast<uint32_t>(slots) * 4u;
+        const uint32_t caps_lds = (slots > 0 && tm_lds + bits_bytes + caps_bytes <= 65536u) ? 1u : 0u;
+        hipLaunchKernelGGL(k_jsonl_sizes_bits<uint32_t>, dim3(static_cast<unsigned>(blocks)), dim3(256), tm_lds + bits_bytes + (caps_lds ? caps_bytes : 0u), stream, t,
+                           static_cast<const uint32_t*>(b.offsets), b.n, b.match_id, b.caps, slots, esc_bits, sizes, split, split_at, tile_flags, n_rules, n_segs, tm_lds,
+                           caps_lds);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     } else {
