@@ -25,9 +25,12 @@ st = torch.cuda.current_stream().cuda_stream
 total = int(d.numel())
 for name, kw, args in (("narrow", {"compact": 2}, (None, rows.data_ptr())), ("dense", {}, (mid.data_ptr(), caps.data_ptr())), ("compact", {"compact": True}, (None, rows.data_ptr())),
                        ("match-only", {"match_only": True}, (mid.data_ptr(), None))):
-    for _ in range(3):
-        g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, *args, stream=st, no_sync=True, line_bytes_hint=lb, max_line_bytes=lb, **kw)
-    torch.cuda.synchronize()
+    import time
+    t_spin = time.perf_counter() + 0.15   # (the device's clocks need 25 ms of unbroken load: profiles/r04_clock_ramp.txt)
+    while time.perf_counter() < t_spin:
+        for _ in range(4):
+            g.extract_batch_device(d.data_ptr(), o.data_ptr(), n, *args, stream=st, no_sync=True, line_bytes_hint=lb, max_line_bytes=lb, **kw)
+        torch.cuda.synchronize()
     ts = []
     for _ in range(7):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
