@@ -174,6 +174,8 @@ def main():
     ap.add_argument("--lines", type=int, default=0, help="lines per GPU (0: the config's size)")
     ap.add_argument("--results", default="auto", choices=["auto", "narrow", "compact", "dense"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--keep-cached-blocks", action="store_true",
+                    help="do not return the workload generator's freed device memory to the driver before the result buffers are allocated")
     ap.add_argument("--spin-up-ms", type=float, default=150.0,
                     help="untimed steps for this long before the W warm-up steps of a timed region: the device at its steady clocks (0: none)")
     ap.add_argument("--no-gather", action="store_true")
@@ -231,6 +233,17 @@ def main():
     setup_s = time.perf_counter() - t0
 
     G = gorp.max_groups
+    # WHERE the result rows lie matters to this kernel: the same launch on the same lines takes 0.325 or 0.345-0.36 ms depending on
+    # nothing but the block of device memory the rows are written to (tools/placement_probe.py, profiles/r04_placement.txt: a
+    # property of the allocation, not of an offset inside it; 90 MB of writes beside 2 GB of reads).  The synthetic lines were
+    # generated on the device, and PyTorch's caching allocator would carve the result rows out of a segment the generator's
+    # temporaries left behind; here that memory goes back to the driver first and the result buffers are allocations of their own,
+    # as a caller's would be.  The u8 rows are ALSO timed in a recycled block (formats.narrow_rows_in_a_recycled_block), so that
+    # both placements are in the line: `value` is the result buffers of their own.
+    rows8_recycled = torch.empty((n, 1 + 2 * G), dtype=torch.uint8, device=dev)   # (carved out of what the generator freed: timed beside, never `value`)
+    if not args.keep_cached_blocks:
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
     mid = torch.empty(n, dtype=torch.int32, device=dev)
     caps = torch.empty((n, 2 * G), dtype=torch.int32, device=dev)
     rows = torch.empty((n, 1 + 2 * G), dtype=torch.int16, device=dev)
@@ -299,12 +312,17 @@ def main():
             return float(t.item()), [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
         return float(t.item()), [ev[0].elapsed_time(ev[1]) / steps] * steps
 
+    def step_recycled():
+        gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, None, rows8_recycled.data_ptr(), stream=stream, no_sync=True,
+                                  line_bytes_hint=hint, compact=2, overflow_ptr=overflow.data_ptr(), max_line_bytes=max_line)
+
     runs = {}
     torch.cuda.synchronize()
     time.sleep(0.25)                                                         # (an idle device, as a first batch finds it)
     from_idle = timed(headline, args.steps, args.warmup)                     # the same W + K steps from idle: reported beside, never `value`
     for fmt in [f for f in formats if f != headline]:
         runs[fmt] = timed(fmt, args.steps, args.warmup, spin_ms=args.spin_up_ms)     # the other result formats, same step count, reported beside
+    recycled = timed(step_recycled, args.steps, args.warmup, spin_ms=args.spin_up_ms) if narrow_ok else None
     elapsed, kernel_ms = runs[headline] = timed(headline, args.steps, args.warmup, spin_ms=args.spin_up_ms)   # THE timed region
     _, step_ms = timed(headline, args.steps, 1, per_step=True)                       # (afterwards: the spread of single steps)
 
@@ -429,6 +447,12 @@ def main():
                                "ms_per_step": f_elapsed * 1e3 / len(f_ms), "kernel_ms_avg": f_avg,
                                "algorithmic_write_bytes": write_bytes[fmt], "read_gb_per_s": algo_read / (f_avg * 1e-3) / 1e9,
                                "frac": algo_read / (f_avg * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if recycled is not None:
+            r_avg = sum(recycled[1]) / len(recycled[1])
+            per_format["narrow_rows_in_a_recycled_block"] = {
+                "results": fmt_desc["narrow"] + ", written to a block PyTorch's allocator carved out of the generator's freed memory", "steps": len(recycled[1]),
+                "lines_per_s": n * world * len(recycled[1]) / recycled[0], "ms_per_step": recycled[0] * 1e3 / len(recycled[1]), "kernel_ms_avg": r_avg,
+                "algorithmic_write_bytes": write_bytes["narrow"], "read_gb_per_s": algo_read / (r_avg * 1e-3) / 1e9, "frac": algo_read / (r_avg * 1e-3) / 1e9 / HBM_PEAK_GBS}
         out = {
             "metric": "lines/sec (Gorp.extract: product-DFA match + capture offsets; results as %s)" % fmt_desc[headline],
             "value": value,
