@@ -1,27 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- Gorp match-and-extract throughput on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config {2,3,4,5}] [--results {compact,dense}]
+    python bench.py --gpus N --steps K --warmup W [--config {2,3,4,5}] [--results {auto,narrow,compact,dense}]
 
 A "step" is one pass of the hot path (gx_extract_batch: product-DFA match + capture scan) over one batch of
 synthetic log lines that is already resident in HBM.  Workloads (BASELINE.json `configs`, 1-based as in BASELINE.md):
 
-  2  README 3-extraction GET/PUT/Other definition, 10 M x 200-byte lines            (default at N = 1: the metric's config)
-  3  64 syslog-like extractions, 10 M x 200-byte lines
-  4  config 3's definition, 10 M lines PER GPU, table blob broadcast + final gather  (default at N > 1)
-  5  512 extractions, lines of 50-2000 bytes, ~2 GB
+  2  README 3-extraction GET/PUT/Other definition, 10 M x 200-byte lines            (the metric's config: `value`)
+  3  64 syslog-like extractions, 10 M x 200-byte lines                              (N = 1: also.config3, same line)
+  4  config 3's definition, 10 M lines PER GPU, table blob broadcast + final gather  (N > 1: configs3_64_extractions)
+  5  512 extractions, lines of 50-2000 bytes, ~2 GB                                  (N = 1: also.config5, same line)
+
+The default run (no --config) times config 2 as the headline and then, at N = 1, configs 3 and 5 with the SAME protocol
+(spin-up, W warm-up steps, K timed steps between barrier + synchronize, two events on the launch stream around the K
+steps) and reports each as a complete object under `also`: ms_per_step, lines_per_s, roofline (achieved, frac, traffic
+from the committed counter passes), cpu_baseline (the oracle on a bounded sample, cores stated) and a bit-exact check of
+the GPU rows against the oracle on that sample.  also.config3 carries a second generator variant beside the lower-case
+one (mixed-case tokens: what a hop table that skips ONE byte interval per state pays for `JohnDoe42`).
 
 Result formats (gx_batch_opts.compact_results): `dense` int32 match id + int32 offsets (4 + 8 G bytes per line), `compact`
-rows of int16 id + uint16 offsets (2 + 4 G; what the gather between GPUs sends), `narrow` rows of int8 id + uint8 offsets
-(1 + 2 G; for batches whose lines are shorter than 255 bytes and definitions of at most 126 extractions).  --results auto
-(the default) takes the narrowest format the workload allows; ALL applicable formats are timed with the full step count
-and reported in `formats`, the headline one is named in `metric` and `config.results`.
+rows of int16 id + uint16 offsets (2 + 4 G), `narrow` rows of int8 id + uint8 offsets (1 + 2 G; for batches whose lines are
+shorter than 255 bytes and definitions of at most 126 extractions).  --results auto takes the narrowest format the workload
+allows; ALL applicable formats are timed with the full step count and reported in `formats`.
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU, RCCL): rank 0 compiles the tables and broadcasts the
-packed blob; every rank builds its handle from the blob, generates its own shard (seeded by rank), and runs the same
-steps -- lines are independent, so there is no collective inside a step (weak scaling).  After the timed region the
-per-line results are gathered to rank 0 once over xGMI and the gather time is reported separately (`gather_ms`); it
-is not part of `value` (Multi-GPU).
+Multi-GPU (one rank per GPU, RCCL): rank 0 compiles the tables and broadcasts the packed blob; every rank builds its
+handle from the blob, generates its own shard (seeded by rank) and runs the same steps -- lines are independent, so there
+is no collective inside a step (weak scaling).  After the timed region the per-line results are gathered to rank 0 over
+xGMI; the gather is reported separately (`gather_*_ms`) and, overlapped with the next batch's kernel on a second stream,
+as `value_with_overlapped_gather`.  Any rank whose parity check fails makes the run exit non-zero.
 
 Prints ONE JSON line on rank 0.
 """
@@ -90,7 +96,7 @@ def cpu_baseline(definition, data_cpu, offsets_cpu, budget_s=20.0):
     orc = O.OracleGorp([b[0] for b in built], [b[1] for b in built])
     cores = host_cores()
     n_all = len(offsets_cpu) - 1
-    # calibrate on a small slice, then size the sample for ~20 CPU-seconds (>= 3 s of wall time)
+    # calibrate on a small slice, then size the sample for ~budget_s CPU-seconds (>= 3 s of wall time)
     probe = min(n_all, 10000 * cores)
     t0 = time.perf_counter()
     orc.extract_batch(data_cpu, offsets_cpu[:probe + 1], nthreads=cores)
@@ -126,9 +132,10 @@ def self_launch(n_ranks):
     return subprocess.run(cmd, env=env).returncode
 
 
-def build_workload(config, n, rank, dev):
+def build_workload(config, n, rank, dev, variant=None):
     """(definition, data u8[total] on dev, offsets u32[n+1] on dev, n, expected match ids or None, known mask or None,
-    line_bytes_hint, description)."""
+    line_bytes_hint, description).  variant "mixed_case" (configs 3-5): the generator's \\w values and padding as mixed-case
+    alphanumeric tokens (`JohnDoe42`) instead of lower-case words."""
     import numpy as np
     import torch
     from gorp_amd import workloads as W
@@ -137,17 +144,20 @@ def build_workload(config, n, rank, dev):
         data, offsets, category = W.readme3_lines(n, seed=2 + rank, device=dev)
         return definition, data, offsets, n, category.to(torch.int32), None, W.LINE_BYTES, \
             "README 3-extraction GET/PUT/Other definition (BASELINE.json configs[1]), %d x %d B lines per GPU, seed 2+rank" % (n, W.LINE_BYTES)
+    mixed = variant == "mixed_case"
     if config in (3, 4):
         rules, meta = W.syslog_definition(64, seed=3)
         base_n = 100_000
-        dh, oh, cats = W.syslog_lines(meta, base_n, seed=3 + rank)
-        desc = "64 syslog-like extractions (BASELINE.json configs[%d]), %%d x 200 B lines per GPU (a %d-line sample tiled), seed 3+rank" % (config - 1, base_n)
+        dh, oh, cats = W.syslog_lines(meta, base_n, seed=3 + rank, mixed_case=mixed)
+        desc = "64 syslog-like extractions (BASELINE.json configs[%d]), %%d x 200 B lines per GPU (a %d-line sample tiled), seed 3+rank%s" % (
+            config - 1, base_n, ", mixed-case \\w values" if mixed else "")
         hint = 200
     else:
         rules, meta = W.syslog_definition(512, seed=3)
         base_n = 20_000
-        dh, oh, cats = W.syslog_lines(meta, base_n, seed=5 + rank, min_len=50, max_len=2000)
-        desc = "512 syslog-like extractions (BASELINE.json configs[4]), %%d lines of 50-2000 B per GPU (a %d-line sample tiled), seed 5+rank" % base_n
+        dh, oh, cats = W.syslog_lines(meta, base_n, seed=5 + rank, min_len=50, max_len=2000, mixed_case=mixed)
+        desc = "512 syslog-like extractions (BASELINE.json configs[4]), %%d lines of 50-2000 B per GPU (a %d-line sample tiled), seed 5+rank%s" % (
+            base_n, ", mixed-case \\w values" if mixed else "")
         hint = int(int(oh[-1]) / base_n + 0.999)
     total = int(oh[-1])
     reps = max(1, n // base_n)
@@ -163,6 +173,151 @@ def build_workload(config, n, rank, dev):
     return rules, data, off, n, want, known, hint, desc % n
 
 
+def recorded_traffic(names, algo_read, algo_write):
+    """HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this kernel on this exact workload
+    (tools/collect_r05.sh: separate --pmc passes, FETCH_SIZE doubled per the gfx950 correction, calibrated against a
+    same-size copy kernel in the same run).  Counters cannot be read from inside this process: the RECORDED figure of
+    the committed summary is reported when its workload and result format match this run, else null."""
+    for name in names:
+        try:
+            path = os.path.join(ROOT, "profiles", name)
+            tj = json.load(open(path))
+            if tj["algorithmic_read_bytes"] == algo_read and tj["algorithmic_write_bytes"] == algo_write:
+                return tj["traffic_bytes_per_launch"], "recorded: profiles/%s (%s)" % (name, time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(path))))
+        except (OSError, ValueError, KeyError):
+            pass
+    return None, None
+
+
+KERNEL_NAMES = {1: "tile kernel", 2: "slice kernel", 3: "per-line kernel", 4: "lane kernel", 5: "tile kernel on the hop tier's tables", 6: "hop slice kernel"}
+
+
+def table_tier(gorp):
+    if int(gorp.stat(14)) > 0:
+        return ("hop tier: run + chain records, %d of %d states' records in LDS (%d of them reachable by well-formed lines), dense rows in global memory"
+                % (int(gorp.stat(15)), int(gorp.stat(14)), int(gorp.stat(16))))
+    return {0: "per-line kernel", 1: "LDS (dense rows)", 2: "L2 (dense rows)", 3: "LDS (range records)", 4: "L2 (range records)"}.get(int(gorp.stat(7)), str(gorp.stat(7)))
+
+
+class Timer:
+    """The timing protocol, one place for every workload of the line: K steps bracketed by barrier + synchronize, max over
+    ranks, and the launches' average duration from two events on the launch stream, one before the first step and one
+    behind the last (per_step: an event behind every step instead -- the spread of the steps, at the price of a marker
+    between the kernels; never used for a headline).
+    spin_ms: untimed steps for that long BEFORE the W warm-up steps -- the device's power management needs ~25 ms of
+    unbroken load to reach its steady clocks (profiles/r04_clock_ramp.txt: 0.54 -> 0.36 -> 0.334 ms per launch over the
+    first 30 ms from idle); W = 5 steps of 0.35 ms are not that.  The throughput of a job that keeps the device busy is
+    the steady one; the from-idle figure is reported beside it."""
+
+    def __init__(self, dev, distributed):
+        self.dev, self.distributed = dev, distributed
+
+    def __call__(self, one, steps, warmup, per_step=False, spin_ms=0.0):
+        import torch
+        import torch.distributed as dist
+        t_spin = time.perf_counter() + spin_ms * 1e-3
+        while time.perf_counter() < t_spin:
+            for _ in range(4):   # (short groups: ranks leave the spin-up within a group's time of each other)
+                one()
+            torch.cuda.current_stream().synchronize()
+        for _ in range(warmup):
+            one()
+        torch.cuda.synchronize()
+        if self.distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1 if per_step else 2)]
+        t_start = time.perf_counter()
+        ev[0].record()
+        for i in range(steps):
+            one()
+            if per_step:
+                ev[i + 1].record()
+        if not per_step:
+            ev[1].record()
+        torch.cuda.synchronize()
+        if self.distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t_start
+        mine = elapsed
+        t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+        if self.distributed:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        self.last_own_elapsed = mine
+        if per_step:
+            return float(t.item()), [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+        return float(t.item()), [ev[0].elapsed_time(ev[1]) / steps] * steps
+
+
+def side_workload(config, args, dev, stream, timer, variant=None, with_cpu=True):
+    """One of the line's other workloads (BASELINE.json configs[2] / configs[4]) as a complete object: the same protocol as
+    the headline, its narrowest result format, roofline with the recorded counter traffic, the oracle on a bounded sample as
+    CPU baseline, and the GPU rows of that sample compared with the oracle's bit for bit."""
+    import numpy as np
+    import torch
+    from gorp_amd.gorp import Gorp, unpack_rows
+    n_req = args.lines or (3_800_000 if config == 5 else 10_000_000)
+    definition, data, offsets, n, want, known, hint, desc = build_workload(config, n_req, 0, dev, variant)
+    t0 = time.perf_counter()
+    gorp = Gorp.construct(definition)
+    setup_s = time.perf_counter() - t0
+    G = gorp.max_groups
+    total_bytes = int(data.numel())
+    max_line = int((offsets[1:].to(torch.int64) - offsets[:-1].to(torch.int64)).max().item())
+    narrow = max_line < 255 and len(definition) <= 126
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    rows = torch.empty((n, 1 + 2 * G), dtype=torch.uint8 if narrow else torch.int16, device=dev)
+    overflow = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def one():
+        gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, None, rows.data_ptr(), stream=stream, no_sync=True,
+                                  line_bytes_hint=hint, compact=2 if narrow else True, overflow_ptr=overflow.data_ptr(), max_line_bytes=max_line)
+
+    elapsed, kernel_ms = timer(one, args.steps, args.warmup, spin_ms=args.spin_up_ms)
+    got = (rows[:, 0].view(torch.int8) if narrow else rows[:, 0]).to(torch.int32)
+    ok = bool(torch.equal(got[known], want[known])) and int(overflow.item()) == 0
+    if not ok:
+        raise SystemExit("bench: config %d%s: match ids differ from the generator's expected categories" % (config, " (%s)" % variant if variant else ""))
+    k_avg = sum(kernel_ms) / len(kernel_ms)
+    algo_read = total_bytes + 4 * (n + 1)
+    algo_write = n * (1 + 2 * G) * (1 if narrow else 2)
+    achieved = algo_read / (k_avg * 1e-3) / 1e9
+    ms_per_step = elapsed * 1e3 / args.steps
+    traffic, traffic_src = recorded_traffic(["r05_config%d%s_traffic.json" % (config, "_" + variant if variant else "")], algo_read, algo_write)
+    obj = {"workload": desc, "baseline_config": config, "lines_per_s": n * args.steps / elapsed, "unit": "lines/s", "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": ms_per_step, "kernel_ms_avg": k_avg, "lines": n, "mean_line_bytes": total_bytes / n, "max_line_bytes": max_line,
+           "gb_per_s_scanned": total_bytes * args.steps / elapsed / 1e9,
+           "results": "%s rows, %d B/line" % ("u8" if narrow else "u16", (1 + 2 * G) * (1 if narrow else 2)),
+           "match_dfa_states": int(gorp.stat(0)), "char_classes": int(gorp.stat(1)), "capture_states": int(gorp.stat(2)), "table_blob_bytes": int(gorp.stat(4)),
+           "table_tier": table_tier(gorp), "kernel": KERNEL_NAMES.get(int(gorp.stat(25)), "?") + " (gx_stat(h, 25): what the library launched)",
+           "setup_s": setup_s,
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "frac_by_wall_clock": algo_read / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                        "wasted_traffic_ratio": (traffic / (algo_read + algo_write)) if traffic else None,
+                        "algorithmic_read_bytes": algo_read, "algorithmic_write_bytes": algo_write}}
+    if with_cpu:
+        sample = min(n, 2_000_000 if config != 5 else 400_000)
+        end = int(offsets[sample].item())
+        d_cpu = data[:end].cpu().numpy()
+        o_cpu = offsets[: sample + 1].cpu().numpy().astype(np.uint32)
+        base, omid, ocaps, ns = cpu_baseline(definition, d_cpu, o_cpu, budget_s=args.side_cpu_budget_s)
+        one()
+        torch.cuda.synchronize()
+        r = rows[:ns].cpu().numpy()
+        gm, gc = unpack_rows(r if narrow else r.view(np.uint16))
+        if not (np.array_equal(gm, omid) and np.array_equal(gc, ocaps)):
+            raise SystemExit("bench: config %d%s: GPU results differ from the oracle on the baseline sample" % (config, " (%s)" % variant if variant else ""))
+        obj["cpu_baseline"] = base
+        obj["parity"] = "GPU rows of the first %d lines bit-identical to the oracle's (ids and capture offsets)" % ns
+    del data, offsets, rows, gorp
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    return obj
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,14 +325,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5],
                     help="BASELINE.md config (0: config 2 per GPU at any N -- the metric's workload, so that the N = 1, 2, 4, 8 values are one "
-                         "weak-scaling curve -- and at N > 1 configs[3], 64 extractions, measured beside it in the same line)")
+                         "weak-scaling curve; at N = 1 configs 3 and 5 are measured beside it as `also`, at N > 1 configs[3] as `configs3_64_extractions`)")
     ap.add_argument("--lines", type=int, default=0, help="lines per GPU (0: the config's size)")
     ap.add_argument("--results", default="auto", choices=["auto", "narrow", "compact", "dense"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--result-buffer-candidates", type=int, default=8,
-                    help="u8 result buffers tried before the timed region; the one the kernel writes fastest to is used (1: no choice)")
-    ap.add_argument("--keep-cached-blocks", action="store_true",
-                    help="do not return the workload generator's freed device memory to the driver before the result buffers are allocated")
+    ap.add_argument("--no-also", action="store_true", help="N = 1, no --config: skip configs 3 and 5 (the `also` objects)")
+    ap.add_argument("--side-cpu-budget-s", type=float, default=10.0, help="CPU-seconds of the oracle per `also` workload")
+    ap.add_argument("--result-buffer-candidates", type=int, default=1,
+                    help="u8 result buffers timed before the timed region; `value` uses the MEDIAN one (1, the default: the buffer as allocated)")
     ap.add_argument("--spin-up-ms", type=float, default=150.0,
                     help="untimed steps for this long before the W warm-up steps of a timed region: the device at its steady clocks (0: none)")
     ap.add_argument("--no-gather", action="store_true")
@@ -194,26 +349,36 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's world size and --gpus must agree" % (args.gpus, world))
     config = args.config or 2
     also_config4 = args.config == 0 and world > 1   # BASELINE.json configs[3]: its hardware run rides along with the scaling curve
+    also_side = args.config == 0 and world == 1 and not args.no_also
 
     import numpy as np
     import torch
     import torch.distributed as dist
     from gorp_amd.gorp import Gorp, unpack_rows
 
-    if os.environ.get("GORP_BENCH_BACKEND", "nccl") != "nccl":
+    backend = os.environ.get("GORP_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
         local_rank = 0   # rehearsal: every rank on the one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL ("nccl") always; GORP_BENCH_BACKEND=gloo only exists to rehearse the N > 1 path with two ranks on ONE GPU
+        # RCCL ("nccl") always; GORP_BENCH_BACKEND=gloo only exists to rehearse the N > 1 path with several ranks on ONE GPU
         # (RCCL refuses two ranks on one device), which is all a one-GPU box allows
-        backend = os.environ.get("GORP_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
+    timer = Timer(dev, distributed)
+
+    def all_ranks_ok(ok, what):
+        """A parity failure on ANY rank ends every rank with a non-zero exit code (the launcher's, and so the parent's)."""
+        okt = torch.tensor([1 if ok else 0], device=dev)
+        if distributed:
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) != 1:
+            raise SystemExit("bench: %s%s" % (what, "" if ok else " (on this rank: %d)" % rank))
 
     # ---- this rank's shard (generated on / copied to the device before anything is timed) ----
     n_req = args.lines or (3_800_000 if config == 5 else 10_000_000)
@@ -235,17 +400,11 @@ def main():
     setup_s = time.perf_counter() - t0
 
     G = gorp.max_groups
-    # WHERE the result rows lie matters to this kernel: the same launch on the same lines takes 0.325 or 0.345-0.36 ms depending on
-    # nothing but the block of device memory the rows are written to (tools/placement_probe.py, profiles/r04_placement.txt: a
-    # property of the allocation, not of an offset inside it; 90 MB of writes beside 2 GB of reads).  The synthetic lines were
-    # generated on the device, and PyTorch's caching allocator would carve the result rows out of a segment the generator's
-    # temporaries left behind; here that memory goes back to the driver first and the result buffers are allocations of their own,
-    # as a caller's would be.  The u8 rows are ALSO timed in a recycled block (formats.narrow_rows_in_a_recycled_block), so that
-    # both placements are in the line: `value` is the result buffers of their own.
-    rows8_recycled = torch.empty((n, 1 + 2 * G), dtype=torch.uint8, device=dev)   # (carved out of what the generator freed: timed beside, never `value`)
-    if not args.keep_cached_blocks:
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()
+    # The result buffers are allocations of their own, as a caller's would be (the generator's freed blocks go back to the
+    # driver first): the buffer as allocated is THE result buffer.  --result-buffer-candidates N > 1 times N such buffers
+    # before the timed region and uses the MEDIAN one; all times are in the line (config.result_buffer_candidates_ms).
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
     mid = torch.empty(n, dtype=torch.int32, device=dev)
     caps = torch.empty((n, 2 * G), dtype=torch.int32, device=dev)
     rows = torch.empty((n, 1 + 2 * G), dtype=torch.int16, device=dev)
@@ -257,120 +416,64 @@ def main():
     if headline not in formats:
         raise SystemExit("--results narrow needs lines shorter than 255 bytes and at most 126 extractions")
     overflow = torch.zeros(1, dtype=torch.int64, device=dev)
-    # ... and of the allocations of their own some are written faster than others, the same ones every time they are tried
-    # (tools/placement_probe4.py: four of six candidates 0.332 ms, two 0.355-0.36, in five processes of five).  The u8 rows are
-    # therefore tried in four buffers before anything is timed, and the one the kernel wrote fastest to is THE result buffer; all
-    # four times are in the line (config.result_buffer_candidates_ms).  An application can do the same once, when it starts.
     cand_ms, cand_pick = None, 0
 
     stream = torch.cuda.current_stream().cuda_stream
 
     # (the caller knows its longest line -- here from the generator, in a pipeline from gx_split_lines_max -- and says so:
     # gx_batch_opts.max_line_bytes, a promise the library checks; it spares every step a second, nearly empty launch)
-    def step(fmt):
+    def step(fmt, on_stream=None):
+        st = on_stream if on_stream is not None else stream
         if fmt == "compact":
-            gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, None, rows.data_ptr(), stream=stream, no_sync=True,
+            gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, None, rows.data_ptr(), stream=st, no_sync=True,
                                       line_bytes_hint=hint, compact=True, overflow_ptr=overflow.data_ptr(), max_line_bytes=max_line)
         elif fmt == "narrow":
-            gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, None, rows8.data_ptr(), stream=stream, no_sync=True,
+            gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, None, rows8.data_ptr(), stream=st, no_sync=True,
                                       line_bytes_hint=hint, compact=2, overflow_ptr=overflow.data_ptr(), max_line_bytes=max_line)
         else:
-            gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=stream, no_sync=True,
+            gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, mid.data_ptr(), caps.data_ptr(), stream=st, no_sync=True,
                                       line_bytes_hint=hint, max_line_bytes=max_line)
 
-    if narrow_ok and not args.keep_cached_blocks and args.result_buffer_candidates > 1:
+    if narrow_ok and args.result_buffer_candidates > 1:
         cands = [rows8] + [torch.empty_like(rows8) for _ in range(args.result_buffer_candidates - 1)]
         cand_ms = []
         for cb in cands:
             launch = lambda: gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, None, cb.data_ptr(), stream=stream, no_sync=True,
                                                        line_bytes_hint=hint, compact=2, overflow_ptr=overflow.data_ptr(), max_line_bytes=max_line)
-            t_spin = time.perf_counter() + 0.06
-            while time.perf_counter() < t_spin:
-                for _ in range(4):
-                    launch()
-                torch.cuda.current_stream().synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                launch()
-            e1.record()
-            torch.cuda.synchronize()
-            cand_ms.append(e0.elapsed_time(e1) / 10)
-        # (every rank picks for itself: its own device, its own allocations)
-        cand_pick = min(range(len(cands)), key=lambda q: cand_ms[q])
+            _, ms = Timer(dev, False)(launch, 10, 2, spin_ms=60.0)
+            cand_ms.append(ms[0])
+        order = sorted(range(len(cands)), key=lambda q: cand_ms[q])
+        cand_pick = order[(len(order) - 1) // 2]   # the median (lower median of an even count), never the best
         rows8 = cands[cand_pick]
         del cands
-
-    def timed(fmt, steps, warmup, per_step=False, spin_ms=0.0):
-        """K steps bracketed by barrier + synchronize, max over ranks, and the launches' average duration from two events on the
-        launch stream, one before the first step and one behind the last (per_step: an event behind every step instead -- the
-        spread of the steps, at the price of a marker between the kernels; never used for the headline).
-        fmt: a result format of this workload's step(), or any callable that launches one step.
-        spin_ms: untimed steps for that long BEFORE the W warm-up steps -- the device's power management needs ~25 ms of
-        unbroken load to reach its steady clocks (profiles/r04_clock_ramp.txt: 0.54 -> 0.36 -> 0.334 ms per launch over the first
-        30 ms from idle, and 0.39 ms for ever when every 7 ms of work is followed by 50 ms of idling); W = 5 steps of 0.35 ms are
-        not that.  The throughput of a job that keeps the device busy is the steady one; the from-idle figure is reported beside it."""
-        one = fmt if callable(fmt) else (lambda: step(fmt))
-        t_spin = time.perf_counter() + spin_ms * 1e-3
-        while time.perf_counter() < t_spin:
-            for _ in range(4):   # (short groups: ranks leave the spin-up within a group's time of each other, and wait that long at the barrier)
-                one()
-            torch.cuda.current_stream().synchronize()
-        for _ in range(warmup):
-            one()
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1 if per_step else 2)]
-        t_start = time.perf_counter()
-        ev[0].record()
-        for i in range(steps):
-            one()
-            if per_step:
-                ev[i + 1].record()
-        if not per_step:
-            ev[1].record()
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t_start
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        if distributed:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        if per_step:
-            return float(t.item()), [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
-        return float(t.item()), [ev[0].elapsed_time(ev[1]) / steps] * steps
-
-    def step_recycled():
-        gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, None, rows8_recycled.data_ptr(), stream=stream, no_sync=True,
-                                  line_bytes_hint=hint, compact=2, overflow_ptr=overflow.data_ptr(), max_line_bytes=max_line)
 
     runs = {}
     torch.cuda.synchronize()
     time.sleep(0.25)                                                         # (an idle device, as a first batch finds it)
-    from_idle = timed(headline, args.steps, args.warmup)                     # the same W + K steps from idle: reported beside, never `value`
+    from_idle = timer(lambda: step(headline), args.steps, args.warmup)       # the same W + K steps from idle: reported beside, never `value`
     for fmt in [f for f in formats if f != headline]:
-        runs[fmt] = timed(fmt, args.steps, args.warmup, spin_ms=args.spin_up_ms)     # the other result formats, same step count, reported beside
-    recycled = timed(step_recycled, args.steps, args.warmup, spin_ms=args.spin_up_ms) if narrow_ok else None
-    elapsed, kernel_ms = runs[headline] = timed(headline, args.steps, args.warmup, spin_ms=args.spin_up_ms)   # THE timed region
-    _, step_ms = timed(headline, args.steps, 1, per_step=True)                       # (afterwards: the spread of single steps)
+        runs[fmt] = timer(lambda: step(fmt), args.steps, args.warmup, spin_ms=args.spin_up_ms)   # the other result formats, same step count, reported beside
+    elapsed, kernel_ms = runs[headline] = timer(lambda: step(headline), args.steps, args.warmup, spin_ms=args.spin_up_ms)   # THE timed region
+    own_elapsed = timer.last_own_elapsed
+    _, step_ms = timer(lambda: step(headline), args.steps, 1, per_step=True)                     # (afterwards: the spread of single steps)
 
     # ---- correctness of what was timed: the generator knows every (uncorrupted) line's answer ----
     got = {"compact": lambda: rows[:, 0].to(torch.int32), "narrow": lambda: rows8[:, 0].view(torch.int8).to(torch.int32), "dense": lambda: mid}[headline]()
     ok = bool(torch.equal(got, want)) if known is None else bool(torch.equal(got[known], want[known]))
     ok = ok and int(overflow.item()) == 0
-    okt = torch.tensor([1 if ok else 0], device=dev)
-    if distributed:
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-    if int(okt.item()) != 1:
-        raise SystemExit("bench: match ids differ from the generator's expected categories")
+    all_ranks_ok(ok, "match ids differ from the generator's expected categories")
 
-    # ---- final gather of results to rank 0 over xGMI (reported, not in `value`) ----
-    gather_ms = None
-    gather_dense_ms = None
-    gather_narrow_ms = None
+    # per-rank step times (N > 1: min / max over the ranks), and the world size as the collective library reports it
+    rank_ms = torch.tensor([own_elapsed * 1e3 / args.steps], dtype=torch.float64, device=dev)
+    rank_ms_all = [rank_ms.clone() for _ in range(world)]
+    if distributed:
+        dist.all_gather(rank_ms_all, rank_ms)
+    rank_ms_all = [float(x.item()) for x in rank_ms_all]
+
+    # ---- final gather of results to rank 0 over xGMI (reported, not in `value`), then the same gather overlapped with the
+    # next batch's kernel on a second stream: what a job pays per batch when it gathers every batch ----
+    gather_ms = gather_dense_ms = gather_narrow_ms = None
+    overlapped = None
     if distributed and not args.no_gather:
         for fmt in formats:
             step(fmt)
@@ -386,9 +489,10 @@ def main():
         gm, gc = gdist.gather_results(mid, caps, dst=0)  # the same in the dense format
         torch.cuda.synchronize()
         gather_dense_ms = (time.perf_counter() - tg) * 1e3
+        same = True
         if rank == 0:
-            assert gr.shape[0] == gm.shape[0] and torch.equal(gr[:n], rows) and torch.equal(gm[:n], mid) and torch.equal(gc[:n], caps)
-            assert torch.equal(gr[:, 0].to(torch.int32), gm)
+            same = gr.shape[0] == gm.shape[0] and torch.equal(gr[:n], rows) and torch.equal(gm[:n], mid) and torch.equal(gc[:n], caps) and \
+                torch.equal(gr[:, 0].to(torch.int32), gm)
         if narrow_ok:
             torch.cuda.synchronize()
             dist.barrier()
@@ -397,9 +501,51 @@ def main():
             torch.cuda.synchronize()
             gather_narrow_ms = (time.perf_counter() - tg) * 1e3
             if rank == 0:
-                assert torch.equal(g8[:n], rows8) and torch.equal(g8[:, 0].view(torch.int8).to(torch.int32), gm)
+                same = same and torch.equal(g8[:n], rows8) and torch.equal(g8[:, 0].view(torch.int8).to(torch.int32), gm)
             del g8
         del gr, gm, gc
+        all_ranks_ok(same, "gathered rows differ from the ranks' own")
+        # two-deep pipeline: batch k+1's kernel is enqueued on the compute stream before the gather of batch k (its rows
+        # in the other of two buffers, on the gather stream behind an event) is waited for
+        head_rows = rows8 if headline == "narrow" else rows
+        if headline != "dense":
+            bufs = [head_rows, torch.empty_like(head_rows)]
+            gstream = torch.cuda.Stream(device=dev)
+            comp = torch.cuda.current_stream()
+
+            def kernel_into(buf):
+                gorp.extract_batch_device(data.data_ptr(), offsets.data_ptr(), n, None, buf.data_ptr(), stream=stream, no_sync=True,
+                                          line_bytes_hint=hint, compact=2 if headline == "narrow" else True, overflow_ptr=overflow.data_ptr(), max_line_bytes=max_line)
+
+            def pipelined(steps):
+                done = [None, None]
+                for k in range(steps + 1):
+                    if k < steps:
+                        kernel_into(bufs[k & 1])               # batch k's kernel: enqueued before batch k-1's gather is waited for
+                        done[k & 1] = torch.cuda.Event()
+                        done[k & 1].record(comp)
+                    if k >= 1:
+                        gstream.wait_event(done[(k - 1) & 1])
+                        with torch.cuda.stream(gstream):
+                            out = gdist.gather_rows(bufs[(k - 1) & 1], dst=0, sizes=[n] * world)
+                        del out
+                        free = torch.cuda.Event()              # (buffer (k-1)&1 is written again by batch k+1: that kernel waits for this gather)
+                        free.record(gstream)
+                        comp.wait_event(free)
+                torch.cuda.synchronize()
+
+            pipelined(2)
+            torch.cuda.synchronize()
+            dist.barrier()
+            tp = time.perf_counter()
+            pipelined(args.steps)
+            dist.barrier()
+            el = time.perf_counter() - tp
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            overlapped = {"value": n * world * args.steps / float(tt.item()), "ms_per_step": float(tt.item()) * 1e3 / args.steps,
+                          "what": "every batch's %s rows gathered to rank 0 on a second stream while the next batch's kernel runs (two row buffers)" % ("u8" if headline == "narrow" else "u16")}
+            del bufs
 
     # ---- N > 1: BASELINE.json configs[3] beside the curve -- 64 extractions, 10 M x 200 B lines per GPU (80 M on 8), the tables
     # compiled on rank 0 and broadcast over RCCL, u8 rows; the same timing protocol, reported as its own object ----
@@ -419,13 +565,10 @@ def main():
         step4 = lambda: gorp4.extract_batch_device(data4.data_ptr(), offsets4.data_ptr(), n4, None, rows4.data_ptr(), stream=stream, no_sync=True,
                                                    line_bytes_hint=hint4, compact=2 if narrow4 else True, overflow_ptr=over4.data_ptr(),
                                                    max_line_bytes=max4)
-        elapsed4, kernel4_ms = timed(step4, args.steps, args.warmup, spin_ms=args.spin_up_ms)
+        elapsed4, kernel4_ms = timer(step4, args.steps, args.warmup, spin_ms=args.spin_up_ms)
         got4 = (rows4[:, 0].view(torch.int8) if narrow4 else rows4[:, 0]).to(torch.int32)
         ok4 = (bool(torch.equal(got4, want4)) if known4 is None else bool(torch.equal(got4[known4], want4[known4]))) and int(over4.item()) == 0
-        ok4t = torch.tensor([1 if ok4 else 0], device=dev)
-        dist.all_reduce(ok4t, op=dist.ReduceOp.MIN)
-        if int(ok4t.item()) != 1:
-            raise SystemExit("bench: configs[3]: match ids differ from the generator's expected categories")
+        all_ranks_ok(ok4, "configs[3]: match ids differ from the generator's expected categories")
         gather4_ms = None
         if not args.no_gather:
             torch.cuda.synchronize()
@@ -444,6 +587,7 @@ def main():
                    "table_bcast_ms": bcast4_ms, "gather_ms": gather4_ms, "table_blob_bytes": int(gorp4.stat(4))}
         del data4, offsets4, rows4
 
+    out = None
     if rank == 0:
         steps = args.steps
         ms_per_step = elapsed * 1e3 / steps
@@ -456,21 +600,10 @@ def main():
                     "compact": "compact rows (int16 id + uint16 offsets, %d B/line)" % (2 + 4 * G),
                     "dense": "dense (int32 id + int32 offsets, %d B/line)" % (4 + 8 * G)}
         achieved = algo_read / (k_avg * 1e-3) / 1e9
-        # HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this kernel on this exact workload
-        # (tools/collect_profiles.sh: FETCH_SIZE doubled per the gfx950 correction, calibrated against a same-size copy
-        # kernel in the same run).  Counters cannot be read from inside this process: the RECORDED figure of the committed
-        # summary is reported when its workload and result format match this run, else null.
-        traffic, traffic_src = None, None
-        for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
-            try:
-                path = os.path.join(ROOT, "profiles", name)
-                tj = json.load(open(path))
-                if tj["algorithmic_read_bytes"] == algo_read and tj["algorithmic_write_bytes"] == write_bytes[headline]:
-                    traffic = tj["traffic_bytes_per_launch"]
-                    traffic_src = "recorded: profiles/%s (%s)" % (name, time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(path))))
-                    break
-            except (OSError, ValueError, KeyError):
-                pass
+        if config == 2:
+            traffic, traffic_src = recorded_traffic(("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"), algo_read, write_bytes[headline])
+        else:
+            traffic, traffic_src = recorded_traffic(("r05_config%d_traffic.json" % config,), algo_read, write_bytes[headline])
         per_format = {}
         for fmt, (f_elapsed, f_ms) in runs.items():
             f_avg = sum(f_ms) / len(f_ms)
@@ -478,12 +611,6 @@ def main():
                                "ms_per_step": f_elapsed * 1e3 / len(f_ms), "kernel_ms_avg": f_avg,
                                "algorithmic_write_bytes": write_bytes[fmt], "read_gb_per_s": algo_read / (f_avg * 1e-3) / 1e9,
                                "frac": algo_read / (f_avg * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        if recycled is not None:
-            r_avg = sum(recycled[1]) / len(recycled[1])
-            per_format["narrow_rows_in_a_recycled_block"] = {
-                "results": fmt_desc["narrow"] + ", written to a block PyTorch's allocator carved out of the generator's freed memory", "steps": len(recycled[1]),
-                "lines_per_s": n * world * len(recycled[1]) / recycled[0], "ms_per_step": recycled[0] * 1e3 / len(recycled[1]), "kernel_ms_avg": r_avg,
-                "algorithmic_write_bytes": write_bytes["narrow"], "read_gb_per_s": algo_read / (r_avg * 1e-3) / 1e9, "frac": algo_read / (r_avg * 1e-3) / 1e9 / HBM_PEAK_GBS}
         out = {
             "metric": "lines/sec (Gorp.extract: product-DFA match + capture offsets; results as %s)" % fmt_desc[headline],
             "value": value,
@@ -501,18 +628,16 @@ def main():
             "config": {"workload": desc, "baseline_config": config,
                        "lines_per_gpu": n, "mean_line_bytes": total_bytes / n, "offsets": "u32",
                        "results": fmt_desc[headline], "max_line_bytes": max_line,
-                       "result_buffer_candidates_ms": cand_ms, "result_buffer_choice": cand_pick,   # (where the rows lie: DESIGN.md section 5)
+                       "result_buffer": "as allocated" if cand_ms is None else "the median of %d candidates" % len(cand_ms),
+                       "result_buffer_candidates_ms": cand_ms, "result_buffer_choice": cand_pick,
                        "match_dfa_states": int(gorp.stat(0)), "char_classes": int(gorp.stat(1)),
                        "capture_states": int(gorp.stat(2)), "table_blob_bytes": int(gorp.stat(4)),
-                       "table_tier": ("hop tier: run + chain records, %d of %d states' records in LDS (%d of them reachable by well-formed lines), dense rows in global memory"
-                                      % (int(gorp.stat(15)), int(gorp.stat(14)), int(gorp.stat(16)))) if int(gorp.stat(14)) > 0 else
-                                     {0: "per-line kernel", 1: "LDS (dense rows)", 2: "L2 (dense rows)", 3: "LDS (range records)", 4: "L2 (range records)"}.get(int(gorp.stat(7)), str(gorp.stat(7))),
-                       "kernel": {1: "tile kernel", 2: "slice kernel", 3: "per-line kernel", 4: "lane kernel", 5: "tile kernel on the hop tier's tables",
-                                  6: "hop slice kernel"}.get(int(gorp.stat(25)), "?") + " (gx_stat(h, 25): what the library launched)",
+                       "table_tier": table_tier(gorp),
+                       "kernel": KERNEL_NAMES.get(int(gorp.stat(25)), "?") + " (gx_stat(h, 25): what the library launched)",
                        "parallelism": "lines sharded by rank (dp%d), no collective in a step" % world},
             "gb_per_s_scanned": total_bytes * world * steps / elapsed / 1e9,
             "kernel_ms": {"avg": k_avg, "clock": "two events on the launch stream around the %d timed steps" % steps,
-                          "spin_up_ms": args.spin_up_ms,   # untimed steps before the W warm-up steps: the device at its steady clocks (see timed())
+                          "spin_up_ms": args.spin_up_ms,   # untimed steps before the W warm-up steps: the device at its steady clocks (see Timer)
                           "from_idle": {"avg": sum(from_idle[1]) / len(from_idle[1]), "ms_per_step": from_idle[0] * 1e3 / steps,
                                         "lines_per_s": n * world * steps / from_idle[0],
                                         "protocol": "0.25 s of idling, then the same W + K steps without the spin-up"},
@@ -532,6 +657,13 @@ def main():
             "gather_dense_ms": gather_dense_ms,
             "gather_narrow_ms": gather_narrow_ms,
         }
+        if distributed:
+            out["collective_world_size"] = dist.get_world_size()   # as the process group (RCCL) reports it
+            out["collective_backend"] = dist.get_backend()
+            out["ms_per_step_by_rank"] = {"min": min(rank_ms_all), "max": max(rank_ms_all), "all": rank_ms_all}
+            if overlapped is not None:
+                out["value_with_overlapped_gather"] = overlapped["value"]
+                out["overlapped_gather"] = overlapped
         if config4 is not None:
             out["configs3_64_extractions"] = config4
         if not args.no_cpu_baseline and world == 1:
@@ -540,7 +672,7 @@ def main():
             d_cpu = data[:end].cpu().numpy()
             o_cpu = offsets[: sample + 1].cpu().numpy().astype(np.uint32)
             base, omid, ocaps, ns = cpu_baseline(definition, d_cpu, o_cpu)
-            # the baseline run doubles as a parity check of the timed GPU output (both formats)
+            # the baseline run doubles as a parity check of the timed GPU output (every format)
             for fmt in formats:
                 step(fmt)
             torch.cuda.synchronize()
@@ -565,6 +697,7 @@ def main():
                         "sample": "first %d lines of the rank-0 shard, %d threads over Gorp.extract on JVM %s (tools/RefBench.java), %.1f s"
                                   % (ref["lines"], ref["cores"], ref["java"], ref["seconds"]), "port": port}
             out["cpu_baseline"] = base
+            del d_cpu, o_cpu
         if world == 1 and config == 2:
             # beside the batch number: what ONE Gorp.extract(String) costs through the same library (gx_extract_one_utf16, the
             # drop-in for a caller that does not batch) -- a latency, reported for context, never part of `value`
@@ -584,6 +717,20 @@ def main():
                 out["one_line_latency_us"] = round((_time.perf_counter() - t_one) / 1000 * 1e6, 1)
             except Exception as e:   # (context only: the bench line does not depend on it)
                 out["one_line_latency_us"] = "unavailable (%s)" % type(e).__name__
+    if also_side:
+        # ---- N = 1: BASELINE.json configs[2] and configs[4] in the same line, the same protocol, complete objects ----
+        del data, offsets, mid, caps, rows, rows8, gorp
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        also = {}
+        also["config3"] = side_workload(3, args, dev, stream, timer, with_cpu=not args.no_cpu_baseline)
+        mixed = side_workload(3, args, dev, stream, timer, variant="mixed_case", with_cpu=not args.no_cpu_baseline)
+        also["config3"]["generator_variants"] = {
+            "lower_case": {k: also["config3"][k] for k in ("ms_per_step", "kernel_ms_avg", "lines_per_s")} | {"frac": also["config3"]["roofline"]["frac"]},
+            "mixed_case": {k: mixed[k] for k in ("workload", "ms_per_step", "kernel_ms_avg", "lines_per_s")} | {"frac": mixed["roofline"]["frac"], "parity": mixed.get("parity")}}
+        also["config5"] = side_workload(5, args, dev, stream, timer, with_cpu=not args.no_cpu_baseline)
+        out["also"] = also
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()

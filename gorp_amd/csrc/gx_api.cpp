@@ -872,6 +872,7 @@ void choose_tile_image(gx_handle* h) {
             L.rec_indexed = P.n_hot;
             L.acc_tab = P.info_lds;   // int16 info words of the hot states
             L.at = P.fin_lds;         // final records in LDS (0: in the global image at fin_tags)
+            L.hop_sets = P.sets_lds;  // the loop sets (the walk's second chance)
             *(q ? small : full) = L;
         }
     };

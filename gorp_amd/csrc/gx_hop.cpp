@@ -2,6 +2,7 @@
 // shortcut in them is a fact about the dense rows).  Host code, once per definition.
 #include "gx_hop.hpp"
 
+#include <algorithm>
 #include <deque>
 
 namespace gx {
@@ -130,6 +131,41 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
     struct Exit { bool any = false; Range r; uint32_t entry = 0; };
     std::vector<Range> run(S);
     std::vector<long> run_weight(S, 0);
+    // LOOP SETS.  A state's run is ONE interval of the bytes it loops on; the others (\\w: digits, upper case, '_' beside lower
+    // case; [^,]: what lies below the comma) cost text that uses them an exact step per byte -- `JohnDoe42` in a \\w+ field was six
+    // round trips through the dense rows in global memory (config 3 with mixed-case values: 4.7 ms against 0.79).  So the
+    // record names the state's loop set: up to four intervals (the heaviest ones, the run among them) in a table of 8-byte
+    // entries in LDS, and the walk gives a lane whose run ended and whose chain did not apply a SECOND CHANCE -- the window
+    // tested against the union of those intervals -- before it takes the exact step (gx_hop_dev.hpp).  A fact about the dense
+    // rows like the run itself (checked below), taken only where the fast tests have failed: text that stays inside the run
+    // intervals never gets there.
+    std::vector<std::array<uint8_t, 8>> set_table(1, std::array<uint8_t, 8>{0, 0, 0, 0, 0x80, 0x80, 0x80, 0x80});   // entry 0: no interval
+    std::map<std::array<uint8_t, 8>, uint32_t> set_index;
+    std::vector<uint32_t> set_of(S, 0);
+    auto loop_set = [&](const ClassSet& cs) -> uint32_t {
+        const ByteSet m = bytes_of(cs);
+        std::vector<Range> rs;
+        for (int i = 0; i < 128; ++i) {
+            if (!in_set(m, i)) continue;
+            int j = i;
+            long w = 0;
+            while (j < 128 && in_set(m, j)) { w += byte_worth(j); ++j; }
+            rs.push_back(Range{i, j - 1, w});
+            i = j;
+        }
+        if (rs.size() < 2) return 0u;   // (one interval: the run is all there is)
+        std::stable_sort(rs.begin(), rs.end(), [](const Range& a, const Range& b) { return a.weight != b.weight ? a.weight > b.weight : (a.hi - a.lo) > (b.hi - b.lo); });
+        if (rs.size() > 4) rs.resize(4);
+        std::sort(rs.begin(), rs.end(), [](const Range& a, const Range& b) { return a.lo < b.lo; });
+        std::array<uint8_t, 8> key{0, 0, 0, 0, 0x80, 0x80, 0x80, 0x80};
+        for (size_t q = 0; q < rs.size(); ++q) { key[q] = static_cast<uint8_t>(rs[q].lo); key[4 + q] = static_cast<uint8_t>(0x7F - rs[q].hi); }
+        auto it = set_index.find(key);
+        if (it != set_index.end()) return it->second;
+        if (set_table.size() >= 256) return 0u;   // (the record has a byte for the index)
+        set_table.push_back(key);
+        set_index[key] = static_cast<uint32_t>(set_table.size() - 1);
+        return static_cast<uint32_t>(set_table.size() - 1);
+    };
     std::vector<Exit> exit_of(S);
     std::vector<std::vector<uint32_t>> plausible_targets(S);
     for (size_t s = 0; s < S; ++s) {
@@ -139,6 +175,7 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
             if (g.entry == static_cast<uint32_t>(s)) {  // the plain self-loop: same state, no program
                 run[s] = best_range(g.set);
                 run_weight[s] = g.weight;
+                if (s != dead) set_of[s] = loop_set(g.set);
                 continue;
             }
             if (g.weight > 0) { ++n_plausible; only = &g; plausible_targets[s].push_back(g.entry & 0xFFFFu); }
@@ -250,10 +287,10 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
         const Chain& ch = chain[s];
         uint32_t run_lo = 0, run_k = 0x80;  // none: every byte fails the test
         if (run[s].hi >= run[s].lo && s != dead) { run_lo = static_cast<uint32_t>(run[s].lo); run_k = 0x7Fu - static_cast<uint32_t>(run[s].hi); ++out.n_runs; }
-        // w0: run_lo | run_k << 8 | klen << 16 | (spare) ; w1: target | off1 << 16 | off2 << 24 ; w2: column1 * 128 | column2 * 128 << 16 ;
+        // w0: run_lo | run_k << 8 | klen << 16 | loop set << 24 ; w1: target | off1 << 16 | off2 << 24 ; w2: column1 * 128 | column2 * 128 << 16 ;
         // w3: tail position (a v_perm selector: 0 .. 7) | tail_lo << 8 | tail_span << 16 ; w4, w5: the chain's single bytes, 0 = no byte to compare
         // (fields sit where SDWA operands can take them: gx_hop_dev.hpp)
-        r[0] = run_lo | run_k << 8 | static_cast<uint32_t>(ch.klen) << 16;
+        r[0] = run_lo | run_k << 8 | static_cast<uint32_t>(ch.klen) << 16 | set_of[s] << 24;   // (byte 3: the state's loop set, 0 = none)
         r[1] = (ch.klen ? perm[ch.target] : 0u) | ch.off[0] << 16 | ch.off[1] << 24;   // (no chain: the field is the LDS row's address / 4, below)
         r[2] = (ch.col[0] << 7) | (ch.col[1] << 7) << 16;
         uint8_t lits[HOP_CHAIN];
@@ -273,6 +310,13 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
         if (run_k != 0x80u)
             for (uint32_t bt = run_lo; bt <= 0x7Fu - run_k; ++bt)
                 if (rows[s * cols + T.cls256[bt]] != static_cast<uint32_t>(s)) throw GxError(GX_E_ARG, "internal: hop tier run does not match the dense rows");
+        {
+            const std::array<uint8_t, 8>& ls = set_table[r[0] >> 24];
+            for (int q = 0; q < 4; ++q)
+                if (ls[4 + q] != 0x80u)
+                    for (uint32_t bt = ls[q]; bt <= 0x7Fu - ls[4 + q]; ++bt)
+                        if (rows[s * cols + T.cls256[bt]] != static_cast<uint32_t>(s)) throw GxError(GX_E_ARG, "internal: hop tier loop set does not match the dense rows");
+        }
         const uint32_t klen = (r[0] >> 16) & 0xFFu;
         const uint8_t* lits = reinterpret_cast<const uint8_t*>(&r[4]);
         const uint32_t tail_pos = r[3] & 0xFFu, tail_lo = (r[3] >> 8) & 0xFFu, tail_span = (r[3] >> 16) & 0xFFu;
@@ -308,6 +352,7 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
     out.dead = perm[dead];
     out.n_regs = n_regs;
     out.match_automaton = match_automaton;
+    out.n_loop_sets = static_cast<uint32_t>(set_table.size() - 1);
     const uint8_t* hb = reinterpret_cast<const uint8_t*>(hops.data());
     // One LDS image per hot budget (the state order does not depend on it, so the global image serves both).  The records
     // in the global image keep a zero row address: a state that is hot under one budget is read from there under the other.
@@ -354,6 +399,10 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
             L.bytes.insert(L.bytes.end(), fl, fl + fin_rec.size() * 2);
             while (L.bytes.size() % 16) L.bytes.push_back(0);
         }
+        // the loop sets: u8 lo[4], u8 k[4] per entry (k = 0x7F - hi; 0x80: no interval), entry 0 = none
+        L.sets_lds = static_cast<uint32_t>(L.bytes.size());
+        for (auto& e : set_table) L.bytes.insert(L.bytes.end(), e.begin(), e.end());
+        while (L.bytes.size() % 16) L.bytes.push_back(0);
         return L;
     };
     out.full = make_lds(out.n_hot);

@@ -47,6 +47,7 @@ constexpr uint32_t HOP_CHAIN = 8;         // elements per chain
 struct HopLds {
     std::vector<uint8_t> bytes;
     uint32_t n_hot = 0, info_lds = 0, fin_lds = 0, n_lds_rows = 0;
+    uint32_t sets_lds = 0;         // the loop sets (gx_hop.cpp): 8 bytes per entry, entry 0 = none
 };
 
 struct HopImage {
@@ -63,7 +64,7 @@ struct HopImage {
     bool match_automaton = false;        // built from the match automaton (PolyMatcher.match batches): an info word is the first
                                          // accepting extraction or -1, there are no programs and no final records
     // diagnostics (gx_stat)
-    uint32_t n_reachable_hot = 0, n_chains = 0, n_runs = 0;
+    uint32_t n_reachable_hot = 0, n_chains = 0, n_runs = 0, n_loop_sets = 0;
 };
 
 // hot_budget_bytes: LDS bytes the hot records may take.  Returns false (out.ok stays false) when the definition is

@@ -32,6 +32,7 @@ struct HopTab {
     uint32_t info_off;     // byte offset of the info column in a row
     uint32_t n_hot;        // states [0, n_hot) have their records in LDS at HOP_LDS_AT
     uint32_t lrow_cols;    // a dense row's copy in LDS: u16 successors, and at this byte offset its u8 register columns
+    uint32_t sets;         // LDS address of the loop sets: u8 lo[4], u8 k[4] per entry (a record's byte 3 is its state's entry; 0 = none)
 };
 
 // two / one dwords at a 4-byte aligned LDS address (ds_read2_b32 / ds_read_b32)
@@ -209,7 +210,30 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
         // ---- 4. one exact step where the chain does not apply ----
         const uint64_t m_exact = m_step & ~m_chain;
         if (m_exact != 0ull) {
-            if (stepping && !chained) {
+            // ---- second chance: the state loops on more than its run interval (\\w: digits, upper case, '_' beside lower case).  The
+            // window is tested against the union of the loop set's intervals (up to four); bytes inside it leave the lane where it is,
+            // in its state, with no program -- as a run does.  Only lanes whose run ended and whose chain did not apply get here, and
+            // only in states that have a loop set: text inside the run intervals never pays for it.  (The flags of an interval are
+            // exact up to its own first offender and only ever too many above it, so the AND over the intervals never calls a byte
+            // inside that is not.) ----
+            bool exact = stepping && !chained;
+            const uint32_t set = h0.x >> 24;
+            if ((__builtin_amdgcn_ballot_w64(set != 0u) & m_exact) != 0ull) {
+                const u32x2 ls = lds_ld<u32x2>(H.sets + ((exact ? set : 0u) << 3));
+                uint32_t o0 = HI_BITS, o1 = HI_BITS, o2 = HI_BITS, o3 = HI_BITS;
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j) {
+                    const uint32_t sel = j * 0x01010101u;
+                    const uint32_t l4 = __builtin_amdgcn_perm(ls.x, ls.x, sel), kk4 = __builtin_amdgcn_perm(ls.y, ls.y, sel);
+                    o0 &= run_flags(x0, l4, kk4); o1 &= run_flags(x1, l4, kk4); o2 &= run_flags(x2, l4, kk4); o3 &= run_flags(x3, l4, kk4);
+                }
+                const uint32_t g0 = static_cast<uint32_t>(__ffs(static_cast<int>(o0)) - 1), g1 = static_cast<uint32_t>(__ffs(static_cast<int>(o1)) - 1);
+                const uint32_t g2 = static_cast<uint32_t>(__ffs(static_cast<int>(o2)) - 1), g3 = static_cast<uint32_t>(__ffs(static_cast<int>(o3)) - 1);
+                uint32_t nu = min3u(g0, sat_add(g1, 32u), min3u(sat_add(g2, 64u), sat_add(g3, 96u), 128u)) >> 3;   // 0 .. 16 bytes of the window inside the union
+                nu = min(nu, e - (q - n));
+                if (exact && nu > n) { p = q - n + nu; exact = false; }
+            }
+            if (exact) {
                 // a state without a chain keeps the LDS address / 4 of its dense row's copy in the target field (0: none)
                 exact_step(((h0.x >> 16) & 0xFFu) == 0u ? (h0.y & 0xFFFFu) << 2 : 0u, v0 & 0xFFu, q);
                 if (ALL_HOT)

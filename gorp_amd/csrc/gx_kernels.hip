@@ -716,6 +716,7 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
     H.info_off = L.ncls * 4u;
     H.n_hot = L.rec_indexed;
     H.lrow_cols = (2u * L.ncls + 3u) & ~3u;
+    H.sets = L.hop_sets;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t slice = L.stage + wave * L.stage_bytes;

@@ -287,6 +287,7 @@ k_extract_tile(GxLds L, TileIO io) {
     H.info_off = L.ncls * 4u;
     H.n_hot = L.rec_indexed;
     H.lrow_cols = (2u * L.ncls + 3u) & ~3u;
+    H.sets = L.hop_sets;
     const uint8_t* __restrict__ data = io.data;
     const OFF* __restrict__ off = static_cast<const OFF*>(io.off);
     const uint64_t n = io.n;

@@ -92,16 +92,20 @@ def gather_results_compact(match_id, caps, dst=0):
     return mid, cp
 
 
-def gather_rows(rows, dst=0):
+def gather_rows(rows, dst=0, sizes=None):
     """Gather the compact result rows the kernels write themselves (gx_batch_opts.compact_results: int16 id + uint16
     offsets per line, [n, 1 + slots] int16/uint16 tensors) on `dst` in rank order -- no pack step, half the bytes of
-    the dense rows on the xGMI links.  Shards may differ in length.  Returns the concatenated rows (or None)."""
+    the dense rows on the xGMI links.  Shards may differ in length.  Returns the concatenated rows (or None).
+    sizes: every rank's row count when the caller knows them (no size exchange, no host read-back: the call only
+    enqueues -- what a pipeline that gathers batch k under the kernel of batch k + 1 needs)."""
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = rows.device
-    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
+    if sizes is None:
+        n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(sizes, n)
+        sizes = [int(s.item()) for s in sizes]
+    assert len(sizes) == world and sizes[rank] == rows.shape[0]
     padded = rows
     if rows.shape[0] != max(sizes):
         padded = torch.zeros((max(sizes), rows.shape[1]), dtype=rows.dtype, device=dev)

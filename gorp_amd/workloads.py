@@ -148,12 +148,24 @@ def syslog_definition(n_rules, seed=3, n_keys=7):
     return rules, meta
 
 
-def syslog_lines(meta, n, seed=3, line_bytes=LINE_BYTES, corrupt_frac=0.02, min_len=None, max_len=None):
+_MIXED = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789"
+
+
+def _token(rng, lo=2, hi=8):
+    """`JohnDoe42`: letters of both cases and digits -- every character is a \\w, few of them lower case."""
+    return "".join(_MIXED[int(c)] for c in rng.integers(0, len(_MIXED), rng.integers(lo, hi)))
+
+
+def syslog_lines(meta, n, seed=3, line_bytes=LINE_BYTES, corrupt_frac=0.02, min_len=None, max_len=None, mixed_case=False):
     """Host-side generator (numpy): lines drawn uniformly over the rules, padded with the
-    last value to `line_bytes` (or to a log-uniform length in [min_len, max_len])."""
+    last value to `line_bytes` (or to a log-uniform length in [min_len, max_len]).
+    mixed_case: the \\w and \\S values are mixed-case alphanumeric tokens (and the padding of such a value cycles through
+    `wW7`) instead of lower-case words: what text with upper-case letters and digits in word fields costs a table that
+    skips one byte interval per state."""
     rng = np.random.default_rng(seed)
     chunks, lens, cats = [], [], []
     digs = "0123456789"
+    word = _token if mixed_case else _word
     for i in range(n):
         r = int(rng.integers(0, len(meta)))
         app, keys, kinds = meta[r]
@@ -167,15 +179,18 @@ def syslog_lines(meta, n, seed=3, line_bytes=LINE_BYTES, corrupt_frac=0.02, min_
             if kind == 0:
                 v = "".join(digs[int(x)] for x in rng.integers(0, 10, rng.integers(1, 6)))
             elif kind == 1:
-                v = _word(rng, 2, 8)
+                v = word(rng, 2, 8)
             else:
-                v = "/" + _word(rng, 2, 8) + "?" + _word(rng, 1, 4)
+                v = "/" + word(rng, 2, 8) + "?" + word(rng, 1, 4)
             body.append(" %s=%s" % (k, v))
         s = head + "".join(body)
         pad = target - len(s)
         if pad > 0:  # extend the last value with characters its class accepts
             fill = {0: "7", 1: "w", 2: "x"}[kinds[-1]]
-            s += fill * pad
+            if mixed_case and kinds[-1] != 0:
+                s += ("wW7" * (pad // 3 + 1))[:pad]
+            else:
+                s += fill * pad
         b = bytearray(s.encode("latin-1"))
         cat = r
         if rng.random() < corrupt_frac:

@@ -44,7 +44,8 @@ Outcome dense_outcome(const Tables& T, const std::vector<uint8_t>& line) {
     return o;
 }
 
-Outcome hop_outcome(const Tables& T, const HopImage& H, const std::vector<uint8_t>& line, size_t* iterations) {
+static size_t second_chances_total = 0;
+Outcome hop_outcome(const Tables& T, const HopImage& H, const std::vector<uint8_t>& line, size_t* iterations, size_t* second_chances = &second_chances_total) {
     const uint32_t* rows = reinterpret_cast<const uint32_t*>(H.global.data());
     const uint32_t cols = H.row_bytes / 4;
     const uint8_t* hops = H.global.data() + H.hops_off;
@@ -77,6 +78,12 @@ Outcome hop_outcome(const Tables& T, const HopImage& H, const std::vector<uint8_
             p = q + klen;
             s = r[1] & 0xFFFFu;
         } else {
+            // the second chance: the window at p against the union of the state's loop set (H.full.bytes at sets_lds: u8 lo[4], u8 k[4] per entry)
+            const uint8_t* ls = H.full.bytes.data() + H.full.sets_lds + 8u * (r[0] >> 24);
+            size_t nu = 0;
+            auto in_union = [&](uint8_t b) { for (int j = 0; j < 4; ++j) if (ls[4 + j] != 0x80u && b < 0x80u && b >= ls[j] && b <= 0x7Fu - ls[4 + j]) return true; return false; };
+            while (nu < 16 && p + nu < e && in_union(cls[p + nu])) ++nu;
+            if (nu > n) { p = p + nu; ++*second_chances; continue; }
             const uint32_t x = rows[static_cast<size_t>(s) * cols + H.full.bytes[cls[q]]];
             col[x >> 16] = static_cast<int>(q);
             s = x & 0xFFFFu;
@@ -207,6 +214,6 @@ int main(int argc, char** argv) {
         } catch (GxError& e) { ++bad; }
     }
     printf("asan driver: %d compiled, %d rejected; damaged blobs: %d accepted, %d refused\n", ok, bad, mutated_ok, mutated_bad);
-    printf("hop tier: %zu definitions, %zu lines agree with the dense automaton\n", hop_defs, hop_lines);
+    printf("hop tier: %zu definitions, %zu lines agree with the dense automaton (%zu second chances on loop sets)\n", hop_defs, hop_lines, second_chances_total);
     return 0;
 }

@@ -76,3 +76,5 @@ def test_host_compiler_under_asan_ubsan(tmp_path):
     # the hop tier's tables (gx_hop.cpp), walked on the host as the kernel walks them, agree with the dense automaton
     hop_defs, hop_lines = [int(x) for x in out.split("hop tier: ")[1].replace(" definitions,", "").split()[:2]]
     assert hop_defs >= len(defs) // 2 and hop_lines >= 400 * hop_defs
+    # ... and some of those lines went through a loop set's second chance (\w fields hold digits and upper case)
+    assert int(out.split("lines agree with the dense automaton (")[1].split()[0]) > 0
