@@ -788,7 +788,7 @@ bool plan_hop_slice_launch(const gx_handle* h, GxLds* out, bool match_only = fal
     const uint32_t per_wave = L.stage_bytes + L.regs_wave_bytes;
     if (L.table_bytes + 4u * per_wave > LDS_BYTES) return false;
     uint32_t nw = (LDS_BYTES - L.table_bytes) / per_wave;
-    if (nw > 16) nw = 16;
+    if (nw > 12) nw = 12;   // (the kernel holds the loads of eight tested lines across its walk: three waves per SIMD by registers)
     L.nwaves = nw;
     L.regs = L.table_bytes;
     L.bitmap = 0;
@@ -859,6 +859,8 @@ void choose_tile_image(gx_handle* h) {
         L.u_start = I.match_automaton ? 0xFFFFFFFFu : I.start;
         L.u_dead = I.match_automaton ? 0xFFFFFFFFu : I.dead;
         L.fin_tags = I.fin_off;
+        L.fin_state_off = I.fin_state_off;
+        L.fin_state_rec = I.fin_state_rec;
         L.simple_ops = 1;
         L.tier = 4;
         L.rec = HOP_AT;

@@ -96,6 +96,7 @@ struct GxLds {
     uint32_t sort_lds;    // lane kernel, length-sorted mode: LDS address of u16 perm[sort_chunk] + u32 hist[64] + u32 cursor[64]
     uint32_t sort_chunk;  // ... lines per chunk (0: tiles in input order)
     uint32_t hop_sets;    // hop tier: LDS address of the loop sets (gx_hop.cpp: u8 lo[4], u8 k[4] per entry, entry 0 = none)
+    uint32_t fin_state_off, fin_state_rec;   // hop tier: the final records by state in the global image (byte offset, 0: none; bytes per record)
 };
 constexpr uint32_t GX_STEAL_MAX = 3072;         // workgroups of a tile-kernel launch at most (256 CUs x 12)
 constexpr uint32_t GX_STEAL_STRIDE = 32;        // u32 words between two workgroups' counters: a cache line each (atomics on ONE line

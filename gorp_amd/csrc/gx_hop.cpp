@@ -128,7 +128,7 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
     };
 
     // per state: the run (plain self-loop) and the one plausible exit, if there is exactly one
-    struct Exit { bool any = false; Range r; uint32_t entry = 0; };
+    struct Exit { bool any = false; Range r; uint32_t entry = 0; ClassSet set{}; };
     std::vector<Range> run(S);
     std::vector<long> run_weight(S, 0);
     // LOOP SETS.  A state's run is ONE interval of the bytes it loops on; the others (\\w: digits, upper case, '_' beside lower
@@ -184,13 +184,14 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
             exit_of[s].any = true;
             exit_of[s].r = best_range(only->set);
             exit_of[s].entry = only->entry;
+            exit_of[s].set = only->set;
         }
     }
 
     // chains
     // (at most ONE element of a chain is a proper interval -- the "tail": typically the first byte of the next field; the others are
     // single bytes, which the walk compares four at a time with v_msad_u8)
-    struct Chain { int klen = 0, tail = -1; uint8_t lo[HOP_CHAIN], span[HOP_CHAIN]; uint32_t target = 0, col[2] = {0, 0}, off[2] = {0, 0}; };
+    struct Chain { int klen = 0, tail = -1; uint8_t lo[HOP_CHAIN], span[HOP_CHAIN]; uint32_t target = 0, col[2] = {0, 0}, off[2] = {0, 0}, tail_set = 0; };
     std::vector<Chain> chain(S);
     for (size_t s = 0; s < S; ++s) {
         if (s == dead) continue;
@@ -212,7 +213,13 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
                 ch.off[nops] = k;
                 ++nops;
             }
-            if (ranged) ch.tail = static_cast<int>(k);
+            if (ranged) {
+                ch.tail = static_cast<int>(k);
+                // (the tail is ONE interval of the exit's bytes -- lower case for a \\w field; a value that begins with a digit or an upper-case
+                // letter failed the whole chain and took its literal bytes as exact steps, one by one.  The exit's other intervals, as a loop
+                // set: the walk looks there when the chain's single bytes matched and only the tail did not.)
+                ch.tail_set = loop_set(x.set);
+            }
             ch.lo[k] = static_cast<uint8_t>(x.r.lo);
             ch.span[k] = static_cast<uint8_t>(x.r.hi - x.r.lo);
             ch.klen = static_cast<int>(k) + 1;
@@ -288,14 +295,14 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
         uint32_t run_lo = 0, run_k = 0x80;  // none: every byte fails the test
         if (run[s].hi >= run[s].lo && s != dead) { run_lo = static_cast<uint32_t>(run[s].lo); run_k = 0x7Fu - static_cast<uint32_t>(run[s].hi); ++out.n_runs; }
         // w0: run_lo | run_k << 8 | klen << 16 | loop set << 24 ; w1: target | off1 << 16 | off2 << 24 ; w2: column1 * 128 | column2 * 128 << 16 ;
-        // w3: tail position (a v_perm selector: 0 .. 7) | tail_lo << 8 | tail_span << 16 ; w4, w5: the chain's single bytes, 0 = no byte to compare
+        // w3: tail position (a v_perm selector: 0 .. 7) | tail_lo << 8 | tail_span << 16 | the tail's byte set << 24 (0: the interval is all) ; w4, w5: the chain's single bytes, 0 = no byte to compare
         // (fields sit where SDWA operands can take them: gx_hop_dev.hpp)
         r[0] = run_lo | run_k << 8 | static_cast<uint32_t>(ch.klen) << 16 | set_of[s] << 24;   // (byte 3: the state's loop set, 0 = none)
         r[1] = (ch.klen ? perm[ch.target] : 0u) | ch.off[0] << 16 | ch.off[1] << 24;   // (no chain: the field is the LDS row's address / 4, below)
         r[2] = (ch.col[0] << 7) | (ch.col[1] << 7) << 16;
         uint8_t lits[HOP_CHAIN];
         for (uint32_t k = 0; k < HOP_CHAIN; ++k) lits[k] = (static_cast<int>(k) < ch.klen && static_cast<int>(k) != ch.tail) ? ch.lo[k] : 0;
-        if (ch.tail >= 0) r[3] = static_cast<uint32_t>(ch.tail) | static_cast<uint32_t>(ch.lo[ch.tail]) << 8 | static_cast<uint32_t>(ch.span[ch.tail]) << 16;
+        if (ch.tail >= 0) r[3] = static_cast<uint32_t>(ch.tail) | static_cast<uint32_t>(ch.lo[ch.tail]) << 8 | static_cast<uint32_t>(ch.span[ch.tail]) << 16 | ch.tail_set << 24;
         else r[3] = 0u | 0u << 8 | 0xFFu << 16;           // no tail: byte 0, any value
         if (ch.klen == 0) r[3] = 0u | 2u << 8 | 0u << 16, lits[0] = 0x01;   // no chain: never matches (byte 0 would have to be 1 and 2 at once); an exact step follows
         else ++out.n_chains;
@@ -329,6 +336,12 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
             if (lits[k] == 0) {
                 if (k != tail_pos) throw GxError(GX_E_ARG, "internal: hop tier chain element without a test");
                 lo = tail_lo; hi = tail_lo + tail_span;
+                // (the tail's other intervals lead where its interval leads)
+                const std::array<uint8_t, 8>& ts = set_table[r[3] >> 24];
+                for (int q = 0; q < 4; ++q)
+                    if (ts[4 + q] != 0x80u)
+                        for (uint32_t bt = ts[q]; bt <= 0x7Fu - ts[4 + q]; ++bt)
+                            if (rows[cur * cols + T.cls256[bt]] != rows[cur * cols + T.cls256[lo]]) throw GxError(GX_E_ARG, "internal: hop tier chain tail set is not one group");
             } else if (k == tail_pos && (lits[k] < tail_lo || lits[k] > tail_lo + tail_span)) lo = 1, hi = 0;   // (accepts nothing: fine)
             if (hi > 0x7Fu) throw GxError(GX_E_ARG, "internal: hop tier chain element out of range");
             if (hi < lo) continue;
@@ -419,6 +432,24 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
     const uint8_t* fr = reinterpret_cast<const uint8_t*>(fin_rec.data());
     out.global.insert(out.global.end(), fr, fr + fin_rec.size() * 2);
     while (out.global.size() % 16) out.global.push_back(0);
+    // ... and BY STATE, for the hop slice kernel: a finished line's row is one read of a record its state names -- no info word out
+    // of the dense rows first, no second round trip for the record behind it (configs[4]: 512 extractions' final records are 32 KB,
+    // the info words of its 5 101 reachable states 10 KB: neither fits LDS beside twelve waves).  The record of a state that accepts
+    // nothing holds no tags and its info (-1 / -2-k) where the extraction's index stands.
+    out.fin_state_rec = static_cast<uint32_t>(rec_len * 2);
+    out.fin_state_off = 0;
+    if (!match_automaton && S * rec_len * 2 <= (64ull << 20)) {
+        out.fin_state_off = static_cast<uint32_t>(out.global.size());
+        std::vector<uint16_t> by_state(S * rec_len, 0);
+        for (size_t s = 0; s < S; ++s) {
+            const int32_t info = static_cast<int32_t>(rows[s * cols + ncls]);
+            if (info >= 0) memcpy(&by_state[s * rec_len], &fin_rec[static_cast<size_t>(info) / 2], rec_len * 2);
+            else by_state[s * rec_len + tag_slots] = static_cast<uint16_t>(static_cast<int16_t>(info));
+        }
+        const uint8_t* bs = reinterpret_cast<const uint8_t*>(by_state.data());
+        out.global.insert(out.global.end(), bs, bs + by_state.size() * 2);
+        while (out.global.size() % 16) out.global.push_back(0);
+    }
     if (out.global.size() > 0xFFFFFFF0ull) { out.refused = 3; return false; }
     out.ok = true;
     return true;

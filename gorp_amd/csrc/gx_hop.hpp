@@ -56,9 +56,10 @@ struct HopImage {
                                    // "register := position" per step, 3 beyond a limit of the tier (states, registers, final records)
     HopLds full;                   // as many reachable states as the hot budget holds (the tile kernel)
     HopLds small;                  // the slice kernel's: fewer records, more waves -- the same as `full` when that holds them all
-    std::vector<uint8_t> global;   // dense rows u32[n_states][ncls + 1] | hop records of ALL states | final records
+    std::vector<uint8_t> global;   // dense rows u32[n_states][ncls + 1] | hop records of ALL states | final records | final records by state
     uint32_t ncls = 0, row_bytes = 0, n_states = 0, n_hot = 0;
     uint32_t hops_off = 0, fin_off = 0;  // byte offsets in `global`
+    uint32_t fin_state_off = 0, fin_state_rec = 0;   // ... of the final records BY STATE (0: none), bytes per record
     uint32_t start = 0, dead = 0;        // state indexes (renumbered)
     uint32_t n_regs = 0;
     bool match_automaton = false;        // built from the match automaton (PolyMatcher.match batches): an info word is the first

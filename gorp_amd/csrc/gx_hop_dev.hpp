@@ -96,9 +96,15 @@ __device__ __forceinline__ uint32_t run_flags(uint32_t x, uint32_t lo4, uint32_t
 // exact steps -- inside that branch -- until it is back in the hot set or its line is over, and the loop proper never looks
 // for a record in global memory.
 // CAPTURE false: the match automaton's tables (no programs anywhere): the register writes are left out.
+// The record a lane holds while it stays in its state (the !ALL_HOT walk; the hop slice kernel keeps it across its rounds and
+// reads the run interval out of it for the loaders' run test)
+struct HopKept {
+    uint32_t kept = 0xFFFFFFFFu;
+    u32x2 k0 = {0u, 0u}, k1 = {0u, 0u}, k2 = {0u, 0u};
+};
 template <bool ALL_HOT, bool CAPTURE>
 __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, uint32_t e, uint32_t limit, uint32_t e_chain, uint32_t p0,
-                                                  uint32_t s, uint32_t dead, uint32_t regs, uint32_t leave_at = 0u) {
+                                                  uint32_t s, uint32_t dead, uint32_t regs, uint32_t leave_at, HopKept& K) {
     const uint32_t dummy_col = regs - 128u;
     const uint32_t last_hot = H.n_hot - 1u;
     // one exact step of this lane from state s on the byte `bt` at LDS address q: the dense row (lrow: its copy in LDS, 0: none)
@@ -119,13 +125,16 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
     // re-reading them came out of L1, keeping them was worth nothing by itself, keeping the hot ones' LDS reads down as well 4 %:
     // 0.856 -> 0.825 ms per 2 M lines).  With every record in LDS (config 3) the plain read per iteration is faster (0.895 against
     // 0.939 ms per 10 M lines): ALL_HOT keeps nothing.
-    uint32_t kept = 0xFFFFFFFFu;
-    u32x2 k0 = {0u, 0u}, k1 = {0u, 0u}, k2 = {0u, 0u};
+    uint32_t kept = K.kept;
+    u32x2 k0 = K.k0, k1 = K.k1, k2 = K.k2;
     for (;;) {
         // (leave_at: the hop slice kernel leaves a round's walk when no more than that many lanes still have bytes -- the others have
         // used up their pieces, and a lane in a long value does so in a third of the iterations a lane in literals needs)
         const uint64_t unfinished = __builtin_amdgcn_ballot_w64(p < limit);
-        if (static_cast<uint32_t>(__builtin_popcountll(unfinished)) <= leave_at) break;
+        if (static_cast<uint32_t>(__builtin_popcountll(unfinished)) <= leave_at) {
+            if (!ALL_HOT) { K.kept = kept; K.k0 = k0; K.k1 = k1; K.k2 = k2; }
+            break;
+        }
         // ---- 1. the state's record ----
         u32x2 h0, h1, h2;
         if (ALL_HOT) {
@@ -217,8 +226,25 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
             // exact up to its own first offender and only ever too many above it, so the AND over the intervals never calls a byte
             // inside that is not.) ----
             bool exact = stepping && !chained;
+            // (the chain first: its single bytes matched and its tail byte lies in another interval of the exit's bytes -- a value that
+            // begins with a digit or an upper-case letter; the intervals stand in ascending order, so no borrow reaches a byte that is
+            // not outside by itself: the test is exact)
+            if ((__builtin_amdgcn_ballot_w64(sad == 0u && (h1.y >> 24) != 0u && qk <= e_chain) & m_exact) != 0ull) {
+                const bool retry = exact && sad == 0u && qk <= e_chain;
+                const u32x2 ts = lds_ld<u32x2>(H.sets + ((retry ? h1.y >> 24 : 0u) << 3));
+                const uint32_t tb = __builtin_amdgcn_perm(v1, v0, h1.y) & 0xFFu;
+                if (retry && run_flags(tb * 0x01010101u, ts.x, ts.y) != HI_BITS) {
+                    if (CAPTURE) {
+                        lds_st<uint16_t>(add_word0(dummy_col, h1.x), static_cast<uint16_t>(add_byte2(rel, h0.y)));
+                        lds_st<uint16_t>(add_word1(dummy_col, h1.x), static_cast<uint16_t>(add_byte3(rel, h0.y)));
+                    }
+                    p = qk;
+                    s = h0.y & 0xFFFFu;
+                    exact = false;
+                }
+            }
             const uint32_t set = h0.x >> 24;
-            if ((__builtin_amdgcn_ballot_w64(set != 0u) & m_exact) != 0ull) {
+            if (__builtin_amdgcn_ballot_w64(exact && set != 0u) != 0ull) {
                 const u32x2 ls = lds_ld<u32x2>(H.sets + ((exact ? set : 0u) << 3));
                 uint32_t o0 = HI_BITS, o1 = HI_BITS, o2 = HI_BITS, o3 = HI_BITS;
 #pragma unroll
@@ -250,8 +276,9 @@ __device__ __forceinline__ uint32_t walk_hop(const HopTab& H, bool all_hot, uint
                                              uint32_t dead, uint32_t regs) {
     const uint32_t p0 = stage + start, e = stage + end;
     uint32_t p = on ? p0 : e;
-    if (all_hot) return walk_hop_span<true, CAPTURE>(H, p, e, e, e, p0, s, dead, regs);
-    return walk_hop_span<false, CAPTURE>(H, p, e, e, e, p0, s, dead, regs);
+    HopKept K;
+    if (all_hot) return walk_hop_span<true, CAPTURE>(H, p, e, e, e, p0, s, dead, regs, 0u, K);
+    return walk_hop_span<false, CAPTURE>(H, p, e, e, e, p0, s, dead, regs, 0u, K);
 }
 
 }  // namespace gx

@@ -164,6 +164,94 @@ __device__ __forceinline__ void write_row(const LineOut& out, uint64_t i, int32_
     }
 }
 
+// The same from the final record OF THE STATE (gx_hop.cpp: fin_state_off): `recp` = its tags (u16 begin, end per group, padded to
+// four groups) and behind them the extraction's index, or -1 / -2-k for a state that accepts nothing.  Everything the row needs
+// from global memory is one cache line, read at once (the first twelve groups' tags and the index before anything waits).
+__device__ __forceinline__ void write_row_rec(const LineOut& out, uint64_t i, const uint8_t* __restrict__ recp, uint32_t regs, uint32_t len, int G) {
+    const uint32_t dummy_col = regs - 128u;
+    const int nblk = (G + 3) >> 2;
+    u32x4 pre[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) pre[b] = *reinterpret_cast<const u32x4*>(recp + 16 * (b < nblk ? b : 0));
+    const int32_t mid = static_cast<int16_t>(*reinterpret_cast<const uint16_t*>(recp + 16 * nblk));
+    const uint32_t unit = out.packed ? (out.narrow ? 1u : 2u) : 4u;
+    uint8_t* row = out.packed ? reinterpret_cast<uint8_t*>(out.packed) + i * static_cast<uint64_t>(1 + out.slots) * unit
+                              : reinterpret_cast<uint8_t*>(out.caps + i * static_cast<uint64_t>(out.slots));
+    if (!out.packed) out.match_id[i] = mid;
+    uint32_t carry = static_cast<uint32_t>(mid) & (out.narrow ? 0xFFu : 0xFFFFu);
+    uint32_t clipped = 0u;
+    for (int g0 = 0; g0 < G; g0 += 4) {
+        u32x4 t = g0 == 0 ? pre[0] : g0 == 4 ? pre[1] : pre[2];
+        if (g0 >= 12) t = *reinterpret_cast<const u32x4*>(recp + 4 * g0);
+        const uint32_t tw[4] = {t.x, t.y, t.z, t.w};
+        uint32_t vb[4], ve[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            vb[q] = lds_ld<uint16_t>(dummy_col + (tw[q] & 0xFF80u));
+            ve[q] = lds_ld<uint16_t>(dummy_col + ((tw[q] >> 16) & 0xFF80u));
+        }
+        int32_t pb[4], pe[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t tb = tw[q] & 0xFFFFu, te = tw[q] >> 16;
+            pb[q] = tb == 1u ? static_cast<int32_t>(len) : static_cast<int32_t>(vb[q]);
+            pe[q] = te == 1u ? static_cast<int32_t>(len) : static_cast<int32_t>(ve[q]);
+            if (tb == 0u || te == 0u) { pb[q] = -1; pe[q] = -1; }   // (a state that accepts nothing has no tags)
+        }
+        const int cnt = G - g0 < 4 ? G - g0 : 4;
+        if (!out.packed) {
+            uint8_t* dst = row + 8u * g0;
+            if (cnt == 4) {
+                reinterpret_cast<UnalignedU32x4*>(dst)->v = u32x4{static_cast<uint32_t>(pb[0]), static_cast<uint32_t>(pe[0]), static_cast<uint32_t>(pb[1]), static_cast<uint32_t>(pe[1])};
+                reinterpret_cast<UnalignedU32x4*>(dst + 16)->v = u32x4{static_cast<uint32_t>(pb[2]), static_cast<uint32_t>(pe[2]), static_cast<uint32_t>(pb[3]), static_cast<uint32_t>(pe[3])};
+            } else {
+                for (int q = 0; q < cnt; ++q) reinterpret_cast<UnalignedU32x2*>(dst + 8 * q)->v = u32x2{static_cast<uint32_t>(pb[q]), static_cast<uint32_t>(pe[q])};
+            }
+        } else if (!out.narrow) {
+            uint32_t hb[4], he[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                clipped += (pb[q] > 65534 ? 1u : 0u) + (pe[q] > 65534 ? 1u : 0u);
+                hb[q] = pb[q] < 0 ? 0xFFFFu : static_cast<uint32_t>(min(pb[q], 65534));
+                he[q] = pe[q] < 0 ? 0xFFFFu : static_cast<uint32_t>(min(pe[q], 65534));
+            }
+            uint8_t* dst = row + 4u * g0;   // (the halfword before group g0's begin: the id, or the end of the group before)
+            if (cnt == 4) {
+                reinterpret_cast<UnalignedU32x4*>(dst)->v = u32x4{carry | hb[0] << 16, he[0] | hb[1] << 16, he[1] | hb[2] << 16, he[2] | hb[3] << 16};
+                carry = he[3];
+            } else {
+                for (int q = 0; q < cnt; ++q) {
+                    reinterpret_cast<UnalignedU32*>(dst + 4 * q)->v = carry | hb[q] << 16;
+                    carry = he[q];
+                }
+            }
+        } else {
+            uint32_t hb[4], he[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                clipped += (pb[q] > 254 ? 1u : 0u) + (pe[q] > 254 ? 1u : 0u);
+                hb[q] = pb[q] < 0 ? 0xFFu : static_cast<uint32_t>(min(pb[q], 254));
+                he[q] = pe[q] < 0 ? 0xFFu : static_cast<uint32_t>(min(pe[q], 254));
+            }
+            uint8_t* dst = row + 2u * g0;
+            if (cnt == 4) {
+                reinterpret_cast<UnalignedU32x2*>(dst)->v = u32x2{carry | hb[0] << 8 | he[0] << 16 | hb[1] << 24, he[1] | hb[2] << 8 | he[2] << 16 | hb[3] << 24};
+                carry = he[3];
+            } else {
+                for (int q = 0; q < cnt; ++q) {
+                    reinterpret_cast<UnalignedU16*>(dst + 2 * q)->v = static_cast<uint16_t>(carry | hb[q] << 8);
+                    carry = he[q];
+                }
+            }
+        }
+    }
+    if (out.packed) {
+        if (out.narrow) row[2 * G] = static_cast<uint8_t>(carry);
+        else reinterpret_cast<UnalignedU16*>(row + 4 * G)->v = static_cast<uint16_t>(carry);
+        if (clipped && out.overflow) atomicAdd(out.overflow, static_cast<unsigned long long>(clipped));
+    }
+}
+
 // ---------------------------------------------------------------------------
 // An extraction whose capture automaton is not built ahead of time (2^n register patterns: gx_compile.hpp, RuleTables::pike):
 // its prioritised Thompson program run as it is -- a Pike VM.  Thread lists in priority order, a thread = (pc, its group
@@ -679,15 +767,64 @@ hipError_t launch_slices_t(const GxDev& dev, const GxLds& lds, const uint8_t* ld
 #define GX_HOP_LEAVE 24u   // (64: a round's walk goes on until every lane has used up its piece)
 #endif
 #ifndef GX_HOP_SERVICE
-#define GX_HOP_SERVICE 24u  // finished lanes write their results and take new lines once that many lanes have nothing to walk
+#define GX_HOP_SERVICE 44u  // finished lanes write their results and take new lines once that many lanes have nothing to walk
+                            // (round 5, with the loaders' run test: 16 / 24 / 32 / 40 / 48 lanes: 1.219 / 1.170 / 1.125 / 1.072 / 1.068 ms per 3.8 M lines)
 #endif
 constexpr uint64_t HOP_POOL_CHUNK = 64;   // lines per draw from the pool (the last quarter of a batch's lines)
 constexpr uint32_t HOP_SLICE = GX_HOP_SLICE_BYTES, HOP_SLICE_ROW = GX_HOP_SLICE_BYTES + 16u, HOP_SLICE_KEEP = 24;
 
+// 16 staged bytes at `src` (WIDE: the low bytes of 16 code units = 32 bytes of the buffer; the high bytes of the first `units` of
+// them ORed into `high`).  GUARDED: never reads at or beyond data_end, byte by byte -- for the last lines of a buffer only (a lane
+// says so: `near_end`); everything else is a global_load_dwordx4 (two for WIDE) at whatever alignment the position has.  (Until
+// round 5 these went out as FLAT loads with a 16-byte fallback unrolled behind each of them: 184 flat_load_ubyte in the kernel, and
+// a flat load counts as an LDS operation too.)
+typedef __attribute__((address_space(1))) const UnalignedWindow GlobalWindow;
+template <bool WIDE, bool GUARDED>
+__device__ __forceinline__ u32x4 load_chunk16(const uint8_t* src, const uint8_t* data_end, uint32_t units, uint32_t& high) {
+    u32x4 a = {0u, 0u, 0u, 0u}, b2 = {0u, 0u, 0u, 0u};   // (WIDE: units 0-7, 8-15)
+    if (!GUARDED) {
+        a = reinterpret_cast<GlobalWindow*>(reinterpret_cast<uintptr_t>(src))->v;
+        if (WIDE) b2 = reinterpret_cast<GlobalWindow*>(reinterpret_cast<uintptr_t>(src + 16))->v;
+    } else {
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma nounroll
+        for (int q = 0; q < (WIDE ? 32 : 16); ++q)
+            if (src + q < data_end) w[q >> 2] |= static_cast<uint32_t>(src[q]) << ((q & 3) * 8);
+        a = u32x4{w[0], w[1], w[2], w[3]}; b2 = u32x4{w[4], w[5], w[6], w[7]};
+    }
+    if (!WIDE) return a;
+    // (only the units of the line count: the units behind its end are another line's)
+    const uint32_t hi[8] = {a.x, a.y, a.z, a.w, b2.x, b2.y, b2.z, b2.w};
+    uint32_t acc = 0u;
+#pragma unroll
+    for (uint32_t q = 0; q < 8u; ++q) {
+        uint32_t m = 0xFF00FF00u;
+        if (2u * q + 1u >= units) m = 2u * q >= units ? 0u : 0x0000FF00u;
+        acc |= hi[q] & m;
+    }
+    high |= acc;
+    // the low bytes of two units per dword -> four staged bytes per pair of dwords (v_perm_b32: bytes 0, 2 of each)
+    return u32x4{__builtin_amdgcn_perm(a.y, a.x, 0x06040200u), __builtin_amdgcn_perm(a.w, a.z, 0x06040200u),
+                 __builtin_amdgcn_perm(b2.y, b2.x, 0x06040200u), __builtin_amdgcn_perm(b2.w, b2.z, 0x06040200u)};
+}
+// all 16 bytes in the run interval runinfo = lo | (0x7F - hi) << 8 (0x8000: no interval -- never)
+__device__ __forceinline__ bool chunk_in_run(const u32x4& v, uint32_t runinfo) {
+    const uint32_t lo4 = splat_byte0(runinfo), k4 = splat_byte1(runinfo);
+    // (x | x - lo | x + k per dword, the top bits of all of them at once)
+    const uint32_t f = (v.x | (v.x - lo4) | (v.x + k4)) | (v.y | (v.y - lo4) | (v.y + k4)) | (v.z | (v.z - lo4) | (v.z + k4)) | (v.w | (v.w - lo4) | (v.w + k4));
+    return (f & HI_BITS) == 0u;
+}
+#ifndef GX_HOP_SPEC
+#define GX_HOP_SPEC 1   // 0: no chunks are tested beyond the piece
+#endif
+#ifndef GX_HOP_SPEC_AHEAD
+#define GX_HOP_SPEC_AHEAD 0u   // (measured: 0, 4, 6 lines ahead 1.167, 1.157, 1.168 ms per 3.8 M lines -- the latency of those loads is not what a round waits for)
+#endif
+
 // WIDE: `data` holds UTF-16 code units (offsets in units): a loading lane fetches 16 units = 32 bytes and stages their low bytes; a line
 // with a unit above 0xFF is flagged (wide_flags[i], *wide_any) for the per-line walk on the units (k_extract_flagged), as the tile kernel's.
 template <typename OFF, bool WIDE>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(1, 4)))
+__global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(1, 3)))   // (12 waves at most: plan_hop_slice_launch)
 k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, const uint8_t* __restrict__ at_global,
                      const uint8_t* __restrict__ data, const OFF* __restrict__ off, uint64_t n, LineOut out, int match_only, int strip_eol,
                      uint32_t* __restrict__ oversize_flag, uint32_t seq, unsigned long long* __restrict__ stamps,
@@ -746,6 +883,9 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
     uint32_t len = 0, pos = 0, row = row0;
     const uint32_t my = slice + lane * HOP_SLICE_ROW;
     bool line_wide = false;   // WIDE: the line holds a unit above 0xFF
+    uint32_t near_end = 0u;   // the line ends within 16 units of the buffer's end: its loaders read byte by byte
+    HopKept K;                // the record the lane holds while it stays in its state (kept across rounds)
+    const bool all_hot = L.rec_indexed >= L.sort_chunk;
 
     for (;;) {
         // ---- finished lanes write their results once a quarter of the wave is idle (k_extract_slices says why) ----
@@ -753,11 +893,16 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
         const uint32_t idle = static_cast<uint32_t>(__popcll(__ballot(finished || !has_line)));
         const bool service = idle >= GX_HOP_SERVICE || !__any(has_line && !finished);
         if (service && finished) {
-            const int32_t hot_info = static_cast<int16_t>(lds_ld<uint16_t>(L.acc_tab + 2u * min(row, H.n_hot - 1u)));
-            int32_t info = hot_info >= 0 && !match_only ? hot_info * 16 : hot_info;
-            if (row >= H.n_hot) info = *reinterpret_cast<const int32_t*>(H.rows + (static_cast<uint64_t>(row) * H.row_bytes + H.info_off));
-            if (match_only) out.id(i, info);
-            else write_row<TIER_HOP>(out, i, info, fin_lds, fin_g, regs, len, T.max_groups);
+            if (!match_only && L.fin_state_off != 0u) {
+                // (the row out of the final record of the state: one read, no info word first)
+                write_row_rec(out, i, at_global + L.fin_state_off + static_cast<uint64_t>(row) * L.fin_state_rec, regs, len, T.max_groups);
+            } else {
+                const int32_t hot_info = static_cast<int16_t>(lds_ld<uint16_t>(L.acc_tab + 2u * min(row, H.n_hot - 1u)));
+                int32_t info = hot_info >= 0 && !match_only ? hot_info * 16 : hot_info;
+                if (row >= H.n_hot) info = *reinterpret_cast<const int32_t*>(H.rows + (static_cast<uint64_t>(row) * H.row_bytes + H.info_off));
+                if (match_only) out.id(i, info);
+                else write_row<TIER_HOP>(out, i, info, fin_lds, fin_g, regs, len, T.max_groups);
+            }
             if (WIDE) {   // (a flagged line's result is the per-line walk's to write again)
                 wide_flags[i] = line_wide ? 1 : 0;
                 if (line_wide) __hip_atomic_store(wide_any, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -796,6 +941,7 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
                     len = static_cast<uint32_t>(len64);
                     pos = 0;
                     row = row0;
+                    near_end = static_cast<uint64_t>(off[i + 1]) + 16u > static_cast<uint64_t>(off[n]) ? 0x10000u : 0u;
                 }
             }
             next = min(range_hi, next + static_cast<uint64_t>(__popcll(free_mask)));
@@ -806,17 +952,28 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
         }
         HS_STAMP(0);
         // ---- stage the next piece of every lane's line, from the lane's own position: lane l fetches 16 bytes (l & 7) of the
-        // line of lane (l >> 3) + 8 r, as class ids ----
+        // line of lane (l >> 3) + 8 r ----
         const bool walking = has_line && pos < len && row != dead_row;
         // (HOP_SLICE / 16 lanes per line: 8 for 128 bytes)
         constexpr uint32_t LPL = HOP_SLICE / 16u, LINES_PER_LOAD = 64u / LPL;
-        // (what a loading lane has to know of the line it loads for -- where its piece begins and how many bytes are left of it -- goes
-        // through the piece buffer itself, which holds nothing at this point: one 16-byte store per lane and one broadcast read per
-        // load, instead of four shuffles per load)
+        static_assert(LPL == 8u, "the loaders' run bits are a byte per line");
+        // The run interval of the state the lane is in, for the LOADERS: a lane in a long value (half of configs[4]'s bytes are the
+        // padded last value; 28 of a line's 43 walk iterations were the next 16 bytes of the same run) has its piece tested where it
+        // is loaded -- 16 bytes per loader, all lanes busy, no dependent LDS round trips -- and begins its walk behind the chunks
+        // that lie in the run.  0x8000: no interval (every byte fails).  The record: the one the lane holds, or the hot one in LDS.
+        uint32_t runinfo = 0x8000u;
+        if (walking) {
+            if (!all_hot && row == K.kept) runinfo = K.k0.x & 0xFFFFu;
+            else if (row < H.n_hot) runinfo = lds_ld<uint32_t>(__umul24(row, HOP_REC_B) + HOP_LDS_AT) & 0xFFFFu;
+        }
+        // (what a loading lane has to know of the line it loads for -- where its piece begins, how many bytes are left of it and
+        // the run interval -- goes through the piece buffer itself, which holds nothing at this point: one 16-byte store per lane
+        // and one broadcast read per load, instead of four shuffles per load)
+        const uint32_t left_now = walking ? len - pos : 0u;
         {
             const uint8_t* mine = data + ((o0 + pos) << (WIDE ? 1 : 0));
             const uint64_t mv = reinterpret_cast<uint64_t>(mine);
-            lds_st<u32x4>(slice + lane * 16u, u32x4{static_cast<uint32_t>(mv), static_cast<uint32_t>(mv >> 32), walking ? len - pos : 0u, 0u});
+            lds_st<u32x4>(slice + lane * 16u, u32x4{static_cast<uint32_t>(mv), static_cast<uint32_t>(mv >> 32), left_now, runinfo | near_end});
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -825,83 +982,109 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
 #pragma unroll
         for (uint32_t r = 0; r < LPL; ++r) who[r] = lds_ld<u32x4>(slice + (lane / LPL + LINES_PER_LOAD * r) * 16u);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();   // (every lane has read before the first piece is stored)
+        __builtin_amdgcn_wave_barrier();   // (every lane has read before anything else is stored there)
         u32x4 pv[LPL];
         uint32_t high_or[LPL];   // WIDE: the high bytes of the units a lane loaded, ORed
 #pragma unroll
         for (uint32_t r = 0; r < LPL; ++r) {
             const uint32_t at_byte = (lane % LPL) * 16u;   // (in staged bytes = code units)
-            u32x4 v = {0u, 0u, 0u, 0u};
+            pv[r] = u32x4{0u, 0u, 0u, 0u};
             high_or[r] = 0u;
-            if (at_byte < who[r].z) {
-                const uint8_t* src = reinterpret_cast<const uint8_t*>(static_cast<uint64_t>(who[r].y) << 32 | who[r].x) + (at_byte << (WIDE ? 1 : 0));
-                if (!WIDE) {
-                    if (src + 16 <= data_end) v = reinterpret_cast<const UnalignedWindow*>(src)->v;
-                    else {
-                        uint32_t w[4] = {0, 0, 0, 0};
-                        for (int b = 0; b < 16; ++b)
-                            if (src + b < data_end) w[b >> 2] |= static_cast<uint32_t>(src[b]) << ((b & 3) * 8);
-                        v = u32x4{w[0], w[1], w[2], w[3]};
-                    }
-                } else {
-                    u32x4 a = {0u, 0u, 0u, 0u}, b2 = {0u, 0u, 0u, 0u};   // units 0-7, 8-15
-                    if (src + 32 <= data_end) { a = reinterpret_cast<const UnalignedWindow*>(src)->v; b2 = reinterpret_cast<const UnalignedWindow*>(src + 16)->v; }
-                    else {
-                        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                        for (int q = 0; q < 32; ++q)
-                            if (src + q < data_end) w[q >> 2] |= static_cast<uint32_t>(src[q]) << ((q & 3) * 8);
-                        a = u32x4{w[0], w[1], w[2], w[3]}; b2 = u32x4{w[4], w[5], w[6], w[7]};
-                    }
-                    // the low bytes of two units per dword -> four staged bytes per pair of dwords (v_perm_b32: bytes 0, 2 of each)
-                    v = u32x4{__builtin_amdgcn_perm(a.y, a.x, 0x06040200u), __builtin_amdgcn_perm(a.w, a.z, 0x06040200u),
-                              __builtin_amdgcn_perm(b2.y, b2.x, 0x06040200u), __builtin_amdgcn_perm(b2.w, b2.z, 0x06040200u)};
-                    // (only the units of the line count: the units behind its end are another line's)
-                    const uint32_t units_left = who[r].z - at_byte;   // >= 1
-                    uint32_t hi[8] = {a.x, a.y, a.z, a.w, b2.x, b2.y, b2.z, b2.w};
-                    uint32_t acc = 0u;
-#pragma unroll
-                    for (uint32_t q = 0; q < 8u; ++q) {
-                        uint32_t m = 0xFF00FF00u;
-                        if (2u * q + 1u >= units_left) m = 2u * q >= units_left ? 0u : 0x0000FF00u;
-                        acc |= hi[q] & m;
-                    }
-                    high_or[r] = acc;
-                }
-            }
-            pv[r] = v;
+            const bool mine = at_byte < who[r].z;
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(static_cast<uint64_t>(who[r].y) << 32 | who[r].x) + (at_byte << (WIDE ? 1 : 0));
+            if (__builtin_amdgcn_ballot_w64(mine && (who[r].w & 0x10000u) != 0u) == 0ull) {   // (wave-uniform: no line of this instruction ends at the buffer's end)
+                if (mine) pv[r] = load_chunk16<WIDE, false>(src, data_end, who[r].z - at_byte, high_or[r]);
+            } else if (mine) pv[r] = load_chunk16<WIDE, true>(src, data_end, who[r].z - at_byte, high_or[r]);
         }
+        // which chunks lie in their line's run (whole chunks inside the line), and -- WIDE -- which lines hold a unit above 0xFF: eight
+        // loaders per line and instruction -> one byte of the instruction's ballot per line; the ballots go through the piece buffer's
+        // first 128 bytes (read again below, before the pieces are stored)
+#pragma unroll
+        for (uint32_t r = 0; r < LPL; ++r) {
+            const uint32_t at_byte = (lane % LPL) * 16u;
+            const bool full = at_byte + 16u <= who[r].z && chunk_in_run(pv[r], who[r].w) && (!WIDE || high_or[r] == 0u);
+            const uint64_t bal = __builtin_amdgcn_ballot_w64(full);
+            if (lane == 0u) lds_st<u32x2>(slice + 8u * r, u32x2{static_cast<uint32_t>(bal), static_cast<uint32_t>(bal >> 32)});
+            if (WIDE) {
+                const uint64_t wbal = __builtin_amdgcn_ballot_w64(high_or[r] != 0u);
+                if (lane == 0u) lds_st<u32x2>(slice + 64u + 8u * r, u32x2{static_cast<uint32_t>(wbal), static_cast<uint32_t>(wbal >> 32)});
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t run_bits = lds_ld<uint8_t>(slice + lane);   // bit c: chunk c of this lane's piece lies in its run
         if (WIDE) {
-            // which lines hold a unit above 0xFF: eight loaders per line and instruction -> one byte of the instruction's ballot per line;
-            // the ballots go through the piece buffer's first 64 bytes (read again below, before the pieces are stored)
-#pragma unroll
-            for (uint32_t r = 0; r < LPL; ++r) {
-                const uint64_t bal = __builtin_amdgcn_ballot_w64(high_or[r] != 0u);
-                if (lane == 0u) lds_st<u32x2>(slice + 8u * r, u32x2{static_cast<uint32_t>(bal), static_cast<uint32_t>(bal >> 32)});
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lds_ld<uint8_t>(slice + lane) != 0u && walking) line_wide = true;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            if (lds_ld<uint8_t>(slice + 64u + lane) != 0u && walking) line_wide = true;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         HS_STAMP(1);
 #pragma unroll
         for (uint32_t r = 0; r < LPL; ++r)
             lds_st<u32x4>(slice + (lane / LPL + LINES_PER_LOAD * r) * HOP_SLICE_ROW + (lane % LPL) * 16u, pv[r]);
+        // the bytes of the piece that the run covers: whole leading chunks
+        const uint32_t skip = walking ? 16u * static_cast<uint32_t>(__builtin_ctz(~run_bits | 0x100u)) : 0u;
+        // ---- a lane whose whole piece lies in its run and whose line goes on: the next kilobyte of the line is TESTED, not staged
+        // -- one load instruction per such line, 64 loaders of 16 bytes -- and the lane moves behind the chunks that lie in the run.
+        // A padded value of a kilobyte is two rounds of loads and no walk iteration (it was 64 iterations over 10 rounds).
+        // The descriptors of those lines go through the pads of the piece buffer's rows (16 bytes behind every row's 128). ----
+        uint32_t extra = 0u;
+        const bool longrun = GX_HOP_SPEC && walking && skip == HOP_SLICE && left_now > HOP_SLICE;
+        const uint64_t lr_mask = __builtin_amdgcn_ballot_w64(longrun);
+        const uint32_t lr_m = static_cast<uint32_t>(__builtin_popcountll(lr_mask));
+        const uint32_t lr_rank = static_cast<uint32_t>(__builtin_popcountll(lr_mask & ((1ull << lane) - 1ull)));
+        // one such line's chunk of this lane: the line's last chunk, when it is a partial one, is read 16 bytes back from the line's
+        // end (what it overlaps lies in the run already -- the chunk before it, or the piece); `high` != 0: not a chunk of the line,
+        // or (WIDE) one with a unit above 0xFF -- not in the run either way
+        auto spec_load = [&](const u32x4& d, uint32_t& high) -> u32x4 {
+            const uint32_t left2 = d.z;
+            int32_t at = static_cast<int32_t>(lane * 16u);
+            const bool mine = static_cast<uint32_t>(at) < left2;
+            if (static_cast<uint32_t>(at) + 16u > left2) at = static_cast<int32_t>(left2) - 16;
+            high = 1u;
+            if (!mine) return u32x4{0u, 0u, 0u, 0u};
+            const uint8_t* base = reinterpret_cast<const uint8_t*>(static_cast<uint64_t>(d.y) << 32 | d.x);
+            const uint8_t* src = WIDE ? base + 2 * static_cast<int64_t>(at) : base + at;
+            high = 0u;
+            return load_chunk16<WIDE, false>(src, data_end, 16u, high);   // (inside the line: the window was moved back from its end)
+        };
+        auto spec_desc = [&](uint32_t j) { return lds_ld<u32x4>(slice + min(j, lr_m - 1u) * HOP_SLICE_ROW + HOP_SLICE); };
+        auto spec_vote = [&](uint32_t j, const u32x4& d, const u32x4& v, uint32_t high) {
+            const uint64_t bal = __builtin_amdgcn_ballot_w64(high == 0u && chunk_in_run(v, d.w));
+            if (lane == 0u && j < lr_m) lds_st<u32x2>(slice + j * HOP_SLICE_ROW + HOP_SLICE, u32x2{static_cast<uint32_t>(bal), static_cast<uint32_t>(bal >> 32)});
+        };
+        constexpr uint32_t AHEAD = GX_HOP_SPEC_AHEAD;   // loads of that many such lines are in flight while the piece is walked
+        u32x4 av[AHEAD > 0 ? AHEAD : 1];
+        uint32_t ah[AHEAD > 0 ? AHEAD : 1];
+        if (lr_mask != 0ull) {
+            if (longrun) {
+                const uint8_t* mine = data + ((o0 + pos + HOP_SLICE) << (WIDE ? 1 : 0));
+                const uint64_t mv = reinterpret_cast<uint64_t>(mine);
+                lds_st<u32x4>(slice + lr_rank * HOP_SLICE_ROW + HOP_SLICE, u32x4{static_cast<uint32_t>(mv), static_cast<uint32_t>(mv >> 32), left_now - HOP_SLICE, runinfo});
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (uint32_t u = 0; u < AHEAD; ++u) {
+                ah[u] = 1u;
+                av[u] = u32x4{0u, 0u, 0u, 0u};
+                if (u < lr_m) av[u] = spec_load(spec_desc(u), ah[u]);
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         HS_STAMP(2);
         // ---- walk the piece ----
         {
-            const uint32_t left = walking ? len - pos : 0u;          // bytes of the line from pos on
+            const uint32_t left = left_now;                          // bytes of the line from pos on
             const bool whole = left <= HOP_SLICE;                   // the line ends inside the piece
             const uint32_t e = my + (whole ? left : HOP_SLICE);
             const uint32_t limit = whole ? e : e - HOP_SLICE_KEEP;
-            uint32_t p = my;
+            uint32_t p = my + skip;                                 // (behind the chunks the loaders found in the run: possibly at e, beyond the limit)
             const uint32_t e_chain = whole ? e : 0xFFFFFFF0u;
-            const bool all_hot = L.rec_indexed >= L.sort_chunk;
             // the round ends when GX_HOP_LEAVE of the lanes that went into it have used up their pieces (or their lines).  BASELINE
             // configs[4], 2 M lines, ms per launch (captures / match only), one device: 64 (the last lane) 0.955 / 0.712, 48 0.914 / 0.666,
             // 32 0.892 / 0.660, 16 0.907 / 0.670; then with 32: results and new lines at 8 idle lanes 0.954, 16 0.877, 24 0.853, 32 0.854;
@@ -909,16 +1092,42 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
             // of a round that waits for its last lane, 85 % with 24)
             const uint32_t went_in = static_cast<uint32_t>(__popcll(__ballot(p < limit)));
             const uint32_t leave_at = went_in > GX_HOP_LEAVE ? went_in - GX_HOP_LEAVE : 0u;
-            if (match_only) row = all_hot ? walk_hop_span<true, false>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at)
-                                          : walk_hop_span<false, false>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at);
-            else row = all_hot ? walk_hop_span<true, true>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at)
-                               : walk_hop_span<false, true>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at);
+            if (match_only) row = all_hot ? walk_hop_span<true, false>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at, K)
+                                          : walk_hop_span<false, false>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at, K);
+            else row = all_hot ? walk_hop_span<true, true>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at, K)
+                               : walk_hop_span<false, true>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at, K);
             pos += p - my;
+        }
+        HS_STAMP(3);
+        // ---- the tested kilobytes: the loads that went out before the walk, then the other such lines four at a time ----
+        if (lr_mask != 0ull) {
+#pragma unroll
+            for (uint32_t u = 0; u < AHEAD; ++u) spec_vote(u, spec_desc(u), av[u], ah[u]);
+            for (uint32_t j0 = AHEAD; j0 < lr_m; j0 += 4u) {
+                u32x4 d[4], sv[4];
+                uint32_t sh[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) d[u] = spec_desc(j0 + u);
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) sv[u] = spec_load(d[u], sh[u]);
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) spec_vote(j0 + u, d[u], sv[u], sh[u]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (longrun) {
+                const u32x2 bits = lds_ld<u32x2>(slice + lr_rank * HOP_SLICE_ROW + HOP_SLICE);
+                const uint64_t inv = ~(static_cast<uint64_t>(bits.y) << 32 | bits.x);
+                const uint32_t chunks = inv == 0ull ? 64u : static_cast<uint32_t>(__builtin_ctzll(inv));
+                extra = min(16u * chunks, left_now - HOP_SLICE);
+            }
+            pos += extra;
         }
         // the slice buffer is rewritten by the next iteration
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        HS_STAMP(3);
+        HS_STAMP(2);   // (the tested kilobytes' votes count with the waiting)
 #ifdef GX_DEV
         ++ph[4];
 #endif

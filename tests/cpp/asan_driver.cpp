@@ -78,6 +78,23 @@ Outcome hop_outcome(const Tables& T, const HopImage& H, const std::vector<uint8_
             p = q + klen;
             s = r[1] & 0xFFFFu;
         } else {
+            // the chain again with the tail byte against the union of the tail's byte set
+            {
+                const uint8_t* ts = H.full.bytes.data() + H.full.sets_lds + 8u * (r[3] >> 24);
+                bool lits_ok = q + klen <= e;
+                for (int j = 0; j < 8 && lits_ok; ++j) lits_ok = lits[j] == 0 || cls[q + j] == lits[j];
+                const uint8_t tb = cls[q + (r[3] & 0xFFu)];
+                bool in = false;
+                for (int j = 0; j < 4; ++j) in = in || (ts[4 + j] != 0x80u && tb < 0x80u && tb >= ts[j] && tb <= 0x7Fu - ts[4 + j]);
+                if (lits_ok && in && (r[3] >> 24) != 0) {
+                    col[(r[2] & 0xFFFFu) >> 7] = static_cast<int>(q + ((r[1] >> 16) & 0xFFu));
+                    col[(r[2] >> 16) >> 7] = static_cast<int>(q + (r[1] >> 24));
+                    p = q + klen;
+                    s = r[1] & 0xFFFFu;
+                    ++*second_chances;
+                    continue;
+                }
+            }
             // the second chance: the window at p against the union of the state's loop set (H.full.bytes at sets_lds: u8 lo[4], u8 k[4] per entry)
             const uint8_t* ls = H.full.bytes.data() + H.full.sets_lds + 8u * (r[0] >> 24);
             size_t nu = 0;

@@ -1606,3 +1606,93 @@ def test_hop_slice_kernel_pool_of_chunks_at_every_size():
         rows, over = gorp.extract_batch(d, o, kernel=N.GX_KERNEL_HOP_SLICES, compact=True)
         cm, cc = G.unpack_rows(rows)
         assert over == 0 and np.array_equal(cm, omid[:n]) and np.array_equal(cc, ocaps[:n]), n
+
+
+@pytest.mark.gpu
+def test_hop_long_runs_and_loop_sets():
+    """Round 5.  (a) The hop slice kernel's loaders test the chunks they load against the run of the state their line is in, and a
+    line whose whole piece lies in the run has its next kilobyte tested without being staged: values of every length around the
+    piece (128 bytes) and the tested kilobyte, runs that end at the line's end, one byte before it, inside a tested chunk, at a byte
+    above 0x7F, lines that go on behind the value; terminators; UTF-16 with a unit above 0xFF inside the tested part.
+    (b) Loop sets: a \\w / [^,] value that leaves its state's run interval (upper case, digits, '_') stays in the state through the
+    second chance, a chain whose tail byte lies in another interval of the exit's bytes is taken all the same -- on both hop kernels."""
+    rng = random.Random(77)
+    rules, meta = W.syslog_definition(64, seed=3)
+    gorp, orc = Gorp.construct(rules), oracle_for(rules)
+    assert gorp.stat(14) > 0
+    base_d, base_o, _ = W.syslog_lines(meta, 300, seed=5, line_bytes=100, corrupt_frac=0.0)
+    base = [bytes(base_d[base_o[i]:base_o[i + 1]]).decode("latin-1").rstrip("w7x") for i in range(300)]   # (the padding off: the last value's first bytes stay)
+    fills = {"7": "0123456789", "w": "abcXYZ_09", "x": "!#%&/azAZ~"}
+    lines = []
+    lengths = [0, 1, 15, 16, 17, 100, 103, 104, 105, 127, 128, 129, 143, 144, 145, 200, 1000, 1151, 1152, 1153, 1167, 1168, 1169, 1500, 2175, 2176, 2177, 2400, 5000]
+    for k, pad in enumerate(lengths * 6):
+        s = base[k % len(base)]
+        kind = meta[[m[0] for m in meta].index(s.split(" ")[2].split("[")[0])][2][-1]
+        fill = {0: "7", 1: "w", 2: "x"}[kind]
+        alphabet = fill if k % 3 == 0 else fills[fill]      # one byte over and over / the whole class (loop sets for \w)
+        body = "".join(rng.choice(alphabet) for _ in range(pad))
+        r = k % 7
+        if r == 1 and pad > 3:
+            body = body[:-1] + " "                            # the run ends one byte before the line's end (no match)
+        elif r == 2 and pad > 40:
+            at = rng.randrange(pad)
+            body = body[:at] + rng.choice(" \t\xe9=") + body[at + 1:]   # ... somewhere inside
+        elif r == 3:
+            body = body + " tail=1"                           # the line goes on behind the value
+        lines.append(s + body)
+    lines += ["", "x" * 3000, base[0] + "w" * 70000]
+    check_batch(gorp, orc, lines)
+    dd, oo = lines_to_csr(lines)
+    om, oc = orc.extract_batch(dd, oo, nthreads=8)
+    assert (om >= 0).sum() > 60
+    for kernel in (N.GX_KERNEL_HOP_SLICES, N.GX_KERNEL_HOPS):
+        m, c = gorp.extract_batch(dd, oo, kernel=kernel)
+        assert np.array_equal(m, om) and np.array_equal(c, oc), kernel
+    rows, over = gorp.extract_batch(dd, oo, kernel=N.GX_KERNEL_HOP_SLICES, compact=True)
+    cm, cc = G.unpack_rows(rows)
+    big = oc > 65534
+    assert over == int(big.sum()) and np.array_equal(cm, om) and np.array_equal(cc, np.where(big, 65534, oc))
+    mo, _ = gorp.extract_batch(dd, oo, kernel=N.GX_KERNEL_HOP_SLICES, match_only=True)
+    assert np.array_equal(mo, np.where(om <= -2, -2 - om, om))
+    # terminated text
+    raw = b"".join(ln.encode("latin-1") + rng.choice([b"\n", b"\r\n"]) for ln in lines if "\r" not in ln and "\n" not in ln)
+    off, _ = G.split_lines(raw)
+    _, want_lines, _ = O.read_lines(raw)
+    cd, co = lines_to_csr(want_lines)
+    om2, oc2 = orc.extract_batch(cd, co, nthreads=8)
+    m2, c2 = gorp.extract_batch(np.frombuffer(raw, np.uint8), off, strip_eol=True, kernel=N.GX_KERNEL_HOP_SLICES)
+    assert np.array_equal(m2, om2) and np.array_equal(c2, oc2)
+    # UTF-16: a unit above 0xFF (low byte inside the run) in the piece, in the tested kilobyte, at its last unit
+    wide = []
+    for k, s in enumerate(lines[:120]):
+        if len(s) > 150 and k % 2 == 0:
+            at = rng.choice([len(s) - 1, len(s) // 2, 130, min(len(s) - 1, 1151), min(len(s) - 1, 1300)])
+            s = s[:at] + "š" + s[at + 1:]                # U+0161: low byte 0x61 'a'
+        wide.append(s)
+    units = [np.frombuffer(s.encode("utf-16-le"), dtype=np.uint16) for s in wide]
+    data = np.concatenate([u for u in units if len(u)])
+    offsets = np.zeros(len(wide) + 1, np.uint32)
+    offsets[1:] = np.cumsum([len(u) for u in units])
+    want = [orc.extract(s) for s in wide]
+    wm = np.array([w[0] for w in want], np.int32)
+    wc = np.full((len(wide), 2 * gorp.max_groups), -1, np.int32)
+    for i, w in enumerate(want):
+        for g, span in enumerate(w[1]):
+            if span is not None:
+                wc[i, 2 * g], wc[i, 2 * g + 1] = span
+    m3, c3 = gorp.extract_batch(data, offsets, kernel=N.GX_KERNEL_HOP_SLICES, uneven=2)
+    assert np.array_equal(m3, wm) and np.array_equal(c3, wc)
+    # (b) mixed-case values on the generator's lines, both kernels, and the definition's 512-extraction sibling (records out of LDS)
+    d5, o5, _ = W.syslog_lines(meta, 20000, seed=8, mixed_case=True, corrupt_frac=0.05)
+    om5, oc5 = orc.extract_batch(d5, o5, nthreads=8)
+    assert (om5 >= 0).sum() > 15000
+    for kernel in (N.GX_KERNEL_HOPS, N.GX_KERNEL_HOP_SLICES):
+        m5, c5 = gorp.extract_batch(d5, o5, kernel=kernel, line_bytes_hint=200)
+        assert np.array_equal(m5, om5) and np.array_equal(c5, oc5), kernel
+    rules2, meta2 = W.syslog_definition(300, seed=11)
+    gorp2, orc2 = Gorp.construct(rules2), oracle_for(rules2)
+    d6, o6, _ = W.syslog_lines(meta2, 6000, seed=9, min_len=50, max_len=2000, mixed_case=True, corrupt_frac=0.05)
+    om6, oc6 = orc2.extract_batch(d6, o6, nthreads=8)
+    for kernel in (N.GX_KERNEL_AUTO, N.GX_KERNEL_HOP_SLICES, N.GX_KERNEL_HOPS):
+        m6, c6 = gorp2.extract_batch(d6, o6, kernel=kernel)
+        assert np.array_equal(m6, om6) and np.array_equal(c6, oc6), kernel
