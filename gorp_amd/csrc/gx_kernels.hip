@@ -167,13 +167,22 @@ __device__ __forceinline__ void write_row(const LineOut& out, uint64_t i, int32_
 // The same from the final record OF THE STATE (gx_hop.cpp: fin_state_off): `recp` = its tags (u16 begin, end per group, padded to
 // four groups) and behind them the extraction's index, or -1 / -2-k for a state that accepts nothing.  Everything the row needs
 // from global memory is one cache line, read at once (the first twelve groups' tags and the index before anything waits).
-__device__ __forceinline__ void write_row_rec(const LineOut& out, uint64_t i, const uint8_t* __restrict__ recp, uint32_t regs, uint32_t len, int G) {
+// (the first twelve groups' tags and the index of a final record, as a lane asks for them when its line is over: FinAhead)
+struct FinAhead {
+    u32x4 t0 = {0u, 0u, 0u, 0u}, t1 = {0u, 0u, 0u, 0u}, t2 = {0u, 0u, 0u, 0u};
+    uint32_t id = 0u;
+    __device__ __forceinline__ void load(const uint8_t* __restrict__ recp, int G) {
+        const int nblk = (G + 3) >> 2;
+        t0 = *reinterpret_cast<const u32x4*>(recp);
+        t1 = *reinterpret_cast<const u32x4*>(recp + (nblk > 1 ? 16 : 0));
+        t2 = *reinterpret_cast<const u32x4*>(recp + (nblk > 2 ? 32 : 0));
+        id = *reinterpret_cast<const uint16_t*>(recp + 16 * nblk);
+    }
+};
+__device__ __forceinline__ void write_row_rec(const LineOut& out, uint64_t i, const uint8_t* __restrict__ recp, const FinAhead& F, uint32_t regs, uint32_t len, int G) {
     const uint32_t dummy_col = regs - 128u;
-    const int nblk = (G + 3) >> 2;
-    u32x4 pre[3];
-#pragma unroll
-    for (int b = 0; b < 3; ++b) pre[b] = *reinterpret_cast<const u32x4*>(recp + 16 * (b < nblk ? b : 0));
-    const int32_t mid = static_cast<int16_t>(*reinterpret_cast<const uint16_t*>(recp + 16 * nblk));
+    const u32x4 pre[3] = {F.t0, F.t1, F.t2};
+    const int32_t mid = static_cast<int16_t>(F.id);
     const uint32_t unit = out.packed ? (out.narrow ? 1u : 2u) : 4u;
     uint8_t* row = out.packed ? reinterpret_cast<uint8_t*>(out.packed) + i * static_cast<uint64_t>(1 + out.slots) * unit
                               : reinterpret_cast<uint8_t*>(out.caps + i * static_cast<uint64_t>(out.slots));
@@ -817,6 +826,9 @@ __device__ __forceinline__ bool chunk_in_run(const u32x4& v, uint32_t runinfo) {
 #ifndef GX_HOP_SPEC
 #define GX_HOP_SPEC 1   // 0: no chunks are tested beyond the piece
 #endif
+#ifndef GX_HOP_PRED
+#define GX_HOP_PRED 0u   // (measured, round 5: 0 / 2 / 4 guessed lines per round 1.022 / 1.032 / 1.052 ms per 3.8 M lines: the registers the loads sit in cost more than the saved trip)
+#endif
 #ifndef GX_HOP_SPEC_AHEAD
 #define GX_HOP_SPEC_AHEAD 0u   // (measured: 0, 4, 6 lines ahead 1.167, 1.157, 1.168 ms per 3.8 M lines -- the latency of those loads is not what a round waits for)
 #endif
@@ -883,7 +895,21 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
     uint32_t len = 0, pos = 0, row = row0;
     const uint32_t my = slice + lane * HOP_SLICE_ROW;
     bool line_wide = false;   // WIDE: the line holds a unit above 0xFF
+    const uint64_t total_units = static_cast<uint64_t>(off[n]);
+    // the offsets of the lines [win_base, win_base + 64]: lane l holds those of line win_base + l
+    uint64_t win_base = ~0ull;
+    OFF w_lo = 0, w_hi = 0;
+    auto refill = [&](uint64_t base) {
+        win_base = base;
+        const uint64_t a = min(base + lane, n);
+        w_lo = off[a];
+        w_hi = off[min(a + 1u, n)];
+    };
+    refill(range_lo);
+    FinAhead F;               // the final record of the state a finished line ended in, asked for behind the walk
+    bool fin_here = false;
     uint32_t near_end = 0u;   // the line ends within 16 units of the buffer's end: its loaders read byte by byte
+    bool in_run = false;      // the lane's last piece ended inside a run (the guess: its next piece lies in the run as well)
     HopKept K;                // the record the lane holds while it stays in its state (kept across rounds)
     const bool all_hot = L.rec_indexed >= L.sort_chunk;
 
@@ -894,8 +920,12 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
         const bool service = idle >= GX_HOP_SERVICE || !__any(has_line && !finished);
         if (service && finished) {
             if (!match_only && L.fin_state_off != 0u) {
-                // (the row out of the final record of the state: one read, no info word first)
-                write_row_rec(out, i, at_global + L.fin_state_off + static_cast<uint64_t>(row) * L.fin_state_rec, regs, len, T.max_groups);
+                // (the row out of the final record of the state: one read, no info word first -- asked for when the line ended, behind
+                // the walk; a line that ended where it began is read now)
+                const uint8_t* recp = at_global + L.fin_state_off + static_cast<uint64_t>(row) * L.fin_state_rec;
+                if (!fin_here) F.load(recp, T.max_groups);
+                write_row_rec(out, i, recp, F, regs, len, T.max_groups);
+                fin_here = false;
             } else {
                 const int32_t hot_info = static_cast<int16_t>(lds_ld<uint16_t>(L.acc_tab + 2u * min(row, H.n_hot - 1u)));
                 int32_t info = hot_info >= 0 && !match_only ? hot_info * 16 : hot_info;
@@ -925,10 +955,21 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
         if (service && free_mask && next < range_hi) {
             const uint32_t rank = static_cast<uint32_t>(__popcll(free_mask & ((1ull << lane) - 1ull)));
             const uint64_t cand = next + rank;
+            // (the offsets of the wave's next 64 lines are on their way since its last hand-out, two per lane: a new line's first piece
+            // was a second trip to memory behind the one for its offsets)
+            const uint32_t n_free = static_cast<uint32_t>(__popcll(free_mask));
+            const bool in_win = next >= win_base && next - win_base + n_free <= 64u;   // (wave-uniform)
+            OFF o_lo = 0, o_hi = 0;
+            if (in_win) {
+                const int src = static_cast<int>(static_cast<uint32_t>(next - win_base) + rank) & 63;
+                o_lo = __shfl(w_lo, src);
+                o_hi = __shfl(w_hi, src);
+            }
             if (!has_line && cand < range_hi) {
                 i = cand;
-                o0 = off[i];
-                int64_t len64 = static_cast<int64_t>(static_cast<uint64_t>(off[i + 1]) - o0);
+                if (!in_win) { o_lo = off[i]; o_hi = off[i + 1]; }
+                o0 = o_lo;
+                int64_t len64 = static_cast<int64_t>(static_cast<uint64_t>(o_hi) - o0);
                 if (strip_eol) len64 = WIDE ? trim_eol(reinterpret_cast<const uint16_t*>(data) + o0, len64) : trim_eol(data + o0, len64);
                 line_wide = false;
                 if (WIDE && len64 > 65535) wide_flags[i] = 0;   // (the follow-up launch walks its units)
@@ -941,10 +982,12 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
                     len = static_cast<uint32_t>(len64);
                     pos = 0;
                     row = row0;
-                    near_end = static_cast<uint64_t>(off[i + 1]) + 16u > static_cast<uint64_t>(off[n]) ? 0x10000u : 0u;
+                    near_end = static_cast<uint64_t>(o_hi) + 16u > total_units ? 0x10000u : 0u;
+                    in_run = false;
                 }
             }
-            next = min(range_hi, next + static_cast<uint64_t>(__popcll(free_mask)));
+            next = min(range_hi, next + static_cast<uint64_t>(n_free));
+            refill(next);
         }
         if (!__any(has_line)) {
             if (next >= range_hi && pool_done) break;
@@ -996,6 +1039,63 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
                 if (mine) pv[r] = load_chunk16<WIDE, false>(src, data_end, who[r].z - at_byte, high_or[r]);
             } else if (mine) pv[r] = load_chunk16<WIDE, true>(src, data_end, who[r].z - at_byte, high_or[r]);
         }
+        // ---- A lane whose whole piece lies in its run and whose line goes on has the next kilobyte of the line TESTED, not staged:
+        // one load instruction per such line, 64 loaders of 16 bytes, and the lane moves behind the chunks that lie in the run -- a
+        // padded value of a kilobyte is two rounds of loads and no walk iteration (it was 64 iterations over ten rounds).  Which lanes
+        // those are is known when the piece's loads have come back -- a second trip to memory behind the first.  So the lanes that
+        // ENDED their last piece inside a run (`in_run`: the walk consumed the piece to its last byte) send those loads out now, with
+        // the piece's: a guess that costs a load when it is wrong.  The descriptors of such lines go through the pads of the piece
+        // buffer's rows (16 bytes behind every row's 128; the who-descriptors above have been read). ----
+        // one such line's chunk of this lane: the line's last chunk, when it is a partial one, is read 16 bytes back from the line's
+        // end (what it overlaps lies in the run already -- the chunk before it, or the piece); `high` != 0: not a chunk of the line,
+        // or (WIDE) one with a unit above 0xFF -- not in the run either way
+        auto spec_load = [&](const u32x4& d, uint32_t& high) -> u32x4 {
+            const uint32_t left2 = d.z;
+            int32_t at = static_cast<int32_t>(lane * 16u);
+            const bool mine = static_cast<uint32_t>(at) < left2;
+            if (static_cast<uint32_t>(at) + 16u > left2) at = static_cast<int32_t>(left2) - 16;
+            high = 1u;
+            if (!mine) return u32x4{0u, 0u, 0u, 0u};
+            const uint8_t* base = reinterpret_cast<const uint8_t*>(static_cast<uint64_t>(d.y) << 32 | d.x);
+            const uint8_t* src = WIDE ? base + 2 * static_cast<int64_t>(at) : base + at;
+            high = 0u;
+            return load_chunk16<WIDE, false>(src, data_end, 16u, high);   // (inside the line: the window was moved back from its end)
+        };
+        auto spec_pad = [&](uint32_t j) { return slice + j * HOP_SLICE_ROW + HOP_SLICE; };
+        auto spec_put = [&](uint32_t j) {   // this lane's line as the j-th of its kind
+            const uint8_t* mine = data + ((o0 + pos + HOP_SLICE) << (WIDE ? 1 : 0));
+            const uint64_t mv = reinterpret_cast<uint64_t>(mine);
+            lds_st<u32x4>(spec_pad(j), u32x4{static_cast<uint32_t>(mv), static_cast<uint32_t>(mv >> 32), left_now - HOP_SLICE, runinfo});
+        };
+        auto spec_vote = [&](uint32_t j, const u32x4& d, const u32x4& v, uint32_t high) {
+            const uint64_t bal = __builtin_amdgcn_ballot_w64(high == 0u && chunk_in_run(v, d.w));
+            if (lane == 0u) lds_st<u32x2>(spec_pad(j), u32x2{static_cast<uint32_t>(bal), static_cast<uint32_t>(bal >> 32)});
+        };
+        auto spec_read = [&](uint32_t j) -> uint32_t {   // the bytes behind the piece that lie in the run
+            const u32x2 bits = lds_ld<u32x2>(spec_pad(j));
+            const uint64_t inv = ~(static_cast<uint64_t>(bits.y) << 32 | bits.x);
+            const uint32_t chunks = inv == 0ull ? 64u : static_cast<uint32_t>(__builtin_ctzll(inv));
+            return min(16u * chunks, left_now - HOP_SLICE);
+        };
+        constexpr uint32_t PRED = GX_HOP_PRED;   // so many guessed lines per round at most (their loads stay in registers until the piece's are back)
+        const bool guess = GX_HOP_SPEC && PRED > 0u && walking && in_run && left_now > HOP_SLICE && runinfo != 0x8000u;
+        const uint64_t g_mask = __builtin_amdgcn_ballot_w64(guess);
+        const uint32_t g_m = min(static_cast<uint32_t>(__builtin_popcountll(g_mask)), PRED);
+        const uint32_t g_rank = static_cast<uint32_t>(__builtin_popcountll(g_mask & ((1ull << lane) - 1ull)));
+        u32x4 gv[PRED > 0u ? PRED : 1u];
+        uint32_t gh[PRED > 0u ? PRED : 1u];
+        if (g_mask != 0ull) {
+            if (guess && g_rank < PRED) spec_put(g_rank);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (uint32_t u = 0; u < PRED; ++u) {
+                gh[u] = 1u;
+                gv[u] = u32x4{0u, 0u, 0u, 0u};
+                if (u < g_m) gv[u] = spec_load(lds_ld<u32x4>(spec_pad(u)), gh[u]);
+            }
+        }
         // which chunks lie in their line's run (whole chunks inside the line), and -- WIDE -- which lines hold a unit above 0xFF: eight
         // loaders per line and instruction -> one byte of the instruction's ballot per line; the ballots go through the piece buffer's
         // first 128 bytes (read again below, before the pieces are stored)
@@ -1025,52 +1125,46 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
             lds_st<u32x4>(slice + (lane / LPL + LINES_PER_LOAD * r) * HOP_SLICE_ROW + (lane % LPL) * 16u, pv[r]);
         // the bytes of the piece that the run covers: whole leading chunks
         const uint32_t skip = walking ? 16u * static_cast<uint32_t>(__builtin_ctz(~run_bits | 0x100u)) : 0u;
-        // ---- a lane whose whole piece lies in its run and whose line goes on: the next kilobyte of the line is TESTED, not staged
-        // -- one load instruction per such line, 64 loaders of 16 bytes -- and the lane moves behind the chunks that lie in the run.
-        // A padded value of a kilobyte is two rounds of loads and no walk iteration (it was 64 iterations over 10 rounds).
-        // The descriptors of those lines go through the pads of the piece buffer's rows (16 bytes behind every row's 128). ----
         uint32_t extra = 0u;
         const bool longrun = GX_HOP_SPEC && walking && skip == HOP_SLICE && left_now > HOP_SLICE;
-        const uint64_t lr_mask = __builtin_amdgcn_ballot_w64(longrun);
-        const uint32_t lr_m = static_cast<uint32_t>(__builtin_popcountll(lr_mask));
-        const uint32_t lr_rank = static_cast<uint32_t>(__builtin_popcountll(lr_mask & ((1ull << lane) - 1ull)));
-        // one such line's chunk of this lane: the line's last chunk, when it is a partial one, is read 16 bytes back from the line's
-        // end (what it overlaps lies in the run already -- the chunk before it, or the piece); `high` != 0: not a chunk of the line,
-        // or (WIDE) one with a unit above 0xFF -- not in the run either way
-        auto spec_load = [&](const u32x4& d, uint32_t& high) -> u32x4 {
-            const uint32_t left2 = d.z;
-            int32_t at = static_cast<int32_t>(lane * 16u);
-            const bool mine = static_cast<uint32_t>(at) < left2;
-            if (static_cast<uint32_t>(at) + 16u > left2) at = static_cast<int32_t>(left2) - 16;
-            high = 1u;
-            if (!mine) return u32x4{0u, 0u, 0u, 0u};
-            const uint8_t* base = reinterpret_cast<const uint8_t*>(static_cast<uint64_t>(d.y) << 32 | d.x);
-            const uint8_t* src = WIDE ? base + 2 * static_cast<int64_t>(at) : base + at;
-            high = 0u;
-            return load_chunk16<WIDE, false>(src, data_end, 16u, high);   // (inside the line: the window was moved back from its end)
-        };
-        auto spec_desc = [&](uint32_t j) { return lds_ld<u32x4>(slice + min(j, lr_m - 1u) * HOP_SLICE_ROW + HOP_SLICE); };
-        auto spec_vote = [&](uint32_t j, const u32x4& d, const u32x4& v, uint32_t high) {
-            const uint64_t bal = __builtin_amdgcn_ballot_w64(high == 0u && chunk_in_run(v, d.w));
-            if (lane == 0u && j < lr_m) lds_st<u32x2>(slice + j * HOP_SLICE_ROW + HOP_SLICE, u32x2{static_cast<uint32_t>(bal), static_cast<uint32_t>(bal >> 32)});
-        };
-        constexpr uint32_t AHEAD = GX_HOP_SPEC_AHEAD;   // loads of that many such lines are in flight while the piece is walked
-        u32x4 av[AHEAD > 0 ? AHEAD : 1];
-        uint32_t ah[AHEAD > 0 ? AHEAD : 1];
-        if (lr_mask != 0ull) {
-            if (longrun) {
-                const uint8_t* mine = data + ((o0 + pos + HOP_SLICE) << (WIDE ? 1 : 0));
-                const uint64_t mv = reinterpret_cast<uint64_t>(mine);
-                lds_st<u32x4>(slice + lr_rank * HOP_SLICE_ROW + HOP_SLICE, u32x4{static_cast<uint32_t>(mv), static_cast<uint32_t>(mv >> 32), left_now - HOP_SLICE, runinfo});
-            }
+        // the guessed lines' votes (their loads are back with the piece's, or soon)
+        if (g_mask != 0ull) {
+#pragma unroll
+            for (uint32_t u = 0; u < PRED; ++u)
+                if (u < g_m) spec_vote(u, lds_ld<u32x4>(spec_pad(u)), gv[u], gh[u]);   // (the descriptor again: its interval is still there)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (longrun && guess && g_rank < PRED) extra = spec_read(g_rank);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ... and the lines nobody guessed (a value's first piece; more than GX_HOP_PRED guesses): the second trip, four lines at a time
+        {
+            const bool late = longrun && !(guess && g_rank < PRED);
+            const uint64_t l_mask = __builtin_amdgcn_ballot_w64(late);
+            if (l_mask != 0ull) {
+                const uint32_t l_m = static_cast<uint32_t>(__builtin_popcountll(l_mask));
+                const uint32_t l_rank = static_cast<uint32_t>(__builtin_popcountll(l_mask & ((1ull << lane) - 1ull)));
+                if (late) spec_put(l_rank);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (uint32_t j0 = 0; j0 < l_m; j0 += 4u) {
+                    u32x4 d[4], sv[4];
+                    uint32_t sh[4];
 #pragma unroll
-            for (uint32_t u = 0; u < AHEAD; ++u) {
-                ah[u] = 1u;
-                av[u] = u32x4{0u, 0u, 0u, 0u};
-                if (u < lr_m) av[u] = spec_load(spec_desc(u), ah[u]);
+                    for (uint32_t u = 0; u < 4u; ++u) d[u] = lds_ld<u32x4>(spec_pad(min(j0 + u, l_m - 1u)));
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) sv[u] = spec_load(d[u], sh[u]);
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u)
+                        if (j0 + u < l_m) spec_vote(j0 + u, d[u], sv[u], sh[u]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (late) extra = spec_read(l_rank);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1089,45 +1183,26 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
             // configs[4], 2 M lines, ms per launch (captures / match only), one device: 64 (the last lane) 0.955 / 0.712, 48 0.914 / 0.666,
             // 32 0.892 / 0.660, 16 0.907 / 0.670; then with 32: results and new lines at 8 idle lanes 0.954, 16 0.877, 24 0.853, 32 0.854;
             // 24 and 24: 0.849 / 0.627 (tools/hop_stats.py replays the rounds: 58 % of the lanes have something to walk in an iteration
-            // of a round that waits for its last lane, 85 % with 24)
+            // of a round that waits for its last lane, 85 % with 24).  Round 5, with the loaders' run test: 16 / 24 / 32 / 40: no difference.
             const uint32_t went_in = static_cast<uint32_t>(__popcll(__ballot(p < limit)));
             const uint32_t leave_at = went_in > GX_HOP_LEAVE ? went_in - GX_HOP_LEAVE : 0u;
             if (match_only) row = all_hot ? walk_hop_span<true, false>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at, K)
                                           : walk_hop_span<false, false>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at, K);
             else row = all_hot ? walk_hop_span<true, true>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at, K)
                                : walk_hop_span<false, true>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at, K);
-            pos += p - my;
+            in_run = walking && !whole && p == e;                   // (the piece went to its last byte: only a run does that)
+            pos += p - my + extra;
         }
-        HS_STAMP(3);
-        // ---- the tested kilobytes: the loads that went out before the walk, then the other such lines four at a time ----
-        if (lr_mask != 0ull) {
-#pragma unroll
-            for (uint32_t u = 0; u < AHEAD; ++u) spec_vote(u, spec_desc(u), av[u], ah[u]);
-            for (uint32_t j0 = AHEAD; j0 < lr_m; j0 += 4u) {
-                u32x4 d[4], sv[4];
-                uint32_t sh[4];
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) d[u] = spec_desc(j0 + u);
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) sv[u] = spec_load(d[u], sh[u]);
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) spec_vote(j0 + u, d[u], sv[u], sh[u]);
+        if (!match_only && L.fin_state_off != 0u) {
+            if (has_line && !fin_here && (pos >= len || row == dead_row)) {
+                F.load(at_global + L.fin_state_off + static_cast<uint64_t>(row) * L.fin_state_rec, T.max_groups);
+                fin_here = true;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (longrun) {
-                const u32x2 bits = lds_ld<u32x2>(slice + lr_rank * HOP_SLICE_ROW + HOP_SLICE);
-                const uint64_t inv = ~(static_cast<uint64_t>(bits.y) << 32 | bits.x);
-                const uint32_t chunks = inv == 0ull ? 64u : static_cast<uint32_t>(__builtin_ctzll(inv));
-                extra = min(16u * chunks, left_now - HOP_SLICE);
-            }
-            pos += extra;
         }
         // the slice buffer is rewritten by the next iteration
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        HS_STAMP(2);   // (the tested kilobytes' votes count with the waiting)
+        HS_STAMP(3);
 #ifdef GX_DEV
         ++ph[4];
 #endif
