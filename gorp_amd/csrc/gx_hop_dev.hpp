@@ -98,10 +98,10 @@ __device__ __forceinline__ uint32_t run_flags(uint32_t x, uint32_t lo4, uint32_t
 // CAPTURE false: the match automaton's tables (no programs anywhere): the register writes are left out.
 // The record a lane holds while it stays in its state (the !ALL_HOT walk; the hop slice kernel keeps it across its rounds and
 // reads the run interval out of it for the loaders' run test)
-#ifndef GX_HOP_AHEAD_REC
-#define GX_HOP_AHEAD_REC 1
-#endif
 struct HopKept {
+#ifdef GX_DEV
+    uint32_t dev_iters = 0u, dev_lane_iters = 0u;   // developer build: iterations of the walk, and lanes that had something to walk in them
+#endif
     uint32_t kept = 0xFFFFFFFFu;
     u32x2 k0 = {0u, 0u}, k1 = {0u, 0u}, k2 = {0u, 0u};
 };
@@ -130,8 +130,6 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
     // 0.939 ms per 10 M lines): ALL_HOT keeps nothing.
     uint32_t kept = K.kept;
     u32x2 k0 = K.k0, k1 = K.k1, k2 = K.k2;
-    uint32_t nxt = 0xFFFFFFFFu;   // the state whose record is on its way into n0..n2 (this call only: a round's last request is lost)
-    u32x2 n0 = {0u, 0u}, n1 = {0u, 0u}, n2 = {0u, 0u};
     for (;;) {
         // (leave_at: the hop slice kernel leaves a round's walk when no more than that many lanes still have bytes -- the others have
         // used up their pieces, and a lane in a long value does so in a third of the iterations a lane in literals needs)
@@ -140,6 +138,10 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
             if (!ALL_HOT) { K.kept = kept; K.k0 = k0; K.k1 = k1; K.k2 = k2; }
             break;
         }
+#ifdef GX_DEV
+        ++K.dev_iters;
+        K.dev_lane_iters += static_cast<uint32_t>(__builtin_popcountll(unfinished));
+#endif
         // ---- 1. the state's record ----
         u32x2 h0, h1, h2;
         if (ALL_HOT) {
@@ -148,8 +150,7 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
         } else {
             if ((__builtin_amdgcn_ballot_w64(s != kept) & unfinished) != 0ull) {
                 if (s != kept && p < limit) {
-                    if (GX_HOP_AHEAD_REC && s == nxt) { k0 = n0; k1 = n1; k2 = n2; }   // (asked for when the lane entered the state before)
-                    else if (s <= last_hot) {
+                    if (s <= last_hot) {
                         const uint32_t la = __umul24(s, HOP_REC_B) + HOP_LDS_AT;
                         k0 = lds_ld<u32x2>(la); k1 = lds_ld<u32x2>(la + 8u); k2 = lds_ld<u32x2>(la + 16u);
                     } else {
@@ -157,16 +158,8 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
                         k0 = g[0]; k1 = g[1]; k2 = g[2];
                     }
                     kept = s;
-                    if (GX_HOP_AHEAD_REC) {
-                        // the record of the chain's target, one state ahead: a line's states are a path (a value, the literal behind it,
-                        // the next value ...), each entered once, and the wave would wait out an L2 round trip for every one of them
-                        const uint32_t t = k0.y & 0xFFFFu;
-                        if (((k0.x >> 16) & 0xFFu) != 0u && t > last_hot) {
-                            const u32x2* g = reinterpret_cast<const u32x2*>(H.hops + static_cast<uint64_t>(t) * HOP_REC_B);
-                            n0 = g[0]; n1 = g[1]; n2 = g[2];
-                            nxt = t;
-                        }
-                    }
+                    // (asking for the chain target's record one state ahead -- a line's states are a path -- was measured in round 5:
+                    // 1.062 against 1.046 ms per 3.8 M lines of configs[4]: the kernel is bound by the instructions it issues, not by that trip)
                 }
             }
             h0 = k0; h1 = k1; h2 = k2;   // (a lane that is done may hold any record: nothing of it is used)

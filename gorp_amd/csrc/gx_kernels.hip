@@ -826,12 +826,7 @@ __device__ __forceinline__ bool chunk_in_run(const u32x4& v, uint32_t runinfo) {
 #ifndef GX_HOP_SPEC
 #define GX_HOP_SPEC 1   // 0: no chunks are tested beyond the piece
 #endif
-#ifndef GX_HOP_PRED
-#define GX_HOP_PRED 0u   // (measured, round 5: 0 / 2 / 4 guessed lines per round 1.022 / 1.032 / 1.052 ms per 3.8 M lines: the registers the loads sit in cost more than the saved trip)
-#endif
-#ifndef GX_HOP_SPEC_AHEAD
-#define GX_HOP_SPEC_AHEAD 0u   // (measured: 0, 4, 6 lines ahead 1.167, 1.157, 1.168 ms per 3.8 M lines -- the latency of those loads is not what a round waits for)
-#endif
+
 
 // WIDE: `data` holds UTF-16 code units (offsets in units): a loading lane fetches 16 units = 32 bytes and stages their low bytes; a line
 // with a unit above 0xFF is flagged (wide_flags[i], *wide_any) for the per-line walk on the units (k_extract_flagged), as the tile kernel's.
@@ -853,6 +848,7 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
     // developer build: cycles per phase summed per wave (tools/hop_slice_phases.py): 0 results + handing out lines, 1 loads issued,
     // 2 waiting for them + LDS stores, 3 walk, 4 rounds
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
+    unsigned long long dv[6] = {0, 0, 0, 0, 0, 0};   // lanes with a piece, lanes that went into the walk, lanes with a tested kilobyte, services, (walk iterations, lanes in them: K)
     const unsigned long long hs_begin = __builtin_amdgcn_s_memrealtime();
 #define HS_STAMP(slot) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[slot] += now_ - ph_t; ph_t = now_; } while (0)
 #else
@@ -909,7 +905,6 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
     FinAhead F;               // the final record of the state a finished line ended in, asked for behind the walk
     bool fin_here = false;
     uint32_t near_end = 0u;   // the line ends within 16 units of the buffer's end: its loaders read byte by byte
-    bool in_run = false;      // the lane's last piece ended inside a run (the guess: its next piece lies in the run as well)
     HopKept K;                // the record the lane holds while it stays in its state (kept across rounds)
     const bool all_hot = L.rec_indexed >= L.sort_chunk;
 
@@ -939,6 +934,9 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
             }
             has_line = false;
         }
+#ifdef GX_DEV
+        if (service) ++dv[3];
+#endif
         HS_STAMP(5);
         // ---- the range is used up: the next chunk of the pool ----
         if (service && next >= range_hi && !pool_done) {
@@ -983,7 +981,6 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
                     pos = 0;
                     row = row0;
                     near_end = static_cast<uint64_t>(o_hi) + 16u > total_units ? 0x10000u : 0u;
-                    in_run = false;
                 }
             }
             next = min(range_hi, next + static_cast<uint64_t>(n_free));
@@ -1042,10 +1039,12 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
         // ---- A lane whose whole piece lies in its run and whose line goes on has the next kilobyte of the line TESTED, not staged:
         // one load instruction per such line, 64 loaders of 16 bytes, and the lane moves behind the chunks that lie in the run -- a
         // padded value of a kilobyte is two rounds of loads and no walk iteration (it was 64 iterations over ten rounds).  Which lanes
-        // those are is known when the piece's loads have come back -- a second trip to memory behind the first.  So the lanes that
-        // ENDED their last piece inside a run (`in_run`: the walk consumed the piece to its last byte) send those loads out now, with
-        // the piece's: a guess that costs a load when it is wrong.  The descriptors of such lines go through the pads of the piece
-        // buffer's rows (16 bytes behind every row's 128; the who-descriptors above have been read). ----
+        // those are is known when the piece's loads have come back: a second trip to memory behind the first.  (Measured, round 5, ms
+        // per 3.8 M lines of configs[4]: without the tested kilobytes 1.304 against 1.168; their loads sent out before the walk and
+        // looked at behind it -- 0 / 4 / 6 lines ahead -- 1.167 / 1.157 / 1.168; sent out WITH the piece's loads for the lanes whose
+        // last piece ended inside a run -- a guess -- 0 / 2 / 4 / 6 lines 1.022 / 1.032 / 1.052 / 1.124: the registers those loads
+        // sit in cost more than the trip they save.  The kernel is bound by the instructions it issues.)  The descriptors of such
+        // lines go through the pads of the piece buffer's rows (16 bytes behind every row's 128). ----
         // one such line's chunk of this lane: the line's last chunk, when it is a partial one, is read 16 bytes back from the line's
         // end (what it overlaps lies in the run already -- the chunk before it, or the piece); `high` != 0: not a chunk of the line,
         // or (WIDE) one with a unit above 0xFF -- not in the run either way
@@ -1077,25 +1076,6 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
             const uint32_t chunks = inv == 0ull ? 64u : static_cast<uint32_t>(__builtin_ctzll(inv));
             return min(16u * chunks, left_now - HOP_SLICE);
         };
-        constexpr uint32_t PRED = GX_HOP_PRED;   // so many guessed lines per round at most (their loads stay in registers until the piece's are back)
-        const bool guess = GX_HOP_SPEC && PRED > 0u && walking && in_run && left_now > HOP_SLICE && runinfo != 0x8000u;
-        const uint64_t g_mask = __builtin_amdgcn_ballot_w64(guess);
-        const uint32_t g_m = min(static_cast<uint32_t>(__builtin_popcountll(g_mask)), PRED);
-        const uint32_t g_rank = static_cast<uint32_t>(__builtin_popcountll(g_mask & ((1ull << lane) - 1ull)));
-        u32x4 gv[PRED > 0u ? PRED : 1u];
-        uint32_t gh[PRED > 0u ? PRED : 1u];
-        if (g_mask != 0ull) {
-            if (guess && g_rank < PRED) spec_put(g_rank);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (uint32_t u = 0; u < PRED; ++u) {
-                gh[u] = 1u;
-                gv[u] = u32x4{0u, 0u, 0u, 0u};
-                if (u < g_m) gv[u] = spec_load(lds_ld<u32x4>(spec_pad(u)), gh[u]);
-            }
-        }
         // which chunks lie in their line's run (whole chunks inside the line), and -- WIDE -- which lines hold a unit above 0xFF: eight
         // loaders per line and instruction -> one byte of the instruction's ballot per line; the ballots go through the piece buffer's
         // first 128 bytes (read again below, before the pieces are stored)
@@ -1127,21 +1107,8 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
         const uint32_t skip = walking ? 16u * static_cast<uint32_t>(__builtin_ctz(~run_bits | 0x100u)) : 0u;
         uint32_t extra = 0u;
         const bool longrun = GX_HOP_SPEC && walking && skip == HOP_SLICE && left_now > HOP_SLICE;
-        // the guessed lines' votes (their loads are back with the piece's, or soon)
-        if (g_mask != 0ull) {
-#pragma unroll
-            for (uint32_t u = 0; u < PRED; ++u)
-                if (u < g_m) spec_vote(u, lds_ld<u32x4>(spec_pad(u)), gv[u], gh[u]);   // (the descriptor again: its interval is still there)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (longrun && guess && g_rank < PRED) extra = spec_read(g_rank);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        // ... and the lines nobody guessed (a value's first piece; more than GX_HOP_PRED guesses): the second trip, four lines at a time
-        {
-            const bool late = longrun && !(guess && g_rank < PRED);
+        {   // (four such lines' loads at a time)
+            const bool late = longrun;
             const uint64_t l_mask = __builtin_amdgcn_ballot_w64(late);
             if (l_mask != 0ull) {
                 const uint32_t l_m = static_cast<uint32_t>(__builtin_popcountll(l_mask));
@@ -1156,7 +1123,11 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
 #pragma unroll
                     for (uint32_t u = 0; u < 4u; ++u) d[u] = lds_ld<u32x4>(spec_pad(min(j0 + u, l_m - 1u)));
 #pragma unroll
-                    for (uint32_t u = 0; u < 4u; ++u) sv[u] = spec_load(d[u], sh[u]);
+                    for (uint32_t u = 0; u < 4u; ++u) {
+                        sh[u] = 1u;
+                        sv[u] = u32x4{0u, 0u, 0u, 0u};
+                        if (j0 + u < l_m) sv[u] = spec_load(d[u], sh[u]);
+                    }
 #pragma unroll
                     for (uint32_t u = 0; u < 4u; ++u)
                         if (j0 + u < l_m) spec_vote(j0 + u, d[u], sv[u], sh[u]);
@@ -1185,12 +1156,16 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
             // 24 and 24: 0.849 / 0.627 (tools/hop_stats.py replays the rounds: 58 % of the lanes have something to walk in an iteration
             // of a round that waits for its last lane, 85 % with 24).  Round 5, with the loaders' run test: 16 / 24 / 32 / 40: no difference.
             const uint32_t went_in = static_cast<uint32_t>(__popcll(__ballot(p < limit)));
+#ifdef GX_DEV
+            dv[0] += static_cast<unsigned long long>(__popcll(__ballot(walking)));
+            dv[1] += went_in;
+            dv[2] += static_cast<unsigned long long>(__popcll(__ballot(longrun)));
+#endif
             const uint32_t leave_at = went_in > GX_HOP_LEAVE ? went_in - GX_HOP_LEAVE : 0u;
             if (match_only) row = all_hot ? walk_hop_span<true, false>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at, K)
                                           : walk_hop_span<false, false>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at, K);
             else row = all_hot ? walk_hop_span<true, true>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at, K)
                                : walk_hop_span<false, true>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at, K);
-            in_run = walking && !whole && p == e;                   // (the piece went to its last byte: only a run does that)
             pos += p - my + extra;
         }
         if (!match_only && L.fin_state_off != 0u) {
@@ -1209,10 +1184,13 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
     }
 #ifdef GX_DEV
     if (stamps && lane == 0) {
-        unsigned long long* st = stamps + 8ull * (static_cast<uint64_t>(blockIdx.x) * L.nwaves + wave);
+        unsigned long long* st = stamps + 16ull * (static_cast<uint64_t>(blockIdx.x) * L.nwaves + wave);
         for (int q = 0; q < 6; ++q) st[q] = ph[q];
         st[6] = hs_begin;
         st[7] = __builtin_amdgcn_s_memrealtime();
+        for (int q = 0; q < 4; ++q) st[8 + q] = dv[q];
+        st[12] = K.dev_iters;
+        st[13] = K.dev_lane_iters;
     }
 #endif
 }

@@ -25,7 +25,7 @@ for d in range(n_defs):
     assert gorp.stat(14) > 0
     lo, hi = rng.choice([(None, None), (30, 300), (50, 2000)])
     data, off, _ = W.syslog_lines(meta, 1500, seed=rng.randrange(1 << 30), corrupt_frac=0.15, min_len=lo, max_len=hi,
-                                  line_bytes=rng.choice([120, 200, 254, 400]))
+                                  line_bytes=rng.choice([120, 200, 254, 400]), mixed_case=rng.random() < 0.5)   # (mixed case: the loop sets' second chance)
     lines = [bytes(data[off[i]:off[i + 1]]).decode("latin-1") for i in range(1500)]
     for i in range(0, 1500, 3):
         ln, r = lines[i], rng.random()
