@@ -40,6 +40,7 @@ SYMBOLS = [
     "gx_pack_results", "gx_unpack_results", "gx_unpack_results8", "gx_text_to_jsonl", "gx_capture_one_utf16",
     "gx_match_batch", "gx_state_accepts", "gx_set_device", "gx_handle_device", "gx_extract_batch_multi",
     "gx_host_register", "gx_host_unregister", "gx_split_lines_max", "gx_extract_batch_multi_device",
+    "gx_create_on_devices", "gx_gather_rows", "gx_gather_wait",
 ]
 
 
@@ -66,6 +67,10 @@ class gx_batch_opts(C.Structure):
 class gx_device_shard(C.Structure):
     _fields_ = [("handle", C.c_void_p), ("bytes", C.c_void_p), ("offsets", C.c_void_p), ("n", C.c_uint64), ("match_id", C.c_void_p),
                 ("caps", C.c_void_p), ("overflow", C.c_void_p), ("stream", C.c_void_p)]
+
+
+class gx_rows_shard(C.Structure):
+    _fields_ = [("handle", C.c_void_p), ("rows", C.c_void_p), ("n", C.c_uint64), ("stream", C.c_void_p)]
 
 
 _lib = None
@@ -158,6 +163,12 @@ def lib():
     L.gx_extract_batch_multi.restype = C.c_int
     L.gx_extract_batch_multi_device.argtypes = [C.POINTER(gx_device_shard), C.c_int32, C.POINTER(gx_batch_opts)]
     L.gx_extract_batch_multi_device.restype = C.c_int
+    L.gx_create_on_devices.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.c_int32, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.gx_create_on_devices.restype = C.c_int
+    L.gx_gather_rows.argtypes = [C.POINTER(gx_rows_shard), C.c_int32, C.c_uint32, C.c_int32, C.c_void_p, C.c_int32]
+    L.gx_gather_rows.restype = C.c_int
+    L.gx_gather_wait.argtypes = [C.POINTER(C.c_void_p), C.c_int32]
+    L.gx_gather_wait.restype = C.c_int
     L.gx_host_register.argtypes = [C.c_void_p, C.c_size_t]
     L.gx_host_register.restype = C.c_int
     L.gx_host_unregister.argtypes = [C.c_void_p]

@@ -25,6 +25,9 @@ using namespace gx;
 namespace {
 
 thread_local std::string g_last_error;
+// gx_create_on_devices: the handle whose table images (already in its device's memory) this thread's upload() copies from, device
+// to device, instead of from host memory
+thread_local const gx_handle* g_peer_src = nullptr;
 
 int fail(int code, const std::string& msg) {
     g_last_error = msg;
@@ -155,6 +158,9 @@ struct gx_handle {
     int32_t* d_pike_scratch = nullptr;    // thread lists of the lanes that run an extraction's program as it is (GxDev::pike_scratch)
     int hop_reason = 4;                   // why capture batches have no hop tables (gx_stat(h, 26); 0: they have)
     hipStream_t multi_stream = nullptr;   // gx_extract_batch_multi_device: the stream of shards that bring none
+    hipStream_t gather_stream = nullptr;  // gx_gather_rows: this handle's rows leave for the root's device on it (a copy queue of its own: seven peers, seven links)
+    hipEvent_t gather_event = nullptr;    // ... "the shard's kernel is done", recorded on the kernel's stream
+    size_t peer_image_bytes = 0;          // table bytes that came from another device's copy (gx_create_on_devices; gx_stat(h, 30))
     std::atomic<int> last_kernel{0};      // GX_KERNEL_* of the most recent batch launch (gx_stat(h, 25))
     // device scratch of gx_results_to_jsonl / gx_text_to_jsonl (sizes, split points, line offsets), kept between calls and grown as
     // batches ask: a hipMalloc + hipFree pair per call cost more than the scan kernels.  Used under `mu` only, and every call that
@@ -896,6 +902,17 @@ void choose_tile_image(gx_handle* h) {
     }
 }
 
+// One table image into the handle's device: from host memory, or -- gx_create_on_devices -- from the same image on the device of
+// the handle that was built first: a copy between devices (over xGMI where the devices are peers; the runtime stages it otherwise).
+static void put_image(gx_handle* h, void* dst, const void* host, size_t bytes, const void* peer) {
+    if (bytes == 0) return;
+    if (peer && g_peer_src && hipMemcpyPeer(dst, h->device, peer, g_peer_src->device, bytes) == hipSuccess) {
+        h->peer_image_bytes += bytes;
+        return;
+    }
+    GX_HIP(hipMemcpy(dst, host, bytes, hipMemcpyHostToDevice));
+}
+
 void upload(gx_handle* h) {
     const Tables& T = h->T;
     int count = 0;
@@ -961,7 +978,7 @@ void upload(gx_handle* h) {
 
     GX_HIP(hipMalloc(&h->dimage, img.bytes.size()));
     h->image_bytes = img.bytes.size();
-    GX_HIP(hipMemcpy(h->dimage, img.bytes.data(), img.bytes.size(), hipMemcpyHostToDevice));
+    put_image(h, h->dimage, img.bytes.data(), img.bytes.size(), g_peer_src ? g_peer_src->dimage : nullptr);
     const uint8_t* base = static_cast<const uint8_t*>(h->dimage);
     GxDev& d = h->dev;
     d.cls256 = base + o_cls;
@@ -999,32 +1016,32 @@ void upload(gx_handle* h) {
     choose_tile_image(h);
     if (h->tile_ok) {
         GX_HIP(hipMalloc(&h->d_lds_image, h->lds_image.size()));
-        GX_HIP(hipMemcpy(h->d_lds_image, h->lds_image.data(), h->lds_image.size(), hipMemcpyHostToDevice));
+        put_image(h, h->d_lds_image, h->lds_image.data(), h->lds_image.size(), g_peer_src ? g_peer_src->d_lds_image : nullptr);
         if (h->has_mo) {
             GX_HIP(hipMalloc(&h->d_lds_image_mo, h->lds_image_mo.size()));
-            GX_HIP(hipMemcpy(h->d_lds_image_mo, h->lds_image_mo.data(), h->lds_image_mo.size(), hipMemcpyHostToDevice));
+            put_image(h, h->d_lds_image_mo, h->lds_image_mo.data(), h->lds_image_mo.size(), g_peer_src ? g_peer_src->d_lds_image_mo : nullptr);
         }
         if (h->tile_global) {
             GX_HIP(hipMalloc(&h->d_l2_image, h->l2_image.size()));
-            GX_HIP(hipMemcpy(h->d_l2_image, h->l2_image.data(), h->l2_image.size(), hipMemcpyHostToDevice));
+            put_image(h, h->d_l2_image, h->l2_image.data(), h->l2_image.size(), g_peer_src ? g_peer_src->d_l2_image : nullptr);
         }
     }
     if (h->tile_ok || h->hop_ok || h->hop_mo_ok) {
         if (h->hop_ok) {
             GX_HIP(hipMalloc(&h->d_lds_image_hop, h->hop.full.bytes.size()));
-            GX_HIP(hipMemcpy(h->d_lds_image_hop, h->hop.full.bytes.data(), h->hop.full.bytes.size(), hipMemcpyHostToDevice));
+            put_image(h, h->d_lds_image_hop, h->hop.full.bytes.data(), h->hop.full.bytes.size(), g_peer_src ? g_peer_src->d_lds_image_hop : nullptr);
             GX_HIP(hipMalloc(&h->d_lds_image_hop_small, h->hop.small.bytes.size()));
-            GX_HIP(hipMemcpy(h->d_lds_image_hop_small, h->hop.small.bytes.data(), h->hop.small.bytes.size(), hipMemcpyHostToDevice));
+            put_image(h, h->d_lds_image_hop_small, h->hop.small.bytes.data(), h->hop.small.bytes.size(), g_peer_src ? g_peer_src->d_lds_image_hop_small : nullptr);
             GX_HIP(hipMalloc(&h->d_hop_global, h->hop.global.size()));
-            GX_HIP(hipMemcpy(h->d_hop_global, h->hop.global.data(), h->hop.global.size(), hipMemcpyHostToDevice));
+            put_image(h, h->d_hop_global, h->hop.global.data(), h->hop.global.size(), g_peer_src ? g_peer_src->d_hop_global : nullptr);
         }
         if (h->hop_mo_ok) {
             GX_HIP(hipMalloc(&h->d_lds_image_hop_mo, h->hop_mo.full.bytes.size()));
-            GX_HIP(hipMemcpy(h->d_lds_image_hop_mo, h->hop_mo.full.bytes.data(), h->hop_mo.full.bytes.size(), hipMemcpyHostToDevice));
+            put_image(h, h->d_lds_image_hop_mo, h->hop_mo.full.bytes.data(), h->hop_mo.full.bytes.size(), g_peer_src ? g_peer_src->d_lds_image_hop_mo : nullptr);
             GX_HIP(hipMalloc(&h->d_lds_image_hop_mo_small, h->hop_mo.small.bytes.size()));
-            GX_HIP(hipMemcpy(h->d_lds_image_hop_mo_small, h->hop_mo.small.bytes.data(), h->hop_mo.small.bytes.size(), hipMemcpyHostToDevice));
+            put_image(h, h->d_lds_image_hop_mo_small, h->hop_mo.small.bytes.data(), h->hop_mo.small.bytes.size(), g_peer_src ? g_peer_src->d_lds_image_hop_mo_small : nullptr);
             GX_HIP(hipMalloc(&h->d_hop_mo_global, h->hop_mo.global.size()));
-            GX_HIP(hipMemcpy(h->d_hop_mo_global, h->hop_mo.global.data(), h->hop_mo.global.size(), hipMemcpyHostToDevice));
+            put_image(h, h->d_hop_mo_global, h->hop_mo.global.data(), h->hop_mo.global.size(), g_peer_src ? g_peer_src->d_hop_mo_global : nullptr);
         }
         GX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_slots), 3 * gx_handle::N_SLOTS * sizeof(uint32_t)));
         GX_HIP(hipMemset(h->d_slots, 0, 3 * gx_handle::N_SLOTS * sizeof(uint32_t)));
@@ -1527,6 +1544,8 @@ void gx_destroy(gx_handle* h) {
         if (h->svc.host) (void)hipHostFree(h->svc.host);
     }
     if (h->multi_stream) (void)hipStreamDestroy(h->multi_stream);
+    if (h->gather_stream) (void)hipStreamDestroy(h->gather_stream);
+    if (h->gather_event) (void)hipEventDestroy(h->gather_event);
     if (h->d_pike_scratch) (void)hipFree(h->d_pike_scratch);
     if (h->one_dev) (void)hipFree(h->one_dev);
     if (h->one_host) (void)hipHostFree(h->one_host);
@@ -1565,6 +1584,7 @@ int64_t gx_stat(const gx_handle* h, int32_t which) {
     case 20: return h->hop_ok ? static_cast<int64_t>(h->hop.full.n_lds_rows) : 0;       // ... whose dense row is in LDS too (branching states)
     case 22: return h->hop_mo_ok ? static_cast<int64_t>(h->hop_mo.n_states) : 0;   // hop tier of the match automaton alone (match-only batches): states
     case 24: return static_cast<int64_t>(h->promises_broken.load());
+    case 30: return static_cast<int64_t>(h->peer_image_bytes);   // table bytes copied from another handle's device (gx_create_on_devices)
     case 25: return h->last_kernel.load();
     case 26: return h->hop_reason;
     case 28: return static_cast<int64_t>(h->svc.enabled ? h->svc.launches : -1);
@@ -2299,6 +2319,121 @@ int gx_extract_batch_multi_device(const gx_device_shard* shards, int32_t n_shard
     }
     (void)hipSetDevice(prev_device);
     if (first_rc != GX_OK) return fail(first_rc, first_msg);
+    return GX_OK;
+}
+
+// ---- one process, all GPUs of a node: the tables on every device, the rows back on one (north_star: "broadcast of the DFA tables
+// and a final gather over xGMI" -- for the caller that is ONE process, core/Gorp.java:22; ranks of a job use RCCL: gorp_amd/dist.py) ----
+int gx_create_on_devices(const void* blob, size_t size, const int32_t* devices, int32_t n_devices, uint32_t flags, gx_handle** handles) {
+    if (!blob || !devices || !handles || n_devices <= 0) return fail(GX_E_ARG, "gx_create_on_devices: bad argument");
+    if (flags & GX_CREATE_HOST_ONLY) return fail(GX_E_ARG, "gx_create_on_devices: host-only handles live on no device");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(GX_E_DEVICE, "no HIP device available (libgorp_hip needs a gfx950 GPU; there is no CPU fallback)");
+    for (int32_t k = 0; k < n_devices; ++k) {
+        handles[k] = nullptr;
+        if (devices[k] < 0 || devices[k] >= count) return fail(GX_E_ARG, "gx_create_on_devices: no such device");
+    }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    // the first handle from the blob (host work + upload over the bus), the others beside it: their host-side tables in threads of
+    // their own, their device images copied from the first handle's device
+    int rc = GX_OK;
+    std::string msg;
+    if (hipSetDevice(devices[0]) != hipSuccess) rc = GX_E_DEVICE, msg = "gx_create_on_devices: hipSetDevice failed";
+    if (rc == GX_OK) {
+        rc = gx_create_from_blob(blob, size, flags, &handles[0]);
+        if (rc != GX_OK) msg = gx_last_error();
+    }
+    if (rc == GX_OK && n_devices > 1) {
+        std::vector<int> rcs(static_cast<size_t>(n_devices), GX_OK);
+        std::vector<std::string> msgs(static_cast<size_t>(n_devices));
+        std::vector<std::thread> th;
+        const gx_handle* first = handles[0];
+        for (int32_t k = 1; k < n_devices; ++k)
+            th.emplace_back([&, k]() {
+                if (hipSetDevice(devices[k]) != hipSuccess) { rcs[k] = GX_E_DEVICE; msgs[k] = "gx_create_on_devices: hipSetDevice failed"; return; }
+                int can = 0;   // (peers read each other's memory directly once this is on; failing that the runtime stages the copy)
+                if (devices[k] != first->device && hipDeviceCanAccessPeer(&can, devices[k], first->device) == hipSuccess && can)
+                    (void)hipDeviceEnablePeerAccess(first->device, 0);
+                (void)hipGetLastError();
+                g_peer_src = first;
+                rcs[k] = gx_create_from_blob(blob, size, flags, &handles[k]);
+                g_peer_src = nullptr;
+                if (rcs[k] != GX_OK) msgs[k] = gx_last_error();
+            });
+        for (auto& t : th) t.join();
+        for (int32_t k = 1; k < n_devices && rc == GX_OK; ++k)
+            if (rcs[k] != GX_OK) { rc = rcs[k]; msg = msgs[k]; }
+    }
+    (void)hipSetDevice(prev);
+    if (rc != GX_OK) {
+        for (int32_t k = 0; k < n_devices; ++k) { if (handles[k]) gx_destroy(handles[k]); handles[k] = nullptr; }
+        return fail(rc, msg);
+    }
+    return GX_OK;
+}
+
+int gx_gather_rows(const gx_rows_shard* shards, int32_t n_shards, uint32_t row_bytes, int32_t dst_device, void* dst_rows, int32_t no_sync) {
+    if (!shards || n_shards <= 0 || row_bytes == 0 || !dst_rows) return fail(GX_E_ARG, "gx_gather_rows: bad argument");
+    for (int32_t k = 0; k < n_shards; ++k)
+        if (!shards[k].handle || !shards[k].handle->on_device || (shards[k].n && !shards[k].rows)) return fail(GX_E_ARG, "gx_gather_rows: NULL or host-only handle, or no rows");
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    int rc = GX_OK;
+    std::string msg;
+    auto bad = [&](const char* what) { if (rc == GX_OK) { rc = GX_E_DEVICE; msg = what; } };
+    uint64_t at = 0;
+    for (int32_t k = 0; k < n_shards && rc == GX_OK; ++k) {
+        gx_handle* h = shards[k].handle;
+        const uint64_t bytes = shards[k].n * static_cast<uint64_t>(row_bytes);
+        uint8_t* dst = static_cast<uint8_t*>(dst_rows) + at;
+        at += bytes;
+        if (bytes == 0) continue;
+        if (hipSetDevice(h->device) != hipSuccess) { bad("gx_gather_rows: hipSetDevice failed"); break; }
+        std::lock_guard<std::mutex> lock(h->slot_mu);
+        if (!h->gather_stream) {
+            if (hipStreamCreateWithFlags(&h->gather_stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&h->gather_event, hipEventDisableTiming) != hipSuccess) { bad("gx_gather_rows: no stream on the shard's device"); break; }
+            int can = 0;   // the shard's device writes into the root's memory itself: one link per peer, all of them at once
+            if (h->device != dst_device && hipDeviceCanAccessPeer(&can, h->device, dst_device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(dst_device, 0);
+            (void)hipGetLastError();
+        }
+        // behind the shard's kernel (the stream it was enqueued on: the caller's, or the one gx_extract_batch_multi_device used) ...
+        hipStream_t ks = static_cast<hipStream_t>(shards[k].stream);
+        if (!ks) ks = h->multi_stream;
+        if (ks) {
+            if (hipEventRecord(h->gather_event, ks) != hipSuccess || hipStreamWaitEvent(h->gather_stream, h->gather_event, 0) != hipSuccess) { bad("gx_gather_rows: event"); break; }
+        }
+        // ... on the copy stream of the shard's own device: the kernels of the next batch go on beside it
+        const hipError_t e = h->device == dst_device ? hipMemcpyAsync(dst, shards[k].rows, bytes, hipMemcpyDeviceToDevice, h->gather_stream)
+                                                     : hipMemcpyPeerAsync(dst, dst_device, shards[k].rows, h->device, bytes, h->gather_stream);
+        if (e != hipSuccess) bad("gx_gather_rows: the copy between the devices failed");
+    }
+    if (rc == GX_OK && !no_sync) {
+        for (int32_t k = 0; k < n_shards; ++k) {
+            gx_handle* h = shards[k].handle;
+            if (!h->gather_stream) continue;
+            if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->gather_stream) != hipSuccess) bad("gx_gather_rows: a copy stream failed");
+        }
+    }
+    (void)hipSetDevice(prev);
+    if (rc != GX_OK) return fail(rc, msg);
+    return GX_OK;
+}
+
+int gx_gather_wait(gx_handle* const* handles, int32_t n_handles) {
+    if (!handles || n_handles <= 0) return fail(GX_E_ARG, "gx_gather_wait: bad argument");
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    int rc = GX_OK;
+    for (int32_t k = 0; k < n_handles; ++k) {
+        gx_handle* h = handles[k];
+        if (!h || !h->on_device) { rc = GX_E_ARG; continue; }
+        if (!h->gather_stream) continue;
+        if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->gather_stream) != hipSuccess) rc = GX_E_DEVICE;
+    }
+    (void)hipSetDevice(prev);
+    if (rc != GX_OK) return fail(rc, "gx_gather_wait: a handle without a device, or a copy stream that failed");
     return GX_OK;
 }
 

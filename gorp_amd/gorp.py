@@ -672,6 +672,30 @@ def extract_batch_multi_device(shards, match_only=False, strip_eol=False, compac
     _check(N.lib().gx_extract_batch_multi_device(arr, len(shards), C.byref(o)))
 
 
+def create_on_devices(gorp, devices, flags=0):
+    """gx_create_on_devices: `gorp`'s tables (its blob) on every device of `devices` -- the first handle from the blob, the others'
+    device images copied from the first one's device (over xGMI between peers).  Returns one Gorp per device, same extractions."""
+    blob = np.ascontiguousarray(gorp.blob())
+    devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+    hs = (C.c_void_p * len(devices))()
+    _check(N.lib().gx_create_on_devices(blob.ctypes.data, len(blob), devs, len(devices), flags | DEFAULT_CREATE_FLAGS, hs))
+    return [Gorp(_Handle(C.c_void_p(h)), gorp._extractions) for h in hs]
+
+
+def gather_rows(shards, row_bytes, dst_device, dst_ptr, no_sync=False):
+    """gx_gather_rows: shards = list of (gorp, rows_ptr, n, stream or None); the rows of all shards onto `dst_device` at dst_ptr,
+    in shard order, each shard's copy behind its kernel on a copy stream of the shard's device."""
+    arr = (N.gx_rows_shard * len(shards))()
+    for a, (g, r, n, st) in zip(arr, shards):
+        a.handle, a.rows, a.n, a.stream = g._h.ptr, r, n, st
+    _check(N.lib().gx_gather_rows(arr, len(shards), int(row_bytes), int(dst_device), dst_ptr, 1 if no_sync else 0))
+
+
+def gather_wait(gorps):
+    hs = (C.c_void_p * len(gorps))(*[g._h.ptr for g in gorps])
+    _check(N.lib().gx_gather_wait(hs, len(gorps)))
+
+
 def split_lines(data, cap_lines=None, offsets_dtype=np.uint32, want_flags=False):
     """gx_split_lines on a host buffer: raw bytes -> (offsets[n+1], flags[n] or None) with readLine() line
     boundaries; every line keeps its terminator (pass strip_eol=True to extract_batch)."""

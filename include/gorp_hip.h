@@ -353,6 +353,34 @@ typedef struct gx_device_shard {
 } gx_device_shard;
 int gx_extract_batch_multi_device(const gx_device_shard* shards, int32_t n_shards, const gx_batch_opts* opts);
 
+/* One process, all GPUs of a node (the reference's caller is ONE JVM, "fully thread-safe and may be used concurrently",
+ * core/Gorp.java:22; BASELINE north_star: "broadcast of the DFA tables and a final gather over xGMI").  Ranks of a multi-process
+ * job exchange the blob and the rows with RCCL (gorp_amd/dist.py); this is the same for the caller that owns every device itself.
+ *
+ * gx_create_on_devices: one handle per device from ONE blob (gx_blob_copy of a handle compiled once).  handles[0] is built from
+ * the blob on devices[0]; the others take their device images -- the class maps, the LDS table images, the dense rows and hop
+ * records in global memory: 9 KB for the README definition, 18 MB for 512 extractions -- from devices[0]'s copy, device to device
+ * (hipMemcpyPeer: over xGMI between peers; gx_stat(h, 30) = bytes that came this way), their host-side tables built in threads of
+ * their own.  All or nothing: on failure every handle that was created is destroyed and handles[] is NULL.
+ *
+ * gx_gather_rows: the result rows of a sharded batch (gx_extract_batch_multi_device with compact_results 1 or 2; any fixed row
+ * size works: dense caps rows are 8 G bytes) onto ONE device, in shard order: dst_rows[sum of n over the shards before k ...].
+ * Each shard's copy is enqueued on a copy stream of the SHARD's device behind the shard's kernel (an event on `stream`: the
+ * stream that kernel was enqueued on; NULL = the stream gx_extract_batch_multi_device uses when the shard brings none), as one
+ * hipMemcpyPeerAsync -- seven peers push into the root over seven links at once, nothing funnels through the host.  no_sync != 0:
+ * returns when everything is enqueued; gx_gather_wait(handles) waits for those copies.  The next batch's kernels may be enqueued
+ * (on the kernel streams) before the gather of this one is waited for -- a two-deep pipeline with two row buffers per shard: wait
+ * for gather k before batch k + 2 writes the rows gather k reads ("One process, eight GPUs"). */
+typedef struct gx_rows_shard {
+    gx_handle* handle;      /* names the shard's device */
+    const void* rows;       /* on that device: n rows of row_bytes bytes */
+    uint64_t n;
+    void* stream;           /* hipStream_t the shard's kernel was enqueued on (NULL: the handle's own multi-device stream) */
+} gx_rows_shard;
+int gx_create_on_devices(const void* blob, size_t size, const int32_t* devices, int32_t n_devices, uint32_t flags, gx_handle** handles);
+int gx_gather_rows(const gx_rows_shard* shards, int32_t n_shards, uint32_t row_bytes, int32_t dst_device, void* dst_rows, int32_t no_sync);
+int gx_gather_wait(gx_handle* const* handles, int32_t n_handles);
+
 /* Host buffers that are handed to gx_extract_batch again and again (a JNI caller's direct ByteBuffers) can be pinned
  * once: copies from and to pinned memory run at the bus' rate without a staging copy by the CPU (hipHostRegister /
  * hipHostUnregister). */

@@ -1696,3 +1696,70 @@ def test_hop_long_runs_and_loop_sets():
     for kernel in (N.GX_KERNEL_AUTO, N.GX_KERNEL_HOP_SLICES, N.GX_KERNEL_HOPS):
         m6, c6 = gorp2.extract_batch(d6, o6, kernel=kernel)
         assert np.array_equal(m6, om6) and np.array_equal(c6, oc6), kernel
+
+
+@pytest.mark.gpu
+def test_tables_on_devices_and_rows_gathered():
+    """Round 5: the north star's multi-GPU split for the caller that is ONE process (core/Gorp.java:22) -- gx_create_on_devices
+    (one blob, a handle per device, the later handles' device images copied from the first handle's device), sharded batches
+    through gx_extract_batch_multi_device, gx_gather_rows (each shard's rows to the root's device behind its kernel, on a copy
+    stream of the shard's device) and the two-deep pipeline: batch k + 1's kernels enqueued before the gather of batch k is
+    waited for.  One GPU here: three handles on the one device, the copies between devices are copies on it -- unmeasured
+    across devices.  Gathered rows against the oracle, shard by shard."""
+    import torch
+    rules, meta = W.syslog_definition(64, seed=3)
+    first = Gorp.construct(rules)
+    orc = oracle_for(rules)
+    gorps = G.create_on_devices(first, [0, 0, 0])
+    assert [g.stat(30) > 0 for g in gorps] == [False, True, True]            # table bytes that came from handle 0's device
+    assert all(g.stat(14) == first.stat(14) and g.stat(0) == first.stat(0) and N.lib().gx_handle_device(g._h.ptr) == 0 for g in gorps)
+    with pytest.raises(G.GorpError):
+        G.create_on_devices(first, [0, 99])
+    Gm = first.max_groups
+    width = 1 + 2 * Gm
+    batches = []
+    for b in range(4):                                                         # four batches of three shards (one of them empty once)
+        shards = []
+        for k, n in enumerate((20000, 0 if b == 1 else 7000, 12345)):
+            d, o, _ = W.syslog_lines(meta, max(n, 1), seed=100 + 10 * b + k, corrupt_frac=0.05)
+            shards.append((torch.from_numpy(d.copy()).cuda(), torch.from_numpy(o.astype(np.uint32)).cuda(), n, d, o))
+        batches.append(shards)
+    for fmt, dtype, unit in ((2, torch.uint8, 1), (1, torch.int16, 2)):
+        rows = [[torch.empty((max(n, 1), width), dtype=dtype, device="cuda") for (_, _, n, _, _) in batches[0]] for _ in range(2)]   # two row buffers per shard
+        sizes = [max(n, 1) for (_, _, n, _, _) in batches[0]]
+        for buf in rows:
+            for r, (_, _, n, _, _) in zip(buf, batches[0]):
+                assert r.shape[0] >= n
+        gathered = [torch.empty((sum(n for (_, _, n, _, _) in sh), width), dtype=dtype, device="cuda") for sh in batches]
+        over = torch.zeros(1, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        for b, sh in enumerate(batches):
+            buf = rows[b & 1]
+            if b >= 2:
+                G.gather_wait(gorps)                                           # gather b - 2 read this buffer (b - 1 is waited for with it: one wait per batch)
+            G.extract_batch_multi_device([(g, d.data_ptr(), o.data_ptr(), n, None, r.data_ptr(), over.data_ptr(), None)
+                                          for g, (d, o, n, _, _), r in zip(gorps, sh, buf)], compact=fmt, line_bytes_hint=200, max_line_bytes=200, no_sync=True)
+            G.gather_rows([(g, r.data_ptr(), n, None) for g, (_, _, n, _, _), r in zip(gorps, sh, buf)], width * unit, 0, gathered[b].data_ptr(), no_sync=True)
+        G.gather_wait(gorps)
+        torch.cuda.synchronize()
+        assert int(over.item()) == 0
+        for b, sh in enumerate(batches):
+            got = gathered[b].cpu().numpy()
+            at = 0
+            for (_, _, n, d, o) in sh:
+                if n == 0:
+                    continue
+                om, oc = orc.extract_batch(d, o[:n + 1].astype(np.uint32), nthreads=4)
+                m, c = G.unpack_rows(got[at:at + n].view(np.uint16) if unit == 2 else got[at:at + n])
+                assert np.array_equal(m, om) and np.array_equal(c, oc), (fmt, b)
+                at += n
+            assert at == got.shape[0]
+    # the synchronous form, caller's streams
+    streams = [torch.cuda.Stream() for _ in gorps]
+    sh = batches[0]
+    buf = rows[0]
+    G.extract_batch_multi_device([(g, d.data_ptr(), o.data_ptr(), n, None, r.data_ptr(), over.data_ptr(), st.cuda_stream)
+                                  for g, (d, o, n, _, _), r, st in zip(gorps, sh, buf, streams)], compact=1, line_bytes_hint=200, max_line_bytes=200, no_sync=True)
+    out = torch.zeros_like(gathered[0])
+    G.gather_rows([(g, r.data_ptr(), n, st.cuda_stream) for g, (_, _, n, _, _), r, st in zip(gorps, sh, buf, streams)], width * 2, 0, out.data_ptr())
+    assert torch.equal(out, gathered[0])
