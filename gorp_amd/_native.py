@@ -40,7 +40,7 @@ SYMBOLS = [
     "gx_pack_results", "gx_unpack_results", "gx_unpack_results8", "gx_text_to_jsonl", "gx_capture_one_utf16",
     "gx_match_batch", "gx_state_accepts", "gx_set_device", "gx_handle_device", "gx_extract_batch_multi",
     "gx_host_register", "gx_host_unregister", "gx_split_lines_max", "gx_extract_batch_multi_device",
-    "gx_create_on_devices", "gx_gather_rows", "gx_gather_wait",
+    "gx_create_on_devices", "gx_gather_rows", "gx_gather_wait", "gx_release_scratch",
 ]
 
 
@@ -169,6 +169,8 @@ def lib():
     L.gx_gather_rows.restype = C.c_int
     L.gx_gather_wait.argtypes = [C.POINTER(C.c_void_p), C.c_int32]
     L.gx_gather_wait.restype = C.c_int
+    L.gx_release_scratch.argtypes = [C.c_int]
+    L.gx_release_scratch.restype = C.c_int
     L.gx_host_register.argtypes = [C.c_void_p, C.c_size_t]
     L.gx_host_register.restype = C.c_int
     L.gx_host_unregister.argtypes = [C.c_void_p]

@@ -142,6 +142,8 @@ struct gx_handle {
     uint32_t* d_steal[N_SLOTS] = {};      // per slot, at its first tile launch: [2][GX_STEAL_MAX * GX_STEAL_STRIDE], the tile kernel's workgroup counters (GxBatch::steal)
     uint32_t steal_parity[N_SLOTS] = {};  // the row the slot's next tile-kernel launch draws from
     uint32_t promise_seq[N_SLOTS] = {};   // the sequence number of the slot's last launch under a promise (0: none)
+    uint32_t broken_seen[N_SLOTS] = {};   // the slot's pinned word as the host last saw it: ANY other value is a promise that broke since --
+                                          // whichever of the stream's batches it was, however many have been enqueued behind it
     std::atomic<uint64_t> promises_broken{0};
     // the resident one-line service (gx_service.hip; GX_CREATE_RESIDENT_ONE)
     struct Service {
@@ -156,6 +158,13 @@ struct gx_handle {
         uint64_t launches = 0;
     } svc;
     int32_t* d_pike_scratch = nullptr;    // thread lists of the lanes that run an extraction's program as it is (GxDev::pike_scratch)
+    // ... ONE set of them per handle, a lane's area named by its place in the grid: two per-line kernels of the handle must not run at
+    // once (the host pipeline's four streams, a caller's streams, the one-String calls beside a batch).  Every launch of such a
+    // handle waits for the one before it, on whatever stream that was (PikeGate).
+    std::recursive_mutex pike_mu;
+    hipEvent_t pike_event = nullptr;
+    bool pike_event_set = false;
+    int pike_depth = 0;
     int hop_reason = 4;                   // why capture batches have no hop tables (gx_stat(h, 26); 0: they have)
     hipStream_t multi_stream = nullptr;   // gx_extract_batch_multi_device: the stream of shards that bring none
     hipStream_t gather_stream = nullptr;  // gx_gather_rows: this handle's rows leave for the root's device on it (a copy queue of its own: seven peers, seven links)
@@ -1108,7 +1117,11 @@ SlotUse take_slot(gx_handle* h, GxBatch& b, hipStream_t stream) {
     }
     // a batch of this stream that promised its longest line, ran without a follow-up launch and met a longer line after all
     // (no_sync batches: nobody has looked yet)
-    if (h->promise_seq[slot] != 0 && __atomic_load_n(&h->h_broken[slot], __ATOMIC_RELAXED) == h->promise_seq[slot]) {
+    // (the word holds the sequence number of the LAST launch that broke its promise; until round 4 it was compared with the newest
+    // promise alone, and a kernel that reached its long line after the next batch had been enqueued was never noticed)
+    const uint32_t word = __atomic_load_n(&h->h_broken[slot], __ATOMIC_RELAXED);
+    if (word != h->broken_seen[slot]) {
+        h->broken_seen[slot] = word;
         h->promise_seq[slot] = 0;
         h->promises_broken.fetch_add(1);
         throw GxError(GX_E_ARG, "an earlier no_sync batch on this stream held a line longer than its gx_batch_opts.max_line_bytes: that line was not "
@@ -1140,11 +1153,75 @@ bool plan_followup(gx_handle* h, GxBatch& b, const SlotUse& u, uint32_t fits, La
     h->promise_seq[u.slot] = 0;
     return true;
 }
+// Has a batch of this stream broken its promise since anybody looked?  (For the calls that wait for their batches themselves:
+// the word is final once the stream is idle.)  Marks it seen.
+bool promise_broken_since(gx_handle* h, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(h->slot_mu);
+    int slot = gx_handle::N_SLOTS - 1;
+    for (int q = 0; q < gx_handle::N_SLOTS - 1; ++q)
+        if (h->slot_taken[q] && h->slot_stream[q] == stream) { slot = q; break; }
+    if (!h->h_broken) return false;
+    const uint32_t word = __atomic_load_n(&h->h_broken[slot], __ATOMIC_RELAXED);
+    if (word == h->broken_seen[slot]) return false;
+    h->broken_seen[slot] = word;
+    h->promise_seq[slot] = 0;
+    h->promises_broken.fetch_add(1);
+    return true;
+}
 void done_slot(gx_handle* h, const SlotUse& u, hipStream_t stream) {
     if (u.shared) GX_HIP(hipEventRecord(h->shared_event, stream));
 }
 
+// Stream-ordered memory out of the handle's own pool (gx_handle::pool) for the length of a scope: freed on the stream when the scope
+// ends -- by a return or by an exception (take_slot and plan_followup throw).
+struct PoolBuffer {
+    void* p = nullptr;
+    hipStream_t s;
+    PoolBuffer(gx_handle* h, size_t bytes, hipStream_t stream) : s(stream) {
+        {
+            std::lock_guard<std::mutex> pool_lock(h->slot_mu);   // (device-pointer batches of several threads come here without h->mu)
+            if (!h->pool) {
+                hipMemPoolProps props{};
+                props.allocType = hipMemAllocationTypePinned;
+                props.handleTypes = hipMemHandleTypeNone;
+                props.location.type = hipMemLocationTypeDevice;
+                props.location.id = h->device;
+                GX_HIP(hipMemPoolCreate(&h->pool, &props));
+                uint64_t keep = ~0ull;
+                GX_HIP(hipMemPoolSetAttribute(h->pool, hipMemPoolAttrReleaseThreshold, &keep));
+            }
+        }
+        GX_HIP(hipMallocFromPoolAsync(&p, bytes, h->pool, stream));
+    }
+    ~PoolBuffer() { if (p) (void)hipFreeAsync(p, s); }
+    PoolBuffer(const PoolBuffer&) = delete;
+    PoolBuffer& operator=(const PoolBuffer&) = delete;
+};
+
+// Launches of a handle that runs an extraction's program as it is take their turns across streams: the thread lists are the handle's.
+struct PikeGate {
+    gx_handle* h;
+    hipStream_t s;
+    bool on;
+    PikeGate(gx_handle* h_, hipStream_t s_) : h(h_), s(s_), on(h_->T.has_pike()) {
+        if (!on) return;
+        h->pike_mu.lock();
+        if (h->pike_depth++ == 0 && h->pike_event_set) (void)hipStreamWaitEvent(s, h->pike_event, 0);
+    }
+    ~PikeGate() {
+        if (!on) return;
+        if (--h->pike_depth == 0) {
+            if (!h->pike_event) (void)hipEventCreateWithFlags(&h->pike_event, hipEventDisableTiming);
+            if (h->pike_event && hipEventRecord(h->pike_event, s) == hipSuccess) h->pike_event_set = true;
+        }
+        h->pike_mu.unlock();
+    }
+    PikeGate(const PikeGate&) = delete;
+    PikeGate& operator=(const PikeGate&) = delete;
+};
+
 void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t kernel, hipStream_t stream, bool uneven = false, Launched* launched = nullptr) {
+    PikeGate pike_gate(h, stream);
     GxLds L;
     if (b.wide && !b.state_out && b.match_only >= 0 && b.n > 0 && line_bytes_hint <= 255u && !uneven &&
         (kernel == GX_KERNEL_AUTO || kernel == GX_KERNEL_TILES || kernel == GX_KERNEL_HOPS)) {
@@ -1159,21 +1236,8 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
                           : (kernel != GX_KERNEL_HOPS && h->tile_ok && !h->tile_global && image_tier == 0 && plan_tile_launch(h, line_bytes_hint, &L, mo, true));
         if (direct && hop && !mo && !(h->lds_hop.u_start != 0xFFFFFFFFu)) direct = false;
         if (direct) {
-            {
-              std::lock_guard<std::mutex> pool_lock(h->slot_mu);
-              if (!h->pool) {
-                hipMemPoolProps props{};
-                props.allocType = hipMemAllocationTypePinned;
-                props.handleTypes = hipMemHandleTypeNone;
-                props.location.type = hipMemLocationTypeDevice;
-                props.location.id = h->device;
-                GX_HIP(hipMemPoolCreate(&h->pool, &props));
-                uint64_t keep = ~0ull;
-                GX_HIP(hipMemPoolSetAttribute(h->pool, hipMemPoolAttrReleaseThreshold, &keep));
-              }
-            }
-            void* flags = nullptr;
-            GX_HIP(hipMallocFromPoolAsync(&flags, b.n + 64, h->pool, stream));
+            PoolBuffer flags_buf(h, b.n + 64, stream);   // (given back to the pool when this scope ends, whatever ends it)
+            void* flags = flags_buf.p;
             hipError_t e = hipSuccess;
             {
                 std::lock_guard<std::mutex> lock(h->slot_mu);
@@ -1193,7 +1257,6 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
                 if (e == hipSuccess && followup) e = launch_extract_oversize(h->dev, b, L.stage_bytes, 0, stream);
                 if (e == hipSuccess) done_slot(h, u, stream);
             }
-            (void)hipFreeAsync(flags, stream);
             GX_HIP(e);
             return;
         }
@@ -1204,21 +1267,8 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
         // units and stages their low bytes) and flags the lines that hold a unit above 0xFF, as the tile kernel above.
         const bool mo = b.match_only != 0 || !h->T.has_capture;
         if ((mo ? h->hop_mo_ok : h->hop_ok) && plan_hop_slice_launch(h, &L, mo)) {
-            {
-              std::lock_guard<std::mutex> pool_lock(h->slot_mu);
-              if (!h->pool) {
-                hipMemPoolProps props{};
-                props.allocType = hipMemAllocationTypePinned;
-                props.handleTypes = hipMemHandleTypeNone;
-                props.location.type = hipMemLocationTypeDevice;
-                props.location.id = h->device;
-                GX_HIP(hipMemPoolCreate(&h->pool, &props));
-                uint64_t keep = ~0ull;
-                GX_HIP(hipMemPoolSetAttribute(h->pool, hipMemPoolAttrReleaseThreshold, &keep));
-              }
-            }
-            void* flags = nullptr;
-            GX_HIP(hipMallocFromPoolAsync(&flags, b.n + 64, h->pool, stream));
+            PoolBuffer flags_buf(h, b.n + 64, stream);   // (given back to the pool when this scope ends, whatever ends it)
+            void* flags = flags_buf.p;
             hipError_t e = hipSuccess;
             {
                 std::lock_guard<std::mutex> lock(h->slot_mu);
@@ -1239,7 +1289,6 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
                 if (e == hipSuccess && followup) e = launch_extract_oversize(h->dev, b, 65535u, 1, stream);
                 if (e == hipSuccess) done_slot(h, u, stream);
             }
-            (void)hipFreeAsync(flags, stream);
             GX_HIP(e);
             return;
         }
@@ -1249,28 +1298,18 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
         // the per-line walk (gx_kernels.hip: k_narrow_units).  The copy is n units long -- the one thing this path has to
         // know on the host, so it reads the two ends of the offsets (a small synchronous copy) -- and lives in
         // stream-ordered memory for the length of the call.
+        if (b.caller_no_sync)
+            throw GxError(GX_E_ARG, "gx_batch_opts.utf16 with no_sync: this batch would take the narrowed copy of its code units (tables other than dense rows "
+                                    "in LDS or hop tables, or a kernel named in gx_batch_opts.kernel), which is sized by a read of the offsets on the host; "
+                                    "call it without no_sync");
         const size_t off_w = b.offsets64 ? 8 : 4;
         uint64_t first = 0, last = 0;
         GX_HIP(hipMemcpyAsync(&first, b.offsets, off_w, hipMemcpyDeviceToHost, stream));
         GX_HIP(hipMemcpyAsync(&last, static_cast<const uint8_t*>(b.offsets) + b.n * off_w, off_w, hipMemcpyDeviceToHost, stream));
         GX_HIP(hipStreamSynchronize(stream));
         const uint64_t units = last >= first ? last - first : 0;
-        void* tmp = nullptr;
-        {
-          std::lock_guard<std::mutex> pool_lock(h->slot_mu);   // (device-pointer batches of several threads come here without h->mu)
-          if (!h->pool) {
-            hipMemPoolProps props{};
-            props.allocType = hipMemAllocationTypePinned;
-            props.handleTypes = hipMemHandleTypeNone;
-            props.location.type = hipMemLocationTypeDevice;
-            props.location.id = h->device;
-            GX_HIP(hipMemPoolCreate(&h->pool, &props));
-            uint64_t keep = ~0ull;
-            GX_HIP(hipMemPoolSetAttribute(h->pool, hipMemPoolAttrReleaseThreshold, &keep));
-          }
-        }
-        GX_HIP(hipMallocFromPoolAsync(&tmp, units + b.n + 64, h->pool, stream));
-        uint8_t* bytes = static_cast<uint8_t*>(tmp);
+        PoolBuffer tmp_buf(h, units + b.n + 64, stream);
+        uint8_t* bytes = static_cast<uint8_t*>(tmp_buf.p);
         uint8_t* flags = bytes + ((units + 15) & ~15ull);
         hipError_t e = launch_narrow_units(b, bytes, flags, stream);
         if (e == hipSuccess) {
@@ -1278,11 +1317,9 @@ void launch_batch(gx_handle* h, GxBatch b, uint32_t line_bytes_hint, uint32_t ke
             nb.wide = 0;
             nb.max_line_bytes = 0;     // (the copy does not outlive this call: its follow-up launch always runs)
             nb.data = bytes - first;   // (addressed like the units: line i at data + offsets[i])
-            try { launch_batch(h, nb, line_bytes_hint, kernel, stream, uneven, launched); }
-            catch (...) { (void)hipFreeAsync(tmp, stream); throw; }
+            launch_batch(h, nb, line_bytes_hint, kernel, stream, uneven, launched);
             e = launch_extract_flagged(h->dev, b, flags, stream);
         }
-        (void)hipFreeAsync(tmp, stream);
         GX_HIP(e);
         return;
     }
@@ -1433,12 +1470,18 @@ struct DevBuf {
 
 // gx_split_lines has no handle to keep its workspace on (an eighth of the text since the text-read-once split: a hipMalloc + hipFree
 // of 250 MB per call were 0.1 ms of a 0.7 ms call): one workspace per device, kept between calls, grown as needed; a call holds the
-// lock while it runs (calls on one device take turns: they would on the device anyway).
+// lock OF ITS DEVICE while it runs (calls on one device take turns: they would on the device anyway; calls on different devices -- one
+// process, eight GPUs -- do not wait for each other).  gx_release_scratch(device) gives a device's workspace back.
 struct SplitScratch {
-    std::mutex mu;
+    std::mutex mu[64];
     void* p[64] = {};
     size_t cap[64] = {};
-    void* get(int dev, size_t bytes) {   // (the caller holds mu)
+    void release(int dev) {
+        if (dev < 0 || dev >= 64) return;
+        std::lock_guard<std::mutex> lock(mu[dev]);
+        if (p[dev]) { (void)hipFree(p[dev]); p[dev] = nullptr; cap[dev] = 0; }
+    }
+    void* get(int dev, size_t bytes) {   // (the caller holds mu[dev])
         if (dev < 0 || dev >= 64) throw GxError(GX_E_DEVICE, "gx_split_lines: device ordinal beyond 63");
         if (cap[dev] < bytes) {
             if (p[dev]) { (void)hipFree(p[dev]); p[dev] = nullptr; cap[dev] = 0; }
@@ -1467,6 +1510,15 @@ void* handle_scratch(gx_handle* h, int which, size_t bytes) {
 extern "C" {
 
 const char* gx_last_error(void) { return g_last_error.c_str(); }
+
+int gx_release_scratch(int device) {
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(device) != hipSuccess) return fail(GX_E_DEVICE, "gx_release_scratch: no such device");
+    g_split_scratch.release(device);
+    (void)hipSetDevice(prev);
+    return GX_OK;
+}
 
 int gx_device_count(void) {
     int count = 0;
@@ -1547,6 +1599,7 @@ void gx_destroy(gx_handle* h) {
     if (h->gather_stream) (void)hipStreamDestroy(h->gather_stream);
     if (h->gather_event) (void)hipEventDestroy(h->gather_event);
     if (h->d_pike_scratch) (void)hipFree(h->d_pike_scratch);
+    if (h->pike_event) (void)hipEventDestroy(h->pike_event);
     if (h->one_dev) (void)hipFree(h->one_dev);
     if (h->one_host) (void)hipHostFree(h->one_host);
     delete h;
@@ -1626,7 +1679,8 @@ int gx_split_lines_max(const uint8_t* bytes, uint64_t size, void* offsets, uint6
         DevBuf d_bytes, d_off, d_flags;
         int dev = 0;
         GX_HIP(hipGetDevice(&dev));
-        std::lock_guard<std::mutex> ws_lock(g_split_scratch.mu);
+        if (dev < 0 || dev >= 64) return fail(GX_E_DEVICE, "gx_split_lines: device ordinal beyond 63");
+        std::lock_guard<std::mutex> ws_lock(g_split_scratch.mu[dev]);
         struct { void* p; } ws{g_split_scratch.get(dev, split_workspace_bytes(size, line_flags != nullptr))};
         const uint8_t* src = bytes;
         void* dst_off = offsets;
@@ -1868,6 +1922,8 @@ int gx_text_to_jsonl(gx_handle* h, const uint8_t* text, uint64_t size, const cha
         GX_HIP(hipMemcpyAsync(&total, loff + n, 8, hipMemcpyDeviceToHost, stream));
         GX_HIP(hipMemcpyAsync(counts, d_counts, 16, hipMemcpyDeviceToHost, stream));
         GX_HIP(hipStreamSynchronize(stream));
+        // (the extraction ran on the split pass's own longest line; a kernel that met a longer one after all left rows unwritten)
+        if (promise_broken_since(h, stream)) throw GxError(GX_E_ARG, "internal: gx_text_to_jsonl: a line longer than the split pass reported");
         *out_size = total;
         if (n_lines) *n_lines = n;
         if (n_matched) *n_matched = counts[0];
@@ -2150,6 +2206,7 @@ static int extract_batch_impl(gx_handle* h, const uint8_t* bytes, const void* of
                 }
             }
             b.max_line_bytes = o.max_line_bytes;
+            b.caller_no_sync = o.no_sync ? 1u : 0u;
             Launched done;
             launch_batch(h, b, hint, o.kernel, stream, uneven, &done);
             if (!o.no_sync) {
@@ -2159,10 +2216,12 @@ static int extract_batch_impl(gx_handle* h, const uint8_t* bytes, const void* of
                     {
                         std::lock_guard<std::mutex> lock(h->slot_mu);
                         if (h->promise_seq[done.slot] == done.seq) h->promise_seq[done.slot] = 0;
+                        h->broken_seen[done.slot] = done.seq;   // (seen, and put right below)
                     }
                     h->promises_broken.fetch_add(1);
                     b.seq = done.seq;
                     b.oversize_flag = h->d_broken + done.slot;
+                    PikeGate pike_gate(h, stream);
                     GX_HIP(launch_extract_oversize(h->dev, b, done.limit, done.by_length, stream));
                     GX_HIP(hipStreamSynchronize(stream));
                 }
@@ -2314,6 +2373,20 @@ int gx_extract_batch_multi_device(const gx_device_shard* shards, int32_t n_shard
             if (!used[k]) continue;
             if (hipSetDevice(shards[k].handle->device) != hipSuccess || hipStreamSynchronize(used[k]) != hipSuccess) {
                 if (first_rc == GX_OK) { first_rc = GX_E_DEVICE; first_msg = "gx_extract_batch_multi_device: a shard's stream failed"; }
+                continue;
+            }
+            // a shard whose max_line_bytes promise did not hold (its kernel left the longer lines' rows unwritten): the shard again,
+            // without the promise -- this call waits for its batches, so its results are right when it returns
+            if (o.max_line_bytes != 0 && shards[k].n && promise_broken_since(shards[k].handle, used[k])) {
+                gx_batch_opts ok = o;
+                ok.struct_size = sizeof(gx_batch_opts);
+                ok.device_pointers = 1;
+                ok.no_sync = 0;
+                ok.max_line_bytes = 0;
+                ok.stream = used[k];
+                ok.overflow = nullptr;   // (the first run has counted)
+                const int rc = gx_extract_batch(shards[k].handle, shards[k].bytes, shards[k].offsets, shards[k].n, shards[k].match_id, shards[k].caps, &ok);
+                if (rc != GX_OK && first_rc == GX_OK) { first_rc = rc; first_msg = gx_last_error(); }
             }
         }
     }
@@ -2543,6 +2616,7 @@ static int one_line(gx_handle* h, const uint16_t* s, int32_t len, int32_t* match
             b.match_only = mode < 0 ? mode : ((mode == 1 || !h->T.has_capture) ? 1 : 0);
             int32_t* out = reinterpret_cast<int32_t*>(hb + in_bytes);
             b.match_id = out; b.state_out = out + 1; b.caps = b.match_only == 1 ? nullptr : out + 2;
+            PikeGate pike_gate(h, nullptr);
             GX_HIP(launch_extract_one(h->dev, reinterpret_cast<const uint16_t*>(hb + 8), static_cast<uint32_t>(len), b, nullptr));
             GX_HIP(hipStreamSynchronize(nullptr));
             const int32_t* host = out;
@@ -2558,6 +2632,7 @@ static int one_line(gx_handle* h, const uint16_t* s, int32_t len, int32_t* match
         b.match_only = mode < 0 ? mode : ((mode == 1 || !h->T.has_capture) ? 1 : 0);
         int32_t* out = reinterpret_cast<int32_t*>(db + in_bytes);
         b.match_id = out; b.state_out = out + 1; b.caps = b.match_only == 1 ? nullptr : out + 2;
+        PikeGate pike_gate(h, nullptr);
         GX_HIP(launch_extract_generic(h->dev, b, nullptr));
         const size_t back = (b.match_only == 1 ? 2 : out_words) * 4;
         GX_HIP(hipMemcpyAsync(hb + in_bytes, db + in_bytes, back, hipMemcpyDeviceToHost, nullptr));

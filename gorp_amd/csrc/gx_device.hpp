@@ -134,6 +134,7 @@ struct GxBatch {
     // kernel.  oversize_flag then points to a word in pinned HOST memory: a kernel that meets such a line after all says so there.
     uint32_t no_followup;
     uint32_t max_line_bytes;   // the promise itself (0: none)
+    uint32_t caller_no_sync;   // host side only: the caller asked for no synchronisation (gx_batch_opts.no_sync): a path that needs one refuses
     // tile kernel: the workgroups' tile counters, u32[2][GX_STEAL_MAX * GX_STEAL_STRIDE] of the launch's stream slot (every GX_STEAL_STRIDE-th word is a counter).  A launch draws from row
     // steal_parity and zeroes the other row, which the stream's next launch draws from.
     uint32_t* steal;

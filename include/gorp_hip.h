@@ -138,12 +138,15 @@ typedef struct gx_batch_opts {
                                   model) and bytes >= 0x80 leave as two-byte UTF-8; 1: copy them unchanged (the
                                   input was UTF-8 all along and the patterns only look at its ASCII structure) */
     uint32_t utf16;            /* gx_extract_batch only.  1: `bytes` holds UTF-16 code units (uint16_t, host byte order), exactly
-                                  the chars of the Java Strings, and offsets count code units.  The units' low bytes go
-                                  through the byte kernels (a copy pass on the device: 16 bytes in, 8 out per lane) and only
-                                  the lines that hold a unit above 0xFF are walked again, per line, on the code units; the
-                                  call reads the two ends of the offsets (one small synchronous copy) to size the copy.
-                                  (With compact rows, an offset that does not fit is counted once per walk: a line with a
-                                  unit above 0xFF is walked twice.) */
+                                  the chars of the Java Strings, and offsets count code units.  On dense rows in LDS and on
+                                  hop tables (gx_stat(h, 7) == 1 or gx_stat(h, 14) > 0, kernel AUTO) the batch kernels read
+                                  the units themselves: no copy, no synchronisation, no_sync means what it says.  On the
+                                  other tables, or with a kernel named in `kernel`, the units' low bytes go through the byte
+                                  kernels as a narrowed copy, sized by a read of the offsets' two ends ON THE HOST: such a
+                                  batch cannot be no_sync and is refused with GX_E_ARG when it asks for it (round 5; until
+                                  then the flag was silently not honoured there).  Either way only the lines that hold a
+                                  unit above 0xFF are walked again, per line, on the code units.  (With compact rows, an
+                                  offset that does not fit is counted once per walk: such a line is walked twice.) */
     uint32_t kernel;           /* gx_extract_batch only: GX_KERNEL_AUTO (0) or one of the kernels below, for measurements and
                                   tests; results never depend on it.  (New fields are only ever appended: a caller compiled
                                   against an older, shorter layout passes its own struct_size and keeps working.) */
@@ -324,6 +327,9 @@ const char* gx_last_error(void);
  * definition, or from one blob (gx_create_from_blob) -- and either its own threads, each calling gx_extract_batch on
  * its handle (Gorp "may be used concurrently", core/Gorp.java:22), or gx_extract_batch_multi below. */
 int gx_device_count(void);
+/* gx_split_lines / gx_split_lines_max keep one workspace per device between calls (an eighth of the largest text they have seen
+ * there, a quarter with line flags); this gives a device's back.  Calls on different devices do not wait for each other. */
+int gx_release_scratch(int device);
 int gx_set_device(int device);
 int gx_handle_device(const gx_handle* h);   /* -1 for a host-only handle */
 

@@ -108,3 +108,15 @@ def test_extract_from_raw_text(tier, monkeypatch):
     kd, ko = lines_to_csr(kept)
     omid2, ocaps2 = orc.extract_batch(kd, ko, nthreads=8)
     assert np.array_equal(mid2, omid2) and np.array_equal(caps2, ocaps2)
+
+
+@pytest.mark.gpu
+def test_split_workspace_can_be_given_back():
+    """gx_release_scratch(device): the per-device workspace of gx_split_lines is freed and comes back with the next call."""
+    from gorp_amd import _native as N
+    raw = b"a\nbb\r\nccc\rdddd"
+    off, _ = split_lines(raw)
+    assert N.lib().gx_release_scratch(0) == 0
+    off2, _ = split_lines(raw)
+    assert np.array_equal(off, off2) and list(off) == [0, 2, 6, 10, 14]
+    assert N.lib().gx_release_scratch(99) != 0

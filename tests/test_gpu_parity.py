@@ -1347,6 +1347,31 @@ def test_max_line_bytes_promise(flags, kernel):
     assert gorp.stat(24) == 2
     mid, caps = run(0, False)     # (reported once)
     assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+    # pipelined (round 5): the batch that breaks its promise, then two more before anybody waits -- whichever of them (or the first
+    # call after the wait) is the first to see the word reports it, once; until round 4 the second batch's own promise hid it
+    raised = 0
+    bufs = [(torch.full((n,), -7, dtype=torch.int32, device="cuda"), torch.full((n, 8), -7, dtype=torch.int32, device="cuda")) for _ in range(3)]
+    for q, promise in enumerate((200, len(long_line), len(long_line))):
+        try:
+            gorp.extract_batch_device(d.data_ptr(), o.data_ptr(), n, bufs[q][0].data_ptr(), bufs[q][1].data_ptr(), stream=st, line_bytes_hint=200,
+                                      kernel=kernel, max_line_bytes=promise, no_sync=True)
+        except G.GorpError as e:
+            assert "max_line_bytes" in str(e)
+            raised += 1
+    torch.cuda.synchronize()
+    if raised == 0:
+        with pytest.raises(G.GorpError, match="max_line_bytes"):
+            run(0, False)
+        raised = 1
+    assert raised == 1 and gorp.stat(24) == 3
+    mid, caps = run(0, False)
+    assert np.array_equal(mid, omid) and np.array_equal(caps, ocaps)
+    # gx_extract_batch_multi_device waits for its shards itself: a shard whose promise did not hold is made good before it returns
+    mid_t = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    caps_t = torch.full((n, 8), -7, dtype=torch.int32, device="cuda")
+    if kernel == N.GX_KERNEL_AUTO:
+        G.extract_batch_multi_device([(gorp, d.data_ptr(), o.data_ptr(), n, mid_t.data_ptr(), caps_t.data_ptr(), None, None)], line_bytes_hint=200, max_line_bytes=200)
+        assert np.array_equal(mid_t.cpu().numpy(), omid) and np.array_equal(caps_t.cpu().numpy(), ocaps) and gorp.stat(24) == 4
 
 
 def test_launches_of_many_streams_share_a_handle():
@@ -1474,6 +1499,28 @@ def test_extractions_run_as_programs_on_the_device():
         # CookedExtraction.match: the capture regexp alone
         cooked = gorp.getExtractions()[1]
         assert cooked.match(lines[0]) is not None or orc.extract(lines[0])[0] != 1
+        if n_fields == 14:
+            # a host batch of several chunks (the host pipeline: four worker threads, each with a stream of its own) and device batches
+            # on several streams at once: the handle has ONE set of thread lists, so its per-line launches take their turns (PikeGate)
+            import torch
+            dd, oo = lines_to_csr(lines)
+            om, oc = orc.extract_batch(dd, oo, nthreads=8)
+            reps = 40 * 1024 * 1024 // len(dd) + 1
+            big_d = np.tile(dd, reps)
+            big_o = np.concatenate([[0], np.cumsum(np.tile(np.diff(oo.astype(np.int64)), reps))]).astype(np.uint32)
+            m, c = gorp.extract_batch(big_d, big_o)
+            assert np.array_equal(m, np.tile(om, reps)) and np.array_equal(c, np.tile(oc, (reps, 1)))
+            n = len(lines)
+            dev_d, dev_o = torch.from_numpy(dd.copy()).cuda(), torch.from_numpy(oo.astype(np.uint32)).cuda()
+            streams = [torch.cuda.Stream() for _ in range(6)]
+            outs = [(torch.full((n,), -9, dtype=torch.int32, device="cuda"), torch.full((n, 2 * gorp.max_groups), -9, dtype=torch.int32, device="cuda")) for _ in streams]
+            torch.cuda.synchronize()
+            for rep in range(3):
+                for st, (mid_t, caps_t) in zip(streams, outs):
+                    gorp.extract_batch_device(dev_d.data_ptr(), dev_o.data_ptr(), n, mid_t.data_ptr(), caps_t.data_ptr(), stream=st.cuda_stream, no_sync=True)
+            torch.cuda.synchronize()
+            for mid_t, caps_t in outs:
+                assert np.array_equal(mid_t.cpu().numpy(), om) and np.array_equal(caps_t.cpu().numpy(), oc)
 
 
 def test_resident_one_line_service():
@@ -1763,3 +1810,43 @@ def test_tables_on_devices_and_rows_gathered():
     out = torch.zeros_like(gathered[0])
     G.gather_rows([(g, r.data_ptr(), n, st.cuda_stream) for g, (_, _, n, _, _), r, st in zip(gorps, sh, buf, streams)], width * 2, 0, out.data_ptr())
     assert torch.equal(out, gathered[0])
+
+
+@pytest.mark.gpu
+def test_utf16_no_sync_is_honoured_or_refused():
+    """gx_batch_opts.utf16 with no_sync (round 5): where the batch kernels read the code units themselves -- dense rows in LDS, hop
+    tables -- forty streams of such batches run with no synchronisation by the library (the caller's wait is the only one: every
+    buffer still holds its fill until then is not observable, so the check is results + no refusal); where the batch would take the
+    narrowed copy, which reads the offsets on the host, the call is refused with GX_E_ARG instead of synchronising silently."""
+    import torch
+    definition = W.readme3_definition()
+    lines = ["[123456789]: %s 5ms /%s" % (v, "x" * k) for k, v in zip(range(1, 120), ["GET", "PUT", "HEAD"] * 40)]
+    lines[7] = lines[7] + "\u4e2d"
+    units = [np.frombuffer(s.encode("utf-16-le"), dtype=np.uint16) for s in lines]
+    data = np.concatenate(units)
+    offsets = np.zeros(len(lines) + 1, np.uint32)
+    offsets[1:] = np.cumsum([len(u) for u in units])
+    orc = oracle_for(definition)
+    want = [orc.extract(s) for s in lines]
+    wm = np.array([w[0] for w in want], np.int32)
+    d, o = torch.from_numpy(data.view(np.int16)).cuda(), torch.from_numpy(offsets).cuda()
+    n = len(lines)
+    for flags, ok in ((0, True), (N.GX_CREATE_TIER_HOP, True), (N.GX_CREATE_TIER_L2, False), (N.GX_CREATE_TIER_RECORDS, False)):
+        gorp = Gorp.construct(definition, flags=flags)
+        streams = [torch.cuda.Stream() for _ in range(40 if ok else 1)]
+        outs = [(torch.full((n,), -7, dtype=torch.int32, device="cuda"), torch.full((n, 8), -7, dtype=torch.int32, device="cuda")) for _ in streams]
+        torch.cuda.synchronize()
+        if not ok:
+            with pytest.raises(G.GorpError, match="no_sync"):
+                gorp.extract_batch_device(d.data_ptr(), o.data_ptr(), n, outs[0][0].data_ptr(), outs[0][1].data_ptr(), stream=streams[0].cuda_stream,
+                                          no_sync=True, utf16=True, line_bytes_hint=100)
+            gorp.extract_batch_device(d.data_ptr(), o.data_ptr(), n, outs[0][0].data_ptr(), outs[0][1].data_ptr(), stream=streams[0].cuda_stream,
+                                      utf16=True, line_bytes_hint=100)      # (without no_sync: the copy path, as before)
+            torch.cuda.synchronize()
+            assert np.array_equal(outs[0][0].cpu().numpy(), wm)
+            continue
+        for st, (m, c) in zip(streams, outs):
+            gorp.extract_batch_device(d.data_ptr(), o.data_ptr(), n, m.data_ptr(), c.data_ptr(), stream=st.cuda_stream, no_sync=True, utf16=True, line_bytes_hint=100)
+        torch.cuda.synchronize()
+        for m, c in outs:
+            assert np.array_equal(m.cpu().numpy(), wm)
