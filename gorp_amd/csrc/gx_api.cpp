@@ -1514,7 +1514,10 @@ const char* gx_last_error(void) { return g_last_error.c_str(); }
 int gx_release_scratch(int device) {
     int prev = 0;
     (void)hipGetDevice(&prev);
-    if (hipSetDevice(device) != hipSuccess) return fail(GX_E_DEVICE, "gx_release_scratch: no such device");
+    if (hipSetDevice(device) != hipSuccess) {
+        (void)hipGetLastError();   // (the runtime keeps the error for the next hipGetLastError(): a later launch's check would see it)
+        return fail(GX_E_DEVICE, "gx_release_scratch: no such device");
+    }
     g_split_scratch.release(device);
     (void)hipSetDevice(prev);
     return GX_OK;
