@@ -2,6 +2,7 @@
 oracle: the tables are decoded from the blob and walked by tests/blob_interp.py
 (the kernel contract), so these tests need no GPU.  The -m gpu tests repeat the
 comparisons through the real kernels."""
+import os
 import random
 
 import numpy as np
@@ -9,7 +10,7 @@ import pytest
 
 from blob_interp import Blob, units_of
 from gorp_amd import _native as N
-from gorp_amd.gorp import DefinitionParseException, FlattenedExtraction, Gorp, PolyMatcher, RegexHelper
+from gorp_amd.gorp import DefinitionParseException, FlattenedExtraction, Gorp, GorpError, PolyMatcher, RegexHelper
 from oracle import oracle as O
 
 
@@ -236,16 +237,75 @@ def sample_from_match_automaton(b, rng, max_len=24):
     return bytes(out).decode("latin-1")
 
 
+# What the library refuses although java.util.regex would compile it: the names gx_regex.cpp gives those constructs.  INTEGRATION.md
+# section 3a is the record for a caller; test_refusal_record_is_what_the_library_refuses keeps the three in step.
+REFUSED_CONSTRUCTS = (
+    "a quantifier applied to a quantifier",
+    "possessive quantifier",
+    "a repeated capturing group that can match the empty string",
+    "\\x{...}",
+    "escape \\",
+    "special group (?...)",
+    "anchor '^'",
+    "anchor '$'",
+    "nested character class",
+    "character class intersection",
+)
+
+
+def construct_both(make_product, make_oracle, tally):
+    """The product and the oracle built SEPARATELY from one definition: (product, oracle), or None when either refuses.  A refusal
+    by one side alone must not vanish (core/jdkre/JDKRegexpExtractionCooker.java:23 refuses nothing the JDK accepts): the product
+    alone may refuse only with GX_E_UNSUPPORTED_CONSTRUCT naming a construct of the record, or GX_E_LIMIT; both kinds are counted."""
+    p_err = o_err = None
+    prod = orc = None
+    try:
+        prod = make_product()
+    except ValueError:     # RegexHelper's own errors (IllegalArgumentException in the reference, which throws there too): before either side
+        tally["front_end"] = tally.get("front_end", 0) + 1
+        return None
+    except GorpError as e:  # (DefinitionParseException is one: gx_create_* refused the regexps)
+        p_err = e
+    try:
+        orc = make_oracle()
+    except O.OracleError as e:
+        o_err = e
+    if p_err is None and o_err is None:
+        return prod, orc
+    if p_err is not None and o_err is not None:
+        tally["both_refuse"] = tally.get("both_refuse", 0) + 1
+        return None
+    if p_err is not None:
+        assert p_err.code in (N.GX_E_UNSUPPORTED_CONSTRUCT, N.GX_E_LIMIT), (p_err.code, str(p_err))
+        if p_err.code == N.GX_E_UNSUPPORTED_CONSTRUCT:
+            assert any(name in str(p_err) for name in REFUSED_CONSTRUCTS), str(p_err)
+        tally["product_only"] = tally.get("product_only", 0) + 1
+        tally.setdefault("product_only_messages", []).append(str(p_err))
+    else:
+        tally["oracle_only"] = tally.get("oracle_only", 0) + 1
+        tally.setdefault("oracle_only_messages", []).append(str(o_err))
+    return None
+
+
 def test_random_definitions_match_and_extract():
     """Whole-path differential: random flattened extractions (1-4 per definition)."""
     rng = random.Random(1234)
     n_defs = n_lines = n_hits = n_exc = 0
+    tally = {}
     while n_defs < 600:
         exts = [{"name": "e%d" % i, "pieces": gen_pieces(rng)} for i in range(rng.randint(1, 4))]
-        try:
-            b, orc = both(exts)
-        except (ValueError, O.OracleError, DefinitionParseException):
+        fl = [FlattenedExtraction(e["name"], e["pieces"], e.get("append")) for e in exts]
+
+        def regexes():
+            built = [f.build() for f in fl]
+            for e, b in zip(exts, built):     # the product's RegexHelper must agree with the oracle's restatement of it
+                assert O.build_regex_strings(e["pieces"]) == b
+            return [b[0] for b in built], [b[1] for b in built]
+
+        pair = construct_both(lambda: product_blob(*regexes()), lambda: O.OracleGorp(*regexes()), tally)
+        if pair is None:
             continue
+        b, orc = pair
         n_defs += 1
         lines = [gen_line(rng) for _ in range(10)] + [sample_from_match_automaton(b, rng) for _ in range(20)]
         for ln in lines:
@@ -258,6 +318,53 @@ def test_random_definitions_match_and_extract():
             n_exc += got[0] <= -2
     assert n_lines == 600 * 30
     assert n_hits > 3000
+    # no definition of this generator's grammar is refused by one side alone (a silent refusal would show here)
+    print("refusals:", {k: v for k, v in tally.items() if not k.endswith("_messages")})
+    assert tally.get("product_only", 0) == 0, tally.get("product_only_messages")
+    assert tally.get("oracle_only", 0) == 0, tally.get("oracle_only_messages")
+
+
+def test_refusal_record_is_what_the_library_refuses():
+    """The constructs the library refuses where java.util.regex compiles: (1) each of them IS refused, by name, with
+    GX_E_UNSUPPORTED_CONSTRUCT (and by the oracle too, so the differentials never see them); (2) the names are exactly the strings
+    gx_regex.cpp passes to unsupported(); (3) INTEGRATION.md section 3a lists exactly these names."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    samples = {
+        "a quantifier applied to a quantifier": "x{2}{3}",
+        "possessive quantifier": "a*+b",
+        "a repeated capturing group that can match the empty string": "(a*)*b",
+        "\\x{...}": "\\x{41}",
+        "escape \\": "a\\bc",
+        "special group (?...)": "(?=a)b",
+        "anchor '^'": "^ab",
+        "anchor '$'": "ab$",
+        "nested character class": "[a[bc]]",
+        "character class intersection": "[a-z&&b]",
+    }
+    assert set(samples) == set(REFUSED_CONSTRUCTS)
+    for name, rx in samples.items():
+        with pytest.raises(GorpError) as ei:
+            product_blob(["ab"], [rx])
+        assert ei.value.code == N.GX_E_UNSUPPORTED_CONSTRUCT and name in str(ei.value), (name, str(ei.value))
+        if name.startswith("anchor"):
+            # the ONE-SIDED refusal of the record: the oracle restates java.util.regex's anchors (no MULTILINE: '^' at the start of
+            # the input, '$' at its end or before a final line terminator), the product refuses them -- a definition that uses one is
+            # turned away by gx_create_*, loudly, and is outside every differential
+            O.OracleGorp(["ab"], [rx])
+        else:
+            with pytest.raises(O.OracleError):
+                O.OracleGorp(["ab"], [rx])
+    src = open(os.path.join(root, "gorp_amd", "csrc", "gx_regex.cpp"), encoding="utf-8").read()
+    in_source = set()
+    for m in re.finditer(r'unsupported\((?:std::string\()?"((?:[^"\\]|\\.)*)"', src):
+        in_source.add(m.group(1).encode("ascii").decode("unicode_escape"))
+    in_source.discard("")
+    assert in_source == set(REFUSED_CONSTRUCTS), in_source
+    text = open(os.path.join(root, "INTEGRATION.md"), encoding="utf-8").read()
+    block = text.split("<!-- refused-constructs:begin -->")[1].split("<!-- refused-constructs:end -->")[0]
+    recorded = set(re.findall(r"^\s*\* `([^`]+)`", block, flags=re.M))
+    assert recorded == set(REFUSED_CONSTRUCTS), recorded
 
 
 def _sample_accepted(rng, rx, tries=40):
