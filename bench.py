@@ -374,6 +374,8 @@ def main():
 
     def all_ranks_ok(ok, what):
         """A parity failure on ANY rank ends every rank with a non-zero exit code (the launcher's, and so the parent's)."""
+        if os.environ.get("GORP_BENCH_FAIL_RANK") == str(rank):   # (tests/: the exit code of a run in which one rank's check fails)
+            ok = False
         okt = torch.tensor([1 if ok else 0], device=dev)
         if distributed:
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)

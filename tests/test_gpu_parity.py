@@ -739,11 +739,15 @@ def test_two_ranks_share_one_gpu():
     assert r.returncode == 0 and "dist_gpu_worker ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
-def test_bench_two_ranks_self_launched():
-    """`python bench.py --gpus 2` with no launcher, as the driver spells the scaling runs: the parent starts the ranks as
-    fresh child processes and relays rank 0's line.  Both ranks share the one GPU of the box, so the process group is gloo
+@pytest.mark.parametrize("ranks,lines", [(2, 200000), (4, 1000000)])
+def test_bench_ranks_self_launched(ranks, lines):
+    """`python bench.py --gpus N` with no launcher, as the driver spells the scaling runs: the parent starts the ranks as
+    fresh child processes and relays rank 0's line.  The ranks share the one GPU of the box, so the process group is gloo
     (RCCL refuses two ranks on one device); everything else -- blob broadcast, per-rank shards, the timed steps with
-    barriers and max over ranks, the final gathers -- is the N > 1 path, for the metric's workload and for configs[3] beside it."""
+    barriers and max over ranks, the final gathers, the gather overlapped with the next batch's kernel -- is the N > 1 path, for
+    the metric's workload and for configs[3] beside it.  Four ranks at a million lines each is the most this box allows (six
+    processes on the card: this one, the launcher and the ranks; five ranks were killed by the box's guard); the eight-rank run is
+    the driver's, on eight devices."""
     import json
     import os
     import subprocess
@@ -751,18 +755,28 @@ def test_bench_two_ranks_self_launched():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["GORP_BENCH_BACKEND"] = "gloo"
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--lines", "200000", "--steps", "3", "--warmup", "1"],
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--lines", str(lines), "--steps", "3", "--warmup", "1"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
+    out_lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(out_lines) == 1, r.stdout[-2000:]
+    out = json.loads(out_lines[0])
     # the metric's workload (configs[1]) per GPU at every N -- one weak-scaling curve -- and configs[3] measured beside it
-    assert out["n_gpus"] == 2 and out["config"]["baseline_config"] == 2 and out["scaling"] == "weak"
-    assert out["table_bcast_ms"] is not None and out["gather_ms"] is not None and out["value"] > 0
+    assert out["n_gpus"] == ranks and out["config"]["baseline_config"] == 2 and out["scaling"] == "weak"
+    assert out["table_bcast_ms"] is not None and out["gather_ms"] is not None and out["gather_narrow_ms"] is not None and out["gather_dense_ms"] is not None
+    assert out["value"] > 0 and out["collective_world_size"] == ranks and out["collective_backend"] == "gloo"
+    by_rank = out["ms_per_step_by_rank"]
+    assert len(by_rank["all"]) == ranks and 0 < by_rank["min"] <= by_rank["max"] <= out["ms_per_step"] * 1.5
+    assert 0 < out["value_with_overlapped_gather"] <= out["value"] * 1.05 and out["overlapped_gather"]["ms_per_step"] > 0
     c4 = out["configs3_64_extractions"]
     assert c4["baseline_config"] == 4 and c4["value"] > 0 and c4["table_bcast_ms"] is not None and c4["gather_ms"] is not None
     assert "64 syslog-like extractions" in c4["workload"]
+    if ranks == 2:
+        # one rank's parity check fails: every rank leaves, the launcher's exit code -- and the parent's -- is not zero, no line is printed
+        env["GORP_BENCH_FAIL_RANK"] = "1"
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--lines", "100000", "--steps", "2", "--warmup", "1", "--no-gather"],
+                           env=env, capture_output=True, text=True, timeout=900, cwd=root)
+        assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], (r.returncode, r.stdout[-500:])
 
 
 def test_utf16_batch_input():
