@@ -239,6 +239,7 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
             // exact up to its own first offender and only ever too many above it, so the AND over the intervals never calls a byte
             // inside that is not.) ----
             bool exact = stepping && !chained;
+#ifndef GX_HOP_NO_SECOND_CHANCE   // (an experiment's switch: what the second chances cost the text that never needs them)
             // (the chain first: its single bytes matched and its tail byte lies in another interval of the exit's bytes -- a value that
             // begins with a digit or an upper-case letter; the intervals stand in ascending order, so no borrow reaches a byte that is
             // not outside by itself: the test is exact)
@@ -259,6 +260,13 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
             const uint32_t set = h0.x >> 24;
             if (__builtin_amdgcn_ballot_w64(exact && set != 0u) != 0ull) {
                 const u32x2 ls = lds_ld<u32x2>(H.sets + ((exact ? set : 0u) << 3));
+                // (the window again, out of LDS: keeping the run test's four dwords alive down to here cost the loop its registers --
+                // config 3, which never comes here with lower-case text, ran 4 % slower for it)
+                const uint32_t pw = q - n, aw = pw & ~3u, sw = pw & 3u;
+                const u32x2 e01 = lds_pair4(aw), e23 = lds_pair4(aw + 8u);
+                const uint32_t e4 = lds_ld<uint32_t>(aw + 16u);
+                const uint32_t x0 = __builtin_amdgcn_alignbyte(e01.y, e01.x, sw), x1 = __builtin_amdgcn_alignbyte(e23.x, e01.y, sw);
+                const uint32_t x2 = __builtin_amdgcn_alignbyte(e23.y, e23.x, sw), x3 = __builtin_amdgcn_alignbyte(e4, e23.y, sw);
                 uint32_t o0 = HI_BITS, o1 = HI_BITS, o2 = HI_BITS, o3 = HI_BITS;
 #pragma unroll
                 for (uint32_t j = 0; j < 4u; ++j) {
@@ -272,6 +280,7 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
                 nu = min(nu, e - (q - n));
                 if (exact && nu > n) { p = q - n + nu; exact = false; }
             }
+#endif
             if (exact) {
                 // a state without a chain keeps the LDS address / 4 of its dense row's copy in the target field (0: none)
                 exact_step(((h0.x >> 16) & 0xFFu) == 0u ? (h0.y & 0xFFFFu) << 2 : 0u, v0 & 0xFFu, q);

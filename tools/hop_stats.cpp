@@ -40,8 +40,11 @@ int main(int argc, char** argv) {
         size_t cold_small = 0, cold_full = 0, cold_switch = 0, next_is_plus1 = 0, cold_moves = 0, in_block4 = 0; uint32_t block = 0xFFFFFFFFu;
         size_t lines = 0, bytes = 0, iters = 0, chains = 0, exacts = 0, exact_cold = 0, run_full = 0, run_bytes = 0, chain_bytes = 0;
         std::vector<std::vector<uint16_t>> traces;
+        std::vector<std::vector<uint8_t>> kinds;   // per iteration: 0 a run that fills its window / ends the line, 1 chain, 2 exact step, 3 second chance (loop set / tail set)
+        size_t second = 0;
         while (std::getline(f, ln)) {
             traces.emplace_back();
+            kinds.emplace_back();
             std::vector<uint8_t> b(ln.begin(), ln.end());
             b.resize(b.size() + 32, 0);
             const size_t e = ln.size();
@@ -60,7 +63,7 @@ int main(int argc, char** argv) {
                 while (n < 16 && p + n < e && run_k != 0x80u && b[p + n] < 0x80u && b[p + n] >= run_lo && b[p + n] <= 0x7Fu - run_k) ++n;
                 run_bytes += n;
                 const size_t q = p + n;
-                if (n == 16 || q >= e) { p = q; ++run_full; continue; }
+                if (n == 16 || q >= e) { p = q; ++run_full; kinds.back().push_back(0); continue; }
                 struct Moved { uint32_t from; uint32_t* to; size_t *moves, *plus1, *b4; uint32_t nh; ~Moved() { if (from >= nh && *to != from) { ++*moves; if (*to == from + 1) ++*plus1; if (*to > from && *to < from + 4) ++*b4; } } } moved{s_before, &s, &cold_moves, &next_is_plus1, &in_block4, H.small.n_hot};
                 const uint8_t* lits = reinterpret_cast<const uint8_t*>(&r[4]);
                 bool ok = q + klen <= e;
@@ -69,8 +72,26 @@ int main(int argc, char** argv) {
                     const uint32_t tb = b[q + (r[3] & 0xFFu)], lo = (r[3] >> 8) & 0xFFu, span = (r[3] >> 16) & 0xFFu;
                     ok = ok && tb >= lo && tb - lo <= span;
                 }
-                if (ok) { p = q + klen; s = r[1] & 0xFFFFu; ++chains; chain_bytes += klen; }
+                if (ok) { p = q + klen; s = r[1] & 0xFFFFu; ++chains; chain_bytes += klen; kinds.back().push_back(1); }
                 else {
+                    // the second chances (gx_hop_dev.hpp): the chain with its tail byte in another interval of the tail's set; the window
+                    // against the union of the state's loop set
+                    {
+                        const uint8_t* sets = H.full.bytes.data() + H.full.sets_lds;
+                        const uint8_t* ts = sets + 8u * (r[3] >> 24);
+                        bool lits_ok = q + klen <= e;
+                        for (int j = 0; j < 8 && lits_ok; ++j) lits_ok = lits[j] == 0 || b[q + j] == lits[j];
+                        const uint8_t tbyte = b[q + (r[3] & 0xFFu)];
+                        bool in = false;
+                        for (int j = 0; j < 4; ++j) in = in || (ts[4 + j] != 0x80u && tbyte < 0x80u && tbyte >= ts[j] && tbyte <= 0x7Fu - ts[4 + j]);
+                        if (lits_ok && in && (r[3] >> 24) != 0) { p = q + klen; s = r[1] & 0xFFFFu; ++second; kinds.back().push_back(3); continue; }
+                        const uint8_t* ls = sets + 8u * (r[0] >> 24);
+                        size_t nu = 0;
+                        auto in_union = [&](uint8_t x) { for (int j = 0; j < 4; ++j) if (ls[4 + j] != 0x80u && x < 0x80u && x >= ls[j] && x <= 0x7Fu - ls[4 + j]) return true; return false; };
+                        while (nu < 16 && p + nu < e && in_union(b[p + nu])) ++nu;
+                        if (nu > n) { p = p + nu; ++second; kinds.back().push_back(3); continue; }
+                    }
+                    kinds.back().push_back(2);
                     ++by_byte[b[q]];
                     if (klen) ++failed_chain; else ++no_chain;
                     const uint32_t x = rows[static_cast<size_t>(s) * cols + H.full.bytes[b[q]]];
@@ -97,6 +118,18 @@ int main(int argc, char** argv) {
             }
             if (tiles) printf("  tiles of 64 consecutive lines: %.1f iterations until the last lane is through, %.1f per lane on average (lanes busy %.0f %%)\n",
                               double(sum_max) / tiles, double(sum_all) / (64.0 * tiles), 100.0 * sum_all / (64.0 * sum_max));
+            // in how many of a tile's iterations does SOME lane leave the common path (an exact step or a second chance: the wave takes that branch)
+            size_t off_iters = 0;
+            for (size_t t0 = 0; t0 + 64 <= kinds.size(); t0 += 64) {
+                size_t mx = 0;
+                for (size_t q = 0; q < 64; ++q) mx = std::max(mx, kinds[t0 + q].size());
+                for (size_t k = 0; k < mx; ++k) {
+                    bool off = false;
+                    for (size_t q = 0; q < 64 && !off; ++q) off = k < kinds[t0 + q].size() && kinds[t0 + q][k] >= 2;
+                    off_iters += off ? 1 : 0;
+                }
+            }
+            if (tiles) printf("  ... of which %.1f have a lane that takes an exact step or a second chance (%.2f second chances per line)\n", double(off_iters) / tiles, double(second) / lines);
         }
         if (pass == 0) {
             // ---- the hop slice kernel's rounds, replayed: 64 lanes, pieces of 128 bytes from a lane's own position, a lane comes back 24 bytes
