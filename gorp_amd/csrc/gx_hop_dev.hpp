@@ -99,13 +99,18 @@ __device__ __forceinline__ uint32_t run_flags(uint32_t x, uint32_t lo4, uint32_t
 // The record a lane holds while it stays in its state (the !ALL_HOT walk; the hop slice kernel keeps it across its rounds and
 // reads the run interval out of it for the loaders' run test)
 struct HopKept {
+    uint32_t hint = 0u;   // see walk_hop_span's SECOND
 #ifdef GX_DEV
     uint32_t dev_iters = 0u, dev_lane_iters = 0u;   // developer build: iterations of the walk, and lanes that had something to walk in them
 #endif
     uint32_t kept = 0xFFFFFFFFu;
     u32x2 k0 = {0u, 0u}, k1 = {0u, 0u}, k2 = {0u, 0u};
 };
-template <bool ALL_HOT, bool CAPTURE>
+// SECOND: the second chances (loop sets, tail sets) are in the loop.  Without them the walk is the same walk -- a lane takes its exact
+// step -- and only notes in K.hint that a lane took one in a state that HAS a set: the tile kernel then walks its next tile with them
+// (K.hint from such a walk: a second chance applied), and goes back when a tile needed none.  The code of the second chances costs
+// the loop 4 % even where it never runs (config 3, lower-case text: 0.930 against 0.891 ms, one device).
+template <bool ALL_HOT, bool CAPTURE, bool SECOND = true>
 __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, uint32_t e, uint32_t limit, uint32_t e_chain, uint32_t p0,
                                                   uint32_t s, uint32_t dead, uint32_t regs, uint32_t leave_at, HopKept& K) {
     const uint32_t dummy_col = regs - 128u;
@@ -239,7 +244,9 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
             // exact up to its own first offender and only ever too many above it, so the AND over the intervals never calls a byte
             // inside that is not.) ----
             bool exact = stepping && !chained;
-#ifndef GX_HOP_NO_SECOND_CHANCE   // (an experiment's switch: what the second chances cost the text that never needs them)
+            if (!SECOND) {
+                if (__builtin_amdgcn_ballot_w64(exact && ((h0.x | h1.y) >> 24) != 0u) != 0ull) K.hint = 1u;
+            } else {
             // (the chain first: its single bytes matched and its tail byte lies in another interval of the exit's bytes -- a value that
             // begins with a digit or an upper-case letter; the intervals stand in ascending order, so no borrow reaches a byte that is
             // not outside by itself: the test is exact)
@@ -280,7 +287,8 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
                 nu = min(nu, e - (q - n));
                 if (exact && nu > n) { p = q - n + nu; exact = false; }
             }
-#endif
+            if (__builtin_amdgcn_ballot_w64(stepping && !chained && !exact) != 0ull) K.hint = 1u;   // (a second chance applied)
+            }
             if (exact) {
                 // a state without a chain keeps the LDS address / 4 of its dense row's copy in the target field (0: none)
                 exact_step(((h0.x >> 16) & 0xFFu) == 0u ? (h0.y & 0xFFFFu) << 2 : 0u, v0 & 0xFFu, q);
@@ -295,12 +303,15 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
 // The tile kernel's case: the whole line [start, end) is staged.
 template <bool CAPTURE>
 __device__ __forceinline__ uint32_t walk_hop(const HopTab& H, bool all_hot, uint32_t stage, uint32_t s, uint32_t start, uint32_t end, bool on,
-                                             uint32_t dead, uint32_t regs) {
+                                             uint32_t dead, uint32_t regs, bool& second) {
     const uint32_t p0 = stage + start, e = stage + end;
     uint32_t p = on ? p0 : e;
     HopKept K;
-    if (all_hot) return walk_hop_span<true, CAPTURE>(H, p, e, e, e, p0, s, dead, regs, 0u, K);
-    return walk_hop_span<false, CAPTURE>(H, p, e, e, e, p0, s, dead, regs, 0u, K);
+    uint32_t r;
+    if (all_hot) r = second ? walk_hop_span<true, CAPTURE, true>(H, p, e, e, e, p0, s, dead, regs, 0u, K) : walk_hop_span<true, CAPTURE, false>(H, p, e, e, e, p0, s, dead, regs, 0u, K);
+    else r = walk_hop_span<false, CAPTURE, true>(H, p, e, e, e, p0, s, dead, regs, 0u, K);
+    second = K.hint != 0u;   // (wave-uniform: the next tile's mode)
+    return r;
 }
 
 }  // namespace gx

@@ -776,8 +776,13 @@ hipError_t launch_slices_t(const GxDev& dev, const GxLds& lds, const uint8_t* ld
 #define GX_HOP_LEAVE 24u   // (64: a round's walk goes on until every lane has used up its piece)
 #endif
 #ifndef GX_HOP_SERVICE
-#define GX_HOP_SERVICE 44u  // finished lanes write their results and take new lines once that many lanes have nothing to walk
-                            // (round 5, with the loaders' run test: 16 / 24 / 32 / 40 / 48 lanes: 1.219 / 1.170 / 1.125 / 1.072 / 1.068 ms per 3.8 M lines)
+#define GX_HOP_SERVICE 64u  // finished lanes write their results and take new lines once that many lanes have nothing to walk.  64: when
+                            // none has -- a wave takes 64 lines, walks them in rounds until the last is done, writes 64 rows, takes the next
+                            // 64.  Round 4 (no run test by the loaders): 8 / 16 / 24 / 32 idle lanes 0.954 / 0.877 / 0.853 / 0.854 ms per 2 M
+                            // lines.  Round 5, ms per 3.8 M lines: 16 / 24 / 32 / 40 / 48 / 56: 1.219 / 1.170 / 1.125 / 1.072 / 1.068 / 1.060;
+                            // with lines done a round or two earlier (tested kilobytes repeated, behind the walk): 44 / 48 / 52 / 56 / 60 /
+                            // 64: 0.994 / 0.961 / 0.970 / 0.958 / 0.950 / 0.944 -- a service costs ~7 K cycles whatever it serves, and a
+                            // round costs its instructions whatever its lanes do
 #endif
 constexpr uint64_t HOP_POOL_CHUNK = 64;   // lines per draw from the pool (the last quarter of a batch's lines)
 constexpr uint32_t HOP_SLICE = GX_HOP_SLICE_BYTES, HOP_SLICE_ROW = GX_HOP_SLICE_BYTES + 16u, HOP_SLICE_KEEP = 24;
@@ -825,6 +830,12 @@ __device__ __forceinline__ bool chunk_in_run(const u32x4& v, uint32_t runinfo) {
 }
 #ifndef GX_HOP_SPEC
 #define GX_HOP_SPEC 1   // 0: no chunks are tested beyond the piece
+#endif
+#ifndef GX_HOP_SPEC_PASSES
+#define GX_HOP_SPEC_PASSES 3u
+#endif
+#ifndef GX_HOP_SPEC_MIN
+#define GX_HOP_SPEC_MIN 0u   // only lines with more than that many bytes behind their piece have them tested (the others: the next pieces' loaders)
 #endif
 
 
@@ -1048,10 +1059,12 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
         // one such line's chunk of this lane: the line's last chunk, when it is a partial one, is read 16 bytes back from the line's
         // end (what it overlaps lies in the run already -- the chunk before it, or the piece); `high` != 0: not a chunk of the line,
         // or (WIDE) one with a unit above 0xFF -- not in the run either way
-        auto spec_load = [&](const u32x4& d, uint32_t& high) -> u32x4 {
+        // `chunk`: which 16 bytes behind the piece this lane tests (a line of its own: 0 .. 63; a line that shares the instruction with
+        // another: 0 .. 31)
+        auto spec_load = [&](const u32x4& d, uint32_t chunk, bool valid, uint32_t& high) -> u32x4 {
             const uint32_t left2 = d.z;
-            int32_t at = static_cast<int32_t>(lane * 16u);
-            const bool mine = static_cast<uint32_t>(at) < left2;
+            int32_t at = static_cast<int32_t>(chunk * 16u);
+            const bool mine = valid && static_cast<uint32_t>(at) < left2;
             if (static_cast<uint32_t>(at) + 16u > left2) at = static_cast<int32_t>(left2) - 16;
             high = 1u;
             if (!mine) return u32x4{0u, 0u, 0u, 0u};
@@ -1061,21 +1074,6 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
             return load_chunk16<WIDE, false>(src, data_end, 16u, high);   // (inside the line: the window was moved back from its end)
         };
         auto spec_pad = [&](uint32_t j) { return slice + j * HOP_SLICE_ROW + HOP_SLICE; };
-        auto spec_put = [&](uint32_t j) {   // this lane's line as the j-th of its kind
-            const uint8_t* mine = data + ((o0 + pos + HOP_SLICE) << (WIDE ? 1 : 0));
-            const uint64_t mv = reinterpret_cast<uint64_t>(mine);
-            lds_st<u32x4>(spec_pad(j), u32x4{static_cast<uint32_t>(mv), static_cast<uint32_t>(mv >> 32), left_now - HOP_SLICE, runinfo});
-        };
-        auto spec_vote = [&](uint32_t j, const u32x4& d, const u32x4& v, uint32_t high) {
-            const uint64_t bal = __builtin_amdgcn_ballot_w64(high == 0u && chunk_in_run(v, d.w));
-            if (lane == 0u) lds_st<u32x2>(spec_pad(j), u32x2{static_cast<uint32_t>(bal), static_cast<uint32_t>(bal >> 32)});
-        };
-        auto spec_read = [&](uint32_t j) -> uint32_t {   // the bytes behind the piece that lie in the run
-            const u32x2 bits = lds_ld<u32x2>(spec_pad(j));
-            const uint64_t inv = ~(static_cast<uint64_t>(bits.y) << 32 | bits.x);
-            const uint32_t chunks = inv == 0ull ? 64u : static_cast<uint32_t>(__builtin_ctzll(inv));
-            return min(16u * chunks, left_now - HOP_SLICE);
-        };
         // which chunks lie in their line's run (whole chunks inside the line), and -- WIDE -- which lines hold a unit above 0xFF: eight
         // loaders per line and instruction -> one byte of the instruction's ballot per line; the ballots go through the piece buffer's
         // first 128 bytes (read again below, before the pieces are stored)
@@ -1105,43 +1103,11 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
             lds_st<u32x4>(slice + (lane / LPL + LINES_PER_LOAD * r) * HOP_SLICE_ROW + (lane % LPL) * 16u, pv[r]);
         // the bytes of the piece that the run covers: whole leading chunks
         const uint32_t skip = walking ? 16u * static_cast<uint32_t>(__builtin_ctz(~run_bits | 0x100u)) : 0u;
-        uint32_t extra = 0u;
-        const bool longrun = GX_HOP_SPEC && walking && skip == HOP_SLICE && left_now > HOP_SLICE;
-        {   // (four such lines' loads at a time)
-            const bool late = longrun;
-            const uint64_t l_mask = __builtin_amdgcn_ballot_w64(late);
-            if (l_mask != 0ull) {
-                const uint32_t l_m = static_cast<uint32_t>(__builtin_popcountll(l_mask));
-                const uint32_t l_rank = static_cast<uint32_t>(__builtin_popcountll(l_mask & ((1ull << lane) - 1ull)));
-                if (late) spec_put(l_rank);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                for (uint32_t j0 = 0; j0 < l_m; j0 += 4u) {
-                    u32x4 d[4], sv[4];
-                    uint32_t sh[4];
-#pragma unroll
-                    for (uint32_t u = 0; u < 4u; ++u) d[u] = lds_ld<u32x4>(spec_pad(min(j0 + u, l_m - 1u)));
-#pragma unroll
-                    for (uint32_t u = 0; u < 4u; ++u) {
-                        sh[u] = 1u;
-                        sv[u] = u32x4{0u, 0u, 0u, 0u};
-                        if (j0 + u < l_m) sv[u] = spec_load(d[u], sh[u]);
-                    }
-#pragma unroll
-                    for (uint32_t u = 0; u < 4u; ++u)
-                        if (j0 + u < l_m) spec_vote(j0 + u, d[u], sv[u], sh[u]);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (late) extra = spec_read(l_rank);
-            }
-        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         HS_STAMP(2);
+        bool used_up = false;
         // ---- walk the piece ----
         {
             const uint32_t left = left_now;                          // bytes of the line from pos on
@@ -1159,15 +1125,98 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
 #ifdef GX_DEV
             dv[0] += static_cast<unsigned long long>(__popcll(__ballot(walking)));
             dv[1] += went_in;
-            dv[2] += static_cast<unsigned long long>(__popcll(__ballot(longrun)));
 #endif
             const uint32_t leave_at = went_in > GX_HOP_LEAVE ? went_in - GX_HOP_LEAVE : 0u;
             if (match_only) row = all_hot ? walk_hop_span<true, false>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at, K)
                                           : walk_hop_span<false, false>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at, K);
             else row = all_hot ? walk_hop_span<true, true>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at, K)
                                : walk_hop_span<false, true>(H, p, e, limit, e_chain, my - pos, row, dead_row, regs, leave_at, K);
-            pos += p - my + extra;
+            pos += p - my;
+            used_up = walking && !whole && p == e;   // (every staged byte consumed: only a run does that -- the loaders' or the walk's)
         }
+        HS_STAMP(3);
+        uint32_t extra = 0u;
+        // (behind the walk since round 5's end: a lane that REACHES its long value in this piece -- the walk ran to the piece's last byte in
+        // a run -- has its next kilobyte tested in this round, not in the next one: a line is done a round earlier)
+        uint32_t runinfo2 = 0x8000u;
+        if (used_up) {
+            if (!all_hot && row == K.kept) runinfo2 = K.k0.x & 0xFFFFu;
+            else if (row < H.n_hot) runinfo2 = lds_ld<uint32_t>(__umul24(row, HOP_REC_B) + HOP_LDS_AT) & 0xFFFFu;
+        }
+        const bool longrun = GX_HOP_SPEC && used_up && runinfo2 != 0x8000u && left_now > HOP_SLICE + GX_HOP_SPEC_MIN;
+#ifdef GX_DEV
+        dv[2] += static_cast<unsigned long long>(__popcll(__ballot(longrun)));
+#endif
+        // (a line whose tested bytes all lay in the run and that has more is tested again at once, up to GX_HOP_SPEC_PASSES times: a round
+        // more in its lane costs more than a trip to memory -- lines with up to 128 / 256 / 384 / 640 bytes behind their piece left to
+        // the next pieces' loaders instead: 1.074 / 1.107 / 1.119 / 1.153 against 1.036 ms per 3.8 M lines)
+        bool again = longrun;
+        for (uint32_t pass = 0; pass < GX_HOP_SPEC_PASSES && __builtin_amdgcn_ballot_w64(again) != 0ull; ++pass) {
+            // A line with more than 512 bytes left behind what is tested has an instruction of its own (64 loaders); two with less share
+            // one, 32 loaders each -- most remainders are short, and an instruction costs the same sixty-odd instructions whatever its
+            // lanes find to do.  Descriptors: the long lines first, then the short ones; four instructions' loads in flight at a time.
+            const uint32_t behind = HOP_SLICE + extra;          // (bytes from pos that are known to lie in the run)
+            const bool is_long = again && left_now - behind > 512u, is_short = again && !is_long;
+            const uint64_t lg_mask = __builtin_amdgcn_ballot_w64(is_long), sh_mask = __builtin_amdgcn_ballot_w64(is_short);
+            const uint64_t below = (1ull << lane) - 1ull;
+            const uint32_t n_lg = static_cast<uint32_t>(__builtin_popcountll(lg_mask)), n_sh = static_cast<uint32_t>(__builtin_popcountll(sh_mask));
+            const uint32_t r_lg = static_cast<uint32_t>(__builtin_popcountll(lg_mask & below)), r_sh = static_cast<uint32_t>(__builtin_popcountll(sh_mask & below));
+            if (again) {
+                const uint8_t* mine = data + ((o0 + pos - HOP_SLICE + behind) << (WIDE ? 1 : 0));   // (pos is behind the piece by now)
+                const uint64_t mv = reinterpret_cast<uint64_t>(mine);
+                lds_st<u32x4>(spec_pad(is_long ? r_lg : n_lg + r_sh), u32x4{static_cast<uint32_t>(mv), static_cast<uint32_t>(mv >> 32), left_now - behind, runinfo2});
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t n_ins = n_lg + ((n_sh + 1u) >> 1);
+            for (uint32_t i0 = 0; i0 < n_ins; i0 += 4u) {
+                u32x4 d[4], sv[4];
+                uint32_t sh[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t i = min(i0 + u, n_ins - 1u);
+                    const uint32_t j = i < n_lg ? i : n_lg + 2u * (i - n_lg) + (lane >> 5);   // (a pair: the lane's half names its line)
+                    d[u] = lds_ld<u32x4>(spec_pad(min(j, n_lg + n_sh - 1u)));
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t i = i0 + u;
+                    const bool pair = i >= n_lg;
+                    const bool valid = i < n_ins && (!pair || 2u * (i - n_lg) + (lane >> 5) < n_sh);
+                    sv[u] = spec_load(d[u], pair ? lane & 31u : lane, valid, sh[u]);
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t i = i0 + u;
+                    const uint64_t bal = __builtin_amdgcn_ballot_w64(sh[u] == 0u && chunk_in_run(sv[u], d[u].w));
+                    // (into the instruction's first descriptor: read by now)
+                    if (lane == 0u && i < n_ins) lds_st<u32x2>(spec_pad(i < n_lg ? i : n_lg + 2u * (i - n_lg)), u32x2{static_cast<uint32_t>(bal), static_cast<uint32_t>(bal >> 32)});
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint32_t got = 0u, all = 0u;
+            if (is_long) {
+                const u32x2 bits = lds_ld<u32x2>(spec_pad(r_lg));
+                const uint64_t inv = ~(static_cast<uint64_t>(bits.y) << 32 | bits.x);
+                got = 16u * (inv == 0ull ? 64u : static_cast<uint32_t>(__builtin_ctzll(inv)));
+                all = 1024u;
+            }
+            if (is_short) {
+                const u32x2 bits = lds_ld<u32x2>(spec_pad(n_lg + (r_sh & ~1u)));
+                const uint32_t inv = ~((r_sh & 1u) ? bits.y : bits.x);
+                got = 16u * (inv == 0u ? 32u : static_cast<uint32_t>(__builtin_ctz(inv)));
+                all = 512u;
+            }
+            const uint32_t rest = left_now - behind;
+            extra += min(got, rest);
+            again = again && got == all && rest > all;          // every chunk in the run, and the line goes on
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                    // (the pads are written again by the next pass)
+        }
+        pos += extra;
         if (!match_only && L.fin_state_off != 0u) {
             if (has_line && !fin_here && (pos >= len || row == dead_row)) {
                 F.load(at_global + L.fin_state_off + static_cast<uint64_t>(row) * L.fin_state_rec, T.max_groups);
@@ -1177,7 +1226,7 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
         // the slice buffer is rewritten by the next iteration
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        HS_STAMP(3);
+        HS_STAMP(2);   // (the tested kilobytes count with the waiting)
 #ifdef GX_DEV
         ++ph[4];
 #endif

@@ -480,6 +480,7 @@ k_extract_tile(GxLds L, TileIO io) {
     const unsigned long long dev_begin = __builtin_amdgcn_s_memrealtime();   // (100 MHz, one clock for the whole chip)
     unsigned long long dev_tiles = 0;
 #endif
+    bool hop_second = false;   // hop tier: this tile's walk carries the second chances (the tile before it met text that wants them)
     u32x4 pre[WIDE ? 2 * KCH : KCH];  // the next round's bytes, in flight or landed
     uint64_t no0 = 0, no1 = 0;
     TileInfo cur;
@@ -542,7 +543,7 @@ k_extract_tile(GxLds L, TileIO io) {
             if (lane == cur.a) __hip_atomic_store(io.oversize_flag, io.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         } else if (MODE == 0 && HOP) {
             // ---- hot loop #1 alone on the match automaton's hop records: a state's info word is its first accepting extraction ----
-            const uint32_t mrow = walk_hop<false>(H, L.rec_indexed >= L.sort_chunk, stage, L.m_start, start, end, true, L.m_dead, regs);
+            const uint32_t mrow = walk_hop<false>(H, L.rec_indexed >= L.sort_chunk, stage, L.m_start, start, end, true, L.m_dead, regs, hop_second);
             int32_t first = static_cast<int16_t>(lds_ld<uint16_t>(L.acc_tab + 2u * min(mrow, H.n_hot - 1u)));
             if (wave_any(mrow >= H.n_hot)) {
                 if (mrow >= H.n_hot) first = *reinterpret_cast<const int32_t*>(H.rows + (static_cast<uint64_t>(mrow) * H.row_bytes + H.info_off));
@@ -560,7 +561,7 @@ k_extract_tile(GxLds L, TileIO io) {
             int32_t info;  // of the state the line's walk ended in: -1 null, -2-k ExtractionException, else its final record
             if (HOP) {
                 // ---- fused pass on the hop records: a run and a chain per iteration (gx_hop_dev.hpp) ----
-                const uint32_t urow = walk_hop<true>(H, L.rec_indexed >= L.sort_chunk, stage, L.u_start, start, end, true, L.u_dead, regs);
+                const uint32_t urow = walk_hop<true>(H, L.rec_indexed >= L.sort_chunk, stage, L.u_start, start, end, true, L.u_dead, regs, hop_second);
                 // the final state's info word: int16 in LDS for the hot states (offset / 16, or -1 / -2-k), else its dense row's last column
                 const int32_t hot_info = static_cast<int16_t>(lds_ld<uint16_t>(L.acc_tab + 2u * min(urow, H.n_hot - 1u)));
                 info = hot_info >= 0 ? hot_info * 16 : hot_info;

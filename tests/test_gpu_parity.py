@@ -1685,7 +1685,7 @@ def test_hop_long_runs_and_loop_sets():
     base = [bytes(base_d[base_o[i]:base_o[i + 1]]).decode("latin-1").rstrip("w7x") for i in range(300)]   # (the padding off: the last value's first bytes stay)
     fills = {"7": "0123456789", "w": "abcXYZ_09", "x": "!#%&/azAZ~"}
     lines = []
-    lengths = [0, 1, 15, 16, 17, 100, 103, 104, 105, 127, 128, 129, 143, 144, 145, 200, 1000, 1151, 1152, 1153, 1167, 1168, 1169, 1500, 2175, 2176, 2177, 2400, 5000]
+    lengths = [0, 1, 15, 16, 17, 100, 103, 104, 105, 127, 128, 129, 143, 144, 145, 200, 500, 520, 540, 560, 580, 600, 620, 640, 660, 680, 1000, 1151, 1152, 1153, 1167, 1168, 1169, 1500, 2175, 2176, 2177, 2400, 5000]
     for k, pad in enumerate(lengths * 6):
         s = base[k % len(base)]
         kind = meta[[m[0] for m in meta].index(s.split(" ")[2].split("[")[0])][2][-1]
