@@ -831,6 +831,12 @@ __device__ __forceinline__ bool chunk_in_run(const u32x4& v, uint32_t runinfo) {
 #ifndef GX_HOP_SPEC
 #define GX_HOP_SPEC 1   // 0: no chunks are tested beyond the piece
 #endif
+#ifndef GX_HOP_SPEC_UNITS
+#define GX_HOP_SPEC_UNITS 24   // 0: an instruction per line (or per two short ones), repeated GX_HOP_SPEC_PASSES times
+#endif
+#ifndef GX_HOP_SPEC_BATCH
+#define GX_HOP_SPEC_BATCH 8u   // (2 / 4 / 8 load instructions in flight: 0.961 / 0.928 / 0.905 ms per 3.8 M lines)
+#endif
 #ifndef GX_HOP_SPEC_PASSES
 #define GX_HOP_SPEC_PASSES 3u
 #endif
@@ -1074,6 +1080,7 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
             return load_chunk16<WIDE, false>(src, data_end, 16u, high);   // (inside the line: the window was moved back from its end)
         };
         auto spec_pad = [&](uint32_t j) { return slice + j * HOP_SLICE_ROW + HOP_SLICE; };
+        (void)spec_pad;
         // which chunks lie in their line's run (whole chunks inside the line), and -- WIDE -- which lines hold a unit above 0xFF: eight
         // loaders per line and instruction -> one byte of the instruction's ballot per line; the ballots go through the piece buffer's
         // first 128 bytes (read again below, before the pieces are stored)
@@ -1147,6 +1154,75 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
 #ifdef GX_DEV
         dv[2] += static_cast<unsigned long long>(__popcll(__ballot(longrun)));
 #endif
+#if GX_HOP_SPEC_UNITS
+        // The bytes behind the pieces, of all such lines at once, in UNITS of 128 bytes (up to GX_HOP_SPEC_UNITS per line and round):
+        // a load instruction tests eight units -- eight loaders each -- of whichever lines they belong to, so its 64 lanes are all busy
+        // (one instruction per line left 60 % of them idle: half of the remainders are shorter than 400 bytes).  Through the piece
+        // buffer, which holds nothing any more: owner[u] = the lane whose line unit u belongs to, the lanes' descriptors, a byte of
+        // chunk bits per unit.
+        {
+            constexpr uint32_t UNIT = 128u, SB = GX_HOP_SPEC_BATCH;   // (that many load instructions in flight)
+            const uint32_t rest0 = longrun ? left_now - HOP_SLICE : 0u;
+            const uint32_t units = longrun ? min((rest0 + UNIT - 1u) / UNIT, static_cast<uint32_t>(GX_HOP_SPEC_UNITS)) : 0u;
+            uint32_t incl = units;
+#pragma unroll
+            for (uint32_t dlt = 1u; dlt < 64u; dlt <<= 1) {
+                const uint32_t up = static_cast<uint32_t>(__shfl_up(static_cast<int>(incl), dlt));
+                if (lane >= dlt) incl += up;
+            }
+            const uint32_t first = incl - units;
+            const uint32_t n_units = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+            if (n_units != 0u) {
+                const uint32_t OWN = slice, BITS = slice + 2048u, DESC = slice + 4096u;
+                if (longrun) {
+                    const uint8_t* mine = data + ((o0 + pos) << (WIDE ? 1 : 0));   // (pos is behind the piece by now)
+                    const uint64_t mv = reinterpret_cast<uint64_t>(mine);
+                    lds_st<u32x4>(DESC + lane * 16u, u32x4{static_cast<uint32_t>(mv), static_cast<uint32_t>(mv >> 32), rest0, runinfo2 | first << 16});
+                }
+                for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(k < units) != 0ull; ++k)
+                    if (k < units) lds_st<uint8_t>(OWN + first + k, static_cast<uint8_t>(lane));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t n_ins = (n_units + 7u) >> 3;
+                for (uint32_t i0 = 0; i0 < n_ins; i0 += SB) {
+                    u32x4 d[SB], sv[SB];
+                    uint32_t sh[SB];
+#pragma unroll
+                    for (uint32_t u = 0; u < SB; ++u) {
+                        const uint32_t unit = min(8u * (i0 + u) + (lane >> 3), n_units - 1u);
+                        d[u] = lds_ld<u32x4>(DESC + static_cast<uint32_t>(lds_ld<uint8_t>(OWN + unit)) * 16u);
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < SB; ++u) {
+                        const uint32_t unit = 8u * (i0 + u) + (lane >> 3);
+                        const uint32_t chunk = (min(unit, n_units - 1u) - (d[u].w >> 16)) * 8u + (lane & 7u);   // of the line
+                        sv[u] = spec_load(d[u], chunk, unit < n_units, sh[u]);
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < SB; ++u) {
+                        const uint64_t bal = __builtin_amdgcn_ballot_w64(sh[u] == 0u && chunk_in_run(sv[u], d[u].w));
+                        if (lane == 0u && i0 + u < n_ins) lds_st<u32x2>(BITS + 8u * (i0 + u), u32x2{static_cast<uint32_t>(bal), static_cast<uint32_t>(bal >> 32)});
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // a line's leading units that lie in the run, and the chunks of the first one that does not
+                uint32_t got = 0u;
+                bool alive = longrun;
+                for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(alive && k < units) != 0ull; ++k) {
+                    const bool look = alive && k < units;
+                    const uint32_t bits = look ? lds_ld<uint8_t>(BITS + first + k) : 0xFFu;
+                    if (look) {
+                        got += 16u * static_cast<uint32_t>(__builtin_ctz(~bits | 0x100u));
+                        alive = bits == 0xFFu;
+                    }
+                }
+                extra = min(got, rest0);
+            }
+        }
+#else
         // (a line whose tested bytes all lay in the run and that has more is tested again at once, up to GX_HOP_SPEC_PASSES times: a round
         // more in its lane costs more than a trip to memory -- lines with up to 128 / 256 / 384 / 640 bytes behind their piece left to
         // the next pieces' loaders instead: 1.074 / 1.107 / 1.119 / 1.153 against 1.036 ms per 3.8 M lines)
@@ -1216,6 +1292,7 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();                    // (the pads are written again by the next pass)
         }
+#endif
         pos += extra;
         if (!match_only && L.fin_state_off != 0u) {
             if (has_line && !fin_here && (pos >= len || row == dead_row)) {
