@@ -832,13 +832,10 @@ __device__ __forceinline__ bool chunk_in_run(const u32x4& v, uint32_t runinfo) {
 #define GX_HOP_SPEC 1   // 0: no chunks are tested beyond the piece
 #endif
 #ifndef GX_HOP_SPEC_UNITS
-#define GX_HOP_SPEC_UNITS 24   // 0: an instruction per line (or per two short ones), repeated GX_HOP_SPEC_PASSES times
+#define GX_HOP_SPEC_UNITS 24   // units of 128 bytes behind its piece that a line has tested per round (8 / 16 / 24: 0.969 / 0.922 / 0.920 ms per 3.8 M lines)
 #endif
 #ifndef GX_HOP_SPEC_BATCH
 #define GX_HOP_SPEC_BATCH 8u   // (2 / 4 / 8 load instructions in flight: 0.961 / 0.928 / 0.905 ms per 3.8 M lines)
-#endif
-#ifndef GX_HOP_SPEC_PASSES
-#define GX_HOP_SPEC_PASSES 3u
 #endif
 #ifndef GX_HOP_SPEC_MIN
 #define GX_HOP_SPEC_MIN 0u   // only lines with more than that many bytes behind their piece have them tested (the others: the next pieces' loaders)
@@ -1053,18 +1050,16 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
                 if (mine) pv[r] = load_chunk16<WIDE, false>(src, data_end, who[r].z - at_byte, high_or[r]);
             } else if (mine) pv[r] = load_chunk16<WIDE, true>(src, data_end, who[r].z - at_byte, high_or[r]);
         }
-        // ---- A lane whose whole piece lies in its run and whose line goes on has the next kilobyte of the line TESTED, not staged:
-        // one load instruction per such line, 64 loaders of 16 bytes, and the lane moves behind the chunks that lie in the run -- a
-        // padded value of a kilobyte is two rounds of loads and no walk iteration (it was 64 iterations over ten rounds).  Which lanes
-        // those are is known when the piece's loads have come back: a second trip to memory behind the first.  (Measured, round 5, ms
-        // per 3.8 M lines of configs[4]: without the tested kilobytes 1.304 against 1.168; their loads sent out before the walk and
-        // looked at behind it -- 0 / 4 / 6 lines ahead -- 1.167 / 1.157 / 1.168; sent out WITH the piece's loads for the lanes whose
-        // last piece ended inside a run -- a guess -- 0 / 2 / 4 / 6 lines 1.022 / 1.032 / 1.052 / 1.124: the registers those loads
-        // sit in cost more than the trip they save.  The kernel is bound by the instructions it issues.)  The descriptors of such
-        // lines go through the pads of the piece buffer's rows (16 bytes behind every row's 128). ----
-        // one such line's chunk of this lane: the line's last chunk, when it is a partial one, is read 16 bytes back from the line's
-        // end (what it overlaps lies in the run already -- the chunk before it, or the piece); `high` != 0: not a chunk of the line,
-        // or (WIDE) one with a unit above 0xFF -- not in the run either way
+        // ---- A lane that used up its piece inside a run (the loaders found every chunk in the run, or the walk ran to the piece's last
+        // byte) has the bytes BEHIND the piece tested, not staged: loaders of 16 bytes, a ballot, and the lane moves behind the chunks
+        // that lie in the run -- a padded value of a kilobyte is one round of loads and no walk iteration (it was 64 iterations over ten
+        // rounds).  How this part got its shape (ms per 3.8 M lines of configs[4], one device per comparison): without it 1.304 against
+        // 1.168; one load instruction per such line, sent out before the walk and looked at behind it -- 0 / 4 / 6 lines ahead -- 1.167 /
+        // 1.157 / 1.168; sent out WITH the piece's loads for lanes guessed to be in a run: 1.022 / 1.032 / 1.052 / 1.124 for 0 / 2 / 4 /
+        // 6 guesses; two short remainders per instruction 1.045 against 1.059; only lines with more than 128 / 256 / 384 / 640 bytes
+        // left: 1.074 / 1.107 / 1.119 / 1.153 against 1.036; repeated while everything tested lay in the run, 1 / 2 / 3 times: 1.055 /
+        // 1.010 / 0.987; behind the walk instead of before it: 0.992 against 0.997; in units of all lines at once (below): 0.920 against
+        // 0.936; 2 / 4 / 8 / 12 load instructions in flight: 0.961 / 0.928 / 0.905 / 0.967. ----
         // `chunk`: which 16 bytes behind the piece this lane tests (a line of its own: 0 .. 63; a line that shares the instruction with
         // another: 0 .. 31)
         auto spec_load = [&](const u32x4& d, uint32_t chunk, bool valid, uint32_t& high) -> u32x4 {
@@ -1079,8 +1074,6 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
             high = 0u;
             return load_chunk16<WIDE, false>(src, data_end, 16u, high);   // (inside the line: the window was moved back from its end)
         };
-        auto spec_pad = [&](uint32_t j) { return slice + j * HOP_SLICE_ROW + HOP_SLICE; };
-        (void)spec_pad;
         // which chunks lie in their line's run (whole chunks inside the line), and -- WIDE -- which lines hold a unit above 0xFF: eight
         // loaders per line and instruction -> one byte of the instruction's ballot per line; the ballots go through the piece buffer's
         // first 128 bytes (read again below, before the pieces are stored)
@@ -1154,7 +1147,6 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
 #ifdef GX_DEV
         dv[2] += static_cast<unsigned long long>(__popcll(__ballot(longrun)));
 #endif
-#if GX_HOP_SPEC_UNITS
         // The bytes behind the pieces, of all such lines at once, in UNITS of 128 bytes (up to GX_HOP_SPEC_UNITS per line and round):
         // a load instruction tests eight units -- eight loaders each -- of whichever lines they belong to, so its 64 lanes are all busy
         // (one instruction per line left 60 % of them idle: half of the remainders are shorter than 400 bytes).  Through the piece
@@ -1222,77 +1214,6 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
                 extra = min(got, rest0);
             }
         }
-#else
-        // (a line whose tested bytes all lay in the run and that has more is tested again at once, up to GX_HOP_SPEC_PASSES times: a round
-        // more in its lane costs more than a trip to memory -- lines with up to 128 / 256 / 384 / 640 bytes behind their piece left to
-        // the next pieces' loaders instead: 1.074 / 1.107 / 1.119 / 1.153 against 1.036 ms per 3.8 M lines)
-        bool again = longrun;
-        for (uint32_t pass = 0; pass < GX_HOP_SPEC_PASSES && __builtin_amdgcn_ballot_w64(again) != 0ull; ++pass) {
-            // A line with more than 512 bytes left behind what is tested has an instruction of its own (64 loaders); two with less share
-            // one, 32 loaders each -- most remainders are short, and an instruction costs the same sixty-odd instructions whatever its
-            // lanes find to do.  Descriptors: the long lines first, then the short ones; four instructions' loads in flight at a time.
-            const uint32_t behind = HOP_SLICE + extra;          // (bytes from pos that are known to lie in the run)
-            const bool is_long = again && left_now - behind > 512u, is_short = again && !is_long;
-            const uint64_t lg_mask = __builtin_amdgcn_ballot_w64(is_long), sh_mask = __builtin_amdgcn_ballot_w64(is_short);
-            const uint64_t below = (1ull << lane) - 1ull;
-            const uint32_t n_lg = static_cast<uint32_t>(__builtin_popcountll(lg_mask)), n_sh = static_cast<uint32_t>(__builtin_popcountll(sh_mask));
-            const uint32_t r_lg = static_cast<uint32_t>(__builtin_popcountll(lg_mask & below)), r_sh = static_cast<uint32_t>(__builtin_popcountll(sh_mask & below));
-            if (again) {
-                const uint8_t* mine = data + ((o0 + pos - HOP_SLICE + behind) << (WIDE ? 1 : 0));   // (pos is behind the piece by now)
-                const uint64_t mv = reinterpret_cast<uint64_t>(mine);
-                lds_st<u32x4>(spec_pad(is_long ? r_lg : n_lg + r_sh), u32x4{static_cast<uint32_t>(mv), static_cast<uint32_t>(mv >> 32), left_now - behind, runinfo2});
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const uint32_t n_ins = n_lg + ((n_sh + 1u) >> 1);
-            for (uint32_t i0 = 0; i0 < n_ins; i0 += 4u) {
-                u32x4 d[4], sv[4];
-                uint32_t sh[4];
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) {
-                    const uint32_t i = min(i0 + u, n_ins - 1u);
-                    const uint32_t j = i < n_lg ? i : n_lg + 2u * (i - n_lg) + (lane >> 5);   // (a pair: the lane's half names its line)
-                    d[u] = lds_ld<u32x4>(spec_pad(min(j, n_lg + n_sh - 1u)));
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) {
-                    const uint32_t i = i0 + u;
-                    const bool pair = i >= n_lg;
-                    const bool valid = i < n_ins && (!pair || 2u * (i - n_lg) + (lane >> 5) < n_sh);
-                    sv[u] = spec_load(d[u], pair ? lane & 31u : lane, valid, sh[u]);
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) {
-                    const uint32_t i = i0 + u;
-                    const uint64_t bal = __builtin_amdgcn_ballot_w64(sh[u] == 0u && chunk_in_run(sv[u], d[u].w));
-                    // (into the instruction's first descriptor: read by now)
-                    if (lane == 0u && i < n_ins) lds_st<u32x2>(spec_pad(i < n_lg ? i : n_lg + 2u * (i - n_lg)), u32x2{static_cast<uint32_t>(bal), static_cast<uint32_t>(bal >> 32)});
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            uint32_t got = 0u, all = 0u;
-            if (is_long) {
-                const u32x2 bits = lds_ld<u32x2>(spec_pad(r_lg));
-                const uint64_t inv = ~(static_cast<uint64_t>(bits.y) << 32 | bits.x);
-                got = 16u * (inv == 0ull ? 64u : static_cast<uint32_t>(__builtin_ctzll(inv)));
-                all = 1024u;
-            }
-            if (is_short) {
-                const u32x2 bits = lds_ld<u32x2>(spec_pad(n_lg + (r_sh & ~1u)));
-                const uint32_t inv = ~((r_sh & 1u) ? bits.y : bits.x);
-                got = 16u * (inv == 0u ? 32u : static_cast<uint32_t>(__builtin_ctz(inv)));
-                all = 512u;
-            }
-            const uint32_t rest = left_now - behind;
-            extra += min(got, rest);
-            again = again && got == all && rest > all;          // every chunk in the run, and the line goes on
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();                    // (the pads are written again by the next pass)
-        }
-#endif
         pos += extra;
         if (!match_only && L.fin_state_off != 0u) {
             if (has_line && !fin_here && (pos >= len || row == dead_row)) {
