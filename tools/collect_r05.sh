@@ -18,6 +18,17 @@ if [ "$part" = bench ] || [ "$part" = all ]; then
   cp "$(find "$out/stats" -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats.csv"; rm -rf "$out/stats"
   echo "kernel-trace done"
 fi
+if [ "$part" = configs ] || [ "$part" = all ]; then
+  # configs 3 and 5 alone: their kernel statistics are not mixed with the other workloads' launches of the same kernel
+  cd /tmp
+  for c in 3 5; do
+    python3 "$root/bench.py" --config $c --no-cpu-baseline > "$out/config${c}_bench.json"
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$out/c${c}stats" -o c$c -- python3 "$root/bench.py" --config $c --no-cpu-baseline > /dev/null
+    cp "$(find "$out/c${c}stats" -name '*kernel_stats.csv' | head -1)" "$out/config${c}_kernel_stats.csv"; rm -rf "$out/c${c}stats"
+  done
+  cd "$root"
+  echo "configs done"
+fi
 if [ "$part" = traffic ] || [ "$part" = all ]; then
   cd /tmp
   for spec in "2 auto - r05" "3 auto - r05_config3" "5 auto - r05_config5" "3 auto mixed_case r05_config3_mixed_case"; do
