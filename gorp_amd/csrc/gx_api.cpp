@@ -882,7 +882,8 @@ void choose_tile_image(gx_handle* h) {
         L.sort_chunk = I.n_reachable_hot;  // (hop tier: the states well-formed lines reach; rec_indexed of them are in LDS)
         L.hot_lo4 = 0;
         L.hot_k4 = 0x80808080u;
-        L.regs_wave_bytes = static_cast<uint32_t>(((I.n_regs + 1) * 64 * 2 + 15) & ~15u);
+        L.regs_wave_bytes = static_cast<uint32_t>(((I.n_regs + 1) * 64 * 2 + 15) & ~15u);   // (the dummy column, then the registers)
+        L.fin_unset = I.col_unset;
         for (int q = 0; q < 2; ++q) {
             const HopLds& P = q ? I.small : I.full;
             L.table_bytes = static_cast<uint32_t>(P.bytes.size());

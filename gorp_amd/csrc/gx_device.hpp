@@ -96,6 +96,7 @@ struct GxLds {
     uint32_t sort_lds;    // lane kernel, length-sorted mode: LDS address of u16 perm[sort_chunk] + u32 hist[64] + u32 cursor[64]
     uint32_t sort_chunk;  // ... lines per chunk (0: tiles in input order)
     uint32_t hop_sets;    // hop tier: LDS address of the loop sets (gx_hop.cpp: u8 lo[4], u8 k[4] per entry, entry 0 = none)
+    uint32_t fin_unset;   // hop tier: byte offset, from a wave's dummy column, of the column a lane fills with 0xFFFF before it reads its result (the one before it: the line's length); the final records' tags name columns
     uint32_t fin_state_off, fin_state_rec;   // hop tier: the final records by state in the global image (byte offset, 0: none; bytes per record)
 };
 constexpr uint32_t GX_STEAL_MAX = 3072;         // workgroups of a tile-kernel launch at most (256 CUs x 12)

@@ -251,8 +251,16 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
 
     // final records, as gx_walk.hpp's line_result reads them (the layout build_tile_image gives the other tiers):
     // u16 [begin tag, end tag] x max_groups padded to four groups, then the extraction; record 0 = nothing set
+    // Round 5: EVERY tag names a column of the wave's register block -- a register's, "the line's length" (which the lane writes there
+    // before it reads its result) or "unset" -- so a group's two values are two reads and one test on the tag (the selects on "tag 0:
+    // unset, tag 1: the length" were half of the results' instructions).  A group with one end unset has both unset.
+    // ("the length" is the dummy column itself -- write-only while the line is walked, free afterwards: no room of its own; "unset"
+    // is a column that does not exist: the test is on the tag, what the read returns is not looked at)
+    const uint16_t col_len = 0u, col_unset = 0xFF80u;
+    out.col_unset = col_unset;
     const size_t tag_slots = 8 * static_cast<size_t>((T.max_groups + 3) / 4), rec_len = tag_slots + 8;
     std::vector<uint16_t> fin_rec(rec_len, 0);
+    for (size_t q = 0; q < tag_slots; ++q) fin_rec[q] = col_unset;
     fin_rec[tag_slots] = 0xFFFFu;
     std::map<int32_t, uint32_t> rec_of;
     auto fin_record = [&](int32_t f) -> uint32_t {
@@ -261,11 +269,13 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
         const int32_t k = static_cast<int32_t>(T.fin_tags[f]);
         const size_t at = fin_rec.size();
         fin_rec.resize(at + rec_len, 0);
-        for (int g = 0; g < T.rules[k].n_groups; ++g)
-            for (int e = 0; e < 2; ++e) {
-                const uint16_t v = T.fin_tags[f + 1 + 2 * g + e];
-                fin_rec[at + 2 * g + e] = v == GX_SRC_NIL ? 0 : v == GX_SRC_POS ? 1 : static_cast<uint16_t>((v + 1u) * 128u);
-            }
+        for (size_t q = 0; q < tag_slots; ++q) fin_rec[at + q] = col_unset;
+        for (int g = 0; g < T.rules[k].n_groups; ++g) {
+            const uint16_t vb = T.fin_tags[f + 1 + 2 * g], ve = T.fin_tags[f + 2 + 2 * g];
+            if (vb == GX_SRC_NIL || ve == GX_SRC_NIL) continue;   // (Matcher.group() is null: both ends)
+            fin_rec[at + 2 * g] = vb == GX_SRC_POS ? col_len : static_cast<uint16_t>((vb + 1u) * 128u);
+            fin_rec[at + 2 * g + 1] = ve == GX_SRC_POS ? col_len : static_cast<uint16_t>((ve + 1u) * 128u);
+        }
         fin_rec[at + tag_slots] = static_cast<uint16_t>(k);
         rec_of[f] = static_cast<uint32_t>(at * 2);
         return static_cast<uint32_t>(at * 2);
@@ -441,6 +451,7 @@ bool build_hop_image(const Tables& T, bool match_automaton, uint32_t hot_budget_
     if (!match_automaton && S * rec_len * 2 <= (64ull << 20)) {
         out.fin_state_off = static_cast<uint32_t>(out.global.size());
         std::vector<uint16_t> by_state(S * rec_len, 0);
+        for (size_t s2 = 0; s2 < S; ++s2) for (size_t q = 0; q < tag_slots; ++q) by_state[s2 * rec_len + q] = col_unset;
         for (size_t s = 0; s < S; ++s) {
             const int32_t info = static_cast<int32_t>(rows[s * cols + ncls]);
             if (info >= 0) memcpy(&by_state[s * rec_len], &fin_rec[static_cast<size_t>(info) / 2], rec_len * 2);

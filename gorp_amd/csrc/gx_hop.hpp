@@ -62,6 +62,7 @@ struct HopImage {
     uint32_t fin_state_off = 0, fin_state_rec = 0;   // ... of the final records BY STATE (0: none), bytes per record
     uint32_t start = 0, dead = 0;        // state indexes (renumbered)
     uint32_t n_regs = 0;
+    uint32_t col_unset = 0;              // byte offset (from a wave's dummy column) of the "unset" column: registers, then "length", then this
     bool match_automaton = false;        // built from the match automaton (PolyMatcher.match batches): an info word is the first
                                          // accepting extraction or -1, there are no programs and no final records
     // diagnostics (gx_stat)

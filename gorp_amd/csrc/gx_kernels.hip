@@ -75,7 +75,7 @@ struct __attribute__((packed)) UnalignedU16 { uint16_t v; };
 
 template <int TIER>
 __device__ __forceinline__ void write_row(const LineOut& out, uint64_t i, int32_t info, uint32_t fin_lds, const uint8_t* fin_g, uint32_t regs,
-                                          uint32_t len, int G) {
+                                          uint32_t len, int G, uint32_t hop_unset = 0u) {
     const uint32_t rec = info >= 0 ? static_cast<uint32_t>(info) : 0u;
     const uint32_t dummy_col = regs - 128u;
     const uint32_t id_at = rec + 16u * static_cast<uint32_t>((G + 3) >> 2);
@@ -98,16 +98,22 @@ __device__ __forceinline__ void write_row(const LineOut& out, uint64_t i, int32_
         uint32_t vb[4], ve[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            vb[q] = lds_ld<uint16_t>(dummy_col + (tw[q] & 0xFF80u));
-            ve[q] = lds_ld<uint16_t>(dummy_col + ((tw[q] >> 16) & 0xFF80u));
+            vb[q] = lds_ld<uint16_t>(dummy_col + (tw[q] & (TIER == TIER_HOP ? 0xFFFFu : 0xFF80u)));
+            ve[q] = lds_ld<uint16_t>(dummy_col + (TIER == TIER_HOP ? tw[q] >> 16 : (tw[q] >> 16) & 0xFF80u));
         }
         int32_t pb[4], pe[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t tb = tw[q] & 0xFFFFu, te = tw[q] >> 16;
-            pb[q] = tb == 1u ? static_cast<int32_t>(len) : static_cast<int32_t>(vb[q]);
-            pe[q] = te == 1u ? static_cast<int32_t>(len) : static_cast<int32_t>(ve[q]);
-            if (tb == 0u || te == 0u || info < 0) { pb[q] = -1; pe[q] = -1; }
+            if (TIER == TIER_HOP) {   // (tags name columns, "the length" and "unset" among them: gx_hop.cpp)
+                const bool unset = tb == hop_unset || info < 0;
+                pb[q] = unset ? -1 : static_cast<int32_t>(vb[q]);
+                pe[q] = unset ? -1 : static_cast<int32_t>(ve[q]);
+            } else {
+                pb[q] = tb == 1u ? static_cast<int32_t>(len) : static_cast<int32_t>(vb[q]);
+                pe[q] = te == 1u ? static_cast<int32_t>(len) : static_cast<int32_t>(ve[q]);
+                if (tb == 0u || te == 0u || info < 0) { pb[q] = -1; pe[q] = -1; }
+            }
         }
         const int cnt = G - g0 < 4 ? G - g0 : 4;
         if (!out.packed) {
@@ -179,7 +185,8 @@ struct FinAhead {
         id = *reinterpret_cast<const uint16_t*>(recp + 16 * nblk);
     }
 };
-__device__ __forceinline__ void write_row_rec(const LineOut& out, uint64_t i, const uint8_t* __restrict__ recp, const FinAhead& F, uint32_t regs, uint32_t len, int G) {
+__device__ __forceinline__ void write_row_rec(const LineOut& out, uint64_t i, const uint8_t* __restrict__ recp, const FinAhead& F, uint32_t regs, uint32_t len, int G,
+                                              uint32_t hop_unset) {
     const uint32_t dummy_col = regs - 128u;
     const u32x4 pre[3] = {F.t0, F.t1, F.t2};
     const int32_t mid = static_cast<int16_t>(F.id);
@@ -196,16 +203,15 @@ __device__ __forceinline__ void write_row_rec(const LineOut& out, uint64_t i, co
         uint32_t vb[4], ve[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            vb[q] = lds_ld<uint16_t>(dummy_col + (tw[q] & 0xFF80u));
-            ve[q] = lds_ld<uint16_t>(dummy_col + ((tw[q] >> 16) & 0xFF80u));
+            vb[q] = lds_ld<uint16_t>(dummy_col + (tw[q] & 0xFFFFu));
+            ve[q] = lds_ld<uint16_t>(dummy_col + (tw[q] >> 16));
         }
         int32_t pb[4], pe[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint32_t tb = tw[q] & 0xFFFFu, te = tw[q] >> 16;
-            pb[q] = tb == 1u ? static_cast<int32_t>(len) : static_cast<int32_t>(vb[q]);
-            pe[q] = te == 1u ? static_cast<int32_t>(len) : static_cast<int32_t>(ve[q]);
-            if (tb == 0u || te == 0u) { pb[q] = -1; pe[q] = -1; }   // (a state that accepts nothing has no tags)
+            const bool unset = (tw[q] & 0xFFFFu) == hop_unset;   // (a state that accepts nothing has every tag unset)
+            pb[q] = unset ? -1 : static_cast<int32_t>(vb[q]);
+            pe[q] = unset ? -1 : static_cast<int32_t>(ve[q]);
         }
         const int cnt = G - g0 < 4 ? G - g0 : 4;
         if (!out.packed) {
@@ -928,19 +934,20 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
         const uint32_t idle = static_cast<uint32_t>(__popcll(__ballot(finished || !has_line)));
         const bool service = idle >= GX_HOP_SERVICE || !__any(has_line && !finished);
         if (service && finished) {
+            if (!match_only) lds_st<uint16_t>(regs - 128u, static_cast<uint16_t>(len));   // (the dummy column, free now: the tag "the line's length" names it)
             if (!match_only && L.fin_state_off != 0u) {
                 // (the row out of the final record of the state: one read, no info word first -- asked for when the line ended, behind
                 // the walk; a line that ended where it began is read now)
                 const uint8_t* recp = at_global + L.fin_state_off + static_cast<uint64_t>(row) * L.fin_state_rec;
                 if (!fin_here) F.load(recp, T.max_groups);
-                write_row_rec(out, i, recp, F, regs, len, T.max_groups);
+                write_row_rec(out, i, recp, F, regs, len, T.max_groups, L.fin_unset);
                 fin_here = false;
             } else {
                 const int32_t hot_info = static_cast<int16_t>(lds_ld<uint16_t>(L.acc_tab + 2u * min(row, H.n_hot - 1u)));
                 int32_t info = hot_info >= 0 && !match_only ? hot_info * 16 : hot_info;
                 if (row >= H.n_hot) info = *reinterpret_cast<const int32_t*>(H.rows + (static_cast<uint64_t>(row) * H.row_bytes + H.info_off));
                 if (match_only) out.id(i, info);
-                else write_row<TIER_HOP>(out, i, info, fin_lds, fin_g, regs, len, T.max_groups);
+                else write_row<TIER_HOP>(out, i, info, fin_lds, fin_g, regs, len, T.max_groups, L.fin_unset);
             }
             if (WIDE) {   // (a flagged line's result is the per-line walk's to write again)
                 wide_flags[i] = line_wide ? 1 : 0;

@@ -590,6 +590,7 @@ k_extract_tile(GxLds L, TileIO io) {
             }
             GX_STAMP(2);
             const uint32_t len = end - start;
+            if (HOP) lds_st<uint16_t>(regs - 128u, static_cast<uint16_t>(len));   // (the dummy column, free now: the tag "the line's length" names it -- gx_hop.cpp)
             const uint8_t* fin_g = GT && !(HOP && L.at != 0u) ? io.at_global + L.fin_tags : nullptr;
             const uint32_t fin_lds = HOP ? L.at : L.fin_tags;
             // The tile's 64 result rows are one contiguous block of the output.  Transpose them through the staging
@@ -607,18 +608,25 @@ k_extract_tile(GxLds L, TileIO io) {
                 if (full_tile && rows_aligned && 64u * row_b + 16u <= L.stage_bytes) {
                     const uint32_t my_row = stage + lane * row_b;
                     int32_t result;
-                    if (narrow) {
+                    if (narrow && !__any(len > 254u)) {
+                        // (no offset of this tile's lines is above 254: nothing to clip or to count)
+                        result = line_result<TIER>(info, fin_lds, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
+                            lds_st<uint8_t>(my_row + 1u + 2u * g, static_cast<uint8_t>(pb));
+                            lds_st<uint8_t>(my_row + 2u + 2u * g, static_cast<uint8_t>(pe));
+                        }, L.fin_unset);
+                        lds_st<uint8_t>(my_row, static_cast<uint8_t>(result));
+                    } else if (narrow) {
                         result = line_result<TIER>(info, fin_lds, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
                             clamped += (pb > 254 ? 1u : 0u) + (pe > 254 ? 1u : 0u);
                             lds_st<uint8_t>(my_row + 1u + 2u * g, static_cast<uint8_t>(pb > 254 ? 254 : pb));
                             lds_st<uint8_t>(my_row + 2u + 2u * g, static_cast<uint8_t>(pe > 254 ? 254 : pe));
-                        });
+                        }, L.fin_unset);
                         lds_st<uint8_t>(my_row, static_cast<uint8_t>(result));
                     } else {
                         result = line_result<TIER>(info, fin_lds, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
                             lds_st<uint16_t>(my_row + 2u + 4u * g, static_cast<uint16_t>(pb));
                             lds_st<uint16_t>(my_row + 4u + 4u * g, static_cast<uint16_t>(pe));
-                        });
+                        }, L.fin_unset);
                         lds_st<uint16_t>(my_row, static_cast<uint16_t>(result));
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -637,14 +645,14 @@ k_extract_tile(GxLds L, TileIO io) {
                             clamped += (pb > 254 ? 1u : 0u) + (pe > 254 ? 1u : 0u);
                             rp[1 + 2 * g] = static_cast<uint8_t>(pb > 254 ? 254 : pb);
                             rp[2 + 2 * g] = static_cast<uint8_t>(pe > 254 ? 254 : pe);
-                        });
+                        }, L.fin_unset);
                         rp[0] = static_cast<uint8_t>(result);
                     } else {
                         uint16_t* rp = io.packed + i * static_cast<uint64_t>(1u + slots);
                         const int32_t result = line_result<TIER>(info, fin_lds, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
                             rp[1 + 2 * g] = static_cast<uint16_t>(pb);
                             rp[2 + 2 * g] = static_cast<uint16_t>(pe);
-                        });
+                        }, L.fin_unset);
                         rp[0] = static_cast<uint16_t>(result);
                     }
                 }
@@ -661,7 +669,7 @@ k_extract_tile(GxLds L, TileIO io) {
                     const uint32_t my_row = stage + lane * row_b;
                     const int32_t result = line_result<TIER>(info, fin_lds, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
                         lds_st<u32x2>(my_row + 8u * g, u32x2{static_cast<uint32_t>(pb), static_cast<uint32_t>(pe)});
-                    });
+                    }, L.fin_unset);
                     const uint32_t ids = stage + 64u * row_b;  // the tile's 64 match ids = 256 bytes
                     lds_st<uint32_t>(ids + 4u * lane, static_cast<uint32_t>(result));
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -676,7 +684,7 @@ k_extract_tile(GxLds L, TileIO io) {
                     io.match_id[i] = line_result<TIER>(info, fin_lds, fin_g, regs, len, G, [&](int g, int32_t pb, int32_t pe) {
                         cp[2 * g] = pb;
                         cp[2 * g + 1] = pe;
-                    });
+                    }, L.fin_unset);
                 }
             }
         }

@@ -322,9 +322,11 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
 // has every tag unset and serves the lines without a match, so the loads below are unconditional and independent:
 // all tags, then all registers, then the selects -- two LDS round trips per four groups instead of two per group.
 // emit(g, begin, end) is called for g = 0 .. G-1 with (-1, -1) for an unset group; returns the match id.
+// TIER_HOP (round 5): every tag names a column -- a register's, "the length" or "unset" (hop_unset: its offset; the lane has filled
+// both in) -- and a group with one end unset has both unset: two reads and one test per group, no selects on tag values.
 template <int TIER, typename EMIT>
 __device__ __forceinline__ int32_t line_result(int32_t info, uint32_t fin_lds, const uint8_t* fin_g, uint32_t regs, uint32_t len, int G,
-                                               EMIT emit) {
+                                               EMIT emit, uint32_t hop_unset = 0u) {
     const uint32_t rec = info >= 0 ? static_cast<uint32_t>(info) : 0u;
     const uint32_t dummy_col = regs - 128u;
     const uint32_t id_at = rec + 16u * static_cast<uint32_t>((G + 3) >> 2);
@@ -341,16 +343,23 @@ __device__ __forceinline__ int32_t line_result(int32_t info, uint32_t fin_lds, c
         uint32_t vb[4], ve[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            vb[q] = lds_ld<uint16_t>(dummy_col + (tw[q] & 0xFF80u));
-            ve[q] = lds_ld<uint16_t>(dummy_col + ((tw[q] >> 16) & 0xFF80u));
+            vb[q] = lds_ld<uint16_t>(dummy_col + (tw[q] & (TIER == TIER_HOP ? 0xFFFFu : 0xFF80u)));
+            ve[q] = lds_ld<uint16_t>(dummy_col + (TIER == TIER_HOP ? tw[q] >> 16 : (tw[q] >> 16) & 0xFF80u));
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (g0 + q < G) {
                 const uint32_t tb = tw[q] & 0xFFFFu, te = tw[q] >> 16;
-                int32_t pb = tb == 1u ? static_cast<int32_t>(len) : static_cast<int32_t>(vb[q]);
-                int32_t pe = te == 1u ? static_cast<int32_t>(len) : static_cast<int32_t>(ve[q]);
-                if (tb == 0u || te == 0u) { pb = -1; pe = -1; }
+                int32_t pb, pe;
+                if (TIER == TIER_HOP) {
+                    const bool unset = tb == hop_unset;
+                    pb = unset ? -1 : static_cast<int32_t>(vb[q]);
+                    pe = unset ? -1 : static_cast<int32_t>(ve[q]);
+                } else {
+                    pb = tb == 1u ? static_cast<int32_t>(len) : static_cast<int32_t>(vb[q]);
+                    pe = te == 1u ? static_cast<int32_t>(len) : static_cast<int32_t>(ve[q]);
+                    if (tb == 0u || te == 0u) { pb = -1; pe = -1; }
+                }
                 emit(g0 + q, pb, pe);
             }
         }

@@ -117,10 +117,11 @@ Outcome hop_outcome(const Tables& T, const HopImage& H, const std::vector<uint8_
     for (int g = 0; g < T.rules[o.id].n_groups; ++g) {
         int v[2];
         for (int e2 = 0; e2 < 2; ++e2) {
+            // (every tag names a column: a register's, "the length" = the dummy column 0, "unset" = H.col_unset)
             const uint16_t t = rec[2 * g + e2];
-            v[e2] = t == 0 ? -1 : t == 1 ? static_cast<int>(line.size()) : col[t / 128];
+            v[e2] = t == H.col_unset ? -1 : t == 0 ? static_cast<int>(line.size()) : col[t / 128];
         }
-        if (rec[2 * g] == 0 || rec[2 * g + 1] == 0) v[0] = v[1] = -1;
+        if (rec[2 * g] == H.col_unset || rec[2 * g + 1] == H.col_unset) v[0] = v[1] = -1;
         o.caps.push_back(v[0]); o.caps.push_back(v[1]);
     }
     return o;
