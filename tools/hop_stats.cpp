@@ -58,6 +58,8 @@ int main(int argc, char** argv) {
                 const uint32_t s_before = s;
                 uint32_t r[6];
                 memcpy(r, hops + static_cast<size_t>(s) * HOP_REC_BYTES, HOP_REC_BYTES);
+                // (a hot state's record as the kernels read it: the LDS image's copy names the state's dense row in LDS, if it has one)
+                if (s < H.full.n_hot) memcpy(r, H.full.bytes.data() + HOP_AT + static_cast<size_t>(s) * HOP_REC_BYTES, HOP_REC_BYTES);
                 const uint32_t run_lo = r[0] & 0xFFu, run_k = (r[0] >> 8) & 0xFFu, klen = (r[0] >> 16) & 0xFFu;
                 size_t n = 0;
                 while (n < 16 && p + n < e && run_k != 0x80u && b[p + n] < 0x80u && b[p + n] >= run_lo && b[p + n] <= 0x7Fu - run_k) ++n;
