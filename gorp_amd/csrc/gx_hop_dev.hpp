@@ -116,8 +116,7 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
     const uint32_t dummy_col = regs - 128u;
     const uint32_t last_hot = H.n_hot - 1u;
     // one exact step of this lane from state s on the byte `bt` at LDS address q: the dense row (lrow: its copy in LDS, 0: none)
-    auto exact_step = [&](uint32_t lrow, uint32_t bt, uint32_t q) {
-        const uint32_t c = lds_ld<uint8_t>(bt);   // (byte -> class id: u8[256] at LDS address 0)
+    auto exact_step_c = [&](uint32_t lrow, uint32_t c, uint32_t q) {   // c: the class id of the byte at q (u8[256] at LDS address 0)
         uint32_t xe;
         if (lrow) xe = lds_ld<uint16_t>(lrow + (c << 1)) | static_cast<uint32_t>(lds_ld<uint8_t>(lrow + H.lrow_cols + c)) << 16;  // (u16 successors, then u8 columns)
         else xe = *reinterpret_cast<const uint32_t*>(H.rows + (static_cast<uint64_t>(s) * H.row_bytes + (c << 2)));
@@ -125,6 +124,7 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
         s = xe & 0xFFFFu;
         p = s == dead ? max(limit, q + 1u) : q + 1u;  // (nothing leaves the dead state: the line is over)
     };
+    auto exact_step = [&](uint32_t lrow, uint32_t bt, uint32_t q) { exact_step_c(lrow, lds_ld<uint8_t>(bt), q); };
     if (ALL_HOT && __builtin_amdgcn_ballot_w64(s > last_hot) != 0ull)   // (the slice kernel: a lane may come back off the path)
         while (s > last_hot && p < limit) exact_step(0u, lds_ld<uint8_t>(p), p);
     // Where not every reachable state's record is in LDS (the hop slice kernel on definitions of hundreds of extractions), a record
@@ -244,15 +244,19 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
             // exact up to its own first offender and only ever too many above it, so the AND over the intervals never calls a byte
             // inside that is not.) ----
             bool exact = stepping && !chained;
+            // Everything this block may look up is asked for at once -- the tail's set, the loop set, the class of the byte at q: three
+            // reads, one trip to LDS.  One behind the other they were three trips before the exact step's row, and in mixed-case text
+            // the lanes come here at different times: 21 of a tile's 26 iterations pay for the block (tools/hop_stats.py, GX_MIXED_CASE=1).
+            const uint32_t cls_q = lds_ld<uint8_t>(v0 & 0xFFu);
             if (!SECOND) {
                 if (__builtin_amdgcn_ballot_w64(exact && ((h0.x | h1.y) >> 24) != 0u) != 0ull) K.hint = 1u;
             } else {
             // (the chain first: its single bytes matched and its tail byte lies in another interval of the exit's bytes -- a value that
             // begins with a digit or an upper-case letter; the intervals stand in ascending order, so no borrow reaches a byte that is
             // not outside by itself: the test is exact)
+            const u32x2 ts = lds_ld<u32x2>(H.sets + ((h1.y >> 24) << 3)), ls = lds_ld<u32x2>(H.sets + ((h0.x >> 24) << 3));   // (entry 0: no interval)
             if ((__builtin_amdgcn_ballot_w64(sad == 0u && (h1.y >> 24) != 0u && qk <= e_chain) & m_exact) != 0ull) {
                 const bool retry = exact && sad == 0u && qk <= e_chain;
-                const u32x2 ts = lds_ld<u32x2>(H.sets + ((retry ? h1.y >> 24 : 0u) << 3));
                 const uint32_t tb = __builtin_amdgcn_perm(v1, v0, h1.y) & 0xFFu;
                 if (retry && run_flags(tb * 0x01010101u, ts.x, ts.y) != HI_BITS) {
                     if (CAPTURE) {
@@ -266,32 +270,26 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
             }
             const uint32_t set = h0.x >> 24;
             if (__builtin_amdgcn_ballot_w64(exact && set != 0u) != 0ull) {
-                const u32x2 ls = lds_ld<u32x2>(H.sets + ((exact ? set : 0u) << 3));
-                // (the window again, out of LDS: keeping the run test's four dwords alive down to here cost the loop its registers --
-                // config 3, which never comes here with lower-case text, ran 4 % slower for it)
-                const uint32_t pw = q - n, aw = pw & ~3u, sw = pw & 3u;
-                const u32x2 e01 = lds_pair4(aw), e23 = lds_pair4(aw + 8u);
-                const uint32_t e4 = lds_ld<uint32_t>(aw + 16u);
-                const uint32_t x0 = __builtin_amdgcn_alignbyte(e01.y, e01.x, sw), x1 = __builtin_amdgcn_alignbyte(e23.x, e01.y, sw);
-                const uint32_t x2 = __builtin_amdgcn_alignbyte(e23.y, e23.x, sw), x3 = __builtin_amdgcn_alignbyte(e4, e23.y, sw);
-                uint32_t o0 = HI_BITS, o1 = HI_BITS, o2 = HI_BITS, o3 = HI_BITS;
+                // (the eight bytes at q, where the run ended -- the chain's window, still in registers: the bytes before q lie in the run
+                // and so in the union.  Round 5 first tested the sixteen bytes from p again, out of LDS: 100 instructions and three reads
+                // where mixed-case text comes through here in 21 of a tile's 26 iterations -- tools/hop_stats.py with GX_MIXED_CASE=1.)
+                uint32_t o0 = HI_BITS, o1 = HI_BITS;
 #pragma unroll
                 for (uint32_t j = 0; j < 4u; ++j) {
                     const uint32_t sel = j * 0x01010101u;
                     const uint32_t l4 = __builtin_amdgcn_perm(ls.x, ls.x, sel), kk4 = __builtin_amdgcn_perm(ls.y, ls.y, sel);
-                    o0 &= run_flags(x0, l4, kk4); o1 &= run_flags(x1, l4, kk4); o2 &= run_flags(x2, l4, kk4); o3 &= run_flags(x3, l4, kk4);
+                    o0 &= run_flags(v0, l4, kk4); o1 &= run_flags(v1, l4, kk4);
                 }
                 const uint32_t g0 = static_cast<uint32_t>(__ffs(static_cast<int>(o0)) - 1), g1 = static_cast<uint32_t>(__ffs(static_cast<int>(o1)) - 1);
-                const uint32_t g2 = static_cast<uint32_t>(__ffs(static_cast<int>(o2)) - 1), g3 = static_cast<uint32_t>(__ffs(static_cast<int>(o3)) - 1);
-                uint32_t nu = min3u(g0, sat_add(g1, 32u), min3u(sat_add(g2, 64u), sat_add(g3, 96u), 128u)) >> 3;   // 0 .. 16 bytes of the window inside the union
-                nu = min(nu, e - (q - n));
-                if (exact && nu > n) { p = q - n + nu; exact = false; }
+                uint32_t nu = min3u(g0, sat_add(g1, 32u), 64u) >> 3;   // 0 .. 8 bytes at q inside the union
+                nu = min(nu, e - q);
+                if (exact && nu != 0u) { p = q + nu; exact = false; }
             }
             if (__builtin_amdgcn_ballot_w64(stepping && !chained && !exact) != 0ull) K.hint = 1u;   // (a second chance applied)
             }
             if (exact) {
                 // a state without a chain keeps the LDS address / 4 of its dense row's copy in the target field (0: none)
-                exact_step(((h0.x >> 16) & 0xFFu) == 0u ? (h0.y & 0xFFFFu) << 2 : 0u, v0 & 0xFFu, q);
+                exact_step_c(((h0.x >> 16) & 0xFFu) == 0u ? (h0.y & 0xFFFFu) << 2 : 0u, cls_q, q);
                 if (ALL_HOT)
                     while (s > last_hot && p < limit) exact_step(0u, lds_ld<uint8_t>(p), p);   // (off the expected path: rare, and short)
             }

@@ -9,6 +9,8 @@ nrules = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 rules, meta = W.syslog_definition(nrules, seed=3)
 kw = dict(min_len=int(sys.argv[3]), max_len=int(sys.argv[4])) if len(sys.argv) > 4 else {}
+if os.environ.get("GX_MIXED_CASE"):   # mixed-case \\w values (the loop sets' second chance)
+    kw["mixed_case"] = True
 data, off, cats = W.syslog_lines(meta, n, seed=3, **kw)
 tmp = tempfile.mkdtemp()
 with open(os.path.join(tmp, "rules.txt"), "w", encoding="utf-8", newline="") as f:
