@@ -196,6 +196,7 @@ __device__ __forceinline__ void write_row_rec(const LineOut& out, uint64_t i, co
     if (!out.packed) out.match_id[i] = mid;
     uint32_t carry = static_cast<uint32_t>(mid) & (out.narrow ? 0xFFu : 0xFFFFu);
     uint32_t clipped = 0u;
+    const bool may_clip = __builtin_amdgcn_ballot_w64(len > 65534u) != 0ull;   // (wave-uniform: of the lanes that are here)
     for (int g0 = 0; g0 < G; g0 += 4) {
         u32x4 t = g0 == 0 ? pre[0] : g0 == 4 ? pre[1] : pre[2];
         if (g0 >= 12) t = *reinterpret_cast<const u32x4*>(recp + 4 * g0);
@@ -224,11 +225,16 @@ __device__ __forceinline__ void write_row_rec(const LineOut& out, uint64_t i, co
             }
         } else if (!out.narrow) {
             uint32_t hb[4], he[4];
+            if (!may_clip) {   // (no line of this service reaches the 65 535th byte: -1 is 0xFFFF, everything else fits; config 5: 1 %)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                clipped += (pb[q] > 65534 ? 1u : 0u) + (pe[q] > 65534 ? 1u : 0u);
-                hb[q] = pb[q] < 0 ? 0xFFFFu : static_cast<uint32_t>(min(pb[q], 65534));
-                he[q] = pe[q] < 0 ? 0xFFFFu : static_cast<uint32_t>(min(pe[q], 65534));
+                for (int q = 0; q < 4; ++q) { hb[q] = static_cast<uint32_t>(pb[q]) & 0xFFFFu; he[q] = static_cast<uint32_t>(pe[q]) & 0xFFFFu; }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    clipped += (pb[q] > 65534 ? 1u : 0u) + (pe[q] > 65534 ? 1u : 0u);
+                    hb[q] = pb[q] < 0 ? 0xFFFFu : static_cast<uint32_t>(min(pb[q], 65534));
+                    he[q] = pe[q] < 0 ? 0xFFFFu : static_cast<uint32_t>(min(pe[q], 65534));
+                }
             }
             uint8_t* dst = row + 4u * g0;   // (the halfword before group g0's begin: the id, or the end of the group before)
             if (cnt == 4) {
