@@ -151,13 +151,18 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
         u32x2 h0, h1, h2;
         if (ALL_HOT) {
             const uint32_t la = __umul24(min(s, last_hot), HOP_REC_B) + HOP_LDS_AT;  // (a lane that is done may sit in any state)
-            h0 = lds_ld<u32x2>(la); h1 = lds_ld<u32x2>(la + 8u); h2 = lds_ld<u32x2>(la + 16u);
+            // Three ds_read_b64, not a ds_read2_b64 and one: the pair is two accesses of four 16-lane groups on 32 banks (8 LDS cycles before
+            // any conflict), a ds_read_b64 two 32-lane groups on 64 banks (2).  tools/hop_stats.py's bank model on config 3: 20.4 cycles per
+            // iteration for the record as the compiler pairs it, 11.3 as three reads.  The addresses are made opaque so that it cannot pair them.
+            uint32_t la1 = la + 8u, la2 = la + 16u;
+            asm volatile("" : "+v"(la1), "+v"(la2));
+            h0 = lds_ld<u32x2>(la); h1 = lds_ld<u32x2>(la1); h2 = lds_ld<u32x2>(la2);
         } else {
             if ((__builtin_amdgcn_ballot_w64(s != kept) & unfinished) != 0ull) {
                 if (s != kept && p < limit) {
                     if (s <= last_hot) {
                         const uint32_t la = __umul24(s, HOP_REC_B) + HOP_LDS_AT;
-                        k0 = lds_ld<u32x2>(la); k1 = lds_ld<u32x2>(la + 8u); k2 = lds_ld<u32x2>(la + 16u);
+                        k0 = lds_ld<u32x2>(la); k1 = lds_ld<u32x2>(la + 8u); k2 = lds_ld<u32x2>(la + 16u);   // (as three ds_read_b64, like the ALL_HOT read below: 0.817 against 0.814 ms, configs[4] -- not here)
                     } else {
                         const u32x2* g = reinterpret_cast<const u32x2*>(H.hops + static_cast<uint64_t>(s) * HOP_REC_B);
                         k0 = g[0]; k1 = g[1]; k2 = g[2];

@@ -41,10 +41,13 @@ int main(int argc, char** argv) {
         size_t lines = 0, bytes = 0, iters = 0, chains = 0, exacts = 0, exact_cold = 0, run_full = 0, run_bytes = 0, chain_bytes = 0;
         std::vector<std::vector<uint16_t>> traces;
         std::vector<std::vector<uint8_t>> kinds;   // per iteration: 0 a run that fills its window / ends the line, 1 chain, 2 exact step, 3 second chance (loop set / tail set)
+        std::vector<std::vector<uint16_t>> st_at, run_at;   // per iteration: the state the lane is in, the bytes its run covers (where the chain's window is read)
         size_t second = 0;
         while (std::getline(f, ln)) {
             traces.emplace_back();
             kinds.emplace_back();
+            st_at.emplace_back();
+            run_at.emplace_back();
             std::vector<uint8_t> b(ln.begin(), ln.end());
             b.resize(b.size() + 32, 0);
             const size_t e = ln.size();
@@ -65,6 +68,8 @@ int main(int argc, char** argv) {
                 while (n < 16 && p + n < e && run_k != 0x80u && b[p + n] < 0x80u && b[p + n] >= run_lo && b[p + n] <= 0x7Fu - run_k) ++n;
                 run_bytes += n;
                 const size_t q = p + n;
+                st_at.back().push_back(static_cast<uint16_t>(s));
+                run_at.back().push_back(static_cast<uint16_t>(n));
                 if (n == 16 || q >= e) { p = q; ++run_full; kinds.back().push_back(0); continue; }
                 struct Moved { uint32_t from; uint32_t* to; size_t *moves, *plus1, *b4; uint32_t nh; ~Moved() { if (from >= nh && *to != from) { ++*moves; if (*to == from + 1) ++*plus1; if (*to > from && *to < from + 4) ++*b4; } } } moved{s_before, &s, &cold_moves, &next_is_plus1, &in_block4, H.small.n_hot};
                 const uint8_t* lits = reinterpret_cast<const uint8_t*>(&r[4]);
@@ -132,6 +137,79 @@ int main(int argc, char** argv) {
                 }
             }
             if (tiles) printf("  ... of which %.1f have a lane that takes an exact step or a second chance (%.2f second chances per line)\n", double(off_iters) / tiles, double(second) / lines);
+            // ---- LDS array cycles of the walk's reads under the bank rules of MI355X_MICROARCH.md (section LDS): only lanes of one group
+            // conflict, equal addresses broadcast, every further address on a busy bank is one more cycle.  The tile's lines lie one behind
+            // the other in the staging area; a lane that is through keeps reading where it stopped (the kernel does not mask it). ----
+            auto dword_access = [](const uint32_t* a, int first, int count, uint32_t banks) {   // one dword per lane, lanes [first, first + count)
+                uint32_t seen[64][8]; int n_seen[64] = {0};
+                int worst = 1;
+                for (int l = first; l < first + count; ++l) {
+                    const uint32_t b = (a[l] >> 2) % banks;
+                    bool dup = false;
+                    for (int k = 0; k < n_seen[b]; ++k) dup = dup || seen[b][k] == (a[l] >> 2);
+                    if (!dup && n_seen[b] < 8) seen[b][n_seen[b]++] = a[l] >> 2;
+                    worst = std::max(worst, n_seen[b]);
+                }
+                return worst;
+            };
+            auto b32 = [&](const uint32_t* a) { return dword_access(a, 0, 32, 32) + dword_access(a, 32, 32, 32); };   // ds_read_b32: 2 x 32 lanes
+            auto wide = [&](const uint32_t* a, int dwords, int group, uint32_t banks) {   // a lane reads `dwords` consecutive dwords; groups of `group` contiguous lanes
+                int cycles = 0;
+                for (int g0 = 0; g0 < 64; g0 += group) {
+                    uint32_t seen[64][16]; int n_seen[64] = {0};
+                    int worst = 1;
+                    for (int l = g0; l < g0 + group; ++l)
+                        for (int d = 0; d < dwords; ++d) {
+                            const uint32_t w = (a[l] >> 2) + d, b = w % banks;
+                            bool dup = false;
+                            for (int k = 0; k < n_seen[b]; ++k) dup = dup || seen[b][k] == w;
+                            if (!dup && n_seen[b] < 16) seen[b][n_seen[b]++] = w;
+                            worst = std::max(worst, n_seen[b]);
+                        }
+                    cycles += worst;
+                }
+                return cycles;
+            };
+            size_t c_win = 0, c_chain = 0, c_rec = 0, n_it = 0, alt_win = 0, alt_chain = 0, alt_rec = 0, alt_rec32 = 0;
+            for (size_t t0 = 0; t0 + 64 <= traces.size(); t0 += 64) {
+                size_t mx = 0, base[64], pos[64] = {0};
+                size_t acc = 0;
+                for (size_t q = 0; q < 64; ++q) { mx = std::max(mx, traces[t0 + q].size()); base[q] = acc; for (auto v : traces[t0 + q]) acc += v; }
+                uint32_t st[64]; for (size_t q = 0; q < 64; ++q) st[q] = H.start;
+                uint32_t run[64] = {0};
+                for (size_t k = 0; k < mx; ++k, ++n_it) {
+                    uint32_t aw[64], ac[64], ar[64];
+                    for (size_t q = 0; q < 64; ++q) {
+                        if (k < traces[t0 + q].size()) { st[q] = st_at[t0 + q][k]; run[q] = run_at[t0 + q][k]; }
+                        aw[q] = static_cast<uint32_t>(base[q] + pos[q]) & ~3u;
+                        ac[q] = static_cast<uint32_t>(base[q] + pos[q] + (k < traces[t0 + q].size() ? run[q] : 0u)) & ~3u;
+                        ar[q] = HOP_AT + std::min<uint32_t>(st[q], H.full.n_hot - 1u) * HOP_REC_BYTES;
+                    }
+                    uint32_t t[64];
+                    for (int d = 0; d < 5; ++d) { for (int q = 0; q < 64; ++q) t[q] = aw[q] + 4u * d; c_win += b32(t); }      // ds_read2_b32 x 2 + ds_read_b32
+                    for (int d = 0; d < 3; ++d) { for (int q = 0; q < 64; ++q) t[q] = ac[q] + 4u * d; c_chain += b32(t); }    // ds_read2_b32 + ds_read_b32
+                    c_rec += wide(ar, 2, 16, 32);                                                                             // ds_read2_b64: two accesses of 4 x 16 lanes
+                    for (int q = 0; q < 64; ++q) t[q] = ar[q] + 8u;
+                    c_rec += wide(t, 2, 16, 32);
+                    for (int q = 0; q < 64; ++q) t[q] = ar[q] + 16u;
+                    c_rec += wide(t, 2, 32, 64);                                                                              // ds_read_b64: 2 x 32 lanes, 64 banks
+                    // alternatives: the windows as 8-byte aligned ds_read_b64 (three / two of them), the record as three ds_read_b64, the
+                    // record in 32 bytes (two ds_read_b128: 4 x 16 lanes, 64 banks)
+                    for (int d = 0; d < 3; ++d) { for (int q = 0; q < 64; ++q) t[q] = (aw[q] & ~7u) + 8u * d; alt_win += wide(t, 2, 32, 64); }
+                    for (int d = 0; d < 2; ++d) { for (int q = 0; q < 64; ++q) t[q] = (ac[q] & ~7u) + 8u * d; alt_chain += wide(t, 2, 32, 64); }
+                    for (int d = 0; d < 3; ++d) { for (int q = 0; q < 64; ++q) t[q] = ar[q] + 8u * d; alt_rec += wide(t, 2, 32, 64); }
+                    for (int d = 0; d < 2; ++d) {
+                        for (int q = 0; q < 64; ++q) t[q] = HOP_AT + std::min<uint32_t>(st[q], H.full.n_hot - 1u) * 32u + 16u * d;
+                        // (ds_read_b128's four groups are not contiguous lanes; contiguous ones model the same load)
+                        alt_rec32 += wide(t, 4, 16, 64);
+                    }
+                    for (size_t q = 0; q < 64; ++q) if (k < traces[t0 + q].size()) pos[q] += traces[t0 + q][k];
+                }
+            }
+            if (n_it) printf("  LDS array cycles per wave iteration under the bank rules: the run's window %.1f (10 without conflicts), the chain's window %.1f (6), the record %.1f (10)\n",
+                             double(c_win) / n_it, double(c_chain) / n_it, double(c_rec) / n_it);
+            if (n_it) printf("  ... alternatives: the run's window as three aligned ds_read_b64 %.1f, the chain's as two %.1f, the record as three ds_read_b64 %.1f, in 32 bytes as two ds_read_b128 %.1f\n",
+                             double(alt_win) / n_it, double(alt_chain) / n_it, double(alt_rec) / n_it, double(alt_rec32) / n_it);
         }
         if (pass == 0) {
             // ---- the hop slice kernel's rounds, replayed: 64 lanes, pieces of 128 bytes from a lane's own position, a lane comes back 24 bytes
