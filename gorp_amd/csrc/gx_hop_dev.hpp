@@ -175,6 +175,8 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
             h0 = k0; h1 = k1; h2 = k2;   // (a lane that is done may hold any record: nothing of it is used)
         }
         // ---- 2. the run: how many of the next 16 class ids lie in [run_lo, run_hi] ----
+        // (The window as three 8-byte aligned ds_read_b64 and a select per dword models at 13.4 instead of 27.8 LDS-array cycles per iteration
+        // -- tools/hop_stats.py -- and costs nine vector instructions: 0.771 against 0.758 ms on config 3, one device.  Not kept.)
         const uint32_t a1 = p & ~3u, sh1 = p & 3u;
         const u32x2 d01 = lds_pair4(a1), d23 = lds_pair4(a1 + 8u);
 #ifdef GX_HOP_ONE_WINDOW

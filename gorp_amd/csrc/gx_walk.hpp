@@ -321,6 +321,8 @@ __device__ __forceinline__ uint32_t steps16(const uint4& win, uint32_t mask, con
 // 0 = unset, 1 = the line length, else the byte offset of a register column from the wave's dummy column.  Record 0
 // has every tag unset and serves the lines without a match, so the loads below are unconditional and independent:
 // all tags, then all registers, then the selects -- two LDS round trips per four groups instead of two per group.
+// (Round 5: the first twelve groups' tags, then all their registers, then the rows -- two trips for config 3's ten groups instead of six:
+// 0.778 against 0.755 ms, one device; the 36 values it holds at once cost more than the trips.  Not kept.)
 // emit(g, begin, end) is called for g = 0 .. G-1 with (-1, -1) for an unset group; returns the match id.
 // TIER_HOP (round 5): every tag names a column -- a register's, "the length" or "unset" (hop_unset: its offset; the lane has filled
 // both in) -- and a group with one end unset has both unset: two reads and one test per group, no selects on tag values.
