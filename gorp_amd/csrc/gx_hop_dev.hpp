@@ -183,8 +183,12 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
         const u32x2 d45 = lds_pair4(a1 + 16u), d67 = lds_pair4(a1 + 24u);
         const uint32_t d4 = d45.x;
 #else
-        const uint32_t d4 = lds_ld<uint32_t>(a1 + 16u);
+        // (four dwords, not five: a window that does not begin on a dword is 16 - (p & 3) bytes long -- the bytes behind the fourth dword
+        // read as 0xFF, outside every run -- and wlen below is what "the run fills its window" means.  One LDS read in eight less per
+        // iteration for a long value's windows being 14.5 bytes on average instead of 16.)
+        const uint32_t d4 = 0xFFFFFFFFu;
 #endif
+        const uint32_t wlen = 16u - sh1;
         const uint32_t x0 = __builtin_amdgcn_alignbyte(d01.y, d01.x, sh1), x1 = __builtin_amdgcn_alignbyte(d23.x, d01.y, sh1);
         const uint32_t x2 = __builtin_amdgcn_alignbyte(d23.y, d23.x, sh1), x3 = __builtin_amdgcn_alignbyte(d4, d23.y, sh1);
         const uint32_t lo4 = splat_byte0(h0.x), k4 = splat_byte1(h0.x);
@@ -196,7 +200,7 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
         n = min(n, e - p);
         const uint32_t q = p + n;
         // (a lane steps when its run ended inside the window and inside the staged bytes; a lane past its limit does not)
-        const uint64_t m_step = __builtin_amdgcn_ballot_w64(n < 16u) & __builtin_amdgcn_ballot_w64(q < e) & unfinished;
+        const uint64_t m_step = __builtin_amdgcn_ballot_w64(n < wlen) & __builtin_amdgcn_ballot_w64(q < e) & unfinished;
         // (Round 5: a loop of its own for the iterations in which NO lane steps -- every lane in a run that fills its window: the tile
         // kernel's lanes reach their lines' long last values together -- window and run test alone, no record, chain or capture stores.
         // Measured on config 3, one device: 0.939 against 0.938 ms with captures, 0.652 against 0.608 match only.  The lanes' values end
@@ -227,9 +231,11 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
         const uint32_t sad = __builtin_amdgcn_msad_u8(v1, h2.y, __builtin_amdgcn_msad_u8(v0, h2.x, 0u));
         const uint32_t tail = sub_b0_b1(__builtin_amdgcn_perm(v1, v0, h1.y), h1.y);   // (the selector's other bytes pick what nobody reads)
         const uint32_t qk = add_byte2(q, h0.x);   // where the chain ends
-        const bool chain_ok = sad == 0u && tail <= ((h1.y >> 16) & 0xFFu) && qk <= e_chain;
-        const uint64_t m_chain = m_step & __builtin_amdgcn_ballot_w64(chain_ok);
-        const bool stepping = n < 16u && q < e && p < limit;  // (the same compares, per lane: their masks ARE the select conditions)
+        const uint32_t span = (h1.y >> 16) & 0xFFu;
+        const bool chain_ok = sad == 0u && tail <= span && qk <= e_chain;
+        // (the masks of the three compares, ANDed: the ballot of the compound condition was a select and a compare more)
+        const uint64_t m_chain = m_step & __builtin_amdgcn_ballot_w64(sad == 0u) & __builtin_amdgcn_ballot_w64(tail <= span) & __builtin_amdgcn_ballot_w64(qk <= e_chain);
+        const bool stepping = n < wlen && q < e && p < limit;  // (the same compares, per lane: their masks ARE the select conditions)
         const bool chained = stepping && chain_ok;
         // a lane that does not take its chain reads its record as "no bytes, same state, no programs"
         const uint32_t cols = chained ? h1.x : 0u;
