@@ -220,6 +220,8 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
         const uint32_t v0 = __builtin_amdgcn_alignbyte(X1, X0, sh2), v1 = __builtin_amdgcn_alignbyte(X2, X1, sh2);
 #else
         // (a second, dependent LDS read: see above for what picking the bytes out of the first window costs instead)
+        // (As two 8-byte aligned ds_read_b64 and a select per dword -- 9.1 instead of 16.4 LDS-array cycles in tools/hop_stats.py's model --
+        // the chain's window made config 3 2.4 % SLOWER, 0.756 against 0.739 ms, as the run's window did: not kept.)
         const uint32_t a2 = q & ~3u, sh2 = q & 3u;
         const u32x2 r01 = lds_pair4(a2);
         const uint32_t r2 = lds_ld<uint32_t>(a2 + 8u);
