@@ -177,28 +177,31 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
         // ---- 2. the run: how many of the next 16 class ids lie in [run_lo, run_hi] ----
         // (The window as three 8-byte aligned ds_read_b64 and a select per dword models at 13.4 instead of 27.8 LDS-array cycles per iteration
         // -- tools/hop_stats.py -- and costs nine vector instructions: 0.771 against 0.758 ms on config 3, one device.  Not kept.)
-        const uint32_t a1 = p & ~3u, sh1 = p & 3u;
-        const u32x2 d01 = lds_pair4(a1), d23 = lds_pair4(a1 + 8u);
-#ifdef GX_HOP_ONE_WINDOW
-        const u32x2 d45 = lds_pair4(a1 + 16u), d67 = lds_pair4(a1 + 24u);
-        const uint32_t d4 = d45.x;
-#else
         // (four dwords, not five: a window that does not begin on a dword is 16 - (p & 3) bytes long -- the bytes behind the fourth dword
-        // read as 0xFF, outside every run -- and wlen below is what "the run fills its window" means.  One LDS read in eight less per
+        // read as 0xFF, outside every run -- and wlen is what "the run fills its window" means.  One LDS read in eight less per
         // iteration for a long value's windows being 14.5 bytes on average instead of 16.)
-        const uint32_t d4 = 0xFFFFFFFFu;
-#endif
-        const uint32_t wlen = 16u - sh1;
-        const uint32_t x0 = __builtin_amdgcn_alignbyte(d01.y, d01.x, sh1), x1 = __builtin_amdgcn_alignbyte(d23.x, d01.y, sh1);
-        const uint32_t x2 = __builtin_amdgcn_alignbyte(d23.y, d23.x, sh1), x3 = __builtin_amdgcn_alignbyte(d4, d23.y, sh1);
         const uint32_t lo4 = splat_byte0(h0.x), k4 = splat_byte1(h0.x);
-        const uint32_t f0 = static_cast<uint32_t>(__ffs(static_cast<int>(run_flags(x0, lo4, k4))) - 1);  // 7, 15, 23, 31 or 0xFFFFFFFF
-        const uint32_t f1 = static_cast<uint32_t>(__ffs(static_cast<int>(run_flags(x1, lo4, k4))) - 1);
-        const uint32_t f2 = static_cast<uint32_t>(__ffs(static_cast<int>(run_flags(x2, lo4, k4))) - 1);
-        const uint32_t f3 = static_cast<uint32_t>(__ffs(static_cast<int>(run_flags(x3, lo4, k4))) - 1);
-        uint32_t n = min3u(f0, sat_add(f1, 32u), min3u(sat_add(f2, 64u), sat_add(f3, 96u), 128u)) >> 3;  // 0 .. 16
-        n = min(n, e - p);
-        const uint32_t q = p + n;
+        uint32_t wlen, n, q;
+        auto run_window = [&]() {
+            const uint32_t a1 = p & ~3u, sh1 = p & 3u;
+            const u32x2 d01 = lds_pair4(a1), d23 = lds_pair4(a1 + 8u);
+            const uint32_t x0 = __builtin_amdgcn_alignbyte(d01.y, d01.x, sh1), x1 = __builtin_amdgcn_alignbyte(d23.x, d01.y, sh1);
+            const uint32_t x2 = __builtin_amdgcn_alignbyte(d23.y, d23.x, sh1), x3 = __builtin_amdgcn_alignbyte(0xFFFFFFFFu, d23.y, sh1);
+            const uint32_t f0 = static_cast<uint32_t>(__ffs(static_cast<int>(run_flags(x0, lo4, k4))) - 1);  // 7, 15, 23, 31 or 0xFFFFFFFF
+            const uint32_t f1 = static_cast<uint32_t>(__ffs(static_cast<int>(run_flags(x1, lo4, k4))) - 1);
+            const uint32_t f2 = static_cast<uint32_t>(__ffs(static_cast<int>(run_flags(x2, lo4, k4))) - 1);
+            const uint32_t f3 = static_cast<uint32_t>(__ffs(static_cast<int>(run_flags(x3, lo4, k4))) - 1);
+            n = min3u(f0, sat_add(f1, 32u), min3u(sat_add(f2, 64u), sat_add(f3, 96u), 128u)) >> 3;  // 0 .. 16
+            n = min(n, e - p);
+            wlen = 16u - sh1;
+            q = p + n;
+        };
+        run_window();
+        // (Round 5, after the LDS array turned out to be what binds the walk: lanes whose run fills the window taking their NEXT window right
+        // here -- four dword reads and the run test, by those lanes alone, while at least 16 / 24 / 40 lanes do -- instead of in an iteration
+        // with its record, chain window and capture stores: 0.967 / 0.929 / 0.915 against 0.743 ms on config 3, one device.  The lanes
+        // reach their long values in different iterations, and a group that runs ahead does so while the others wait: the walk's
+        // strength is that every iteration serves every lane, whatever it is in the middle of.  Not kept.)
         // (a lane steps when its run ended inside the window and inside the staged bytes; a lane past its limit does not)
         const uint64_t m_step = __builtin_amdgcn_ballot_w64(n < wlen) & __builtin_amdgcn_ballot_w64(q < e) & unfinished;
         // (Round 5: a loop of its own for the iterations in which NO lane steps -- every lane in a run that fills its window: the tile
@@ -206,27 +209,17 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
         // Measured on config 3, one device: 0.939 against 0.938 ms with captures, 0.652 against 0.608 match only.  The lanes' values end
         // in different windows, so few iterations qualify, and the loop's own tests cost what it saves.  Not kept.)
         // ---- 3. the chain: the 8 bytes at q ----
-#ifdef GX_HOP_ONE_WINDOW
-        // out of the window that is already here (8 dwords were read at a1: bytes p .. p + 28 at least), picked with selects: no second,
-        // dependent LDS round trip.  t = byte offset of q from a1 (0 .. 18), j = its dword.  (An experiment: python -m gorp_amd.build
-        // --variant onewin -DGX_HOP_ONE_WINDOW, tools/ab_bench.py.  Measured twice, in round 3 and again in round 4 on the byte-space
-        // tables: 7 % SLOWER on config 3 -- 0.968 against 0.903 ms, dense results, one device -- and 2.5 % on config 5: the 19 more
-        // vector instructions cost more than the round trip they save.  Both pipes, vector and LDS, are near their share.)
-        const uint32_t t = sh1 + n, j = t >> 2, sh2 = t & 3u;
-        const bool b0 = (j & 1u) != 0u, b1 = (j & 2u) != 0u, b2 = (j & 4u) != 0u;
-        const uint32_t A0 = b0 ? d01.y : d01.x, A1 = b0 ? d23.x : d01.y, A2 = b0 ? d23.y : d23.x, A3 = b0 ? d45.x : d23.y, A4 = b0 ? d45.y : d45.x;
-        const uint32_t B0 = b1 ? A2 : A0, B1 = b1 ? A3 : A1, B2 = b1 ? A4 : A2;
-        const uint32_t X0 = b2 ? d45.x : B0, X1 = b2 ? d45.y : B1, X2 = b2 ? d67.x : B2;   // (j = 4: b0 = b1 = 0)
-        const uint32_t v0 = __builtin_amdgcn_alignbyte(X1, X0, sh2), v1 = __builtin_amdgcn_alignbyte(X2, X1, sh2);
-#else
+        // (Picking the chain's bytes out of the run's window with selects instead of a second, dependent LDS read -- an eight-dword window --
+        // was measured twice, in round 3 and again in round 4 on the byte-space tables: 7 % SLOWER on config 3, 0.968 against 0.903 ms, dense
+        // results, one device, and 2.5 % on config 5.)
         // (a second, dependent LDS read: see above for what picking the bytes out of the first window costs instead)
         // (As two 8-byte aligned ds_read_b64 and a select per dword -- 9.1 instead of 16.4 LDS-array cycles in tools/hop_stats.py's model --
         // the chain's window made config 3 2.4 % SLOWER, 0.756 against 0.739 ms, as the run's window did: not kept.)
+        // (read by the lanes whose run ended alone -- fewer lanes, fewer bank conflicts: 0.766 against 0.748 ms, config 3, one device.  Not kept.)
         const uint32_t a2 = q & ~3u, sh2 = q & 3u;
         const u32x2 r01 = lds_pair4(a2);
         const uint32_t r2 = lds_ld<uint32_t>(a2 + 8u);
         const uint32_t v0 = __builtin_amdgcn_alignbyte(r01.y, r01.x, sh2), v1 = __builtin_amdgcn_alignbyte(r2, r01.y, sh2);
-#endif
         // the single bytes: sum of |v - literal| over the reference bytes that are not 0; the tail: byte `pos` of the eight in [lo, lo + span]
         // (record: h0.x run_lo | run_k << 8 | klen << 16; h0.y target | off1 << 16 | off2 << 24; h1.x column1 * 128 | column2 * 128 << 16;
         //  h1.y tail pos | lo << 8 | span << 16; h2 the single bytes)
