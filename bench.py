@@ -173,6 +173,22 @@ def build_workload(config, n, rank, dev, variant=None):
     return rules, data, off, n, want, known, hint, desc % n
 
 
+def box_read_rate(data):
+    """What a plain read-only sweep of this very buffer reaches on THIS box, GB/s (a torch int64 sum -- the fastest of torch's
+    reductions here, tools/read_bw.py: a reference kernel, not the product's) -- devices of the pool differ by 10 % on the headline, and this says how much of that is the box."""
+    import torch
+    v = data[: data.numel() & ~15].view(torch.int64)
+    for _ in range(3):
+        v.sum()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        v.sum()
+    e1.record()
+    torch.cuda.synchronize()
+    return v.numel() * 8 / (e0.elapsed_time(e1) / 10 * 1e-3) / 1e9
+
+
 def recorded_traffic(names, algo_read, algo_write):
     """HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this kernel on this exact workload
     (tools/collect_r05.sh: separate --pmc passes, FETCH_SIZE doubled per the gfx950 correction, calibrated against a
@@ -602,6 +618,7 @@ def main():
                     "compact": "compact rows (int16 id + uint16 offsets, %d B/line)" % (2 + 4 * G),
                     "dense": "dense (int32 id + int32 offsets, %d B/line)" % (4 + 8 * G)}
         achieved = algo_read / (k_avg * 1e-3) / 1e9
+        box_rate = box_read_rate(data) if world == 1 else None   # (after the timed region; the same buffer, the same clocks)
         if config == 2:
             traffic, traffic_src = recorded_traffic(("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"), algo_read, write_bytes[headline])
         else:
@@ -651,7 +668,10 @@ def main():
                          "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,
                          "algorithmic_read_bytes": algo_read, "algorithmic_write_bytes": write_bytes[headline],
-                         "frac_of_measured_copy_ceiling": achieved / 6290.0},
+                         "frac_of_measured_copy_ceiling": achieved / 6290.0,
+                         "this_box": None if box_rate is None else {
+                             "plain_read_gb_per_s": box_rate, "frac_of_it": achieved / box_rate,
+                             "what": "a torch int64 sum over the same 2 GB buffer right after the timed steps: what a read-only sweep reaches on this device"}},
             "formats": per_format,
             "setup_s": setup_s,
             "table_bcast_ms": bcast_ms,
