@@ -168,6 +168,10 @@ __device__ __forceinline__ uint32_t walk_hop_span(const HopTab& H, uint32_t& p, 
                         k0 = g[0]; k1 = g[1]; k2 = g[2];
                     }
                     kept = s;
+                    // (A lane that ASKS for such a record and sits the iteration out -- the record in other registers, in its hands when the next
+                    // iteration begins, the wave not waiting for the trip; round 4's plan -- was built in round 5: 168 registers, no spills,
+                    // and 0.972 against 0.815 ms per 3.8 M lines of configs[4], one device: a line enters 8 such states in its 43
+                    // iterations, the trip ends in L1, and the iterations sat out cost more than the waits did.  Not kept.)
                     // (asking for the chain target's record one state ahead -- a line's states are a path -- was measured in round 5:
                     // 1.062 against 1.046 ms per 3.8 M lines of configs[4]: the kernel is bound by the instructions it issues, not by that trip)
                 }
