@@ -1050,6 +1050,8 @@ k_extract_hop_slices(GxDev T, GxLds L, const uint8_t* __restrict__ lds_image, co
         for (uint32_t r = 0; r < LPL; ++r) who[r] = lds_ld<u32x4>(slice + (lane / LPL + LINES_PER_LOAD * r) * 16u);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();   // (every lane has read before anything else is stored there)
+        // (Round 5: one dword of the 128-byte line that the lane's NEXT piece will begin to need, asked for with this piece's loads -- a
+        // round ahead, so that those loads find it in L2: 0.829 against 0.814 ms per 3.8 M lines of configs[4], one device.  Not kept.)
         u32x4 pv[LPL];
         uint32_t high_or[LPL];   // WIDE: the high bytes of the units a lane loaded, ORed
 #pragma unroll
