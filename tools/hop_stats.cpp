@@ -31,6 +31,10 @@ int main(int argc, char** argv) {
         if (!build_hop_image(T, pass == 1, 48u * 1024u, 12u * 1024u, H)) { printf("no hop image\n"); return 1; }
         printf("%s: %u states, %u reachable, %u hot, %u chains, %u runs, %u rows in LDS\n", pass ? "match automaton" : "fused automaton", H.n_states,
                H.n_reachable_hot, H.full.n_hot, H.n_chains, H.n_runs, H.full.n_lds_rows);
+        printf("  the tile kernel's LDS image: %zu bytes = class map %u | %u records %u | info words %u | %u branching rows of %u classes %u | final records %u | loop sets %zu; %u register columns\n",
+               H.full.bytes.size(), HOP_AT, H.full.n_hot, H.full.n_hot * HOP_REC_BYTES, (H.full.n_hot * 2u + 15u) & ~15u, H.full.n_lds_rows, H.ncls,
+               H.full.fin_lds ? H.full.fin_lds - (H.full.info_lds + ((H.full.n_hot * 2u + 15u) & ~15u)) : 0u, H.full.fin_lds ? H.full.sets_lds - H.full.fin_lds : 0u,
+               H.full.bytes.size() - H.full.sets_lds, H.n_regs);
         const uint32_t* rows = reinterpret_cast<const uint32_t*>(H.global.data());
         const uint32_t cols = H.row_bytes / 4;
         const uint8_t* hops = H.global.data() + H.hops_off;
